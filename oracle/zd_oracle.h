@@ -1,0 +1,117 @@
+/* zd_oracle.h -- CPU oracle for the Zipc_deflate hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C restatement of the algorithm in
+ * the reference's src/zipc_deflate.ml (dbuenzli/zipc), written function by
+ * function from that file (each function below cites the lines it follows).
+ * It is the parity checker for the HIP path and the "port" CPU baseline of
+ * bench.py.  Nothing in zipc_amd/ (the product) may include, link or call it:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * Pinning: the reference cannot be built here (no OCaml
+ * toolchain in the image), so this oracle is pinned by
+ *   - the reference's own known-answer tests (test/test.ml:16-26 CRC/Adler),
+ *   - its round-trip strings and their expected block types (test/test.ml:38-42),
+ *   - its size-limit test (test/test.ml:45-55),
+ *   - its embedded zip-docs.zip fixture (test/test.ml:131-3294; sizes + CRCs),
+ *   - Python zlib as an independent inflate / CRC-32 / Adler-32 implementation.
+ * The reference's tests never assert compressed BYTES, so deflate byte parity is
+ * "parity unpinned" beyond these: it is defined by the source semantics this
+ * file restates (incl. quirks Q1-Q7 of SURVEY.md Appendix A).
+ */
+#ifndef ZD_ORACLE_H
+#define ZD_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes; zd_strerror maps them to the reference's messages */
+enum {
+  ZD_OK = 0,
+  ZD_ERR_CORRUPTED = 1,     /* "Corrupted data stream"                  zd.ml:233 */
+  ZD_ERR_SIZE_EXCEEDED = 2, /* "Expected decompression size exceeded"   zd.ml:29  */
+  ZD_ERR_ZLIB_METHOD = 3,   /* "Unknown compression method (%d)"        zd.ml:728 */
+  ZD_ERR_ZLIB_WINDOW = 4,   /* "Window size too large"                  zd.ml:729 */
+  ZD_ERR_ZLIB_DICT = 5,     /* "Preset dictionary unsupported"          zd.ml:730 */
+  ZD_ERR_CHECKSUM = 6,      /* "Checksum mismatch, expected %lx found %lx)" zd.ml:104 */
+  ZD_ERR_NOMEM = 7
+};
+
+/* crc_op  zd.ml:210 */
+enum { ZD_CRC_NOP = 0, ZD_CRC_CRC32 = 1, ZD_CRC_ADLER32 = 2 };
+
+/* level  zd.ml:752; note the reference's effective default is BEST (zd.ml:817) */
+enum { ZD_LEVEL_NONE = 0, ZD_LEVEL_FAST = 1, ZD_LEVEL_DEFAULT = 2, ZD_LEVEL_BEST = 3 };
+
+/* block kinds reported by zd_deflate_trace */
+enum { ZD_BLOCK_STORED = 0, ZD_BLOCK_FIXED = 1, ZD_BLOCK_DYNAMIC = 2 };
+
+typedef struct {
+  int kind;            /* ZD_BLOCK_* */
+  int final;
+  uint32_t src_start;  /* block_src_start */
+  uint32_t src_len;    /* block_src_len   */
+  uint32_t n_syms;     /* block_syms_len incl. end-of-block */
+  int64_t nlen, flen, dlen; /* the three cost estimates of write_block */
+} zd_block_info;
+
+const char *zd_strerror(int status);
+
+/* Crc_32  zd.ml:106-164.  *_update work on the raw running state (init
+ * 0xFFFFFFFF, finish = xor 0xFFFFFFFF), like Crc_32.string_update. */
+uint32_t zd_crc32_update(uint32_t state, const uint8_t *s, size_t len);
+uint32_t zd_crc32(const uint8_t *s, size_t len);
+
+/* Adler_32  zd.ml:166-206, including the signed-remainder behaviour (Q6) and
+ * the per-call first-chunk rule (Q7). */
+uint32_t zd_adler32_update(uint32_t state, const uint8_t *s, size_t len);
+uint32_t zd_adler32(const uint8_t *s, size_t len);
+
+/* inflate_and_crc  zd.ml:692-709.  *out is malloc'ed (zd_free).  has_limit=1
+ * gives ?decompressed_size = limit. */
+int zd_inflate(const uint8_t *src, size_t len, int has_limit, size_t limit,
+               int crc_op, uint8_t **out, size_t *out_len, uint32_t *crc);
+
+/* Same contract, writing into a caller buffer of dst_cap bytes.  With
+ * has_limit=0 the caller promises dst_cap is large enough; running out then
+ * returns ZD_ERR_NOMEM (never happens for a valid bound). */
+int zd_inflate_into(const uint8_t *src, size_t len, int has_limit, size_t limit,
+                    int crc_op, uint8_t *dst, size_t dst_cap, size_t *out_len,
+                    uint32_t *crc);
+
+/* zlib_decompress  zd.ml:720-740 (start = 0).  On ZD_ERR_CHECKSUM,
+ * *expect / *found hold the two Adler-32 values. */
+int zd_zlib_decompress(const uint8_t *src, size_t len, int has_limit,
+                       size_t limit, uint8_t **out, size_t *out_len,
+                       uint32_t *adler, uint32_t *expect, uint32_t *found);
+
+/* crc_and_deflate  zd.ml:1247-1251 (start = 0). */
+int zd_deflate(const uint8_t *src, size_t len, int level, int crc_op,
+               uint8_t **out, size_t *out_len, uint32_t *crc);
+
+/* as zd_deflate, also recording up to max_blocks block descriptors */
+int zd_deflate_trace(const uint8_t *src, size_t len, int level, int crc_op,
+                     uint8_t **out, size_t *out_len, uint32_t *crc,
+                     zd_block_info *blocks, size_t max_blocks, size_t *n_blocks);
+
+/* zlib_compress  zd.ml:1262-1277 (start = 0). */
+int zd_zlib_compress(const uint8_t *src, size_t len, int level, uint8_t **out,
+                     size_t *out_len, uint32_t *adler);
+
+/* worst-case deflate output size for len input bytes (all stored blocks) */
+size_t zd_deflate_bound(size_t len);
+
+/* Huffman.lengths_of_freqs zd.ml:404-473, exposed for unit tests: fills
+ * lengths[0..max_sym]. */
+void zd_huffman_lengths_of_freqs(const int64_t *freqs, int max_sym,
+                                 int max_code_len, int *lengths);
+
+void zd_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
