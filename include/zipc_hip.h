@@ -1,0 +1,195 @@
+/* zipc_hip.h -- C ABI of the MI355X-native Zipc_deflate hot path.
+ *
+ * This is the drop-in boundary for the reference's src/zipc_deflate.ml: every
+ * entry point below replaces one value of the reference's module signature
+ * src/zipc_deflate.mli (cited per function).  The reference has no FFI of its
+ * own -- the seam is that OCaml signature -- so an OCaml shim
+ * (bindings/ocaml/, shown in INTEGRATION.md) marshals strings to these calls,
+ * applies ?start as a pointer offset, supplies the reference's default level
+ * (`Best, zipc_deflate.ml:817) and maps status codes to the reference's error
+ * strings (zipc_hip_strerror).
+ *
+ * Plain C: pointers and sizes only, no C++/torch types.  Status codes, never
+ * exceptions.  The library never frees or retains caller memory.
+ *
+ * Two families:
+ *   - host forms   (zipc_hip_crc32 ... zipc_hip_zlib_decompress): host
+ *     pointers in, host buffers out; one stream = a batch of one.  They copy
+ *     H2D/D2H around the same kernels as the batch forms.
+ *   - batch forms  (zipc_hip_*_batch, zipc_hip_checksum_device): descriptors
+ *     over DEVICE-resident arenas; nothing crosses PCIe.  These are what
+ *     bench.py times.
+ *
+ * All compute happens in HIP kernels on gfx950.  There is no CPU fallback: with
+ * no usable device every call returns ZIPC_HIP_ERR_NO_DEVICE / _HIP.
+ */
+#ifndef ZIPC_HIP_H
+#define ZIPC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZIPC_HIP_ABI_VERSION 1
+
+/* ---- status codes --------------------------------------------------------
+ * 1..6 are the reference's Failure messages (zipc_deflate.ml:233,29,728-730,104) */
+enum {
+  ZIPC_HIP_OK = 0,
+  ZIPC_HIP_ERR_CORRUPTED = 1,     /* "Corrupted data stream" */
+  ZIPC_HIP_ERR_SIZE_EXCEEDED = 2, /* "Expected decompression size exceeded" */
+  ZIPC_HIP_ERR_ZLIB_METHOD = 3,   /* "Unknown compression method (%d)" */
+  ZIPC_HIP_ERR_ZLIB_WINDOW = 4,   /* "Window size too large" */
+  ZIPC_HIP_ERR_ZLIB_DICT = 5,     /* "Preset dictionary unsupported" */
+  ZIPC_HIP_ERR_CHECKSUM = 6,      /* "Checksum mismatch, expected %lx found %lx)" */
+  /* boundary-only conditions (no reference counterpart) */
+  ZIPC_HIP_ERR_DST_TOO_SMALL = 16, /* dst_cap too small and no decompressed_size
+                                      limit was given: retry with a larger dst */
+  ZIPC_HIP_ERR_HIP = 17,           /* a HIP runtime call failed */
+  ZIPC_HIP_ERR_INVALID_ARG = 18,
+  ZIPC_HIP_ERR_NO_DEVICE = 19,
+  ZIPC_HIP_ERR_NOMEM = 20
+};
+
+/* crc_op (zipc_deflate.ml:210): which checksum is fused into inflate (over the
+ * output) / deflate (over the input), updated once per deflate block. */
+enum { ZIPC_HIP_CRC_NOP = 0, ZIPC_HIP_CRC_CRC32 = 1, ZIPC_HIP_CRC_ADLER32 = 2 };
+
+/* type level (zipc_deflate.mli:123-125) */
+enum {
+  ZIPC_HIP_LEVEL_NONE = 0,
+  ZIPC_HIP_LEVEL_FAST = 1,
+  ZIPC_HIP_LEVEL_DEFAULT = 2,
+  ZIPC_HIP_LEVEL_BEST = 3
+};
+
+/* ---- context ---------------------------------------------------------------
+ * Owns a HIP stream, constant tables and device scratch (grown on demand and
+ * reused).  One context per host thread; contexts are independent (the
+ * reference is re-entrant with no shared state). */
+typedef struct zipc_hip_ctx zipc_hip_ctx;
+
+int zipc_hip_abi_version(void);
+int zipc_hip_device_count(void);
+int zipc_hip_create(zipc_hip_ctx **ctx, int device);
+void zipc_hip_destroy(zipc_hip_ctx *ctx);
+/* the hipStream_t all of this context's work is enqueued on */
+void *zipc_hip_stream(zipc_hip_ctx *ctx);
+int zipc_hip_synchronize(zipc_hip_ctx *ctx);
+/* text of the last HIP runtime error seen by this context ("" if none) */
+const char *zipc_hip_last_error(zipc_hip_ctx *ctx);
+/* the reference's message for a status (format strings kept verbatim) */
+const char *zipc_hip_strerror(int status);
+
+/* ---- per-kernel timing -----------------------------------------------------
+ * With profiling on, every kernel launch is bracketed by HIP events on the
+ * context stream; zipc_hip_kernel_times reports, per kernel name, launches and
+ * total milliseconds since the last reset.  bench.py uses this for the
+ * roofline's live per-launch duration. */
+typedef struct {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} zipc_hip_kernel_time;
+int zipc_hip_set_profiling(zipc_hip_ctx *ctx, int enabled);
+int zipc_hip_reset_kernel_times(zipc_hip_ctx *ctx);
+int zipc_hip_kernel_times(zipc_hip_ctx *ctx, zipc_hip_kernel_time *out, size_t cap,
+                          size_t *n);
+
+/* ---- host forms ------------------------------------------------------------ */
+
+/* Crc_32.string  (zipc_deflate.mli:46; zipc_deflate.ml:161) */
+int zipc_hip_crc32(zipc_hip_ctx *ctx, const void *src, size_t len, uint32_t *crc);
+/* Adler_32.string (zipc_deflate.mli:72; zipc_deflate.ml:203), signed-remainder
+ * behaviour of zipc_deflate.ml:95,196 included */
+int zipc_hip_adler32(zipc_hip_ctx *ctx, const void *src, size_t len, uint32_t *adler);
+
+/* inflate / inflate_and_crc_32 / inflate_and_adler_32
+ * (zipc_deflate.mli:79-102; zipc_deflate.ml:692-718).
+ * has_limit != 0  <=>  ?decompressed_size = limit.  dst_cap >= limit required
+ * then.  With has_limit == 0 the reference grows its buffer without bound; here
+ * ZIPC_HIP_ERR_DST_TOO_SMALL asks the caller to retry with a larger dst. */
+int zipc_hip_inflate(zipc_hip_ctx *ctx, const void *src, size_t len, int has_limit,
+                     size_t limit, int crc_op, void *dst, size_t dst_cap,
+                     size_t *out_len, uint32_t *checksum);
+
+/* zlib_decompress (zipc_deflate.mli:104-118; zipc_deflate.ml:720-740).  On
+ * ZIPC_HIP_ERR_CHECKSUM, *expect and *found hold the two Adler-32 values. */
+int zipc_hip_zlib_decompress(zipc_hip_ctx *ctx, const void *src, size_t len,
+                             int has_limit, size_t limit, void *dst, size_t dst_cap,
+                             size_t *out_len, uint32_t *adler, uint32_t *expect,
+                             uint32_t *found);
+
+/* upper bound of the deflate output for len input bytes, any level */
+size_t zipc_hip_deflate_bound(size_t len);
+size_t zipc_hip_zlib_bound(size_t len);
+
+/* deflate / crc_32_and_deflate / adler_32_and_deflate
+ * (zipc_deflate.mli:128-150; zipc_deflate.ml:1247-1260).  level is explicit
+ * here; the shim passes ZIPC_HIP_LEVEL_BEST when ?level is absent, which is
+ * what the reference does (zipc_deflate.ml:817). */
+int zipc_hip_deflate(zipc_hip_ctx *ctx, const void *src, size_t len, int level,
+                     int crc_op, void *dst, size_t dst_cap, size_t *out_len,
+                     uint32_t *checksum);
+
+/* zlib_compress (zipc_deflate.mli:152-162; zipc_deflate.ml:1262-1277) */
+int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int level,
+                           void *dst, size_t dst_cap, size_t *out_len,
+                           uint32_t *adler);
+
+/* ---- batch forms (device-resident) ----------------------------------------- */
+
+/* One independent stream: bytes [src_off, src_off+src_len) of the source arena
+ * go to [dst_off, dst_off+dst_cap) of the destination arena.  For inflate,
+ * limit is ?decompressed_size when flags & ZIPC_HIP_STREAM_HAS_LIMIT. */
+typedef struct {
+  uint64_t src_off;
+  uint64_t src_len;
+  uint64_t dst_off;
+  uint64_t dst_cap;
+  uint64_t limit;
+  uint32_t flags;
+  uint32_t reserved;
+} zipc_hip_stream_desc;
+#define ZIPC_HIP_STREAM_HAS_LIMIT 1u
+
+typedef struct {
+  uint32_t status;   /* ZIPC_HIP_OK or an error code */
+  uint32_t checksum; /* per crc_op, finished (0 for NOP) */
+  uint64_t out_len;  /* bytes produced at dst_off */
+} zipc_hip_stream_result;
+
+/* All pointers are DEVICE pointers (descs and results too).  Work is enqueued
+ * on the context stream and NOT synchronised: call zipc_hip_synchronize (or
+ * synchronise the stream) before reading results. */
+/* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). */
+int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
+                           const zipc_hip_stream_desc *d_descs,
+                           zipc_hip_stream_result *d_results, size_t n_streams,
+                           size_t max_dst_cap, int crc_op);
+
+/* max_src_len: upper bound of src_len over the batch (sizes the scratch);
+ * total_src_len: sum of src_len over the batch. */
+int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
+                           const zipc_hip_stream_desc *d_descs,
+                           zipc_hip_stream_result *d_results, size_t n_streams,
+                           size_t max_src_len, size_t total_src_len, int level,
+                           int crc_op);
+
+/* CRC-32 and Adler-32 of one device buffer, both in ONE pass over the bytes
+ * (Crc_32.string + Adler_32.string).  d_out receives {crc32, adler32}.
+ * Either selector may be 0 to skip that checksum. */
+int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len,
+                             int want_crc32, int want_adler32, uint32_t *d_out);
+
+/* grow the context scratch up front (keeps hipMalloc out of timed regions) */
+int zipc_hip_reserve(zipc_hip_ctx *ctx, size_t n_streams, size_t max_src_len,
+                     size_t total_src_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

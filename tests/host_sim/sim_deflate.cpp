@@ -1,0 +1,138 @@
+// Host simulation of the lane-serial deflate pieces (zipc_amd/csrc/deflate_lane.h).
+// TEST TOOLING ONLY: builds the hash-chain links serially (the GPU builds them
+// with lz_chain_kernel), then runs the SAME match / parse / block-coder / bit
+// item functions the kernels run, packing bits with a plain serial writer.  The
+// result must equal the oracle's deflate byte for byte.
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "../../zipc_amd/csrc/deflate_lane.h"
+
+using namespace zd;
+
+namespace {
+struct BitWriter {
+  std::vector<uint8_t> out;
+  uint64_t acc = 0;
+  int nbits = 0;
+  void put(uint64_t v, int n) {
+    acc |= v << nbits;
+    nbits += n;
+    while (nbits >= 8) { out.push_back((uint8_t)acc); acc >>= 8; nbits -= 8; }
+  }
+  void flush() { if (nbits > 0) { out.push_back((uint8_t)acc); acc = 0; nbits = 0; } }
+};
+
+uint32_t adler_update_serial(uint32_t a, const uint8_t *p, uint32_t n) {
+  uint32_t s1, s2;
+  adler_unpack(a, s1, s2);
+  uint32_t start = 0, block_len = n % ADLER_CHUNK;
+  while (start < n) {
+    uint32_t S1 = 0, S2 = 0;
+    for (uint32_t i = 0; i < block_len; i++) { S1 += p[start + i]; S2 += (block_len - i) * p[start + i]; }
+    adler_chunk_step(s1, s2, block_len, S1, S2);
+    start += block_len;
+    block_len = ADLER_CHUNK;
+  }
+  return adler_pack(s1, s2);
+}
+}  // namespace
+
+// kinds[] receives the block kinds (0 stored, 1 fixed, 2 dynamic), up to max_kinds
+extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t *dst, uint64_t dst_cap,
+                           uint64_t *out_len, uint32_t *adler_out, int *kinds, int max_kinds,
+                           int *n_kinds) {
+  BitWriter w;
+  uint32_t adler = 1;
+  int nk = 0;
+  if (level == LEVEL_NONE) {  // write_all_non_compressed zd.ml:1106-1116
+    uint32_t start = 0;
+    for (;;) {
+      uint32_t n = len - start < (uint32_t)MAX_BLOCK_SRC_LEN ? len - start : (uint32_t)MAX_BLOCK_SRC_LEN;
+      bool final = start + n == len;
+      adler = adler_update_serial(adler, src + start, n);
+      w.put(final ? 1 : 0, 3);
+      w.flush();
+      w.put(n & 0xFFFF, 16);
+      w.put((~n) & 0xFFFF, 16);
+      for (uint32_t i = 0; i < n; i++) w.put(src[start + i], 8);
+      if (nk < max_kinds) kinds[nk] = 0;
+      nk++;
+      if (final) break;
+      start += n;
+    }
+  } else {
+    int good_match, K;
+    level_params(level, good_match, K);
+    std::vector<uint16_t> prev(len + 8, 0);
+    std::vector<uint64_t> match(len + 8, 0);
+    if (len >= 4) {
+      std::vector<int64_t> head(32768, -1);
+      for (uint32_t p = 0; p + 4 <= len; p++) {
+        uint32_t h = hash4(load_u32_le(src + p));
+        int64_t q = head[h];
+        prev[p] = (q >= 0 && p - q <= 32768) ? (uint16_t)(p - q) : 0;
+        head[h] = p;
+      }
+      for (uint32_t p = 0; p + 4 <= len; p++) match[p] = lz_match_position(src, len, p, prev.data(), K, K / 4);
+    }
+    std::vector<uint32_t> syms(len + 8);
+    std::vector<BlockDesc> blocks(len / 65277 + 4);
+    uint32_t nblk = lz_parse_stream(src, len, match.data(), good_match, syms.data(), blocks.data());
+
+    uint32_t lit_freq[288], dist_freq[32], codelen_freq[19] = {0}, dyn_lit[288], dyn_dist[32],
+        dyn_codelen[32], fix_lit[288], fix_dist[32], codelen_syms[320], heap[577];
+    memset(dyn_lit, 0, sizeof dyn_lit); memset(dyn_dist, 0, sizeof dyn_dist);
+    memset(dyn_codelen, 0, sizeof dyn_codelen); memset(heap, 0, sizeof heap);
+    BlockCoder c;
+    c.lit_freq = lit_freq; c.dist_freq = dist_freq; c.codelen_freq = codelen_freq;
+    c.dyn_lit = dyn_lit; c.dyn_dist = dyn_dist; c.dyn_codelen = dyn_codelen;
+    c.fix_lit = fix_lit; c.fix_dist = fix_dist; c.codelen_syms = codelen_syms; c.heap = heap;
+    huff_fixed_encoders(fix_lit, fix_dist);
+    for (uint32_t b = 0; b < nblk; b++) {
+      const BlockDesc &bd = blocks[b];
+      const bool final = b + 1 == nblk;
+      adler = adler_update_serial(adler, src + bd.src_start, bd.src_len);
+      memset(lit_freq, 0, sizeof lit_freq);
+      memset(dist_freq, 0, sizeof dist_freq);
+      for (uint32_t k = 0; k < bd.n_syms; k++) {
+        uint32_t s = syms[bd.sym_start + k];
+        if ((s >> 9) == 0) lit_freq[s]++;
+        else { lit_freq[length_to_sym(s & 0x1FF)]++; dist_freq[dist_to_sym(s >> 9)]++; }
+      }
+      lit_freq[LITLEN_EOB] = 1;
+      coder_make_dynamic(c);
+      uint64_t flen, dlen;
+      int kind = coder_choose(c, bd.src_len, w.nbits, flen, dlen);
+      if (nk < max_kinds) kinds[nk] = kind;
+      nk++;
+      if (kind == 0) {
+        w.put(final ? 1 : 0, 3);
+        w.flush();
+        w.put(bd.src_len & 0xFFFF, 16);
+        w.put((~bd.src_len) & 0xFFFF, 16);
+        for (uint32_t i = 0; i < bd.src_len; i++) w.put(src[bd.src_start + i], 8);
+      } else {
+        const uint32_t *hl = kind == 1 ? fix_lit : dyn_lit, *hd = kind == 1 ? fix_dist : dyn_dist;
+        w.put((final ? 1 : 0) | (kind << 1), 3);
+        if (kind == 2) {
+          int items = dyn_header_items(c);
+          for (int i = 0; i < items; i++) { uint32_t v; int n; dyn_header_item(c, i, v, n); w.put(v, n); }
+        }
+        for (uint32_t k = 0; k <= bd.n_syms; k++) {
+          uint32_t s = k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
+          uint64_t v; int n;
+          symbol_bits(s, hl, hd, v, n);
+          w.put(v, n);
+        }
+      }
+    }
+    w.flush();
+  }
+  *out_len = w.out.size();
+  *adler_out = adler;
+  *n_kinds = nk;
+  if (w.out.size() > dst_cap) return 16;
+  memcpy(dst, w.out.data(), w.out.size());
+  return 0;
+}

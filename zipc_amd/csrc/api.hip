@@ -1,0 +1,457 @@
+// api.hip -- the C ABI of include/zipc_hip.h: context, scratch, kernel launches.
+//
+// Host forms stage one stream through device scratch and run the same kernels as
+// the batch forms (a batch of one).  Nothing here computes on the CPU: with no
+// usable device the calls fail with ZIPC_HIP_ERR_NO_DEVICE / ZIPC_HIP_ERR_HIP.
+#include "../../include/zipc_hip.h"
+
+#include <stdio.h>
+#include <string.h>
+
+#include "ctx.h"
+
+using namespace zd;
+
+static_assert(sizeof(zipc_hip_stream_desc) == sizeof(StreamDesc), "desc layout");
+static_assert(sizeof(zipc_hip_stream_result) == sizeof(StreamResult), "result layout");
+
+#define HIP_TRY(ctx, expr)                                                             \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);           \
+      return ZIPC_HIP_ERR_HIP;                                                         \
+    }                                                                                  \
+  } while (0)
+
+// ---- context internals -------------------------------------------------------
+
+int zipc_hip_ctx::name_index(const char *name) {
+  for (size_t i = 0; i < acc.size(); i++)
+    if (acc[i].name == name) return (int)i;
+  Acc a;
+  a.name = name;
+  acc.push_back(a);
+  return (int)acc.size() - 1;
+}
+
+hipEvent_t zipc_hip_ctx::get_event() {
+  if (!event_pool.empty()) {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void zipc_hip_ctx::begin(const char *, hipEvent_t &start) {
+  start = get_event();
+  (void)hipEventRecord(start, stream);
+}
+
+void zipc_hip_ctx::end(const char *name, hipEvent_t start) {
+  Pending p;
+  p.name_idx = name_index(name);
+  p.start = start;
+  p.stop = get_event();
+  (void)hipEventRecord(p.stop, stream);
+  pending.push_back(p);
+}
+
+hipError_t zipc_hip_ctx::ensure(Buf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return hipSuccess;
+  if (b.p) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes < 256 ? 256 : bytes;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) { b.p = nullptr; return e; }
+  b.cap = want;
+  return hipSuccess;
+}
+
+hipError_t zipc_hip_ctx::collect_times() {
+  if (pending.empty()) return hipSuccess;
+  hipError_t e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return e;
+  for (auto &p : pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+      acc[p.name_idx].launches++;
+      acc[p.name_idx].total_ms += ms;
+    }
+    event_pool.push_back(p.start);
+    event_pool.push_back(p.stop);
+  }
+  pending.clear();
+  return hipSuccess;
+}
+
+static void free_buf(zipc_hip_ctx::Buf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// ---- context API -------------------------------------------------------------
+
+extern "C" {
+
+int zipc_hip_abi_version(void) { return ZIPC_HIP_ABI_VERSION; }
+
+int zipc_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *zipc_hip_strerror(int status) {
+  switch (status) {
+  case ZIPC_HIP_OK: return "";
+  case ZIPC_HIP_ERR_CORRUPTED: return "Corrupted data stream";
+  case ZIPC_HIP_ERR_SIZE_EXCEEDED: return "Expected decompression size exceeded";
+  case ZIPC_HIP_ERR_ZLIB_METHOD: return "Unknown compression method (%d)";
+  case ZIPC_HIP_ERR_ZLIB_WINDOW: return "Window size too large";
+  case ZIPC_HIP_ERR_ZLIB_DICT: return "Preset dictionary unsupported";
+  case ZIPC_HIP_ERR_CHECKSUM: return "Checksum mismatch, expected %lx found %lx)";
+  case ZIPC_HIP_ERR_DST_TOO_SMALL: return "destination buffer too small";
+  case ZIPC_HIP_ERR_HIP: return "HIP runtime error";
+  case ZIPC_HIP_ERR_INVALID_ARG: return "invalid argument";
+  case ZIPC_HIP_ERR_NO_DEVICE: return "no usable HIP device";
+  case ZIPC_HIP_ERR_NOMEM: return "out of memory";
+  default: return "unknown status";
+  }
+}
+
+int zipc_hip_create(zipc_hip_ctx **out, int device) {
+  if (!out) return ZIPC_HIP_ERR_INVALID_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ZIPC_HIP_ERR_NO_DEVICE;
+  if (device < 0 || device >= n) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (hipSetDevice(device) != hipSuccess) return ZIPC_HIP_ERR_HIP;
+  zipc_hip_ctx *ctx = new (std::nothrow) zipc_hip_ctx();
+  if (!ctx) return ZIPC_HIP_ERR_NOMEM;
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return ZIPC_HIP_ERR_HIP;
+  }
+  // CRC merge constants (zd_common.h), computed with the same GF(2) routines the
+  // kernels use
+  uint32_t x = gf2_xpow8n(256);
+  for (int k = 0; k < 8; k++) { ctx->crc_consts.xpiece[k] = x; x = gf2_mul(x, x); }
+  ctx->crc_consts.xseg = gf2_xpow8n(CRC_SEG_BYTES);
+  *out = ctx;
+  return ZIPC_HIP_OK;
+}
+
+void zipc_hip_destroy(zipc_hip_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto &p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
+  for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+  free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
+  free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->adler_sums);
+  free_buf(ctx->deflate_scratch);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+void *zipc_hip_stream(zipc_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
+  if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return ZIPC_HIP_OK;
+}
+
+const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int zipc_hip_set_profiling(zipc_hip_ctx *ctx, int enabled) {
+  if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, ctx->collect_times());
+  ctx->profiling = enabled != 0;
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_reset_kernel_times(zipc_hip_ctx *ctx) {
+  if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, ctx->collect_times());
+  for (auto &a : ctx->acc) { a.launches = 0; a.total_ms = 0; }
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_kernel_times(zipc_hip_ctx *ctx, zipc_hip_kernel_time *out, size_t cap, size_t *n) {
+  if (!ctx || !n) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, ctx->collect_times());
+  size_t k = 0;
+  for (auto &a : ctx->acc) {
+    if (a.launches == 0) continue;
+    if (out && k < cap) {
+      memset(&out[k], 0, sizeof out[k]);
+      snprintf(out[k].name, sizeof out[k].name, "%s", a.name.c_str());
+      out[k].launches = a.launches;
+      out[k].total_ms = a.total_ms;
+    }
+    k++;
+  }
+  *n = k;
+  return ZIPC_HIP_OK;
+}
+
+size_t zipc_hip_deflate_bound(size_t len) {
+  // all-stored worst case: 5 header bytes per <= 65534 source bytes, +1 per block
+  // because the reference's stored-block estimate can be 8 bits high
+  // (src/zipc_deflate.ml:1045-1047), so a compressed block may beat it by < 1 byte
+  size_t blocks = len / 65534 + 1;
+  return len + 6 * blocks + 8;
+}
+size_t zipc_hip_zlib_bound(size_t len) { return zipc_hip_deflate_bound(len) + 6; }
+
+// ---- batch forms ---------------------------------------------------------------
+
+static int pick_log2L(size_t n_streams) {
+  // spread the batch over the 1024 SIMDs before packing lanes; 16 streams per
+  // wave is the LDS limit (4 waves x 36 KiB per CU)
+  int log2L = 0;
+  while (log2L < 4 && (n_streams >> (log2L + 1)) >= 1024) log2L++;
+  return log2L;
+}
+
+static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
+                      StreamResult *d_results, size_t n_ranges, uint64_t single_off,
+                      uint64_t single_len, size_t max_len, uint32_t *d_single_out) {
+  size_t segs = (max_len + CRC_SEG_BYTES - 1) / CRC_SEG_BYTES;
+  if (segs == 0) segs = 1;
+  if (n_ranges * segs > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_ranges * segs * sizeof(uint32_t)));
+  uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
+  ZD_LAUNCH(ctx, "crc32_segments", crc32_segments_kernel, dim3((unsigned)(n_ranges * segs)), dim3(256), 0,
+            base, mode, d_descs, (const StreamResult *)d_results, single_off, single_len,
+            (uint32_t)segs, ctx->crc_consts, partials);
+  ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
+            d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts,
+            (const uint32_t *)partials, d_single_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
+                           const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
+                           size_t n_streams, size_t max_dst_cap, int crc_op) {
+  if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (crc_op < 0 || crc_op > 2 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (n_streams == 0) return ZIPC_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int log2L = pick_log2L(n_streams);
+  const size_t L = (size_t)1 << log2L;
+  const unsigned grid = (unsigned)((n_streams + L - 1) / L);
+  const size_t lds = (size_t)INFLATE_LDS_BYTES_PER_LANE << log2L;
+  ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3(grid), dim3(64), lds,
+            (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
+            (StreamResult *)d_results, (uint32_t)n_streams, log2L, crc_op);
+  HIP_TRY(ctx, hipGetLastError());
+  if (crc_op == ZIPC_HIP_CRC_CRC32)
+    return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,
+                      (StreamResult *)d_results, n_streams, 0, 0, max_dst_cap, nullptr);
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
+                           const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
+                           size_t n_streams, size_t max_src_len, size_t total_src_len, int level,
+                           int crc_op) {
+  if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n_streams > 0x7FFFFFFFull)
+    return ZIPC_HIP_ERR_INVALID_ARG;
+  if (max_src_len > 0xFFFFFFF0ull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (n_streams == 0) return ZIPC_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, ctx->ensure(ctx->deflate_scratch,
+                           deflate_scratch_bytes(n_streams, max_src_len, total_src_len, level)));
+  HIP_TRY(ctx, launch_deflate(ctx, (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena,
+                              (const StreamDesc *)d_descs, (StreamResult *)d_results, n_streams,
+                              max_src_len, total_src_len, level, crc_op));
+  if (crc_op == ZIPC_HIP_CRC_CRC32)
+    return crc32_pass(ctx, (const uint8_t *)d_src_arena, RANGE_DEFLATE_SRC, (const StreamDesc *)d_descs,
+                      (StreamResult *)d_results, n_streams, 0, 0, max_src_len, nullptr);
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_reserve(zipc_hip_ctx *ctx, size_t n_streams, size_t max_src_len, size_t total_src_len) {
+  if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, ctx->ensure(ctx->deflate_scratch,
+                           deflate_scratch_bytes(n_streams, max_src_len, total_src_len, ZIPC_HIP_LEVEL_BEST)));
+  size_t segs = (max_src_len + CRC_SEG_BYTES - 1) / CRC_SEG_BYTES + 1;
+  HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_streams * segs * sizeof(uint32_t)));
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, int want_crc32,
+                             int want_adler32, uint32_t *d_out) {
+  if (!ctx || !d_out || (!d_buf && len)) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (want_crc32) {
+    int st = crc32_pass(ctx, (const uint8_t *)d_buf, RANGE_SINGLE, nullptr, nullptr, 1, 0, len, len, d_out);
+    if (st != ZIPC_HIP_OK) return st;
+  }
+  if (want_adler32) {
+    const uint64_t n_chunks = len ? len / ADLER_CHUNK + 1 : 0;
+    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (size_t)(n_chunks + 1) * sizeof(uint2)));
+    uint2 *sums = (uint2 *)ctx->adler_sums.p;
+    if (n_chunks) {
+      if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+      ZD_LAUNCH(ctx, "adler_chunks", adler_chunks_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
+                (const uint8_t *)d_buf, (uint64_t)len, n_chunks, sums);
+    }
+    ZD_LAUNCH(ctx, "adler_chain", adler_chain_kernel, dim3(1), dim3(64), 0, (const uint2 *)sums,
+              (uint64_t)len, n_chunks, d_out + 1);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return ZIPC_HIP_OK;
+}
+
+// ---- host forms ------------------------------------------------------------------
+
+static int stage_in(zipc_hip_ctx *ctx, const void *src, size_t len) {
+  HIP_TRY(ctx, ctx->ensure(ctx->io_src, len + 64));
+  if (len) HIP_TRY(ctx, hipMemcpyAsync(ctx->io_src.p, src, len, hipMemcpyHostToDevice, ctx->stream));
+  return ZIPC_HIP_OK;
+}
+
+static int checksum_host(zipc_hip_ctx *ctx, const void *src, size_t len, int want_crc, uint32_t *out) {
+  if (!ctx || !out || (!src && len)) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int st = stage_in(ctx, src, len);
+  if (st) return st;
+  HIP_TRY(ctx, ctx->ensure(ctx->io_small, 64));
+  uint32_t *d_out = (uint32_t *)ctx->io_small.p;
+  st = zipc_hip_checksum_device(ctx, ctx->io_src.p, len, want_crc, !want_crc, d_out);
+  if (st) return st;
+  uint32_t h[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(h, d_out, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *out = want_crc ? h[0] : h[1];
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_crc32(zipc_hip_ctx *ctx, const void *src, size_t len, uint32_t *crc) {
+  return checksum_host(ctx, src, len, 1, crc);
+}
+int zipc_hip_adler32(zipc_hip_ctx *ctx, const void *src, size_t len, uint32_t *adler) {
+  return checksum_host(ctx, src, len, 0, adler);
+}
+
+// one stream through the batch kernels; is_inflate selects the direction
+static int one_stream(zipc_hip_ctx *ctx, bool is_inflate, const void *src, size_t len, int has_limit,
+                      size_t limit, int level, int crc_op, void *dst, size_t dst_cap, size_t *out_len,
+                      uint32_t *checksum) {
+  if (!ctx || (!src && len) || (!dst && dst_cap) || !out_len) return ZIPC_HIP_ERR_INVALID_ARG;
+  *out_len = 0;
+  if (checksum) *checksum = 0;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  int st = stage_in(ctx, src, len);
+  if (st) return st;
+  HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dst_cap + 64));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_desc, sizeof(StreamDesc)));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_res, sizeof(StreamResult)));
+  StreamDesc d;
+  memset(&d, 0, sizeof d);
+  d.src_off = 0; d.src_len = len; d.dst_off = 0; d.dst_cap = dst_cap;
+  d.limit = limit; d.flags = has_limit ? STREAM_HAS_LIMIT : 0;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, &d, sizeof d, hipMemcpyHostToDevice, ctx->stream));
+  if (is_inflate)
+    st = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
+                                (zipc_hip_stream_result *)ctx->io_res.p, 1, dst_cap, crc_op);
+  else
+    st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
+                                (zipc_hip_stream_result *)ctx->io_res.p, 1, len, len, level, crc_op);
+  if (st) return st;
+  StreamResult r;
+  HIP_TRY(ctx, hipMemcpyAsync(&r, ctx->io_res.p, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (r.status != ST_OK) return (int)r.status;
+  if (r.out_len > dst_cap) return ZIPC_HIP_ERR_DST_TOO_SMALL;
+  if (r.out_len) {
+    HIP_TRY(ctx, hipMemcpyAsync(dst, ctx->io_dst.p, r.out_len, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *out_len = r.out_len;
+  if (checksum) *checksum = r.checksum;
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_inflate(zipc_hip_ctx *ctx, const void *src, size_t len, int has_limit, size_t limit,
+                     int crc_op, void *dst, size_t dst_cap, size_t *out_len, uint32_t *checksum) {
+  return one_stream(ctx, true, src, len, has_limit, limit, 0, crc_op, dst, dst_cap, out_len, checksum);
+}
+
+int zipc_hip_deflate(zipc_hip_ctx *ctx, const void *src, size_t len, int level, int crc_op, void *dst,
+                     size_t dst_cap, size_t *out_len, uint32_t *checksum) {
+  if (level < 0 || level > 3) return ZIPC_HIP_ERR_INVALID_ARG;
+  return one_stream(ctx, false, src, len, 0, 0, level, crc_op, dst, dst_cap, out_len, checksum);
+}
+
+// zlib_decompress src/zipc_deflate.ml:720-740 (start = 0): header checks on the
+// host (6 bytes of parsing), body through the inflate kernel with Adler-32
+int zipc_hip_zlib_decompress(zipc_hip_ctx *ctx, const void *src, size_t len, int has_limit,
+                             size_t limit, void *dst, size_t dst_cap, size_t *out_len,
+                             uint32_t *adler, uint32_t *expect, uint32_t *found) {
+  if (!ctx || (!src && len) || !out_len) return ZIPC_HIP_ERR_INVALID_ARG;
+  *out_len = 0;
+  const uint8_t *s = (const uint8_t *)src;
+  if (len < 6) return ZIPC_HIP_ERR_CORRUPTED;
+  const int cmf = s[0], flg = s[1];
+  if ((256 * cmf + flg) % 31 != 0) return ZIPC_HIP_ERR_CORRUPTED;
+  if ((cmf & 0x0F) != 8) return ZIPC_HIP_ERR_ZLIB_METHOD;
+  if ((cmf >> 4) > 7) return ZIPC_HIP_ERR_ZLIB_WINDOW;
+  if ((flg & 0x20) != 0) return ZIPC_HIP_ERR_ZLIB_DICT;
+  const uint32_t e = ((uint32_t)s[len - 4] << 24) | ((uint32_t)s[len - 3] << 16) |
+                     ((uint32_t)s[len - 2] << 8) | (uint32_t)s[len - 1];
+  uint32_t f = 0;
+  // the reference hands inflate the range [2, len-2) (src/zipc_deflate.ml:732)
+  int st = zipc_hip_inflate(ctx, s + 2, len - 4, has_limit, limit, ZIPC_HIP_CRC_ADLER32, dst, dst_cap,
+                            out_len, &f);
+  if (st) return st;
+  if (expect) *expect = e;
+  if (found) *found = f;
+  if (e != f) { *out_len = 0; return ZIPC_HIP_ERR_CHECKSUM; }
+  if (adler) *adler = f;
+  return ZIPC_HIP_OK;
+}
+
+// zlib_compress src/zipc_deflate.ml:1262-1277 (start = 0)
+int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int level, void *dst,
+                           size_t dst_cap, size_t *out_len, uint32_t *adler) {
+  if (!ctx || !dst || !out_len || level < 0 || level > 3) return ZIPC_HIP_ERR_INVALID_ARG;
+  *out_len = 0;
+  if (dst_cap < 6) return ZIPC_HIP_ERR_DST_TOO_SMALL;
+  uint8_t *o = (uint8_t *)dst;
+  const int cmf = (7 << 4) | 8;
+  const int header = (cmf << 8) | (level << 6);
+  const int flg = (header + 31 - (header % 31)) & 0xFF;
+  o[0] = (uint8_t)cmf;
+  o[1] = (uint8_t)flg;
+  size_t body = 0;
+  uint32_t a = 0;
+  int st = zipc_hip_deflate(ctx, src, len, level, ZIPC_HIP_CRC_ADLER32, o + 2, dst_cap - 6, &body, &a);
+  if (st) return st;
+  o[2 + body] = (uint8_t)(a >> 24);
+  o[3 + body] = (uint8_t)(a >> 16);
+  o[4 + body] = (uint8_t)(a >> 8);
+  o[5 + body] = (uint8_t)a;
+  *out_len = body + 6;
+  if (adler) *adler = a;
+  return ZIPC_HIP_OK;
+}
+
+}  // extern "C"

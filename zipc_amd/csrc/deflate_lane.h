@@ -1,0 +1,404 @@
+// deflate_lane.h -- the lane-serial pieces of the deflate pipeline (deflate.hip).
+//
+// The reference's encoder (src/zipc_deflate.ml:742-1277) is one sequential loop.
+// It is split here along what is and is not order dependent:
+//   * the hash chains do not depend on parse decisions, so the chain links
+//     (lz_chain_kernel) and, per position, the best match over the first K and
+//     first K/4 chain candidates (lz_match_position) are computed for ALL
+//     positions in parallel;
+//   * the lazy parse (lz_parse_stream) is then a cheap serial walk over those
+//     two tables, one lane per stream;
+//   * per block, code construction and the stored/fixed/dynamic choice
+//     (BlockCoder) are serial per stream because codelen_sym_freqs (Q1) and the
+//     pending bit count (Q3) carry from block to block.
+// Every function cites the reference lines it reproduces; all of it is checked
+// byte for byte against the oracle through tests/host_sim.
+#pragma once
+
+#include "zd_common.h"
+
+namespace zd {
+
+struct BlockDesc {
+  uint32_t src_start, src_len;  // block_src_start / block_src_len (zd.ml:788-789)
+  uint32_t sym_start, n_syms;   // slice of the stream's symbol array (no EOB stored)
+};
+
+// level_params zd.ml:754-764: (good_match, max_chain_len); the other two are never read
+ZD_HD void level_params(int level, int &good_match, int &max_chain) {
+  switch (level) {
+  case LEVEL_FAST: good_match = 4; max_chain = 4; break;
+  case LEVEL_DEFAULT: good_match = 8; max_chain = 128; break;
+  case LEVEL_BEST: good_match = 32; max_chain = 4096; break;
+  default: good_match = 0; max_chain = 0; break;
+  }
+}
+
+// Common prefix of s[q..] and s[p..], capped at maxlen (match_bwd/match_fwd,
+// zd.ml:1154-1174, without the early-out order: the result is the same length).
+ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t maxlen) {
+  uint32_t i = 0;
+  while (i + 8 <= maxlen) {
+    uint64_t x = load_u64_le(s + q + i) ^ load_u64_le(s + p + i);
+    if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+    i += 8;
+  }
+  while (i < maxlen && s[q + i] == s[p + i]) i++;
+  return i;
+}
+
+// find_backref zd.ml:1176-1201 as a pure function of the position: walks the
+// hash chain of p (prev[] holds the distance to the previous position with the
+// same hash, 0 = none within 32768) and returns, packed like the reference's
+// backref (dist << 9 | len), the best match among the first K candidates (low
+// word) and among the first Kq = K/4 candidates (high word): longest common
+// prefix, nearest candidate on ties, only if longer than min_match_len - 1 = 3.
+// The reference's running threshold starts at the pending match length instead
+// of 3; lz_parse_stream applies that comparison afterwards, which selects the
+// same candidate (the maximum does not depend on the threshold).
+ZD_HD uint64_t lz_match_position(const uint8_t *s, uint32_t len, uint32_t p, const uint16_t *prev,
+                                 int K, int Kq) {
+  const uint32_t maxlen = len - p < (uint32_t)MAX_MATCH_LEN ? len - p : (uint32_t)MAX_MATCH_LEN;
+  uint32_t best_len = MIN_MATCH_LEN - 1, best = 0, snap = 0;
+  bool snapped = false;
+  uint32_t q = p;
+  int steps = 0;
+  if (best_len < maxlen) {  // zd.ml:1181
+    for (;;) {
+      uint32_t d = prev[q];
+      if (d == 0 || steps == K) break;
+      q -= d;
+      if (p - q > (uint32_t)MAX_MATCH_DIST) break;  // zd.ml:1187
+      steps++;
+      uint32_t l = common_prefix(s, q, p, maxlen);
+      if (l > best_len) {
+        best_len = l;
+        best = ((p - q) << 9) | l;
+      }
+      if (steps == Kq) { snap = best; snapped = true; }
+      if (l == maxlen) break;  // zd.ml:1194: nothing later can be longer
+    }
+  }
+  if (!snapped) snap = best;  // chain ended before K/4 candidates
+  if (Kq == 0) snap = 0;
+  return (uint64_t)best | ((uint64_t)snap << 32);
+}
+
+// Lz77.compress zd.ml:1203-1244 + write_block_symbol zd.ml:1118-1123: the lazy
+// parse and the greedy block cut at 65534 source bytes.  match[p] is
+// lz_match_position(p).  Writes the symbol array (literal = byte, backref =
+// dist << 9 | len; the end-of-block symbol is implicit) and one BlockDesc per
+// block, the last one being the final block.  Returns the number of blocks.
+ZD_HD uint32_t lz_parse_stream(const uint8_t *s, uint32_t len, const uint64_t *match, int good_match,
+                               uint32_t *syms, BlockDesc *blocks) {
+  uint32_t nsym = 0, nblk = 0;
+  uint32_t blk_src_start = 0, blk_src_len = 0, blk_sym_start = 0;
+#define ZD_EMIT(sym, n)                                                              \
+  do {                                                                               \
+    if (blk_src_len + (n) > (uint32_t)MAX_BLOCK_SRC_LEN) {                           \
+      BlockDesc b_;                                                                  \
+      b_.src_start = blk_src_start; b_.src_len = blk_src_len;                        \
+      b_.sym_start = blk_sym_start; b_.n_syms = nsym - blk_sym_start;                \
+      blocks[nblk++] = b_;                                                           \
+      blk_src_start += blk_src_len; blk_src_len = 0; blk_sym_start = nsym;           \
+    }                                                                                \
+    syms[nsym++] = (sym);                                                            \
+    blk_src_len += (n);                                                              \
+  } while (0)
+
+  const int64_t max_pos = (int64_t)len - MIN_MATCH_LEN;
+  int64_t i = 0;
+  uint32_t pend = 0;
+  while (i <= max_pos) {
+    const uint64_t m = match[i];
+    const uint32_t prev_len = pend & 0x1FF;
+    const uint32_t pl = prev_len ? prev_len : (uint32_t)(MIN_MATCH_LEN - 1);
+    const uint32_t rem = len - (uint32_t)i;
+    const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
+    uint32_t b = 0;
+    if (pl < maxlen) {
+      // chain_steps / 4 when prev_match_len >= good_match (zd.ml:1182-1185)
+      const uint32_t c = pl >= (uint32_t)good_match ? (uint32_t)(m >> 32) : (uint32_t)m;
+      if ((c & 0x1FF) > pl) b = c;
+    }
+    const uint32_t ml = b & 0x1FF;
+    if (prev_len != 0 && prev_len > ml) {  // previous match wins: emit it, skip past it
+      ZD_EMIT(pend, prev_len);
+      i = i - 1 + prev_len;
+      pend = 0;
+    } else if (ml == 0) {
+      ZD_EMIT((uint32_t)s[i], 1u);
+      i++;
+      pend = 0;
+    } else {  // defer the new, longer match
+      if (prev_len != 0) ZD_EMIT((uint32_t)s[i - 1], 1u);
+      i++;
+      pend = b;
+    }
+  }
+  {
+    const uint32_t prev_len = pend & 0x1FF;
+    if (prev_len != 0) {  // pending match at the end (zd.ml:1211-1212)
+      ZD_EMIT(pend, prev_len);
+      i = max_pos + prev_len;
+    }
+    for (int64_t k = i; k < (int64_t)len; k++) ZD_EMIT((uint32_t)s[k], 1u);
+  }
+  BlockDesc b_;
+  b_.src_start = blk_src_start; b_.src_len = blk_src_len;
+  b_.sym_start = blk_sym_start; b_.n_syms = nsym - blk_sym_start;
+  blocks[nblk++] = b_;
+#undef ZD_EMIT
+  return nblk;
+}
+
+// ---------------------------------------------------------------------------
+// Huffman encoder construction (zd.ml:393-528) on u32 arrays (LDS on device).
+
+// heapdown zd.ml:408-417
+ZD_HD void huff_heapdown(uint32_t *h, int max, int i) {
+  for (;;) {
+    int l = 2 * i, r = l + 1;
+    if (l > max) return;
+    int k = (r > max) ? l : (h[l] < h[r] ? l : r);
+    if (h[i] > h[k]) { uint32_t v = h[i]; h[i] = h[k]; h[k] = v; i = k; }
+    else return;
+  }
+}
+
+// Huffman.lengths_of_freqs zd.ml:404-473.  Node = (freq << 10) | link; with
+// leaf freqs capped at 65535 and at most 286 leaves the packed value stays
+// below 2^32.  heap: 577 words.  Writes plain code lengths to e[0..max_sym].
+ZD_HD void huff_lengths_of_freqs(uint32_t *heap, uint32_t *e, const uint32_t *freqs, int max_sym,
+                                 int max_code_len) {
+  uint32_t freq_cap = 65535;
+  for (;;) {
+    int max = 0;
+    for (int sym = 0; sym <= max_sym; sym++) {
+      uint32_t f = freqs[sym];
+      if (f == 0) continue;
+      if (f > freq_cap) f = freq_cap;
+      max++;
+      heap[max] = (f << 10) | (uint32_t)(max_sym + 1 + max);
+    }
+    for (int i = max / 2; i >= 1; i--) huff_heapdown(heap, max, i);
+    if (max < 2) {  // trivial_codeword_lengths zd.ml:462-466
+      for (int sym = 0; sym <= max_sym; sym++) e[sym] = freqs[sym] == 0 ? 0u : 1u;
+      return;
+    }
+    for (int m = max; m > 1; m--) {  // make_huffman_tree zd.ml:432-445
+      const int new_max = m - 1;
+      const uint32_t p = heap[1];
+      heap[1] = heap[m];
+      huff_heapdown(heap, new_max, 1);
+      const uint32_t q = heap[1];
+      const uint32_t f = (p >> 10) + (q >> 10);
+      heap[1] = (f << 10) | (uint32_t)m;
+      heap[p & 0x3FF] = (uint32_t)m;
+      heap[q & 0x3FF] = (uint32_t)m;
+      huff_heapdown(heap, new_max, 1);
+    }
+    bool overflow = false;  // code_lengths_of_tree zd.ml:446-461
+    int rank = 0;
+    for (int sym = 0; sym <= max_sym; sym++) {
+      if (freqs[sym] == 0) { e[sym] = 0; continue; }
+      rank++;
+      uint32_t p = heap[max_sym + 1 + rank];
+      int l = 1;
+      while (p != 2) { l++; p = heap[p]; }
+      if (l > max_code_len) { overflow = true; break; }
+      e[sym] = (uint32_t)l;
+    }
+    if (!overflow) return;
+    freq_cap >>= 1;  // flatten and retry zd.ml:470-473
+  }
+}
+
+// Huffman.init_with_lengths zd.ml:477-506: canonical codes, stored bit-reversed,
+// packed (code << 5) | len
+ZD_HD void huff_init_with_lengths(uint32_t *e, int max_sym) {
+  uint32_t count[16], code[16];
+  for (int i = 0; i < 16; i++) { count[i] = 0; code[i] = 0; }
+  for (int sym = 0; sym <= max_sym; sym++) count[e[sym] & 0x1F]++;
+  count[0] = 0;
+  for (int l = 1; l <= 15; l++) code[l] = (code[l - 1] + count[l - 1]) << 1;
+  for (int sym = 0; sym <= max_sym; sym++) {
+    const uint32_t l = e[sym] & 0x1F;
+    if (l != 0) {
+      const uint32_t c = code[l];
+      e[sym] = (bitrev(c, (int)l) << 5) | l;
+      code[l] = c + 1;
+    }
+  }
+}
+
+// fixed_litlen_encoder / fixed_dist_encoder zd.ml:514-527
+ZD_HD void huff_fixed_encoders(uint32_t *lit /*288*/, uint32_t *dist /*32*/) {
+  for (int i = 0; i <= 143; i++) lit[i] = 8;
+  for (int i = 144; i <= 255; i++) lit[i] = 9;
+  for (int i = 256; i <= 279; i++) lit[i] = 7;
+  for (int i = 280; i <= 287; i++) lit[i] = 8;
+  huff_init_with_lengths(lit, 287);
+  for (int i = 0; i <= 31; i++) dist[i] = 5;
+  huff_init_with_lengths(dist, 31);
+}
+
+// Per-stream block coder state: what the reference keeps in its encoder record
+// across blocks (zd.ml:778-815).  All arrays live in LDS on the device.
+struct BlockCoder {
+  uint32_t *lit_freq;      // 286 (+2 pad)   litlen_sym_freqs
+  uint32_t *dist_freq;     // 30 (+2 pad)    dist_sym_freqs
+  uint32_t *codelen_freq;  // 19             codelen_sym_freqs: NEVER reset (Q1, zd.ml:849-854)
+  uint32_t *dyn_lit;       // 288            dyn_litlen
+  uint32_t *dyn_dist;      // 32             dyn_dist
+  uint32_t *dyn_codelen;   // 32 (19 used)   dyn_codelen
+  uint32_t *fix_lit;       // 288
+  uint32_t *fix_dist;      // 32
+  uint32_t *codelen_syms;  // 316 + 4        codelen_syms (sym | repeat_bits << 8)
+  uint32_t *heap;          // 577
+  int codelen_syms_len, hlit, hdist, hclen;
+};
+
+// make_dynamic_huffman zd.ml:953-957 + make_dynamic_huffman_encoding zd.ml:959-1043
+ZD_HD void coder_make_dynamic(BlockCoder &c) {
+  huff_lengths_of_freqs(c.heap, c.dyn_lit, c.lit_freq, LITLEN_SYM_MAX, 15);
+  huff_init_with_lengths(c.dyn_lit, LITLEN_SYM_MAX);
+  huff_lengths_of_freqs(c.heap, c.dyn_dist, c.dist_freq, DIST_SYM_MAX, 15);
+  huff_init_with_lengths(c.dyn_dist, DIST_SYM_MAX);
+  // gather_dynamic_huffman_code_lengths zd.ml:963-988
+  int litlen_count = LITLEN_SYM_MAX;
+  while (litlen_count >= 0 && (c.dyn_lit[litlen_count] & 0x1F) == 0) litlen_count--;
+  litlen_count++;
+  int dist_count = DIST_SYM_MAX;
+  while (dist_count >= 0 && (c.dyn_dist[dist_count] & 0x1F) == 0) dist_count--;
+  dist_count++;
+  if (dist_count == 0) {  // HDIST 0 means 1: symbol 0 gets length 1, code 0 (zd.ml:974-979)
+    c.dyn_dist[0] = 1;
+    dist_count = 1;
+  }
+  c.hlit = litlen_count - 257;
+  c.hdist = dist_count - 1;
+  uint32_t *l = c.codelen_syms;
+  for (int i = 0; i < litlen_count; i++) l[i] = c.dyn_lit[i] & 0x1F;
+  for (int i = 0; i < dist_count; i++) l[litlen_count + i] = c.dyn_dist[i] & 0x1F;
+  // compute_codelen_syms zd.ml:989-1030 (in place: the encoding never expands)
+  const int len_max = litlen_count + dist_count - 1;
+  int k = 0, i = 0;
+  while (i <= len_max) {
+    if (l[i] == 0) {
+      const int mx = len_max < i + 138 - 1 ? len_max : i + 138 - 1;
+      int j = i + 1;
+      while (j <= mx && l[j] == 0) j++;
+      const int zcount = j - i;
+      if (zcount < 3) { l[k] = 0; c.codelen_freq[0]++; i = i + 1; }
+      else if (zcount <= 10) { l[k] = ((uint32_t)(zcount - 3) << 8) | 17; c.codelen_freq[17]++; i = j; }
+      else { l[k] = ((uint32_t)(zcount - 11) << 8) | 18; c.codelen_freq[18]++; i = j; }
+      k++;
+    } else {
+      const uint32_t sym = l[i];
+      const int mx = len_max < i + 6 ? len_max : i + 6;
+      int j = i + 1;
+      while (j <= mx && l[j] == sym) j++;
+      const int scount = j - i;
+      l[k] = sym;
+      c.codelen_freq[sym]++;
+      if (scount <= 3) { k++; i = i + 1; }
+      else {
+        l[k + 1] = ((uint32_t)(scount - 3 - 1) << 8) | 16;
+        c.codelen_freq[16]++;
+        k += 2;
+        i = j;
+      }
+    }
+  }
+  c.codelen_syms_len = k;
+  huff_lengths_of_freqs(c.heap, c.dyn_codelen, c.codelen_freq, CODELEN_SYM_MAX, 7);
+  huff_init_with_lengths(c.dyn_codelen, CODELEN_SYM_MAX);
+  int o = CODELEN_SYM_MAX;  // codelen_length_count zd.ml:1032-1036
+  while (o > 0 && (c.dyn_codelen[k_codelen_order[o]] & 0x1F) == 0) o--;
+  c.hclen = (o + 1) - 4;
+}
+
+ZD_HD int length_extra_bits(int sym) { return sym < LITLEN_FIRST_LEN ? 0 : (int)(k_length_value_of_sym[sym - LITLEN_FIRST_LEN] & 0xF); }
+
+// bit_length_of_block_symbols zd.ml:1049-1064
+ZD_HD uint64_t coder_symbols_bits(const BlockCoder &c, const uint32_t *hlit, const uint32_t *hdist) {
+  uint64_t acc = 0;
+  for (int sym = 0; sym <= LITLEN_SYM_MAX; sym++)
+    acc += (uint64_t)c.lit_freq[sym] * ((hlit[sym] & 0x1F) + (uint32_t)length_extra_bits(sym));
+  for (int sym = 0; sym <= DIST_SYM_MAX; sym++)
+    acc += (uint64_t)c.dist_freq[sym] * ((hdist[sym] & 0x1F) + (k_dist_value_of_sym[sym] & 0xF));
+  return acc;
+}
+
+// write_block's three estimates and its choice (zd.ml:1045-1047,1066-1079,1099-1104).
+// pending_bits = dst_bits_len.  Returns 0 stored / 1 fixed / 2 dynamic.
+ZD_HD int coder_choose(const BlockCoder &c, uint32_t block_src_len, int pending_bits, uint64_t &flen,
+                       uint64_t &dlen) {
+  const uint64_t nlen = 3 + (uint64_t)(8 - ((pending_bits + 3) % 8)) + (4 + (uint64_t)block_src_len) * 8;
+  flen = 3 + coder_symbols_bits(c, c.fix_lit, c.fix_dist);
+  uint64_t acc = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4);
+  for (int sym = 0; sym <= CODELEN_SYM_MAX; sym++) {
+    const uint32_t rb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+    acc += (uint64_t)c.codelen_freq[sym] * ((c.dyn_codelen[sym] & 0x1F) + rb);
+  }
+  dlen = acc + coder_symbols_bits(c, c.dyn_lit, c.dyn_dist);
+  if (nlen <= dlen && nlen <= flen) return 0;
+  if (flen <= dlen) return 1;
+  return 2;
+}
+
+// One block symbol as bits (write_block_symbols zd.ml:879-910): value holds the
+// code, then the extra bits, LSB first; at most 48 bits.
+ZD_HD void symbol_bits(uint32_t bref, const uint32_t *hlit, const uint32_t *hdist, uint64_t &value,
+                       int &nbits) {
+  const uint32_t dist = bref >> 9, len = bref & 0x1FF;
+  if (dist == 0) {
+    const uint32_t si = hlit[len];
+    value = si >> 5;
+    nbits = (int)(si & 0x1F);
+    return;
+  }
+  const int lsym = length_to_sym((int)len);
+  uint32_t si = hlit[lsym];
+  int count = (int)(si & 0x1F);
+  const uint32_t lv = k_length_value_of_sym[lsym - LITLEN_FIRST_LEN];
+  uint64_t v = (uint64_t)(si >> 5) | ((uint64_t)(len - (lv >> 4)) << count);
+  int n = count + (int)(lv & 0xF);
+  const int dsym = dist_to_sym((int)dist);
+  si = hdist[dsym];
+  count = (int)(si & 0x1F);
+  const uint32_t dv = k_dist_value_of_sym[dsym];
+  v |= ((uint64_t)(si >> 5) | ((uint64_t)(dist - (dv >> 4)) << count)) << n;
+  n += count + (int)(dv & 0xF);
+  value = v;
+  nbits = n;
+}
+
+// The header of a dynamic block after the 3 type bits (write_dynamic_codes,
+// zd.ml:919-941) as a sequence of (value, nbits) items: item index -> bits.
+// Items: 0 hlit(5) 1 hdist(5) 2 hclen(4), then hclen+4 lengths of 3 bits, then
+// the codelen symbols.  Returns the number of items.
+ZD_HD int dyn_header_items(const BlockCoder &c) { return 3 + (c.hclen + 4) + c.codelen_syms_len; }
+ZD_HD void dyn_header_item(const BlockCoder &c, int idx, uint32_t &value, int &nbits) {
+  if (idx == 0) { value = (uint32_t)c.hlit; nbits = 5; return; }
+  if (idx == 1) { value = (uint32_t)c.hdist; nbits = 5; return; }
+  if (idx == 2) { value = (uint32_t)c.hclen; nbits = 4; return; }
+  idx -= 3;
+  if (idx < c.hclen + 4) {
+    value = c.dyn_codelen[k_codelen_order[idx]] & 0x1F;
+    nbits = 3;
+    return;
+  }
+  idx -= c.hclen + 4;
+  const uint32_t symref = c.codelen_syms[idx];
+  const uint32_t sym = symref & 0xFF;
+  const uint32_t si = c.dyn_codelen[sym];
+  const int count = (int)(si & 0x1F);
+  if (sym <= 15) { value = si >> 5; nbits = count; return; }
+  const int rb = sym == 16 ? 2 : sym == 17 ? 3 : 7;
+  value = (si >> 5) | ((symref >> 8) << count);
+  nbits = count + rb;
+}
+
+}  // namespace zd

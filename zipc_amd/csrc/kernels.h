@@ -1,0 +1,39 @@
+// kernels.h -- declarations of the HIP kernels launched by api.hip.
+#pragma once
+
+#include "zd_common.h"
+
+namespace zd {
+
+// ---- inflate.hip
+constexpr int INFLATE_LDS_BYTES_PER_LANE = 2304;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
+__global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
+                                     uint8_t *__restrict__ dst_arena,
+                                     const StreamDesc *__restrict__ descs,
+                                     StreamResult *__restrict__ results, uint32_t n_streams,
+                                     int log2L, int crc_op);
+
+// ---- checksum.hip
+constexpr uint32_t CRC_SEG_BYTES = 65536;
+enum : int { RANGE_INFLATE_OUT = 0, RANGE_DEFLATE_SRC = 1, RANGE_SINGLE = 2 };
+struct CrcConsts {
+  uint32_t xpiece[8];
+  uint32_t xseg;
+};
+__global__ void crc32_segments_kernel(const uint8_t *__restrict__ base, int mode,
+                                      const StreamDesc *__restrict__ descs,
+                                      const StreamResult *__restrict__ results,
+                                      uint64_t single_off, uint64_t single_len,
+                                      uint32_t segs_per_range, CrcConsts K,
+                                      uint32_t *__restrict__ partials);
+__global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ descs,
+                                    StreamResult *__restrict__ results, uint64_t single_len,
+                                    uint32_t segs_per_range, CrcConsts K,
+                                    const uint32_t *__restrict__ partials,
+                                    uint32_t *__restrict__ single_out);
+__global__ void adler_chunks_kernel(const uint8_t *__restrict__ p, uint64_t n, uint64_t n_chunks,
+                                    uint2 *__restrict__ sums);
+__global__ void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks,
+                                   uint32_t *__restrict__ out);
+
+}  // namespace zd
