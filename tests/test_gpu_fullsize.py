@@ -1,0 +1,81 @@
+"""BASELINE.json's full-size configurations, checked through size-independent
+properties on the device plus oracle samples (the oracle would need minutes for
+the whole GiB)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _c2_round_trip(gpu_ctx, oracle, n_streams, bits, level, config, sample):
+    import torch
+
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    L = 65536
+    src = synth.batch_bytes_torch(config, 0, n_streams, L, bits, dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n_streams, L, cap)
+    slot = int(descs["dst_off"][1]) if n_streams > 1 else cap
+    comp = torch.zeros(n_streams * slot + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    d_res = torch.zeros(n_streams * 16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(gpu_ctx, src, comp, d_descs, d_res, n_streams, L, n_streams * L, level, 1)
+    res = batch.results_from_device(d_res)
+    assert (res["status"] == 0).all()
+    # inverse: compressed slots -> fresh output arena, limit = original length
+    idescs = batch.compact_descs(res, descs, L)
+    out = torch.zeros(n_streams * L + 256, dtype=torch.uint8, device=dev)
+    d_idescs = batch.to_device(idescs, dev)
+    d_ires = torch.zeros(n_streams * 16, dtype=torch.uint8, device=dev)
+    batch.inflate_batch(gpu_ctx, comp, out, d_idescs, d_ires, n_streams, L, 1)
+    ires = batch.results_from_device(d_ires)
+    assert (ires["status"] == 0).all() and (ires["out_len"] == L).all()
+    assert torch.equal(out[:n_streams * L], src)              # encode -> decode round trip, every byte
+    assert (ires["checksum"] == res["checksum"]).all()        # CRC of output == CRC of input, per stream
+    # oracle samples: compressed bytes and CRC bit-exact
+    comp_h = None
+    rng = np.random.default_rng(1)
+    for j in sorted(set([0, n_streams - 1] + rng.integers(0, n_streams, size=sample).tolist())):
+        plain = synth.stream_bytes_np(config, j, L, bits).tobytes()
+        st, c0, crc0 = oracle.deflate(plain, level=level, crc_op=oracle.CRC_CRC32)
+        o = int(descs["dst_off"][j])
+        got = comp[o:o + int(res["out_len"][j])].cpu().numpy().tobytes()
+        assert got == c0, j
+        assert int(res["checksum"][j]) == crc0
+    return res
+
+
+def test_config2_full_1gib_default_round_trip(gpu_ctx, oracle):
+    """C2: 16 384 x 64 KiB of 4-bit symbols, level `Default, deflate then inflate."""
+    res = _c2_round_trip(gpu_ctx, oracle, 16384, 4, 2, 2, sample=6)
+    ratio = res["out_len"].sum() / (16384 * 65536)
+    assert 0.5 < ratio < 0.6  # SURVEY.md 8d expects ~0.545
+
+
+def test_config5_stored_heavy(gpu_ctx, oracle):
+    """C5 shape at 1/16 scale: uniform random bytes -> stored 65534 + 2-literal fixed block."""
+    res = _c2_round_trip(gpu_ctx, oracle, 8192, 8, 2, 5, sample=3)
+    assert (res["out_len"] == 65543).all()
+
+
+def test_config3_checksum_large_buffer(gpu_ctx, oracle):
+    """C3 shape at 1/16 scale (256 MiB): CRC-32 + Adler-32 of one random buffer; the
+    oracle takes ~1 s for this size.  Linearity check: CRC of halves combines."""
+    import torch
+    import zlib
+
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    n = 256 << 20
+    buf = synth.batch_bytes_torch(3, 0, 1, n, 8, dev)
+    crc, adler = batch.checksum_device(gpu_ctx, buf)
+    host = buf.cpu().numpy()
+    assert crc == zlib.crc32(host)
+    assert crc == oracle.crc32(host)
+    assert adler == oracle.adler32(host)  # Q6 fires in about half of the 48k chunks
+    # odd length / unaligned start
+    crc2, adler2 = batch.checksum_device(gpu_ctx, buf[3:n - 5])
+    assert crc2 == oracle.crc32(host[3:n - 5]) and adler2 == oracle.adler32(host[3:n - 5])

@@ -1,0 +1,221 @@
+"""Parity of the HIP path against the CPU oracle, through the C ABI
+(include/zipc_hip.h), on a real MI355X.  Bar: bit-exact bytes, identical
+accept/reject status, identical checksums (integer/byte work: no tolerance)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+LEVELS = {"none": 0, "fast": 1, "default": 2, "best": 3}
+
+
+# ---------------------------------------------------------------- host forms
+
+
+def test_checksum_kats_like_reference(gpu_ctx):  # test/test.ml:16-26
+    from zipc_amd.zipc_deflate import Adler_32, Crc_32
+
+    assert Crc_32.string(b"") == 0
+    assert Crc_32.string(util.FOX) == 0x414FA339
+    assert Adler_32.string(b"") == 1
+    assert Adler_32.string(util.FOX) == 0x5BDC0FDA
+    assert Crc_32.string(b"xx" + util.FOX + b"yy", start=2, len=len(util.FOX)) == 0x414FA339
+    assert Crc_32.check(1, 1).is_ok() and Crc_32.check(1, 2).is_error()
+    assert Crc_32.check(0xABC, 0x1).error == "Checksum mismatch, expected abc found 1)"
+
+
+def test_checksums_match_oracle(gpu_ctx, oracle):
+    from zipc_amd.zipc_deflate import Adler_32, Crc_32
+
+    sizes = [0, 1, 3, 4, 5, 255, 256, 257, 4200, 5551, 5552, 5553, 11104, 65535, 65536, 65537,
+             200000, (1 << 20) + 3, 3 * 5552 * 100]
+    for n in sizes:
+        for kind in ("rand", "ff", "text"):
+            d = util.rand_bytes(n, n) if kind == "rand" else (b"\xff" * n if kind == "ff" else util.text(n, n))
+            assert Crc_32.string(d) == oracle.crc32(d), (n, kind)
+            assert Adler_32.string(d) == oracle.adler32(d), (n, kind)  # incl. Q6 signed remainder
+    assert Adler_32.string(b"\xff" * 4200) == 0xA2045889  # not RFC 1950's a2d65889
+
+
+def test_deflate_trip_like_reference(gpu_ctx, oracle):  # test/test.ml:28-43,123-126
+    from zipc_amd import zipc_deflate as Z
+
+    for level in ("default", "fast", "best", "none"):
+        for s, _kind in util.trip_strings():
+            cs = Z.deflate(s, level=level).get_ok()
+            assert Z.inflate(cs).get_ok() == s
+            assert cs == oracle.deflate(s, level=LEVELS[level])[1]  # bit-exact vs the reference algorithm
+
+
+def test_decompression_size_limits_like_reference(gpu_ctx):  # test/test.ml:45-55
+    from zipc_amd import zipc_deflate as Z
+
+    src = util.kat()["limits"].encode()
+    limit = len(src)
+    csrc = Z.deflate(src).get_ok()
+    assert Z.inflate(csrc).get_ok() == src
+    assert Z.inflate(csrc, decompressed_size=limit).get_ok() == src
+    assert Z.inflate(csrc, decompressed_size=limit + 1).get_ok() == src
+    r = Z.inflate(csrc, decompressed_size=limit - 1)
+    assert r.is_error() and r.error == "Expected decompression size exceeded"
+
+
+def test_zip_docs_fixture_like_reference(gpu_ctx, oracle):  # test/test.ml:57-118
+    from zipc_amd import zipc_deflate as Z
+
+    z = util.zip_docs()
+    for m, raw in util.zip_docs_members():
+        # decoded straight out of the archive string with ~start ~len, like Zipc.File does
+        data, crc = Z.inflate_and_crc_32(z, decompressed_size=m["decompressed_size"],
+                                         start=m["data_start"], len=m["compressed_size"]).get_ok()
+        assert len(data) == m["decompressed_size"] and crc == m["crc32"]
+        assert data == zlib.decompress(raw, -15)
+        crc2, cs = Z.crc_32_and_deflate(data).get_ok()  # default level (= best), re-encode
+        assert crc2 == m["crc32"]
+        assert cs == oracle.deflate(data)[1]
+        assert Z.inflate(cs, decompressed_size=len(data)).get_ok() == data
+
+
+def test_deflate_bytes_equal_oracle_all_cases(gpu_ctx, oracle):
+    from zipc_amd import zipc_deflate as Z
+
+    for name, data in util.deflate_cases().items():
+        for level, lv in LEVELS.items():
+            st, c0, a0 = oracle.deflate(data, level=lv, crc_op=oracle.CRC_ADLER32)
+            adler, cs = Z.adler_32_and_deflate(data, level=level).get_ok()
+            assert cs == c0, (name, level)
+            assert adler == a0, (name, level)  # per-block chaining (Q7)
+            crc, cs2 = Z.crc_32_and_deflate(data, level=level).get_ok()
+            assert cs2 == c0 and crc == zlib.crc32(data), (name, level)
+
+
+def test_inflate_golden_streams_and_limits(gpu_ctx, oracle):
+    from zipc_amd import zipc_deflate as Z
+
+    for s in util.zlib_streams():
+        data, crc = Z.inflate_and_crc_32(s["raw"]).get_ok()
+        assert len(data) == s["plain_len"] and crc == s["plain_crc32"], s["name"]
+        data2, adler = Z.inflate_and_adler_32(s["raw"]).get_ok()
+        assert data2 == data and adler == oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)[2]
+        for lim in (s["plain_len"], max(0, s["plain_len"] - 1)):
+            st0, d0, _ = oracle.inflate(s["raw"], decompressed_size=lim)
+            r = Z.inflate(s["raw"], decompressed_size=lim)
+            assert r.is_ok() == (st0 == 0), (s["name"], lim)
+            if st0 == 0:
+                assert r.get_ok() == d0
+            else:
+                assert r.error == oracle.MESSAGES[st0]
+
+
+def test_zlib_container(gpu_ctx, oracle):
+    from zipc_amd import zipc_deflate as Z
+
+    for level, lv in LEVELS.items():
+        d = util.rand_bytes(200000, lv)  # Q6/Q7 fire on random data
+        adler, cs = Z.zlib_compress(d, level=level).get_ok()
+        st, c0, a0 = oracle.zlib_compress(d, level=lv)
+        assert cs == c0 and adler == a0
+        out, a2 = Z.zlib_decompress(cs).get_ok()
+        assert out == d and a2 == adler
+    cs = bytearray(Z.zlib_compress(b"hello world", level="default").get_ok()[1])
+    cs[-1] ^= 1
+    r = Z.zlib_decompress(bytes(cs))
+    assert r.is_error() and r.error[0] is not None and r.error[1].startswith("Checksum mismatch")
+    assert Z.zlib_decompress(b"\x78\x9c\x03\x00").error == (None, "Corrupted data stream")
+    assert Z.zlib_decompress(b"\x78\xbb\x03\x00\x00\x00\x00\x01").error == (None, "Preset dictionary unsupported")
+    assert Z.zlib_decompress(b"\x77\x85\x03\x00\x00\x00\x00\x01").error[1].startswith("Unknown compression method")
+
+
+# ---------------------------------------------------------------- batch forms
+
+
+def test_inflate_batch_ragged_with_errors(gpu_ctx, oracle):
+    streams, expect = [], []
+    for i, s in enumerate(util.zlib_streams()):
+        streams.append(s["raw"])
+        if len(s["raw"]) < 40000:
+            streams.extend(util.corrupt_variants(s["raw"], i, 6))
+    streams += [b"", b"\x07", b"\x01\x00\x00\xff\xff", b"\x03\x00"]
+    caps = []
+    for s in streams:
+        st, d, _ = oracle.inflate(s, decompressed_size=1 << 20)
+        caps.append(max(len(d) + 8, 1024))
+    for crc_op in (0, 1, 2):
+        # limit = cap: same accept/reject as the oracle with ?decompressed_size
+        import torch
+
+        from zipc_amd import batch
+
+        dev = torch.device("cuda", 0)
+        src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+        slots = [(c + 255) // 256 * 256 + 256 for c in caps]
+        dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+        descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps, limit=caps)
+        src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+        dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+        d_descs = batch.to_device(descs, dev)
+        d_res = torch.zeros(len(streams) * 16, dtype=torch.uint8, device=dev)
+        batch.inflate_batch(gpu_ctx, src, dst, d_descs, d_res, len(streams), max(caps), crc_op)
+        res = batch.results_from_device(d_res)
+        out = dst.cpu().numpy()
+        n_ok = 0
+        for i, s in enumerate(streams):
+            st0, d0, c0 = oracle.inflate(s, decompressed_size=caps[i], crc_op=crc_op)
+            assert res["status"][i] == st0, (i, crc_op)
+            if st0 == 0:
+                n_ok += 1
+                assert res["out_len"][i] == len(d0)
+                o = int(dst_off[i])
+                assert out[o:o + len(d0)].tobytes() == d0, i
+                assert res["checksum"][i] == c0, (i, crc_op)
+        assert n_ok > 40 and n_ok < len(streams)
+
+
+def test_deflate_batch_ragged_equals_oracle(gpu_ctx, oracle):
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    cases = util.deflate_cases()
+    names = list(cases)
+    streams = [cases[n] for n in names]
+    src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+    caps = [batch.deflate_bound(len(s)) for s in streams]
+    slots = [(c + 255) // 256 * 256 for c in caps]
+    dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+    descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+    src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+    d_descs = batch.to_device(descs, dev)
+    total = int(sum(len(s) for s in streams))
+    for level in (0, 1, 2, 3):
+        for crc_op in (1, 2):
+            dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+            d_res = torch.zeros(len(streams) * 16, dtype=torch.uint8, device=dev)
+            batch.deflate_batch(gpu_ctx, src, dst, d_descs, d_res, len(streams), max(len(s) for s in streams),
+                                total, level, crc_op)
+            res = batch.results_from_device(d_res)
+            out = dst.cpu().numpy()
+            for i, s in enumerate(streams):
+                st0, c0, k0 = oracle.deflate(s, level=level, crc_op=crc_op)
+                assert res["status"][i] == 0, (names[i], level)
+                o = int(dst_off[i])
+                assert int(res["out_len"][i]) == len(c0), (names[i], level)
+                assert out[o:o + len(c0)].tobytes() == c0, (names[i], level)
+                assert res["checksum"][i] == k0, (names[i], level, crc_op)
+
+
+def test_deflate_dst_too_small_is_reported(gpu_ctx):
+    import ctypes as C
+
+    from zipc_amd import _lib
+
+    d = util.rand_bytes(5000, 1)
+    dst = C.create_string_buffer(100)
+    ol, ck = C.c_size_t(), C.c_uint32()
+    st = _lib.lib().zipc_hip_deflate(gpu_ctx.handle, d, len(d), 2, 0, dst, 100, C.byref(ol), C.byref(ck))
+    assert st == _lib.ERR_DST_TOO_SMALL

@@ -1,0 +1,114 @@
+"""The lane-serial halves of the kernels (zipc_amd/csrc/*_lane.h) compiled with
+g++ and driven on the CPU, against the oracle.  This checks the kernel LOGIC on
+the build box; the kernels themselves are checked on the GPU (test_gpu_*.py).
+No GPU, and nothing here is a product path."""
+import ctypes as C
+import random
+
+import pytest
+
+import util
+from host_sim import lib as sim_lib
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return sim_lib()
+
+
+def sim_inflate(sim, raw, cap, limit=None, crc_op=0, budget=512):
+    dst = C.create_string_buffer(max(cap, 1) + 64)
+    ol, ck = C.c_uint64(), C.c_uint32()
+    st = sim.sim_inflate(raw, len(raw), dst, cap, int(limit is not None), limit or 0, crc_op,
+                         C.byref(ol), C.byref(ck), budget)
+    return st, dst.raw[:ol.value], ck.value
+
+
+def sim_deflate(sim, oracle, data, level):
+    cap = oracle.deflate_bound(len(data))
+    dst = C.create_string_buffer(cap)
+    ol, ad, kinds, nk = C.c_uint64(), C.c_uint32(), (C.c_int * 64)(), C.c_int()
+    st = sim.sim_deflate(data, len(data), level, dst, cap, C.byref(ol), C.byref(ad), kinds, 64, C.byref(nk))
+    return st, dst.raw[:ol.value], ad.value, list(kinds[:min(nk.value, 64)])
+
+
+def test_inflate_lane_golden_streams(sim, oracle):
+    for s in util.zlib_streams():
+        st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
+        for budget in (512, 7):
+            st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=budget)
+            assert (st, d, a) == (st0, d0, a0), s["name"]
+        for lim in (s["plain_len"], s["plain_len"] + 1, max(0, s["plain_len"] - 1)):
+            st0, d0, _ = oracle.inflate(s["raw"], decompressed_size=lim)
+            st, d, _ = sim_inflate(sim, s["raw"], lim, limit=lim)
+            assert (st, d) == (st0, d0), (s["name"], lim)
+
+
+def test_inflate_lane_accept_reject_fuzz(sim, oracle):
+    seen = {}
+    for i, s in enumerate(util.zlib_streams()):
+        if len(s["raw"]) > 40000:
+            continue
+        cap = s["plain_len"] * 2 + 1000
+        for r in util.corrupt_variants(s["raw"], i, 60):
+            st0, d0, a0 = oracle.inflate(r, decompressed_size=cap, crc_op=oracle.CRC_ADLER32)
+            st, d, a = sim_inflate(sim, r, cap, limit=cap, crc_op=2)
+            assert st == st0 and d == d0 and (st != 0 or a == a0), s["name"]
+            seen[st] = seen.get(st, 0) + 1
+    assert seen.get(0, 0) > 50 and seen.get(1, 0) > 50
+
+
+def test_deflate_lane_logic_bytes_equal_oracle(sim, oracle):
+    for name, data in util.deflate_cases().items():
+        for lvl in (0, 1, 2, 3):
+            st0, c0, a0, blocks = oracle.deflate_trace(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+            st, c, a, kinds = sim_deflate(sim, oracle, data, lvl)
+            assert st == 0 and c == c0 and a == a0, (name, lvl)
+            assert kinds == [b.kind for b in blocks][:64], (name, lvl)
+
+
+def test_deflate_lane_logic_fuzz(sim, oracle):
+    rnd = random.Random(11)
+    for t in range(600):
+        n = rnd.randrange(0, 600)
+        kind = rnd.randrange(4)
+        if kind == 0:
+            data = util.rand_bytes(n, t)
+        elif kind == 1:
+            data = util.rand_bytes(n, t, 2)
+        elif kind == 2:
+            data = (util.rand_bytes(rnd.randrange(1, 20), t) * (n // 2 + 1))[:n]
+        else:
+            data = util.text(n, t)
+        lvl = rnd.randrange(1, 4)
+        st0, c0, a0 = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+        st, c, a, _ = sim_deflate(sim, oracle, data, lvl)
+        assert st == 0 and c == c0 and a == a0, (t, n, kind, lvl)
+
+
+def test_chain_round_model_equals_serial_chain(sim):
+    """lz_chain_kernel's round algorithm, with the surviving LDS store picked at
+    random, yields the reference's insert_hash links."""
+    cases = {
+        "zeros": bytes(70000), "rand": util.rand_bytes(70000, 1), "nib": util.rand_bytes(70000, 2, 4),
+        "nib3": util.rand_bytes(100000, 3, 3), "p2": b"ab" * 20000, "p9": b"abcdefghi" * 6000,
+        "p300": util.rand_bytes(300, 4) * 200, "text": util.text(80000, 5), "bin": util.rand_bytes(50000, 6, 1),
+        "short": b"abcabcabcab", "tiny": b"abcd", "n1027": util.rand_bytes(1027, 7),
+        "old": util.rand_bytes(100, 8) + bytes(70000) + util.rand_bytes(100, 8) + bytes(70000),
+    }
+    for name, d in cases.items():
+        n = len(d)
+        for seed in (1, 2):
+            a, b, mt = (C.c_uint16 * (n + 8))(), (C.c_uint16 * (n + 8))(), C.c_int()
+            sim.sim_chain(d, n, a, seed, C.byref(mt))
+            sim.sim_chain_serial(d, n, b)
+            assert list(a[:max(0, n - 3)]) == list(b[:max(0, n - 3)]), name
+
+
+def test_crc_combination_rule(sim, oracle):
+    rnd = random.Random(5)
+    for _ in range(100):
+        a, b = util.rand_bytes(rnd.randrange(0, 5000), rnd.random()), util.rand_bytes(rnd.randrange(0, 5000), rnd.random())
+        raw_b = oracle.crc32_update(0, b)
+        st_a = oracle.crc32_update(0xFFFFFFFF, a)
+        assert sim.sim_crc_advance(st_a, raw_b, len(b)) == oracle.crc32_update(0xFFFFFFFF, a + b)

@@ -1,0 +1,173 @@
+"""Pins the CPU oracle (oracle/zd_oracle.c) to everything the reference's own
+tests hold for this path and to Python zlib as an independent
+decoder / checksum.  No GPU."""
+import zlib
+
+import pytest
+
+import util
+
+LEVELS = {"none": 0, "fast": 1, "default": 2, "best": 3}
+KIND = {0: "stored", 1: "fixed", 2: "dynamic"}
+
+
+def test_crc32_kat(oracle):  # test/test.ml:16-20
+    assert oracle.crc32(b"") == 0
+    assert oracle.crc32(util.FOX) == 0x414FA339
+
+
+def test_adler32_kat(oracle):  # test/test.ml:22-26
+    assert oracle.adler32(b"") == 1
+    assert oracle.adler32(util.FOX) == 0x5BDC0FDA
+
+
+def test_crc32_matches_zlib(oracle):
+    for n in (0, 1, 3, 4, 5, 255, 4096, 70001):
+        d = util.rand_bytes(n, n)
+        assert oracle.crc32(d) == zlib.crc32(d)
+    a, b = util.rand_bytes(1000, 1), util.rand_bytes(777, 2)
+    st = oracle.crc32_update(oracle.crc32_update(0xFFFFFFFF, a), b) ^ 0xFFFFFFFF
+    assert st == zlib.crc32(a + b)  # chaining across calls is exact
+
+
+def test_adler32_matches_zlib_when_q6_does_not_fire(oracle):
+    for d in (b"", b"a", util.text(100000, 1), bytes(70000), util.rand_bytes(50000, 3, 4)):
+        assert oracle.adler32(d) == zlib.adler32(d)
+
+
+def test_adler32_signed_remainder_q6(oracle):
+    # 0xFF x 4200 differs from RFC 1950
+    d = b"\xff" * 4200
+    assert oracle.adler32(d) == 0xA2045889
+    assert zlib.adler32(d) == 0xA2D65889
+
+
+def test_adler32_chunking_q7(oracle):
+    # the value depends on how the bytes are split over update calls
+    d = util.rand_bytes(200000, 42)
+    whole = oracle.adler32(d)
+    st = 1
+    for i in range(0, len(d), 65534):
+        st = oracle.adler32_update(st, d[i:i + 65534])
+    assert whole != zlib.adler32(d)
+    assert st != whole
+
+
+@pytest.mark.parametrize("level", ["default", "fast", "best", "none"])
+def test_deflate_trip_and_block_kinds(oracle, level):  # test/test.ml:28-43,123-126
+    for s, kind in util.trip_strings():
+        st, c, _, blocks = oracle.deflate_trace(s, level=LEVELS[level])
+        assert st == 0
+        st, d, _ = oracle.inflate(c)
+        assert st == 0 and d == s
+        assert zlib.decompress(c, -15) == s  # independent decoder
+        if level != "none":
+            assert [KIND[b.kind] for b in blocks] == [kind]
+        else:
+            assert all(b.kind == 0 for b in blocks)
+
+
+def test_decompression_size_limits(oracle):  # test/test.ml:45-55
+    src = util.kat()["limits"].encode()
+    st, c, _ = oracle.deflate(src)  # default level = best
+    assert st == 0
+    assert oracle.inflate(c)[1] == src
+    assert oracle.inflate(c, decompressed_size=len(src))[:2] == (0, src)
+    assert oracle.inflate(c, decompressed_size=len(src) + 1)[:2] == (0, src)
+    assert oracle.inflate(c, decompressed_size=len(src) - 1)[0] == oracle.ERR_SIZE_EXCEEDED
+
+
+def test_zip_docs_fixture(oracle):  # test/test.ml:57-118
+    z = util.zip_docs()
+    assert len(z) == 56924
+    for m, raw in util.zip_docs_members():
+        st, d, crc = oracle.inflate(raw, decompressed_size=m["decompressed_size"],
+                                    crc_op=oracle.CRC_CRC32)
+        assert st == 0 and len(d) == m["decompressed_size"] and crc == m["crc32"]
+        assert d == zlib.decompress(raw, -15)
+        # re-deflate with the default level and re-check (redeflate_recode, test/test.ml:58-73)
+        st, c, crc2 = oracle.deflate(d, crc_op=oracle.CRC_CRC32)
+        assert st == 0 and crc2 == m["crc32"]
+        st, d2, crc3 = oracle.inflate(c, decompressed_size=len(d), crc_op=oracle.CRC_CRC32)
+        assert st == 0 and d2 == d and crc3 == m["crc32"]
+        assert zlib.decompress(c, -15) == d
+
+
+def test_inflate_zlib_made_streams(oracle):
+    n = 0
+    for s in util.zlib_streams():
+        st, d, crc = oracle.inflate(s["raw"], crc_op=oracle.CRC_CRC32)
+        assert st == 0 and len(d) == s["plain_len"] and crc == s["plain_crc32"], s["name"]
+        assert d == zlib.decompress(s["raw"], -15)
+        n += 1
+    assert n >= 30
+
+
+def test_inflate_rejects(oracle):
+    # BTYPE 3, LEN/NLEN mismatch, truncated input, distance before start
+    assert oracle.inflate(b"\x07")[0] == oracle.ERR_CORRUPTED
+    assert oracle.inflate(b"\x01\x01\x00\xff\xff\x00")[0] == oracle.ERR_CORRUPTED
+    assert oracle.inflate(b"\x01\x02\x00\xfd\xffa")[0] == oracle.ERR_CORRUPTED
+    assert oracle.inflate(b"")[0] == oracle.ERR_CORRUPTED
+    # fixed block: literal 'a' then a match with distance 2 > 1 byte produced
+    import struct
+    bad = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+    ok = bad.compress(b"aaaaaaaaaaaaaaaa") + bad.flush()
+    assert oracle.inflate(ok)[:2] == (0, b"a" * 16)
+    # trailing garbage after the final block is ignored (zipc_deflate.ml:704)
+    assert oracle.inflate(ok + b"garbage")[:2] == (0, b"a" * 16)
+
+
+def test_deflate_matches_independent_decoder_on_all_cases(oracle):
+    for name, data in util.deflate_cases().items():
+        for lvl in (0, 1, 2, 3):
+            st, c, crc = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_CRC32)
+            assert st == 0 and crc == zlib.crc32(data), name
+            assert zlib.decompress(c, -15) == data, (name, lvl)
+            assert len(c) <= oracle.deflate_bound(len(data))
+
+
+def test_survey_anchors(oracle):
+    # SURVEY.md Appendix B (from an independent scratch model of the reference)
+    assert oracle.deflate(b"", level=2)[1] == bytes.fromhex("0300")
+    assert oracle.deflate(b"a", level=2)[1] == bytes.fromhex("4b0400")
+    assert oracle.deflate(b"hellohello", level=2)[1] == bytes.fromhex("cb48cdc9c9071300")
+    assert oracle.deflate(b"", level=0)[1] == bytes.fromhex("010000ffff")
+    st, c, _, blocks = oracle.deflate_trace(bytes(1 << 20), level=1)
+    assert len(c) == 1224 and len(blocks) == 17
+    assert c[:16] == bytes.fromhex("ecc0810000000080a0fda917a9000000")
+    assert [b.kind for b in blocks] == [2] * 16 + [1]
+    st, c, _, blocks = oracle.deflate_trace(util.rand_bytes(65536, 5), level=2)
+    assert len(c) == 65543 and [b.kind for b in blocks] == [0, 1]
+
+
+def test_zlib_container(oracle):
+    for lvl, hdr in ((0, "7801"), (1, "785e"), (2, "789c"), (3, "78da")):
+        d = util.text(5000, lvl)
+        st, c, adler = oracle.zlib_compress(d, level=lvl)
+        assert st == 0 and c[:2].hex() == hdr and adler == zlib.adler32(d)
+        assert zlib.decompress(c) == d
+        st, d2, a2, _, _ = oracle.zlib_decompress(c)
+        assert st == 0 and d2 == d and a2 == adler
+    c = bytearray(oracle.zlib_compress(b"hello world", level=2)[1])
+    c[-1] ^= 1
+    st, _, _, expect, found = oracle.zlib_decompress(bytes(c))
+    assert st == oracle.ERR_CHECKSUM and expect != found
+    assert oracle.zlib_decompress(b"\x78\x9c\x03\x00")[0] == oracle.ERR_CORRUPTED  # < 6 bytes
+    assert oracle.zlib_decompress(b"\x79\x9c\x03\x00\x00\x00\x00\x01")[0] == oracle.ERR_CORRUPTED
+    assert oracle.zlib_decompress(b"\x78\xbb\x03\x00\x00\x00\x00\x01")[0] == oracle.ERR_ZLIB_DICT
+
+
+def test_huffman_length_limit_retry(oracle):
+    # Fibonacci-like frequencies force codes longer than the limit: the
+    # reference halves freq_cap and retries (zipc_deflate.ml:470-473)
+    fib = [1, 1]
+    while len(fib) < 30:
+        fib.append(fib[-1] + fib[-2])
+    lens = oracle.huffman_lengths(fib[:30], 15)
+    assert max(lens) <= 15 and min(lens) >= 1
+    assert sum(2.0 ** -l for l in lens) <= 1.0 + 1e-12
+    lens7 = oracle.huffman_lengths(fib[:19], 7)
+    assert max(lens7) <= 7
+    assert oracle.huffman_lengths([0, 5, 0], 15) == [0, 1, 0]  # single symbol -> length 1
+    assert oracle.huffman_lengths([0, 0, 0], 15) == [0, 0, 0]

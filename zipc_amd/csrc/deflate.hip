@@ -1,0 +1,551 @@
+// deflate.hip -- batch deflate pipeline for gfx950 (CDNA4, wave64).
+//
+// The reference encoder (src/zipc_deflate.ml:742-1277) is one sequential loop per
+// stream.  It is restated as five kernels over a batch of independent streams
+// (deflate_lane.h explains why each split preserves the output bit for bit):
+//
+//   deflate_offsets_kernel   per-stream bases into the scratch arrays (one scan)
+//   lz_chain_kernel          hash + chain links: prev[p] = distance to the previous
+//                            position with the same 15-bit hash4 (insert_hash,
+//                            zd.ml:1145-1152).  One 1024-thread workgroup per
+//                            stream, the 32 Ki-entry head table as u16 in LDS
+//                            (64 KiB), 1024 positions inserted per round.
+//   lz_match_kernel          one lane per position: best match over the first K and
+//                            the first K/4 chain candidates (find_backref,
+//                            zd.ml:1176-1201) -> 8 bytes per position.
+//   lz_parse_kernel          one lane per stream: lazy parse + block cut
+//                            (Lz77.compress zd.ml:1203-1244, write_block_symbol
+//                            zd.ml:1118-1123) -> symbol array + block list.
+//   deflate_emit_kernel      one wave per stream, blocks in order: histogram (LDS
+//                            atomics), Huffman codes + stored/fixed/dynamic choice
+//                            (write_block zd.ml:1094-1104, lane 0), then all 64 lanes
+//                            pack bits: wave prefix-scan of the per-symbol bit
+//                            lengths, scatter-OR into an LDS staging row, coalesced
+//                            flush of the completed bytes.
+//   deflate_stored_kernel    level `None (write_all_non_compressed zd.ml:1106-1116).
+#include "ctx.h"
+#include "deflate_lane.h"
+#include "wave_ops.h"
+
+namespace zd {
+
+constexpr uint32_t POS_PAD = 128;            // scratch slack per stream, in positions
+constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 - 258 source bytes
+
+// streams with an out-of-range length are rejected by every kernel and take no scratch
+__host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
+  if (src_len > 0xFFFFFFF0ull) src_len = 0;
+  return ((src_len + 63) & ~63ull) + POS_PAD;
+}
+__host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
+  if (src_len > 0xFFFFFFF0ull) src_len = 0;
+  return src_len / MIN_BLOCK_SRC + 2;
+}
+
+struct DeflateScratch {
+  uint64_t *pos_base;   // [n] first position slot of stream i
+  uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
+  uint32_t *n_blocks;   // [n]
+  uint32_t *error;      // [1] != 0: scratch too small for the batch (bad total_src_len)
+  uint16_t *prev;       // [P]
+  uint64_t *match;      // [P]
+  uint32_t *syms;       // [P]
+  BlockDesc *blocks;    // [Bk]
+  uint64_t cap_positions, cap_blocks;
+};
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static void scratch_caps(size_t n, size_t total_src_len, uint64_t &P, uint64_t &Bk) {
+  P = total_src_len + (uint64_t)(POS_PAD + 64) * n + 256;
+  Bk = total_src_len / MIN_BLOCK_SRC + 2 * (uint64_t)n + 16;
+}
+
+size_t deflate_scratch_bytes(size_t n, size_t /*max_src_len*/, size_t total_src_len, int level) {
+  uint64_t P, Bk;
+  scratch_caps(n, total_src_len, P, Bk);
+  size_t b = 0;
+  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
+  if (level != LEVEL_NONE) {
+    b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
+    b += align_up(Bk * sizeof(BlockDesc), 256);
+  }
+  return b + 1024;
+}
+
+static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int level) {
+  DeflateScratch s;
+  uint64_t P, Bk;
+  scratch_caps(n, total_src_len, P, Bk);
+  uint8_t *p = (uint8_t *)base;
+  s.pos_base = (uint64_t *)p; p += align_up(n * 8, 256);
+  s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
+  s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
+  s.error = (uint32_t *)p; p += 256;
+  s.prev = nullptr; s.match = nullptr; s.syms = nullptr; s.blocks = nullptr;
+  if (level != LEVEL_NONE) {
+    s.prev = (uint16_t *)p; p += align_up(P * 2, 256);
+    s.match = (uint64_t *)p; p += align_up(P * 8, 256);
+    s.syms = (uint32_t *)p; p += align_up(P * 4, 256);
+    s.blocks = (BlockDesc *)p; p += align_up(Bk * sizeof(BlockDesc), 256);
+  }
+  s.cap_positions = P;
+  s.cap_blocks = Bk;
+  return s;
+}
+
+// ---------------------------------------------------------------------------------
+// Exclusive scan of the per-stream scratch needs (single workgroup).
+__global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc *__restrict__ descs,
+                                                               uint32_t n, DeflateScratch S) {
+  __shared__ uint64_t part_p[1024], part_b[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (n + 1023) / 1024;
+  const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+  uint64_t sp = 0, sb = 0;
+  for (uint32_t i = lo; i < hi; i++) { sp += padded_positions(descs[i].src_len); sb += max_blocks_of(descs[i].src_len); }
+  part_p[t] = sp;
+  part_b[t] = sb;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t ap = 0, ab = 0;
+    for (int i = 0; i < 1024; i++) {
+      uint64_t vp = part_p[i], vb = part_b[i];
+      part_p[i] = ap; part_b[i] = ab;
+      ap += vp; ab += vb;
+    }
+    S.error[0] = (ap > S.cap_positions || ab > S.cap_blocks) ? 1u : 0u;
+  }
+  __syncthreads();
+  sp = part_p[t];
+  sb = part_b[t];
+  for (uint32_t i = lo; i < hi; i++) {
+    S.pos_base[i] = sp;
+    S.blk_base[i] = sb;
+    sp += padded_positions(descs[i].src_len);
+    sb += max_blocks_of(descs[i].src_len);
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// Hash-chain links.  Round = 1024 consecutive positions, one per thread.  The
+// reference inserts positions one by one (head/prev arrays, zd.ml:1150-1152); a
+// round reproduces the same links for all its positions at once:
+//   * every thread first reads head[h] (latest earlier position with its hash);
+//   * members of the round that share a hash are ordered by a "peel": the not yet
+//     ordered ones all store their position to head[h], exactly one store lands,
+//     everybody with that hash reads back who it was -- after as many turns as
+//     the largest group has members every thread knows its nearest smaller
+//     member.  Threads with an equal hash at most 8 positions to their left take
+//     that neighbour directly, and only threads with no equal hash within 8 to
+//     their right take part in the peel, so runs and short periods cost one turn;
+//   * the largest member of each group leaves its position in head[h].
+// head holds positions mod 2^16; every 16384 positions entries older than 32768
+// are replaced by a marker that decodes as "none" until the next sweep.
+constexpr uint32_t CHAIN_THREADS = 1024;
+constexpr uint32_t SWEEP_PERIOD = 16384;
+constexpr uint32_t SWEEP_MARK = 20000;
+constexpr int NEAR = 8;
+
+__global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
+                                                                 const StreamDesc *__restrict__ descs,
+                                                                 DeflateScratch S) {
+  __shared__ uint16_t head[32768];
+  __shared__ uint16_t hs[CHAIN_THREADS + 2 * NEAR];
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x;
+  const uint32_t t = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint8_t *s = src_arena + sd.src_off;
+  uint16_t *prev = S.prev + S.pos_base[stream];
+  const uint32_t max_pos = len - 4;
+  if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_THREADS + NEAR + t] = 0xFFFF; }
+
+  for (uint32_t B = 0; B <= max_pos; B += CHAIN_THREADS) {
+    if ((B % SWEEP_PERIOD) == 0) {
+      const uint16_t mark = (uint16_t)(B + SWEEP_MARK);
+      for (uint32_t i = t; i < 32768; i += CHAIN_THREADS) {
+        bool keep = false;
+        if (B != 0) {
+          const uint32_t d = (B - head[i]) & 0xFFFFu;
+          keep = d >= 1 && d <= 32768;
+        }
+        if (!keep) head[i] = mark;
+      }
+      __syncthreads();
+    }
+    const uint32_t p = B + t;
+    const bool active = p <= max_pos;
+    const uint32_t h = active ? hash4(load_u32_le(s + p)) : 0xFFFFu;
+    hs[NEAR + t] = (uint16_t)h;
+    const uint32_t e_old = active ? head[h] : 0;
+    __syncthreads();
+
+    uint32_t near_pred = 0;
+    bool has_succ = false;
+    if (active) {
+#pragma unroll
+      for (int k = NEAR; k >= 1; k--)
+        if (hs[NEAR + t - k] == h) near_pred = (uint32_t)k;  // ends with the nearest
+#pragma unroll
+      for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + t + k] == h;
+    }
+    const bool reader = active && near_pred == 0;
+    const bool writer = active && !has_succ;
+    bool pending = writer, notmax = false;
+    int pred_local = -1;
+    for (;;) {
+      if (pending) head[h] = (uint16_t)p;
+      __syncthreads();
+      if (reader || writer) {
+        const uint32_t r_local = ((uint32_t)head[h] - B) & 0xFFFFu;
+        if (r_local == t) pending = false;
+        else if (r_local < t) { if (reader && (int)r_local > pred_local) pred_local = (int)r_local; }
+        else notmax = true;
+      }
+      if (!__syncthreads_or(pending ? 1 : 0)) break;
+    }
+    if (writer && !notmax) head[h] = (uint16_t)p;
+    if (active) {
+      uint32_t d;
+      if (near_pred) d = near_pred;
+      else if (pred_local >= 0) d = t - (uint32_t)pred_local;
+      else {
+        d = (p - e_old) & 0xFFFFu;
+        if (d > 32768) d = 0;
+      }
+      prev[p] = (uint16_t)d;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------
+constexpr uint32_t MATCH_THREADS = 256;
+
+__global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *__restrict__ src_arena,
+                                                                 const StreamDesc *__restrict__ descs,
+                                                                 DeflateScratch S, uint32_t chunks_per_stream,
+                                                                 int K, int Kq) {
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x / chunks_per_stream;
+  const uint32_t chunk = blockIdx.x % chunks_per_stream;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint32_t p = chunk * MATCH_THREADS + threadIdx.x;
+  if (p > len - 4) return;
+  const uint64_t base = S.pos_base[stream];
+  S.match[base + p] = lz_match_position(src_arena + sd.src_off, len, p, S.prev + base, K, Kq);
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
+                                                      const StreamDesc *__restrict__ descs, uint32_t n,
+                                                      DeflateScratch S, int good_match) {
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x * 64 + threadIdx.x;
+  if (stream >= n) return;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len > 0xFFFFFFF0ull) { S.n_blocks[stream] = 0; return; }
+  const uint64_t base = S.pos_base[stream];
+  S.n_blocks[stream] = lz_parse_stream(src_arena + sd.src_off, (uint32_t)sd.src_len, S.match + base,
+                                       good_match, S.syms + base, S.blocks + S.blk_base[stream]);
+}
+
+// ---------------------------------------------------------------------------------
+// Bit packing by the whole wave.  Items (block header, dynamic-header fields,
+// symbols) are taken 64 at a time: each lane turns one item into (value, nbits),
+// an inclusive wave scan gives its bit offset, lanes OR their bits into the LDS
+// staging row, and the completed bytes are flushed with coalesced stores.
+constexpr int STAGE_WORDS = 104;  // 7 carried bits + 64 x 48 bits = 3079 bits < 104 words
+
+struct BitOut {
+  uint8_t *dst;        // stream output base
+  uint32_t out_pos;    // bytes already in global memory
+  uint32_t acc;        // pending bits (< 8), dst_bits of the reference (zd.ml:784)
+  int acc_bits;        // dst_bits_len (zd.ml:785)
+};
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+
+// pack one tile: lane holds (value, nbits) (nbits = 0 for idle lanes)
+__device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t value, int nbits, int lane) {
+  // stage[] is zero except stage[0] = pending bits
+  const uint32_t incl = wave_incl_scan((uint32_t)nbits, lane);
+  const uint32_t total = __shfl(incl, 63, 64) + (uint32_t)bo.acc_bits;
+  if (nbits) {
+    const uint32_t o = incl - (uint32_t)nbits + (uint32_t)bo.acc_bits;
+    const uint32_t wi = o >> 5, sh = o & 31;
+    const uint64_t lo = value << sh;
+    atomicOr(&stage[wi], (uint32_t)lo);
+    const uint32_t mid = (uint32_t)(lo >> 32);
+    if (mid) atomicOr(&stage[wi + 1], mid);
+    if (sh && nbits + (int)sh > 64) atomicOr(&stage[wi + 2], (uint32_t)(value >> (64 - sh)));
+  }
+  __syncthreads();
+  const uint32_t full_bytes = total >> 3;
+  const uint32_t full_words = full_bytes >> 2;
+  uint8_t *o = bo.dst + bo.out_pos;
+  for (uint32_t w = (uint32_t)lane; w < full_words; w += 64) store_u32_unaligned(o + 4 * w, stage[w]);
+  const uint32_t tail = full_bytes & 3u;
+  if ((uint32_t)lane < tail) o[4 * full_words + lane] = (uint8_t)(stage[full_words] >> (8 * lane));
+  const uint32_t rem_bits = total & 7u;
+  const uint32_t last = (stage[full_bytes >> 2] >> (8 * (full_bytes & 3u))) & ((1u << rem_bits) - 1u);
+  __syncthreads();
+  // reset the staging row for the next tile
+  for (int w = lane; w < STAGE_WORDS; w += 64) stage[w] = 0;
+  __syncthreads();
+  if (lane == 0) stage[0] = last;
+  bo.out_pos += full_bytes;
+  bo.acc = last;
+  bo.acc_bits = (int)rem_bits;
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
+                                                          uint8_t *__restrict__ dst_arena,
+                                                          const StreamDesc *__restrict__ descs,
+                                                          StreamResult *__restrict__ results,
+                                                          DeflateScratch S, int crc_op) {
+  __shared__ uint32_t lit_freq[288], dist_freq[32], codelen_freq[32];
+  __shared__ uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], fix_lit[288], fix_dist[32];
+  __shared__ uint32_t codelen_syms[320], heap[580];
+  __shared__ uint32_t stage[STAGE_WORDS];
+  __shared__ int sh_info[8];
+
+  const uint32_t stream = blockIdx.x;
+  const int lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (S.error[0] || sd.src_len > 0xFFFFFFF0ull || sd.dst_cap > 0xFFFFFFF0ull) {
+    if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
+    return;
+  }
+  const uint8_t *src = src_arena + sd.src_off;
+  const uint32_t dst_cap = (uint32_t)sd.dst_cap;
+  const uint32_t nblk = S.n_blocks[stream];
+  const BlockDesc *blocks = S.blocks + S.blk_base[stream];
+  const uint32_t *syms = S.syms + S.pos_base[stream];
+
+  BlockCoder c;
+  c.lit_freq = lit_freq; c.dist_freq = dist_freq; c.codelen_freq = codelen_freq;
+  c.dyn_lit = dyn_lit; c.dyn_dist = dyn_dist; c.dyn_codelen = dyn_codelen;
+  c.fix_lit = fix_lit; c.fix_dist = fix_dist; c.codelen_syms = codelen_syms; c.heap = heap;
+  c.codelen_syms_len = 0; c.hlit = 0; c.hdist = 0; c.hclen = 0;
+
+  for (int i = lane; i < 32; i += 64) { codelen_freq[i] = 0; dyn_dist[i] = 0; dyn_codelen[i] = 0; }
+  for (int i = lane; i < 288; i += 64) dyn_lit[i] = 0;
+  for (int i = lane; i < STAGE_WORDS; i += 64) stage[i] = 0;
+  if (lane == 0) huff_fixed_encoders(fix_lit, fix_dist);
+  __syncthreads();
+
+  BitOut bo;
+  bo.dst = dst_arena + sd.dst_off;
+  bo.out_pos = 0;
+  bo.acc = 0;
+  bo.acc_bits = 0;
+  uint32_t adler = 1;  // Adler_32.init
+  uint32_t status = ST_OK;
+
+  for (uint32_t b = 0; b < nblk && status == ST_OK; b++) {
+    const BlockDesc bd = blocks[b];
+    const bool final = b + 1 == nblk;
+    // deflated_block_src_crc zd.ml:1081-1086 (Adler: one update call per block)
+    if (crc_op == CRC_ADLER32) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane);
+
+    // symbol histograms (write_lit_symbol / write_backref_symbol zd.ml:1125-1136)
+    for (int i = lane; i < 288; i += 64) lit_freq[i] = 0;
+    if (lane < 32) dist_freq[lane] = 0;
+    __syncthreads();
+    for (uint32_t k = (uint32_t)lane; k < bd.n_syms; k += 64) {
+      const uint32_t sref = syms[bd.sym_start + k];
+      if ((sref >> 9) == 0) atomicAdd(&lit_freq[sref], 1u);
+      else {
+        atomicAdd(&lit_freq[length_to_sym((int)(sref & 0x1FF))], 1u);
+        atomicAdd(&dist_freq[dist_to_sym((int)(sref >> 9))], 1u);
+      }
+    }
+    __syncthreads();
+    if (lane == 0) {
+      lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
+      coder_make_dynamic(c);
+      uint64_t flen, dlen;
+      const int kind = coder_choose(c, bd.src_len, bo.acc_bits, flen, dlen);
+      sh_info[0] = kind;
+      sh_info[1] = c.codelen_syms_len;
+      sh_info[2] = c.hlit;
+      sh_info[3] = c.hdist;
+      sh_info[4] = c.hclen;
+      const uint64_t bits = kind == 1 ? flen : dlen;
+      sh_info[5] = (int)(bits & 0xFFFFFFFFu);
+      sh_info[6] = (int)(bits >> 32);
+    }
+    __syncthreads();
+    const int kind = sh_info[0];
+    c.codelen_syms_len = sh_info[1];
+    c.hlit = sh_info[2];
+    c.hdist = sh_info[3];
+    c.hclen = sh_info[4];
+    const uint64_t block_bits = (uint64_t)(uint32_t)sh_info[5] | ((uint64_t)(uint32_t)sh_info[6] << 32);
+
+    if (kind == 0) {
+      // write_non_compressed_block zd.ml:873-877
+      const uint32_t hdr_bits = (uint32_t)bo.acc_bits + 3;
+      const uint32_t hdr_bytes = (hdr_bits + 7) >> 3;
+      const uint64_t need = (uint64_t)bo.out_pos + hdr_bytes + 4 + bd.src_len;
+      if (need > dst_cap) { status = ST_DST_TOO_SMALL; break; }
+      uint8_t *o = bo.dst + bo.out_pos;
+      if (lane == 0) {
+        const uint32_t v = bo.acc | ((final ? 1u : 0u) << bo.acc_bits);
+        o[0] = (uint8_t)v;
+        if (hdr_bytes == 2) o[1] = (uint8_t)(v >> 8);
+        uint8_t *q = o + hdr_bytes;
+        q[0] = (uint8_t)bd.src_len;
+        q[1] = (uint8_t)(bd.src_len >> 8);
+        q[2] = (uint8_t)(~bd.src_len);
+        q[3] = (uint8_t)((~bd.src_len) >> 8);
+        stage[0] = 0;
+      }
+      wave_copy(o + hdr_bytes + 4, src + bd.src_start, bd.src_len, lane);
+      bo.out_pos = (uint32_t)need;
+      bo.acc = 0;
+      bo.acc_bits = 0;
+      __syncthreads();
+      continue;
+    }
+
+    // fixed (zd.ml:912-916) or dynamic (zd.ml:918-945) block
+    {
+      const uint64_t need = (uint64_t)bo.out_pos + (((uint64_t)bo.acc_bits + block_bits + 7) >> 3);
+      if (need > dst_cap) { status = ST_DST_TOO_SMALL; break; }
+    }
+    const uint32_t *hl = kind == 1 ? fix_lit : dyn_lit;
+    const uint32_t *hd = kind == 1 ? fix_dist : dyn_dist;
+    const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
+    const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
+    for (uint32_t base = 0; base < n_items; base += 64) {
+      const uint32_t idx = base + (uint32_t)lane;
+      uint64_t value = 0;
+      int nbits = 0;
+      if (idx < n_items) {
+        if (idx == 0) {
+          value = (final ? 1u : 0u) | ((uint32_t)kind << 1);
+          nbits = 3;
+        } else if (idx <= n_hdr) {
+          uint32_t v;
+          dyn_header_item(c, (int)idx - 1, v, nbits);
+          value = v;
+        } else {
+          const uint32_t k = idx - 1 - n_hdr;
+          const uint32_t sref = k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
+          symbol_bits(sref, hl, hd, value, nbits);
+        }
+      }
+      pack_tile(bo, stage, value, nbits, lane);
+    }
+  }
+
+  if (status == ST_OK && bo.acc_bits > 0) {  // flush zd.ml:856-858
+    if (bo.out_pos + 1 > dst_cap) status = ST_DST_TOO_SMALL;
+    else {
+      if (lane == 0) bo.dst[bo.out_pos] = (uint8_t)bo.acc;
+      bo.out_pos += 1;
+    }
+  }
+  if (lane == 0) {
+    StreamResult r;
+    r.status = status;
+    r.out_len = status == ST_OK ? bo.out_pos : 0;
+    r.checksum = (crc_op == CRC_ADLER32 && status == ST_OK) ? adler : 0u;  // CRC-32: checksum pass
+    results[stream] = r;
+  }
+}
+
+// ---------------------------------------------------------------------------------
+// level `None: stored blocks of up to 65534 bytes (zd.ml:1106-1116); empty input
+// gives one empty final stored block.
+__global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__restrict__ src_arena,
+                                                            uint8_t *__restrict__ dst_arena,
+                                                            const StreamDesc *__restrict__ descs,
+                                                            StreamResult *__restrict__ results, int crc_op) {
+  const uint32_t stream = blockIdx.x;
+  const int lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  StreamResult r;
+  r.status = ST_OK; r.checksum = 0; r.out_len = 0;
+  if (sd.src_len > 0xFFFFFFF0ull || sd.dst_cap > 0xFFFFFFF0ull) {
+    r.status = ST_INVALID_ARG;
+    if (lane == 0) results[stream] = r;
+    return;
+  }
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint64_t nblocks = (uint64_t)len / MAX_BLOCK_SRC_LEN + ((len % MAX_BLOCK_SRC_LEN) || len == 0 ? 1 : 0);
+  const uint64_t need = (uint64_t)len + 5 * nblocks;
+  if (need > sd.dst_cap) {
+    r.status = ST_DST_TOO_SMALL;
+    if (lane == 0) results[stream] = r;
+    return;
+  }
+  const uint8_t *src = src_arena + sd.src_off;
+  uint8_t *dst = dst_arena + sd.dst_off;
+  uint32_t adler = 1, start = 0;
+  uint64_t out = 0;
+  for (;;) {
+    const uint32_t n = len - start < (uint32_t)MAX_BLOCK_SRC_LEN ? len - start : (uint32_t)MAX_BLOCK_SRC_LEN;
+    const bool final = start + n == len;
+    if (crc_op == CRC_ADLER32) adler = wave_adler_update(adler, src + start, n, lane);
+    if (lane == 0) {
+      uint8_t *q = dst + out;
+      q[0] = final ? 1 : 0;
+      q[1] = (uint8_t)n;
+      q[2] = (uint8_t)(n >> 8);
+      q[3] = (uint8_t)(~n);
+      q[4] = (uint8_t)((~n) >> 8);
+    }
+    wave_copy(dst + out + 5, src + start, n, lane);
+    out += 5 + (uint64_t)n;
+    if (final) break;
+    start += n;
+  }
+  r.out_len = out;
+  r.checksum = crc_op == CRC_ADLER32 ? adler : 0u;
+  if (lane == 0) results[stream] = r;
+}
+
+// ---------------------------------------------------------------------------------
+hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
+                          const StreamDesc *d_descs, StreamResult *d_results, size_t n,
+                          size_t max_src_len, size_t total_src_len, int level, int crc_op) {
+  if (level == LEVEL_NONE) {
+    ZD_LAUNCH(ctx, "deflate_stored", deflate_stored_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst,
+              d_descs, d_results, crc_op);
+    return hipGetLastError();
+  }
+  DeflateScratch S = carve(ctx->deflate_scratch.p, n, total_src_len, level);
+  int good_match, K;
+  level_params(level, good_match, K);
+  ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S);
+  ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
+  const size_t cps = max_src_len >= 4 ? (max_src_len - 4) / MATCH_THREADS + 1 : 1;
+  if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)(n * cps)), dim3(MATCH_THREADS), 0, d_src,
+            d_descs, S, (uint32_t)cps, K, K / 4);
+  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, d_src, d_descs,
+            (uint32_t)n, S, good_match);
+  ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
+            d_results, S, crc_op);
+  return hipGetLastError();
+}
+
+}  // namespace zd
