@@ -1,0 +1,167 @@
+(* zipc_deflate.ml -- drop-in replacement for the reference's src/zipc_deflate.ml,
+   same signature (src/zipc_deflate.mli), every function backed by the MI355X
+   library libzipc_hip.so through ocaml-ctypes (no C stubs).
+
+   NOT COMPILED in this repository's build image (no OCaml toolchain there); kept
+   tiny on purpose.  See INTEGRATION.md for how a zipc maintainer links it:
+   replace src/zipc_deflate.ml by this file and add `ctypes.foreign` to the
+   package's dependencies; src/zipc.ml is unchanged (it only uses the signature,
+   src/zipc.ml:174,183,210,216,223). *)
+
+open Ctypes
+open Foreign
+
+type uint16 = int
+type uint32 = int32
+
+let lib = Dl.dlopen ~filename:"libzipc_hip.so" ~flags:[Dl.RTLD_NOW]
+let ctx_t = ptr void
+let f name ty = foreign ~from:lib name ty
+
+let c_create = f "zipc_hip_create" (ptr ctx_t @-> int @-> returning int)
+let c_strerror = f "zipc_hip_strerror" (int @-> returning string)
+let c_crc32 = f "zipc_hip_crc32" (ctx_t @-> ocaml_string @-> size_t @-> ptr uint32_t @-> returning int)
+let c_adler32 = f "zipc_hip_adler32" (ctx_t @-> ocaml_string @-> size_t @-> ptr uint32_t @-> returning int)
+let c_inflate =
+  f "zipc_hip_inflate"
+    (ctx_t @-> ocaml_string @-> size_t @-> int @-> size_t @-> int @-> ocaml_bytes @-> size_t @->
+     ptr size_t @-> ptr uint32_t @-> returning int)
+let c_deflate_bound = f "zipc_hip_deflate_bound" (size_t @-> returning size_t)
+let c_deflate =
+  f "zipc_hip_deflate"
+    (ctx_t @-> ocaml_string @-> size_t @-> int @-> int @-> ocaml_bytes @-> size_t @->
+     ptr size_t @-> ptr uint32_t @-> returning int)
+
+(* status codes and enums of include/zipc_hip.h *)
+let ok = 0 and err_dst_too_small = 16
+let crc_nop = 0 and crc_crc32 = 1 and crc_adler32 = 2
+
+let ctx = lazy begin
+  let p = allocate ctx_t null in
+  let st = c_create p 0 in
+  if st <> ok then failwith ("zipc_hip_create: " ^ c_strerror st);
+  !@ p
+end
+
+(* ?start ?len -> the selected bytes (a copy only when a proper sub-range is asked);
+   out-of-range arguments raise Invalid_argument like the reference's bounds checks *)
+let range ?(start = 0) ?len s =
+  let len = match len with None -> String.length s - start | Some l -> l in
+  if start = 0 && len = String.length s then s else String.sub s start len
+
+let u32 p = Unsigned.UInt32.to_int32 (!@ p)
+let sz = Unsigned.Size_t.of_int
+
+let crc_error e f =
+  Error (Printf.sprintf "Checksum mismatch, expected %lx found %lx)" e f)
+
+module type CHECKSUM = sig
+  type t = uint32
+  val equal : t -> t -> bool
+  val check : expect:t -> found:t -> (unit, string) result
+  val pp : Format.formatter -> t -> unit
+  val string : ?start:int -> ?len:int -> string -> t
+end
+
+let checksum c_fn : (module CHECKSUM) = (module struct
+  type t = uint32
+  let equal = Int32.equal
+  let pp ppf crc = Format.fprintf ppf "%lx" crc
+  let check ~expect:e ~found:f = if equal e f then Ok () else crc_error e f
+  let string ?start ?len s =
+    let s = range ?start ?len s in
+    let out = allocate uint32_t Unsigned.UInt32.zero in
+    let st = c_fn (Lazy.force ctx) (ocaml_string_start s) (sz (String.length s)) out in
+    if st <> ok then failwith (c_strerror st);
+    u32 out
+end)
+
+module Crc_32 = (val checksum c_crc32)
+module Adler_32 = (val checksum c_adler32)
+
+(* inflate: with ?decompressed_size the destination is exactly that large
+   (Buf.make ~fixed:true, zipc_deflate.ml:554); without it start at 3x the input
+   and double on ZIPC_HIP_ERR_DST_TOO_SMALL (Buf.grow, zipc_deflate.ml:27-38) *)
+let inflate_and_crc ?decompressed_size ?start ?len s ~crc_op =
+  let s = range ?start ?len s in
+  let n = String.length s in
+  let has_limit, limit = match decompressed_size with None -> 0, 0 | Some d -> 1, d in
+  let rec go cap =
+    let dst = Bytes.create cap in
+    let out_len = allocate size_t Unsigned.Size_t.zero in
+    let crc = allocate uint32_t Unsigned.UInt32.zero in
+    let st =
+      c_inflate (Lazy.force ctx) (ocaml_string_start s) (sz n) has_limit (sz limit) crc_op
+        (ocaml_bytes_start dst) (sz cap) out_len crc
+    in
+    if st = err_dst_too_small && has_limit = 0 then go (2 * cap) else
+    if st <> ok then Error (c_strerror st) else
+    Ok (Bytes.sub_string dst 0 (Unsigned.Size_t.to_int (!@ out_len)), u32 crc)
+  in
+  go (if has_limit = 1 then limit else max (3 * n) 1024)
+
+let inflate_and_crc_32 ?decompressed_size ?start ?len s =
+  inflate_and_crc ?decompressed_size ?start ?len s ~crc_op:crc_crc32
+
+let inflate_and_adler_32 ?decompressed_size ?start ?len s =
+  inflate_and_crc ?decompressed_size ?start ?len s ~crc_op:crc_adler32
+
+let inflate ?decompressed_size ?start ?len s =
+  Result.map fst (inflate_and_crc ?decompressed_size ?start ?len s ~crc_op:crc_nop)
+
+(* zlib_decompress zipc_deflate.ml:720-740: the 6 bytes of container are parsed
+   here, the body goes through inflate_and_adler_32 *)
+let zlib_decompress ?decompressed_size ?start ?len s =
+  let s = range ?start ?len s in
+  let len = String.length s in
+  let err m = Error (None, m) in
+  if len < 6 then err "Corrupted data stream" else
+  let cmf = String.get_uint8 s 0 and flg = String.get_uint8 s 1 in
+  if (256 * cmf + flg) mod 31 <> 0 then err "Corrupted data stream" else
+  let cm = cmf land 0x0F in
+  if cm <> 8 then err (Printf.sprintf "Unknown compression method (%d)" cm) else
+  if cmf lsr 4 > 7 then err "Window size too large" else
+  if flg land 0x20 <> 0 then err "Preset dictionary unsupported" else
+  let expect = String.get_int32_be s (len - 4) in
+  match inflate_and_adler_32 ?decompressed_size s ~start:2 ~len:(len - 4) with
+  | Error e -> err e
+  | Ok (_, found) as r ->
+      match Adler_32.check ~expect ~found with
+      | Error e -> Error (Some (expect, found), e)
+      | Ok () -> r
+
+type level = [ `None | `Fast | `Default | `Best ]
+
+let level_code = function `None -> 0 | `Fast -> 1 | `Default -> 2 | `Best -> 3
+
+(* the reference's effective default is `Best (make_encoder, zipc_deflate.ml:817) *)
+let crc_and_deflate ?(level = `Best) ?start ?len s ~crc_op =
+  let s = range ?start ?len s in
+  let n = String.length s in
+  let cap = Unsigned.Size_t.to_int (c_deflate_bound (sz n)) in
+  let dst = Bytes.create cap in
+  let out_len = allocate size_t Unsigned.Size_t.zero in
+  let crc = allocate uint32_t Unsigned.UInt32.zero in
+  let st =
+    c_deflate (Lazy.force ctx) (ocaml_string_start s) (sz n) (level_code level) crc_op
+      (ocaml_bytes_start dst) (sz cap) out_len crc
+  in
+  if st <> ok then Error (c_strerror st) else
+  Ok (u32 crc, Bytes.sub_string dst 0 (Unsigned.Size_t.to_int (!@ out_len)))
+
+let crc_32_and_deflate ?level ?start ?len s = crc_and_deflate ?level ?start ?len s ~crc_op:crc_crc32
+let adler_32_and_deflate ?level ?start ?len s = crc_and_deflate ?level ?start ?len s ~crc_op:crc_adler32
+let deflate ?level ?start ?len s = Result.map snd (crc_and_deflate ?level ?start ?len s ~crc_op:crc_nop)
+
+(* zlib_compress zipc_deflate.ml:1262-1277 *)
+let zlib_compress ?(level = `Best) ?start ?len s =
+  match adler_32_and_deflate ~level ?start ?len s with
+  | Error _ as e -> e
+  | Ok (adler, body) ->
+      let cmf = (7 lsl 4) lor 8 in
+      let header = (cmf lsl 8) lor (level_code level lsl 6) in
+      let flg = (header + 31 - (header mod 31)) land 0xFF in
+      let b = Buffer.create (String.length body + 6) in
+      Buffer.add_uint8 b cmf; Buffer.add_uint8 b flg; Buffer.add_string b body;
+      Buffer.add_int32_be b adler;
+      Ok (adler, Buffer.contents b)

@@ -83,6 +83,14 @@ def lib():
     """The loaded library; raises if libzipc_hip.so has not been built."""
     global _lib
     if _lib is None:
+        # PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so).  A
+        # process that uses both must load torch's copy FIRST: if libzipc_hip.so pulls
+        # in /opt/rocm's runtime before torch is imported, torch later fails with
+        # "No HIP GPUs are available" (two runtimes, one SONAME).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 "zipc_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
