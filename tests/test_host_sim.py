@@ -105,6 +105,10 @@ def test_chain_round_model_equals_serial_chain(sim):
             assert list(a[:max(0, n - 3)]) == list(b[:max(0, n - 3)]), name
 
 
+def test_symbol_value_closed_forms_equal_rfc_tables(sim):
+    assert sim.sim_sym_values_match_tables() == 0
+
+
 def test_crc_combination_rule(sim, oracle):
     rnd = random.Random(5)
     for _ in range(100):

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Experiment driver: times the inflate / deflate kernels on the C2 workload with
+whatever libzipc_hip.so ZIPC_HIP_LIB points at (per-kernel HIP-event times)."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import zipc_amd
+from zipc_amd import batch, synth
+
+def main():
+    n = int(os.environ.get("N_STREAMS", "16384")); L = 65536; bits = int(os.environ.get("BITS", "4"))
+    level = int(os.environ.get("LEVEL", "2"))
+    reps = int(os.environ.get("REPS", "3"))
+    dev = torch.device("cuda", 0)
+    ctx = zipc_amd.Context(0)
+    src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    slot = int(descs["dst_off"][1])
+    comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_ires = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, 0)
+    res = batch.results_from_device(d_res)
+    idescs = batch.compact_descs(res, descs, L)
+    d_idescs = batch.to_device(idescs, dev)
+    batch.inflate_batch(ctx, comp, out, d_idescs, d_ires, n, L, 0)
+    ok = bool(torch.equal(out[:n * L], src))
+    ctx.set_profiling(True); ctx.reset_kernel_times()
+    for _ in range(reps):
+        if os.environ.get("DEFLATE", "1") == "1":
+            batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, 0)
+        batch.inflate_batch(ctx, comp, out, d_idescs, d_ires, n, L, 0)
+    t = ctx.kernel_times()
+    print(json.dumps({"lib": os.environ.get("ZIPC_HIP_LIB", "default"), "roundtrip_ok": ok,
+                      "ratio": float(res["out_len"].sum()) / (n * L),
+                      "ms": {k: round(v[1] / v[0], 3) for k, v in t.items()}}))
+
+main()

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libzipc_hip.so")
+LIB_PATH = os.environ.get("ZIPC_HIP_LIB") or os.path.join(HERE, "lib", "libzipc_hip.so")
 
 OK = 0
 ERR_CORRUPTED = 1

@@ -6,6 +6,7 @@
 #include "../../include/zipc_hip.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ctx.h"
@@ -223,6 +224,10 @@ static int pick_log2L(size_t n_streams) {
   // wave is the LDS limit (4 waves x 36 KiB per CU)
   int log2L = 0;
   while (log2L < 4 && (n_streams >> (log2L + 1)) >= 1024) log2L++;
+  if (const char *e = getenv("ZIPC_HIP_LOG2L")) {  // tuning knob for experiments
+    int v = atoi(e);
+    if (v >= 0 && v <= 4) log2L = v;
+  }
   return log2L;
 }
 

@@ -319,7 +319,17 @@ ZD_HD void coder_make_dynamic(BlockCoder &c) {
   c.hclen = (o + 1) - 4;
 }
 
-ZD_HD int length_extra_bits(int sym) { return sym < LITLEN_FIRST_LEN ? 0 : (int)(k_length_value_of_sym[sym - LITLEN_FIRST_LEN] & 0xF); }
+ZD_HD int length_extra_bits(int sym) {
+  if (sym < LITLEN_FIRST_LEN) return 0;
+  uint32_t b, e;
+  length_sym_value(sym, b, e);
+  return (int)e;
+}
+ZD_HD int dist_extra_bits(int sym) {
+  uint32_t b, e;
+  dist_sym_value(sym, b, e);
+  return (int)e;
+}
 
 // bit_length_of_block_symbols zd.ml:1049-1064
 ZD_HD uint64_t coder_symbols_bits(const BlockCoder &c, const uint32_t *hlit, const uint32_t *hdist) {
@@ -327,7 +337,7 @@ ZD_HD uint64_t coder_symbols_bits(const BlockCoder &c, const uint32_t *hlit, con
   for (int sym = 0; sym <= LITLEN_SYM_MAX; sym++)
     acc += (uint64_t)c.lit_freq[sym] * ((hlit[sym] & 0x1F) + (uint32_t)length_extra_bits(sym));
   for (int sym = 0; sym <= DIST_SYM_MAX; sym++)
-    acc += (uint64_t)c.dist_freq[sym] * ((hdist[sym] & 0x1F) + (k_dist_value_of_sym[sym] & 0xF));
+    acc += (uint64_t)c.dist_freq[sym] * ((hdist[sym] & 0x1F) + (uint32_t)dist_extra_bits(sym));
   return acc;
 }
 
@@ -362,15 +372,16 @@ ZD_HD void symbol_bits(uint32_t bref, const uint32_t *hlit, const uint32_t *hdis
   const int lsym = length_to_sym((int)len);
   uint32_t si = hlit[lsym];
   int count = (int)(si & 0x1F);
-  const uint32_t lv = k_length_value_of_sym[lsym - LITLEN_FIRST_LEN];
-  uint64_t v = (uint64_t)(si >> 5) | ((uint64_t)(len - (lv >> 4)) << count);
-  int n = count + (int)(lv & 0xF);
+  uint32_t vbase, vextra;
+  length_sym_value(lsym, vbase, vextra);
+  uint64_t v = (uint64_t)(si >> 5) | ((uint64_t)(len - vbase) << count);
+  int n = count + (int)vextra;
   const int dsym = dist_to_sym((int)dist);
   si = hdist[dsym];
   count = (int)(si & 0x1F);
-  const uint32_t dv = k_dist_value_of_sym[dsym];
-  v |= ((uint64_t)(si >> 5) | ((uint64_t)(dist - (dv >> 4)) << count)) << n;
-  n += count + (int)(dv & 0xF);
+  dist_sym_value(dsym, vbase, vextra);
+  v |= ((uint64_t)(si >> 5) | ((uint64_t)(dist - vbase) << count)) << n;
+  n += count + (int)vextra;
   value = v;
   nbits = n;
 }

@@ -1,20 +1,24 @@
 // inflate.hip -- batch inflate kernel for gfx950 (CDNA4, wave64).
 //
-// Decomposition: ONE WAVEFRONT PER WORKGROUP carrying up to L <= 16 independent
-// deflate streams, one per lane (inflate_lane.h), each with its own decode
-// tables in LDS (2304 B per stream, interleaved across lanes so neighbouring
-// lanes hit neighbouring banks).  A deflate stream is a serial dependency chain
-// (the bit position of symbol k+1 depends on symbol k), so throughput comes from
-// streams in flight: L is picked by the host so that the batch spreads over all
-// 1024 SIMDs of the chip before lanes are packed (16 streams x 4 waves per CU
-// is what 160 KiB of LDS holds).
+// Decomposition: ONE WAVEFRONT PER WORKGROUP carrying L <= 16 independent deflate
+// streams, one per lane (inflate_lane.h).  A deflate stream is a serial
+// dependency chain (the bit position of symbol k+1 depends on symbol k), so
+// throughput comes from streams in flight; 2496 B of LDS per stream (tables +
+// input ring + deferred-copy queue) lets a CU hold 64 of them.
 //
-// What the 64 lanes do TOGETHER: when a lane reaches a stored block
-// (read_uncompressed_block, src/zipc_deflate.ml:671-680) or the end of a block
-// with crc_op = Adler_32 (inflated_block_crc, src/zipc_deflate.ml:682-690) it
-// parks with a request; the wave collects requests with a ballot and serves
-// them one by one with all 64 lanes -- coalesced 16 B/lane copies, and the
-// reference's 5552-byte Adler chunking with a wave reduction per chunk.
+// The wave alternates two phases:
+//   decode   every lane runs its own stream for up to ROUND_SYMBOLS symbols out
+//            of LDS only (no global loads; literals leave as 8-byte stores);
+//   service  wave-uniform code doing everything that needs global loads, once
+//            per round and for all lanes at the same time, so their latencies
+//            overlap instead of serialising the wave:
+//              1. fill the queued match copies (8 per lane in flight),
+//              2. copy parked long/overlapping matches (Buf.recopy zd.ml:63-75),
+//              3. copy stored blocks with all 64 lanes (read_uncompressed_block
+//                 zd.ml:671-680), 16 B per lane,
+//              4. per-block Adler-32 with the reference's 5552-byte chunking
+//                 (inflated_block_crc zd.ml:682-690),
+//              5. top up every lane's input ring with coalesced loads.
 #include "inflate_lane.h"
 #include "kernels.h"
 #include "wave_ops.h"
@@ -22,7 +26,83 @@
 namespace zd {
 
 static_assert(LDS_BYTES_PER_LANE == INFLATE_LDS_BYTES_PER_LANE, "kernels.h");
-constexpr int SYMBOL_BUDGET = 512;  // symbols a lane may decode between two service polls
+constexpr int ROUND_SYMBOLS = 64;  // symbols a lane may decode between two service points
+constexpr int MAX_L = 16;
+
+// Top up the input rings: for each stream j of the wave, lanes 0..63 load the
+// next (up to 64) words of its compressed input; all loads are issued before the
+// first LDS write so that one memory latency covers the whole wave.
+__device__ __forceinline__ void service_refill(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa,
+                                               int lane, int Lcount) {
+  uint32_t w[MAX_L];
+  uint32_t idx[MAX_L];
+#pragma unroll
+  for (int j = 0; j < MAX_L; j++) {
+    w[j] = 0;
+    idx[j] = 0xFFFFFFFFu;
+    if (j < Lcount) {
+      const uint32_t wr = __shfl(d.ring_wr, j, 64);
+      const uint32_t rd = __shfl(d.in_word, j, 64);
+      const uint32_t slen = __shfl(d.src_len, j, 64);
+      const unsigned long long so = __shfl((unsigned long long)d.src_off, j, 64);
+      const int ph = __shfl(d.phase, j, 64);
+      const uint32_t total = (slen + 3u) >> 2;
+      uint32_t lim = rd + (uint32_t)RING_WORDS;
+      if (lim > total) lim = total;
+      const uint32_t my = wr + (uint32_t)lane;
+      if (ph != PH_DONE && my < lim) {
+        idx[j] = my;
+        const uint8_t *p = sa + so + (uint64_t)my * 4u;
+        if (my * 4u + 4u <= slen) w[j] = load_u32_le(p);
+        else {
+          uint32_t v = 0;
+          for (uint32_t b = 0; my * 4u + b < slen; b++) v |= (uint32_t)p[b] << (8 * b);
+          w[j] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MAX_L; j++) {
+    if (j < Lcount && idx[j] != 0xFFFFFFFFu)
+      L.r[((idx[j] & (uint32_t)(RING_WORDS - 1)) << L.log2L) + j] = w[j];
+  }
+  // publish the new write cursors
+  if (d.phase != PH_DONE) {
+    const uint32_t total = d.total_words();
+    uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
+    if (lim > total) lim = total;
+    uint32_t nw = d.ring_wr + 64u;
+    if (nw > lim) nw = lim;
+    if (nw > d.ring_wr) d.ring_wr = nw;
+  }
+}
+
+// Fill the deferred copies of every lane, 8 per lane at a time: all loads of a
+// batch are issued before its stores.  Entries never depend on one another (a
+// match reaching into an unfilled hole is parked instead of queued).
+__device__ __forceinline__ void service_resolve(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ da) {
+  uint32_t maxc = d.q_count;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t u = __shfl_xor(maxc, o, 64);
+    maxc = u > maxc ? u : maxc;
+  }
+  uint8_t *dst = da + d.dst_off;
+  for (uint32_t base = 0; base < maxc; base += 8) {
+    DeferredCopy c[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      c[k].len = 0;
+      if (base + k < d.q_count)
+        deferred_load(c[k], dst, L.queue((int)(base + k), 0), L.queue((int)(base + k), 1));
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      if (c[k].len) deferred_store(c[k], dst);
+  }
+  d.q_count = 0;
+}
 
 __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
@@ -38,7 +118,7 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
 
   LaneLds L;
   L.w = (uint16_t *)lds_raw;
-  L.b = lds_raw + ((size_t)(LDS_U16_PER_LANE * 2) << log2L);
+  L.r = (uint32_t *)(lds_raw + ((size_t)(LDS_U16_PER_LANE * 2) << log2L));
   L.lane = lane & (Lcount - 1);
   L.log2L = log2L;
 
@@ -54,14 +134,23 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
     d.phase = PH_DONE;
   }
 
-  for (;;) {
-    if (d.phase == PH_HEADER || d.phase == PH_SYMBOLS) lane_step(d, L, A, SYMBOL_BUDGET, crc_adler);
+  service_refill(d, L, src_arena, lane, Lcount);
 
-    // --- cooperative services (wave-uniform control flow from here) ---
+  for (;;) {
+    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, ROUND_SYMBOLS, crc_adler);
+
+    // ---- service point: wave-uniform control flow from here ----
+    if (__ballot(d.q_count != 0)) service_resolve(d, L, dst_arena);
+
+    if (__ballot(d.phase == PH_REQ_MATCH)) {
+      if (d.phase == PH_REQ_MATCH) {
+        lane_copy_match(dst_arena + d.dst_off, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
+        lane_after_match(d);
+      }
+    }
+
     unsigned long long m = __ballot(d.phase == PH_REQ_COPY);
     if (m) {
-      // our own earlier byte stores must be visible to the wide copies below
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       while (m) {
         const int leader = __ffsll((long long)m) - 1;
         m &= m - 1;
@@ -70,25 +159,27 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
         const uint32_t len = __shfl(d.req_len, leader, 64);
         wave_copy(dst_arena + oo, src_arena + so, len, lane);
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       if (d.phase == PH_REQ_COPY) lane_after_copy(d, crc_adler);
     }
+
     m = __ballot(d.phase == PH_REQ_ADLER);
     if (m) {
+      // the block's bytes were stored by other lanes of this wave: make them visible
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       while (m) {
         const int leader = __ffsll((long long)m) - 1;
         m &= m - 1;
         const unsigned long long po = __shfl((unsigned long long)(d.dst_off + d.blk_out_start), leader, 64);
-        const uint8_t *p = dst_arena + po;
         const uint32_t n = __shfl(d.out_pos - d.blk_out_start, leader, 64);
         const uint32_t a = __shfl(d.adler, leader, 64);
-        const uint32_t r = wave_adler_update(a, p, n, lane);
+        const uint32_t r = wave_adler_update(a, dst_arena + po, n, lane);
         if (lane == leader) d.adler = r;
       }
       if (d.phase == PH_REQ_ADLER) lane_after_adler(d);
     }
+
     if (!__ballot(d.phase != PH_DONE)) break;
+    service_refill(d, L, src_arena, lane, Lcount);
   }
 
   if (has_stream) {

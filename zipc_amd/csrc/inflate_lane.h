@@ -1,13 +1,24 @@
 // inflate_lane.h -- one deflate stream decoded by ONE lane.
 //
 // This is the lane-serial half of the batch inflate kernel (inflate.hip): a
-// wavefront carries up to 16 independent streams, one per lane, each running the
-// decoder below against its own tables in LDS; the wave's other half -- bulk
-// copies of stored blocks and per-block Adler-32 -- is served cooperatively by
-// all 64 lanes (inflate.hip).  The decoder is table driven (9-bit litlen /
-// 7-bit dist lookup, canonical walk for longer codes) instead of the
-// reference's bit-at-a-time walk, but it accepts and rejects exactly the same
-// streams, in the same order of checks:
+// wavefront carries up to 16 independent streams, one per lane.  Everything a
+// lane touches while it decodes symbols lives in LDS -- its decode tables, a
+// 64-word ring of its compressed input, a queue of deferred match copies -- so
+// the symbol loop issues NO global loads: the only vector-memory traffic it
+// generates are the literal stores (8 literals per 8-byte store).  Whatever
+// needs a global load is parked and done by the whole wave at the next service
+// point (inflate.hip), in lockstep, so that one memory latency is paid per
+// round instead of one per match:
+//   * short non-overlapping matches (len <= 16 <= dist) are queued as holes
+//     {dst_pos, dist, len} and filled later -- legal because a later symbol can
+//     only observe those bytes through another match, and a match whose source
+//     reaches into an unfilled hole parks until the holes are filled;
+//   * long or overlapping matches, stored blocks, per-block Adler-32 and the
+//     refill of the input ring are requests served by all 64 lanes.
+//
+// The decoder is table driven (9-bit litlen / 7-bit dist lookup, canonical walk
+// for longer codes) instead of the reference's bit-at-a-time walk, but accepts
+// and rejects exactly the same streams, in the same order of checks:
 //   read_bits / read_symbol        src/zipc_deflate.ml:564-591
 //   read_block_symbols             src/zipc_deflate.ml:593-616
 //   read_fixed_block               src/zipc_deflate.ml:618-621
@@ -34,24 +45,33 @@ constexpr int LDS_DIST_SYMS = LDS_LIT_SYMS + 288;       // 32 x u16
 constexpr int LDS_LIT_COUNTS = LDS_DIST_SYMS + 32;      // 16 x u16
 constexpr int LDS_DIST_COUNTS = LDS_LIT_COUNTS + 16;    // 16 x u16
 constexpr int LDS_U16_PER_LANE = LDS_DIST_COUNTS + 16;  // 992
-constexpr int LDS_LENGTHS_BYTES = 320;                  // code lengths scratch (u8)
-constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_LENGTHS_BYTES;  // 2304
+// While a dynamic header is read the litlen table is not built yet: its region
+// holds the distribution-sort cursors [0,16) and the 316 code lengths [16,336).
+constexpr int LDS_LENGTHS = LDS_LIT_TBL + 16;
+constexpr int RING_WORDS = 64;       // input ring, 32-bit words
+constexpr int QUEUE_ENTRIES = 32;    // deferred copies, 2 words each
+constexpr int LDS_U32_PER_LANE = RING_WORDS + 2 * QUEUE_ENTRIES;  // 128
+constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 2496
+constexpr uint32_t DEFER_MAX_LEN = 16;
 
 struct LaneLds {
   uint16_t *w;  // u16 regions of this wave's block
-  uint8_t *b;   // u8 lengths region of this wave's block
+  uint32_t *r;  // u32 regions (ring, queue) of this wave's block
   int lane;     // my slot, < (1 << log2L)
   int log2L;
   ZD_HD uint16_t &u16(int off, int i) const { return w[((off + i) << log2L) + lane]; }
-  ZD_HD uint8_t &len8(int i) const { return b[(i << log2L) + lane]; }
+  ZD_HD uint32_t &ring(uint32_t word) const { return r[((word & (RING_WORDS - 1)) << log2L) + lane]; }
+  ZD_HD uint32_t &queue(int k, int half) const { return r[((RING_WORDS + 2 * k + half) << log2L) + lane]; }
 };
 
 enum : int {
-  PH_HEADER = 0,     // at a block header
-  PH_SYMBOLS = 1,    // inside a compressed block
-  PH_REQ_COPY = 2,   // stored block validated: waiting for the cooperative copy
-  PH_REQ_ADLER = 3,  // block finished: waiting for the cooperative Adler-32 update
-  PH_DONE = 4
+  PH_HEADER = 0,       // at a block header
+  PH_HDR_LENGTHS = 1,  // inside a dynamic header, reading the code lengths
+  PH_SYMBOLS = 2,      // inside a compressed block
+  PH_REQ_COPY = 3,     // stored block validated: waiting for the cooperative copy
+  PH_REQ_MATCH = 4,    // a match that cannot be deferred: waiting for the lockstep copy
+  PH_REQ_ADLER = 5,    // block finished: waiting for the cooperative Adler-32 update
+  PH_DONE = 6
 };
 
 // Arena base pointers stay kernel arguments (so every access is a global_*
@@ -61,11 +81,21 @@ struct Arenas {
   uint8_t *__restrict__ dst;
 };
 
+ZD_HD void store_u32_le(uint8_t *p, uint32_t v) {
+  typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
+  *(u32u *)p = v;
+}
+
 struct InflateLane {
   uint64_t src_off, dst_off;
-  uint64_t bits;
-  uint32_t src_len, in_pos;
-  int32_t nbits;
+  uint64_t bits;       // bit buffer, LSB first (src_bits zd.ml:536)
+  uint64_t lit_acc;    // up to 8 literals not yet stored: bytes [out_pos - lit_n, out_pos)
+  uint32_t src_len;
+  uint32_t in_word;    // next input word to pull from the ring
+  uint32_t ring_wr;    // one past the last word staged in the ring
+  uint32_t skip;       // bytes to drop from the next pulled word (after a stored block)
+  int32_t nbits;       // REAL bits in `bits` (src_bits_len zd.ml:537)
+  uint32_t lit_n;
   uint32_t out_pos;
   uint32_t cap_min;    // min(limit, dst_cap): fast overflow test
   uint32_t limit;      // ?decompressed_size, or 0xFFFFFFFF
@@ -75,28 +105,37 @@ struct InflateLane {
   int32_t final_block;
   int32_t lit_max_sym, dist_max_sym;
   uint32_t blk_out_start;  // first output byte of the current block
-  uint32_t req_src, req_len;
-  uint32_t adler;          // running Adler_32 value (zd.ml:542) when crc_op = Adler
+  uint32_t req_src, req_len, req_dist;
+  uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position
+  int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max;  // dynamic header in progress
+  uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
 
-  // read_bits' refill (zd.ml:570-575) done a word at a time: nbits only ever
-  // counts REAL bits, so "count > nbits" after a refill is the reference's
-  // "src_pos > src_max" exhaustion test.
-  ZD_HD void refill(const uint8_t *__restrict__ sa) {
-    if (nbits <= 32) {
-      const uint8_t *src = sa + src_off;
-      if (in_pos + 4 <= src_len) {
-        bits |= (uint64_t)load_u32_le(src + in_pos) << nbits;
-        nbits += 32;
-        in_pos += 4;
-      } else {
-#pragma unroll 1
-        while (in_pos < src_len && nbits <= 56) {
-          bits |= (uint64_t)src[in_pos++] << nbits;
-          nbits += 8;
-        }
+  ZD_HD uint32_t total_words() const { return (src_len + 3u) >> 2; }
+  // enough staged input for `words` more pulls, or nothing left to stage
+  ZD_HD bool input_ready(uint32_t words) const {
+    return ring_wr - in_word >= words || ring_wr >= total_words();
+  }
+
+  // read_bits' refill (zd.ml:570-575), a word at a time out of the LDS ring.
+  // nbits only ever counts REAL bits (bytes past the end are masked to zero and
+  // not counted), so "count > nbits" with nothing left to pull is the
+  // reference's "src_pos > src_max" exhaustion test.
+  ZD_HD void pull(const LaneLds &L) {
+    if (nbits <= 32 && in_word < ring_wr) {
+      uint32_t w = L.ring(in_word);
+      const uint32_t base = in_word * 4u;
+      int32_t valid = (int32_t)(src_len - base < 4u ? src_len - base : 4u);
+      if (skip) {
+        w = skip >= 4 ? 0u : w >> (8 * skip);
+        valid -= (int32_t)skip;
+        if (valid < 0) valid = 0;
+        skip = 0;
       }
+      bits |= (uint64_t)w << nbits;
+      nbits += 8 * valid;
+      in_word++;
     }
   }
   ZD_HD bool take(int n, uint32_t &v) {  // false = input exhausted
@@ -106,8 +145,8 @@ struct InflateLane {
     nbits -= n;
     return true;
   }
-  ZD_HD bool read_bits(const uint8_t *__restrict__ sa, int n, uint32_t &v) {
-    refill(sa);
+  ZD_HD bool read_bits(const LaneLds &L, int n, uint32_t &v) {
+    pull(L);
     return take(n, v);
   }
 
@@ -115,21 +154,35 @@ struct InflateLane {
   // decompression size exceeded" (zd.ml:27-29); running out of the caller's
   // dst_cap with no limit given is the boundary's DST_TOO_SMALL.
   ZD_HD void overflow(uint64_t need) { fail(need > limit ? ST_SIZE_EXCEEDED : ST_DST_TOO_SMALL); }
+
+  // store the pending literals (one 8-byte store; the bytes past lit_n lie at or
+  // beyond out_pos, where nothing valid exists yet)
+  ZD_HD void flush_literals(uint8_t *__restrict__ da) {
+    if (lit_n) {
+      uint8_t *o = da + dst_off + (out_pos - lit_n);
+      if ((uint64_t)(out_pos - lit_n) + 8 <= hard_cap) store_u64_le(o, lit_acc);
+      else {
+#pragma unroll 1
+        for (uint32_t i = 0; i < lit_n; i++) o[i] = (uint8_t)(lit_acc >> (8 * i));
+      }
+      lit_acc = 0;
+      lit_n = 0;
+    }
+  }
 };
 
 // Huffman.init_decoder zd.ml:355-391 on lengths[start .. start+n) held in the
-// lane's u8 scratch; fills counts/syms regions.  Returns false when the
-// reference raises "Corrupted data stream".
+// lane's lengths scratch; fills counts/syms regions.  scratch_off: 16 free u16
+// slots for the reference's `offs` cursors.  Returns false when the reference
+// raises "Corrupted data stream".
 ZD_HD bool init_decoder(const LaneLds &L, int counts_off, int syms_off, int scratch_off,
                         int start, int n, int &max_sym) {
-  // scratch_off: 16 free u16 slots (the lookup-table region that is built next)
-  // holding the reference's `offs` distribution-sort cursors
 #pragma unroll 1
   for (int i = 0; i < 16; i++) L.u16(counts_off, i) = 0;
   max_sym = -1;
 #pragma unroll 1
   for (int i = 0; i < n; i++) {
-    int len = L.len8(start + i);
+    int len = L.u16(LDS_LENGTHS, start + i);
     if (len != 0) { max_sym = i; L.u16(counts_off, len) += 1; }
   }
   int available = 1, num_codes = 0;
@@ -145,7 +198,7 @@ ZD_HD bool init_decoder(const LaneLds &L, int counts_off, int syms_off, int scra
     return false;  // zd.ml:377-378
 #pragma unroll 1
   for (int i = 0; i < n; i++) {
-    int len = L.len8(start + i);
+    int len = L.u16(LDS_LENGTHS, start + i);
     if (len != 0) {
       int off = L.u16(scratch_off, len);
       L.u16(syms_off, off) = (uint16_t)i;
@@ -243,65 +296,80 @@ ZD_HD void setup_fixed(InflateLane &d, const LaneLds &L) {
   build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
 }
 
-// read_dynamic_codes zd.ml:638-667 (+ read_codelen_code zd.ml:624-636)
-ZD_HD bool setup_dynamic(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
+// read_dynamic_codes zd.ml:638-643 + read_codelen_code zd.ml:624-636: the fixed
+// part of a dynamic header (at most 71 bits: the caller made 3 words ready).
+ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
   uint32_t v;
-  if (!d.read_bits(sa, 5, v)) return false;
-  int hlit = 257 + (int)v;
-  if (!d.read_bits(sa, 5, v)) return false;
-  int hdist = 1 + (int)v;
+  if (!d.read_bits(L, 5, v)) return false;
+  const int hlit = 257 + (int)v;
+  if (!d.read_bits(L, 5, v)) return false;
+  const int hdist = 1 + (int)v;
   if (hlit > 286 || hdist > 30) return false;  // zd.ml:641
-  if (!d.read_bits(sa, 4, v)) return false;
-  int hclen = 4 + (int)v;
+  if (!d.read_bits(L, 4, v)) return false;
+  const int hclen = 4 + (int)v;
 #pragma unroll 1
-  for (int i = 0; i < 19; i++) L.len8(i) = 0;
+  for (int i = 0; i < 19; i++) L.u16(LDS_LENGTHS, i) = 0;
 #pragma unroll 1
   for (int i = 0; i < hclen; i++) {
-    if (!d.read_bits(sa, 3, v)) return false;
-    L.len8(k_codelen_order[i]) = (uint8_t)v;
+    if (!d.read_bits(L, 3, v)) return false;
+    L.u16(LDS_LENGTHS, k_codelen_order[i]) = (uint16_t)v;
   }
   // the code-length code lives in the dist regions while the header is read
   int cl_max_sym;
   if (!init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, 0, 19, cl_max_sym)) return false;
   if (cl_max_sym == -1) return false;  // zd.ml:635
   build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-  int num = 0;
-  const int total = hlit + hdist;
+  d.hdr_num = 0;
+  d.hdr_hlit = hlit;
+  d.hdr_hdist = hdist;
+  d.hdr_cl_max = cl_max_sym;
+  return true;
+}
+
+// zd.ml:644-667: the code lengths.  Returns 1 when the header is complete, 0 when
+// the lane must wait for input, -1 for "Corrupted data stream".
+ZD_HD int setup_dynamic_lengths(InflateLane &d, const LaneLds &L) {
+  const int total = d.hdr_hlit + d.hdr_hdist;
+  int num = d.hdr_num;
+  uint32_t v;
 #pragma unroll 1
   while (num < total) {
-    d.refill(sa);
+    if (!d.input_ready(1)) { d.hdr_num = num; return 0; }  // <= 14 bits per turn
+    d.pull(L);
     int sym = read_symbol(d, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-    if (sym < 0 || sym > cl_max_sym) return false;  // zd.ml:649
+    if (sym < 0 || sym > d.hdr_cl_max) return -1;  // zd.ml:649
     int repeat;
     switch (sym) {
     case 16:
-      if (num == 0) return false;  // zd.ml:653
-      if (!d.read_bits(sa, 2, v)) return false;
+      if (num == 0) return -1;  // zd.ml:653
+      if (!d.take(2, v)) return -1;
       repeat = 3 + (int)v;
-      sym = L.len8(num - 1);
+      sym = L.u16(LDS_LENGTHS, num - 1);
       break;
     case 17:
-      if (!d.read_bits(sa, 3, v)) return false;
+      if (!d.take(3, v)) return -1;
       repeat = 3 + (int)v;
       sym = 0;
       break;
     case 18:
-      if (!d.read_bits(sa, 7, v)) return false;
+      if (!d.take(7, v)) return -1;
       repeat = 11 + (int)v;
       sym = 0;
       break;
     default: repeat = 1; break;
     }
-    if (repeat > total - num) return false;  // zd.ml:659 (may span litlen/dist)
+    if (repeat > total - num) return -1;  // zd.ml:659 (may span litlen/dist)
 #pragma unroll 1
-    while (repeat > 0) { repeat--; L.len8(num) = (uint8_t)sym; num++; }
+    while (repeat > 0) { repeat--; L.u16(LDS_LENGTHS, num) = (uint16_t)sym; num++; }
   }
-  if (L.len8(256) == 0) return false;  // zd.ml:662
-  if (!init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, hlit, d.lit_max_sym)) return false;
-  if (!init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, hlit, hdist, d.dist_max_sym)) return false;
+  d.hdr_num = num;
+  if (L.u16(LDS_LENGTHS, 256) == 0) return -1;  // zd.ml:662
+  if (!init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, d.hdr_hlit, d.lit_max_sym)) return -1;
+  if (!init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, d.hdr_hlit, d.hdr_hdist, d.dist_max_sym))
+    return -1;
   build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
   build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-  return true;
+  return 1;
 }
 
 // Buf.recopy zd.ml:63-75 into global memory.  Far matches move 8 bytes at a
@@ -320,100 +388,139 @@ ZD_HD void lane_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t l
 }
 
 // One block header (inflate_loop zd.ml:694-701) up to the point where symbols
-// can be decoded, or a stored block can be copied.
-ZD_HD void lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
+// can be decoded, or a stored block can be copied.  Returns false when the lane
+// must wait for input (nothing consumed).
+ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
+  if (!d.input_ready(3)) return false;  // 3 + 14 + 57 header bits at most
   uint32_t v;
   const uint8_t *src = sa + d.src_off;
-  if (!d.read_bits(sa, 1, v)) return d.fail(ST_CORRUPTED);
+  if (!d.read_bits(L, 1, v)) { d.fail(ST_CORRUPTED); return true; }
   d.final_block = (int)v;
-  if (!d.read_bits(sa, 2, v)) return d.fail(ST_CORRUPTED);
+  if (!d.read_bits(L, 2, v)) { d.fail(ST_CORRUPTED); return true; }
   d.blk_out_start = d.out_pos;
   switch (v) {
   case 0: {  // read_uncompressed_block zd.ml:671-680
     // the reference buffers < 8 bits, so its src_pos is the byte after the
     // last one touched: ceil(consumed_bits / 8)
-    uint32_t consumed_bits = d.in_pos * 8u - (uint32_t)d.nbits;
-    uint32_t pos = (consumed_bits + 7u) >> 3;
-    if (d.src_len - pos < 4) return d.fail(ST_CORRUPTED);
-    uint32_t length = src[pos] | ((uint32_t)src[pos + 1] << 8);
-    uint32_t inv = src[pos + 2] | ((uint32_t)src[pos + 3] << 8);
-    if (length != ((~inv) & 0xFFFFu)) return d.fail(ST_CORRUPTED);
+    const uint64_t pulled = (uint64_t)d.in_word * 4u < d.src_len ? (uint64_t)d.in_word * 4u : d.src_len;
+    const uint64_t consumed_bits = pulled * 8u - (uint64_t)d.nbits;
+    uint32_t pos = (uint32_t)((consumed_bits + 7u) >> 3);
+    if (d.src_len - pos < 4) { d.fail(ST_CORRUPTED); return true; }
+    const uint32_t length = src[pos] | ((uint32_t)src[pos + 1] << 8);
+    const uint32_t inv = src[pos + 2] | ((uint32_t)src[pos + 3] << 8);
+    if (length != ((~inv) & 0xFFFFu)) { d.fail(ST_CORRUPTED); return true; }
     pos += 4;
-    if (d.src_len - pos < length) return d.fail(ST_CORRUPTED);
-    if ((uint64_t)d.out_pos + length > d.cap_min) return d.overflow((uint64_t)d.out_pos + length);
+    if (d.src_len - pos < length) { d.fail(ST_CORRUPTED); return true; }
+    if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return true; }
     d.req_src = pos;
     d.req_len = length;
-    d.in_pos = pos + length;
+    // input resumes at the byte after the block: word-aligned pull + byte skip
+    const uint32_t next = pos + length;
+    d.in_word = next >> 2;
+    d.skip = next & 3u;
+    if (d.ring_wr < d.in_word) d.ring_wr = d.in_word;  // ring holds nothing useful
     d.bits = 0;
     d.nbits = 0;
     d.phase = PH_REQ_COPY;
-    return;
+    return true;
   }
   case 1:
     setup_fixed(d, L);
     d.phase = PH_SYMBOLS;
-    return;
+    return true;
   case 2:
-    if (!setup_dynamic(d, L, sa)) return d.fail(ST_CORRUPTED);
-    d.phase = PH_SYMBOLS;
-    return;
-  default: return d.fail(ST_CORRUPTED);  // zd.ml:701
+    if (!setup_dynamic_begin(d, L)) { d.fail(ST_CORRUPTED); return true; }
+    d.phase = PH_HDR_LENGTHS;
+    return true;
+  default: d.fail(ST_CORRUPTED); return true;  // zd.ml:701
   }
 }
 
-// read_block_symbols zd.ml:593-616, at most `budget` symbols.  Returns true
-// when the end-of-block symbol was read.
-ZD_HD bool lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int budget) {
+enum : int { SYM_BUDGET = 0, SYM_EOB = 1, SYM_STOP = 2 };
+
+// read_block_symbols zd.ml:593-616, at most `budget` symbols.  SYM_STOP: failed,
+// parked on a request, or waiting for input / for the deferred copies.
+ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int budget) {
   uint8_t *dst = A.dst + d.dst_off;
 #pragma unroll 1
   for (int n = 0; n < budget; n++) {
-    d.refill(A.src);
+    if (!d.input_ready(2)) return SYM_STOP;  // a symbol pulls at most twice
+    d.pull(L);
     int sym = read_symbol(d, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
-    if (sym < 0) { d.fail(ST_CORRUPTED); return false; }
+    if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
     if (sym < LITLEN_EOB) {
-      if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return false; }
-      dst[d.out_pos++] = (uint8_t)sym;
+      if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
+      d.lit_acc |= (uint64_t)(uint32_t)sym << (8 * d.lit_n);
+      d.lit_n++;
+      d.out_pos++;
+      if (d.lit_n == 8) {
+        store_u64_le(dst + d.out_pos - 8, d.lit_acc);  // out_pos <= cap_min <= hard_cap
+        d.lit_acc = 0;
+        d.lit_n = 0;
+      }
       continue;
     }
-    if (sym == LITLEN_EOB) return true;
-    if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return false; }
-    uint32_t lv = k_length_value_of_sym[sym - LITLEN_FIRST_LEN], v = 0;
-    if ((lv & 0xF) != 0 && !d.take((int)(lv & 0xF), v)) { d.fail(ST_CORRUPTED); return false; }
-    uint32_t length = (lv >> 4) + v;
-    d.refill(A.src);
+    if (sym == LITLEN_EOB) return SYM_EOB;
+    if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    uint32_t vbase, vextra, v = 0;
+    length_sym_value(sym, vbase, vextra);
+    if (vextra != 0 && !d.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    const uint32_t length = vbase + v;
+    d.pull(L);
     int dsym = read_symbol(d, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-    if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return false; }
-    uint32_t dv = k_dist_value_of_sym[dsym];
+    if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    dist_sym_value(dsym, vbase, vextra);
     v = 0;
-    if ((dv & 0xF) != 0 && !d.take((int)(dv & 0xF), v)) { d.fail(ST_CORRUPTED); return false; }
-    uint32_t dist = (dv >> 4) + v;
-    if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return false; }  // zd.ml:614
-    if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return false; }
-    lane_copy_match(dst, d.out_pos, dist, length, d.hard_cap);
-    d.out_pos += length;
+    if (vextra != 0 && !d.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    const uint32_t dist = vbase + v;
+    if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
+    if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
+    // Buf.recopy zd.ml:615 -- queued, or handed to the wave
+    d.flush_literals(A.dst);
+    const uint32_t src_pos = d.out_pos - dist;
+    const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
+    if (length <= DEFER_MAX_LEN && dist >= length && !hazard && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+      if (d.q_count == 0) d.hole_min = d.out_pos;
+      L.queue((int)d.q_count, 0) = d.out_pos;
+      L.queue((int)d.q_count, 1) = dist | (length << 16);
+      d.q_count++;
+      d.out_pos += length;
+    } else {
+      d.req_dist = dist;
+      d.req_len = length;
+      d.phase = PH_REQ_MATCH;
+      return SYM_STOP;
+    }
   }
-  return false;
+  return SYM_BUDGET;
 }
 
-// Runs the lane until it finishes, fails, needs a cooperative service, or has
-// spent `budget` symbols.  crc_adler selects the per-block Adler-32 request.
+// Runs the lane until it finishes, fails, parks, or has spent `budget` symbols.
+// Pending literals are always stored before returning.
 ZD_HD void lane_step(InflateLane &d, const LaneLds &L, const Arenas &A, int budget, bool crc_adler) {
 #pragma unroll 1
   while (budget > 0) {
     if (d.phase == PH_HEADER) {
-      lane_block_header(d, L, A.src);
+      if (!lane_block_header(d, L, A.src)) break;  // waits for input
+      budget -= 8;
+    } else if (d.phase == PH_HDR_LENGTHS) {
+      const int r = setup_dynamic_lengths(d, L);
+      if (r == 0) break;
+      if (r < 0) { d.fail(ST_CORRUPTED); break; }
+      d.phase = PH_SYMBOLS;
       budget -= 8;
     } else if (d.phase == PH_SYMBOLS) {
-      bool eob = lane_symbols(d, L, A, budget);
-      if (!eob) return;  // failed or budget spent
+      const int r = lane_symbols(d, L, A, budget);
+      if (r != SYM_EOB) break;
       // inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
-      if (crc_adler) { d.phase = PH_REQ_ADLER; return; }
+      if (crc_adler) { d.phase = PH_REQ_ADLER; break; }
       d.phase = d.final_block ? PH_DONE : PH_HEADER;
       budget -= 8;
     } else {
-      return;
+      break;
     }
   }
+  d.flush_literals(A.dst);
 }
 
 // after the cooperative copy of a stored block
@@ -422,25 +529,61 @@ ZD_HD void lane_after_copy(InflateLane &d, bool crc_adler) {
   if (crc_adler) d.phase = PH_REQ_ADLER;
   else d.phase = d.final_block ? PH_DONE : PH_HEADER;
 }
+// after the lockstep copy of a parked match
+ZD_HD void lane_after_match(InflateLane &d) {
+  d.out_pos += d.req_len;
+  d.phase = PH_SYMBOLS;
+}
 // after the cooperative Adler-32 update of the block's output
 ZD_HD void lane_after_adler(InflateLane &d) {
   d.blk_out_start = d.out_pos;
   d.phase = d.final_block ? PH_DONE : PH_HEADER;
 }
 
+// One deferred copy: 3 <= len <= 16, dist >= len.  Two possibly overlapping
+// 8-byte (or 4-byte) moves cover exactly [0, len), so neighbours are untouched;
+// len = 3 (never produced by the reference's encoder, but legal) loads 4 bytes
+// -- the 4th lies at or before the hole's first byte -- and stores 2 + 1.
+struct DeferredCopy {
+  uint64_t a, b;
+  uint32_t dst_pos, len;
+};
+ZD_HD void deferred_load(DeferredCopy &c, const uint8_t *dst, uint32_t dst_pos, uint32_t dist_len) {
+  const uint32_t dist = dist_len & 0xFFFFu, len = dist_len >> 16;
+  const uint8_t *s = dst + dst_pos - dist;
+  c.dst_pos = dst_pos;
+  c.len = len;
+  if (len >= 8) { c.a = load_u64_le(s); c.b = load_u64_le(s + len - 8); }
+  else if (len >= 4) { c.a = load_u32_le(s); c.b = load_u32_le(s + len - 4); }
+  else { c.a = load_u32_le(s); c.b = 0; }
+}
+ZD_HD void deferred_store(const DeferredCopy &c, uint8_t *dst) {
+  uint8_t *o = dst + c.dst_pos;
+  if (c.len >= 8) { store_u64_le(o, c.a); store_u64_le(o + c.len - 8, c.b); }
+  else if (c.len >= 4) { store_u32_le(o, (uint32_t)c.a); store_u32_le(o + c.len - 4, (uint32_t)c.b); }
+  else { o[0] = (uint8_t)c.a; o[1] = (uint8_t)(c.a >> 8); o[2] = (uint8_t)(c.a >> 16); }
+}
+
 ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.src_off = s.src_off;
   d.dst_off = s.dst_off;
   d.bits = 0;
+  d.lit_acc = 0;
   d.nbits = 0;
-  d.in_pos = 0;
+  d.lit_n = 0;
+  d.in_word = 0;
+  d.ring_wr = 0;
+  d.skip = 0;
   d.out_pos = 0;
   d.status = ST_OK;
   d.phase = PH_HEADER;
   d.final_block = 0;
   d.lit_max_sym = d.dist_max_sym = -1;
   d.blk_out_start = 0;
-  d.req_src = d.req_len = 0;
+  d.req_src = d.req_len = d.req_dist = 0;
+  d.q_count = 0;
+  d.hole_min = 0;
+  d.hdr_num = d.hdr_hlit = d.hdr_hdist = d.hdr_cl_max = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
   if (s.src_len > 0xFFFFFFF0ull || s.dst_cap > 0xFFFFFFF0ull) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;

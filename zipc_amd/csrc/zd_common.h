@@ -79,6 +79,22 @@ ZD_CONST uint32_t k_dist_value_of_sym[30] = {
 // zd.ml:312-313
 ZD_CONST uint8_t k_codelen_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
+// The two tables above in closed form (no memory access: a table read in the
+// middle of a symbol loop is a global load, and its s_waitcnt also drains every
+// store the wave has in flight).  sym: litlen symbol 257..285 / dist symbol 0..29.
+ZD_HD void length_sym_value(int sym, uint32_t &base, uint32_t &extra) {
+  const uint32_t idx = (uint32_t)(sym - LITLEN_FIRST_LEN);
+  if (idx < 4) { base = 3 + idx; extra = 0; return; }
+  if (idx == 28) { base = 258; extra = 0; return; }
+  extra = (idx - 4) >> 2;
+  base = 3 + ((4 + (idx & 3)) << extra);
+}
+ZD_HD void dist_sym_value(int sym, uint32_t &base, uint32_t &extra) {
+  if (sym < 4) { base = 1 + (uint32_t)sym; extra = 0; return; }
+  extra = ((uint32_t)sym >> 1) - 1;
+  base = 1 + ((2 + ((uint32_t)sym & 1)) << extra);
+}
+
 // length value -> litlen symbol (zd.ml:260-267; later rows overwrite, so 258 -> 285)
 ZD_HD int length_to_sym(int len) {
   if (len == 258) return 285;
