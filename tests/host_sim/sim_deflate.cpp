@@ -76,10 +76,46 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       }
       for (uint32_t p = 0; p + 4 <= len; p++) match[p] = lz_match_position(src, len, p, prev.data(), K, K / 4);
     }
+    // macro step of every position (+ literal runs), then the walk in small
+    // resumable slices like the kernel's ring, then the symbol emission
+    std::vector<uint32_t> brefs(len + 8, 0), steps(len + 8, 0);
+    auto get = [&](uint32_t j) { return match[j]; };
+    for (uint32_t p = 0; p < len; p++) {
+      MacroStep m = lz_macro_position(p, len, good_match, get);
+      brefs[p] = m.bref;
+      steps[p] = m.step;
+    }
+    for (uint32_t p = 0; p < len; p++) {  // literal runs, capped and cut at 256-position tiles like the kernel
+      if (brefs[p]) continue;
+      uint32_t run = 1;
+      const uint32_t tile_end = (p / 256 + 1) * 256 + 32;
+      while (run < MAX_LIT_RUN && p + run < len && p + run < tile_end && brefs[p + run] == 0) run++;
+      steps[p] = macro_literal_run(run);
+    }
+    std::vector<uint64_t> bitmap((len + 63) / 64 + 1, ~0ull);
+    std::vector<uint32_t> tile_sym(len / WALK_TILE + 2, 0xFFFFFFFFu);
     std::vector<uint32_t> syms(len + 8);
     std::vector<BlockDesc> blocks(len / 65277 + 4);
-    uint32_t nblk = lz_parse_stream(src, len, match.data(), good_match, syms.data(), blocks.data());
-
+    WalkState ws;
+    lz_walk_init(ws);
+    auto gets = [&](uint32_t j) { return steps[j]; };
+    uint32_t stop = 0;
+    while (ws.p < len) {
+      stop = ws.p + 64;  // ring window
+      lz_walk_advance(ws, len, stop, 48, gets, bitmap.data(), tile_sym.data(), blocks.data());
+    }
+    uint32_t nblk = lz_walk_finish(ws, len, bitmap.data(), tile_sym.data(), blocks.data());
+    for (uint32_t t = 0; t * WALK_TILE < len; t++) {
+      uint32_t idx = tile_sym[t];
+      for (uint32_t p = t * WALK_TILE; p < len && p < (t + 1) * WALK_TILE; p++) {
+        if (!((bitmap[p >> 6] >> (p & 63)) & 1)) continue;
+        MacroStep m;
+        m.bref = brefs[p];
+        m.step = steps[p];
+        lz_emit_position(src, p, m, syms.data(), idx);
+        idx += macro_sym_count(m);
+      }
+    }
     uint32_t lit_freq[288], dist_freq[32], codelen_freq[19] = {0}, dyn_lit[288], dyn_dist[32],
         dyn_codelen[32], fix_lit[288], fix_dist[32], codelen_syms[320], heap[577];
     memset(dyn_lit, 0, sizeof dyn_lit); memset(dyn_dist, 0, sizeof dyn_dist);

@@ -12,10 +12,15 @@
 //                            (64 KiB), 1024 positions inserted per round.
 //   lz_match_kernel          one lane per position: best match over the first K and
 //                            the first K/4 chain candidates (find_backref,
-//                            zd.ml:1176-1201) -> 8 bytes per position.
-//   lz_parse_kernel          one lane per stream: lazy parse + block cut
-//                            (Lz77.compress zd.ml:1203-1244, write_block_symbol
-//                            zd.ml:1118-1123) -> symbol array + block list.
+//                            zd.ml:1176-1201), exchanged through LDS with the
+//                            following positions to form the position's "macro
+//                            step" of the lazy parse (deflate_lane.h) -> 8 bytes
+//                            per position.
+//   lz_walk_kernel           one lane per stream: follows the macro steps from
+//                            position 0 (Lz77.compress zd.ml:1203-1244): visited
+//                            bitmap, symbol counts, block cut (zd.ml:1118-1123).
+//   lz_symbols_kernel        one lane per position: visited positions write their
+//                            symbols (block scan for the symbol index).
 //   deflate_emit_kernel      one wave per stream, blocks in order: histogram (LDS
 //                            atomics), Huffman codes + stored/fixed/dynamic choice
 //                            (write_block zd.ml:1094-1104, lane 0), then all 64 lanes
@@ -29,13 +34,13 @@
 
 namespace zd {
 
-constexpr uint32_t POS_PAD = 128;            // scratch slack per stream, in positions
+constexpr uint32_t POS_PAD = 256;            // scratch slack per stream, in positions
 constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 - 258 source bytes
 
 // streams with an out-of-range length are rejected by every kernel and take no scratch
 __host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
   if (src_len > 0xFFFFFFF0ull) src_len = 0;
-  return ((src_len + 63) & ~63ull) + POS_PAD;
+  return ((src_len + 255) & ~255ull) + POS_PAD;  // multiple of WALK_TILE and of 64
 }
 __host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
   if (src_len > 0xFFFFFFF0ull) src_len = 0;
@@ -47,8 +52,11 @@ struct DeflateScratch {
   uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
   uint32_t *n_blocks;   // [n]
   uint32_t *error;      // [1] != 0: scratch too small for the batch (bad total_src_len)
-  uint16_t *prev;       // [P]
-  uint64_t *match;      // [P]
+  uint16_t *prev;       // [P] chain links
+  uint32_t *bref;       // [P] MacroStep::bref
+  uint32_t *step;       // [P] MacroStep::step
+  uint64_t *bitmap;     // [P / 64] visited positions
+  uint32_t *tile_sym;   // [P / 256] first symbol index of each tile
   uint32_t *syms;       // [P]
   BlockDesc *blocks;    // [Bk]
   uint64_t cap_positions, cap_blocks;
@@ -57,7 +65,7 @@ struct DeflateScratch {
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static void scratch_caps(size_t n, size_t total_src_len, uint64_t &P, uint64_t &Bk) {
-  P = total_src_len + (uint64_t)(POS_PAD + 64) * n + 256;
+  P = total_src_len + (uint64_t)(POS_PAD + 256) * n + 256;
   Bk = total_src_len / MIN_BLOCK_SRC + 2 * (uint64_t)n + 16;
 }
 
@@ -67,7 +75,8 @@ size_t deflate_scratch_bytes(size_t n, size_t /*max_src_len*/, size_t total_src_
   size_t b = 0;
   b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
   if (level != LEVEL_NONE) {
-    b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
+    b += align_up(P * 2, 256) + 3 * align_up(P * 4, 256) + align_up(P / 8 + 64, 256) +
+         align_up(P / 64 + 64, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
   }
   return b + 1024;
@@ -82,11 +91,15 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
-  s.prev = nullptr; s.match = nullptr; s.syms = nullptr; s.blocks = nullptr;
+  s.prev = nullptr; s.bref = nullptr; s.step = nullptr; s.bitmap = nullptr; s.tile_sym = nullptr;
+  s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
     s.prev = (uint16_t *)p; p += align_up(P * 2, 256);
-    s.match = (uint64_t *)p; p += align_up(P * 8, 256);
+    s.bref = (uint32_t *)p; p += align_up(P * 4, 256);
+    s.step = (uint32_t *)p; p += align_up(P * 4, 256);
     s.syms = (uint32_t *)p; p += align_up(P * 4, 256);
+    s.bitmap = (uint64_t *)p; p += align_up(P / 8 + 64, 256);
+    s.tile_sym = (uint32_t *)p; p += align_up(P / 64 + 64, 256);
     s.blocks = (BlockDesc *)p; p += align_up(Bk * sizeof(BlockDesc), 256);
   }
   s.cap_positions = P;
@@ -224,35 +237,184 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
 
 // ---------------------------------------------------------------------------------
 constexpr uint32_t MATCH_THREADS = 256;
+constexpr uint32_t MATCH_HALO = 32;  // following positions whose matches are shared through LDS
+
+// match pairs of the tile (+ halo) in LDS; anything further is recomputed
+struct TileMatches {
+  const uint64_t *sm;
+  uint32_t base, count;
+  const uint8_t *s;
+  const uint16_t *prev;
+  uint32_t len;
+  int K, Kq;
+  __device__ __forceinline__ uint64_t operator()(uint32_t j) const {
+    const uint32_t k = j - base;
+    if (k < count) return sm[k];
+    return lz_match_position(s, len, j, prev, K, Kq);
+  }
+};
 
 __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
                                                                  DeflateScratch S, uint32_t chunks_per_stream,
-                                                                 int K, int Kq) {
+                                                                 int K, int Kq, int good_match) {
+  __shared__ uint64_t sm[MATCH_THREADS + MATCH_HALO];
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x / chunks_per_stream;
   const uint32_t chunk = blockIdx.x % chunks_per_stream;
   const StreamDesc sd = descs[stream];
-  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len == 0 || sd.src_len > 0xFFFFFFF0ull) return;
   const uint32_t len = (uint32_t)sd.src_len;
-  const uint32_t p = chunk * MATCH_THREADS + threadIdx.x;
-  if (p > len - 4) return;
+  const uint32_t base_pos = chunk * MATCH_THREADS;
+  if (base_pos >= len) return;  // uniform per workgroup
+  const uint8_t *s = src_arena + sd.src_off;
   const uint64_t base = S.pos_base[stream];
-  S.match[base + p] = lz_match_position(src_arena + sd.src_off, len, p, S.prev + base, K, Kq);
+  const uint16_t *prev = S.prev + base;
+  const uint32_t t = threadIdx.x;
+  const uint32_t p = base_pos + t;
+  const bool has_match = len >= 4;  // positions <= len - 4 have chain links
+  sm[t] = (has_match && p <= len - 4) ? lz_match_position(s, len, p, prev, K, Kq) : 0ull;
+  if (t < MATCH_HALO) {
+    const uint32_t ph = base_pos + MATCH_THREADS + t;
+    sm[MATCH_THREADS + t] = (has_match && ph <= len - 4) ? lz_match_position(s, len, ph, prev, K, Kq) : 0ull;
+  }
+  __syncthreads();
+  if (p >= len) return;
+  TileMatches get;
+  get.sm = sm; get.base = base_pos; get.count = MATCH_THREADS + MATCH_HALO;
+  get.s = s; get.prev = prev; get.len = len; get.K = K; get.Kq = Kq;
+  MacroStep m = lz_macro_position(p, len, good_match, get);
+  if (m.bref == 0) {
+    // literal position: let one walk step cover the run of literal positions
+    // that follows (as far as this tile's LDS image shows them)
+    uint32_t run = 1;
+    while (run < MAX_LIT_RUN && p + run < len && t + run < MATCH_THREADS + MATCH_HALO &&
+           ((uint32_t)sm[t + run] & 0x1FF) == 0)
+      run++;
+    m.step = macro_literal_run(run);
+  }
+  S.bref[base + p] = m.bref;
+  S.step[base + p] = m.step;
 }
 
 // ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
-                                                      const StreamDesc *__restrict__ descs, uint32_t n,
-                                                      DeflateScratch S, int good_match) {
+// One lane per stream, 16 streams per wave.  The step table of each stream is
+// staged through a 64-entry LDS ring that the wave refills with coalesced loads
+// between slices of WALK_SLICE steps, so a step costs an LDS read instead of a
+// dependent global load.
+constexpr int WALK_LANES = 16;
+constexpr int WALK_RING = 64;
+constexpr int WALK_SLICE = 48;
+
+struct WalkRing {
+  const uint32_t *ring;  // [WALK_RING][WALK_LANES]
+  int lane;
+  __device__ __forceinline__ uint32_t operator()(uint32_t q) const {
+    return ring[(q & (WALK_RING - 1)) * WALK_LANES + lane];
+  }
+};
+
+__global__ __launch_bounds__(64) void lz_walk_kernel(const StreamDesc *__restrict__ descs, uint32_t n,
+                                                     DeflateScratch S) {
+  __shared__ uint32_t ring[WALK_RING * WALK_LANES];
   if (S.error[0]) return;
-  const uint32_t stream = blockIdx.x * 64 + threadIdx.x;
-  if (stream >= n) return;
+  const int lane = threadIdx.x;
+  const uint32_t stream = blockIdx.x * WALK_LANES + (uint32_t)lane;
+  bool active = lane < WALK_LANES && stream < n;
+  uint32_t len = 0;
+  uint64_t base = 0, blk_base = 0;
+  if (active) {
+    const StreamDesc sd = descs[stream];
+    if (sd.src_len > 0xFFFFFFF0ull) { S.n_blocks[stream] = 0; active = false; }
+    else {
+      len = (uint32_t)sd.src_len;
+      base = S.pos_base[stream];
+      blk_base = S.blk_base[stream];
+    }
+  }
+  WalkState w;
+  lz_walk_init(w);
+  uint32_t ring_hi = 0;  // steps of positions < ring_hi are staged (those >= w.p are still needed)
+  WalkRing get;
+  get.ring = ring;
+  get.lane = lane;
+  uint64_t *bitmap = S.bitmap + (base >> 6);
+  uint32_t *tile_sym = S.tile_sym + base / WALK_TILE;
+  BlockDesc *blocks = S.blocks + blk_base;
+
+  for (;;) {
+    // ---- refill (wave-uniform): stream j gets positions [max(hi, p), min(p + 64, len))
+    uint32_t v[WALK_LANES], idx[WALK_LANES];
+#pragma unroll
+    for (int j = 0; j < WALK_LANES; j++) {
+      const uint32_t pj = __shfl(w.p, j, 64);
+      const uint32_t hj = __shfl(ring_hi, j, 64);
+      const uint32_t lj = __shfl(len, j, 64);
+      const unsigned long long bj = __shfl((unsigned long long)base, j, 64);
+      const uint32_t start = hj > pj ? hj : pj;
+      uint32_t lim = pj + (uint32_t)WALK_RING;
+      if (lim > lj) lim = lj;
+      const uint32_t my = start + (uint32_t)lane;
+      idx[j] = 0xFFFFFFFFu;
+      v[j] = 0;
+      if (my < lim) { idx[j] = my; v[j] = S.step[bj + my]; }
+    }
+#pragma unroll
+    for (int j = 0; j < WALK_LANES; j++)
+      if (idx[j] != 0xFFFFFFFFu) ring[(idx[j] & (WALK_RING - 1)) * WALK_LANES + j] = v[j];
+    {
+      uint32_t lim = w.p + (uint32_t)WALK_RING;
+      if (lim > len) lim = len;
+      if (lim > ring_hi) ring_hi = lim;
+    }
+    __syncthreads();
+    if (active) lz_walk_advance(w, len, ring_hi, WALK_SLICE, get, bitmap, tile_sym, blocks);
+    __syncthreads();
+    if (!__ballot(active && w.p < len)) break;
+  }
+  if (active) S.n_blocks[stream] = lz_walk_finish(w, len, bitmap, tile_sym, blocks);
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(WALK_TILE) void lz_symbols_kernel(const uint8_t *__restrict__ src_arena,
+                                                               const StreamDesc *__restrict__ descs,
+                                                               DeflateScratch S, uint32_t tiles_per_stream) {
+  __shared__ uint32_t wave_tot[WALK_TILE / 64];
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x / tiles_per_stream;
+  const uint32_t tile = blockIdx.x % tiles_per_stream;
   const StreamDesc sd = descs[stream];
-  if (sd.src_len > 0xFFFFFFF0ull) { S.n_blocks[stream] = 0; return; }
+  if (sd.src_len > 0xFFFFFFF0ull) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  if (tile * WALK_TILE >= len) return;  // uniform per workgroup
   const uint64_t base = S.pos_base[stream];
-  S.n_blocks[stream] = lz_parse_stream(src_arena + sd.src_off, (uint32_t)sd.src_len, S.match + base,
-                                       good_match, S.syms + base, S.blocks + S.blk_base[stream]);
+  const uint32_t t = threadIdx.x;
+  const uint32_t p = tile * WALK_TILE + t;
+  MacroStep m;
+  m.bref = 0;
+  m.step = 0;
+  uint32_t cnt = 0;
+  if (p < len && ((S.bitmap[(base >> 6) + (p >> 6)] >> (p & 63)) & 1ull)) {
+    m.bref = S.bref[base + p];
+    m.step = S.step[base + p];
+    cnt = macro_sym_count(m);
+  }
+  // exclusive scan of cnt over the 256 threads
+  const int lane = t & 63;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wave_tot[t >> 6] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+  for (uint32_t w = 0; w < (t >> 6); w++) before += wave_tot[w];
+  if (cnt) {
+    const uint32_t first = S.tile_sym[base / WALK_TILE + tile] + before + incl - cnt;
+    lz_emit_position(src_arena + sd.src_off, p, m, S.syms + base, first);
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -537,12 +699,14 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   level_params(level, good_match, K);
   ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S);
   ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
-  const size_t cps = max_src_len >= 4 ? (max_src_len - 4) / MATCH_THREADS + 1 : 1;
+  const size_t cps = max_src_len ? (max_src_len + MATCH_THREADS - 1) / MATCH_THREADS : 1;
   if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
   ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)(n * cps)), dim3(MATCH_THREADS), 0, d_src,
-            d_descs, S, (uint32_t)cps, K, K / 4);
-  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, d_src, d_descs,
-            (uint32_t)n, S, good_match);
+            d_descs, S, (uint32_t)cps, K, K / 4, good_match);
+  ZD_LAUNCH(ctx, "lz_walk", lz_walk_kernel, dim3((unsigned)((n + WALK_LANES - 1) / WALK_LANES)), dim3(64), 0,
+            d_descs, (uint32_t)n, S);
+  ZD_LAUNCH(ctx, "lz_symbols", lz_symbols_kernel, dim3((unsigned)(n * cps)), dim3(WALK_TILE), 0, d_src,
+            d_descs, S, (uint32_t)cps);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
             d_results, S, crc_op);
   return hipGetLastError();

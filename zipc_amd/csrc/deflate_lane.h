@@ -6,8 +6,9 @@
 //     (lz_chain_kernel) and, per position, the best match over the first K and
 //     first K/4 chain candidates (lz_match_position) are computed for ALL
 //     positions in parallel;
-//   * the lazy parse (lz_parse_stream) is then a cheap serial walk over those
-//     two tables, one lane per stream;
+//   * the lazy parse is then: a "macro step" per position (lz_macro_position,
+//     parallel), a serial walk over the steps (lz_walk_stream, one lane per
+//     stream, one table read per step) and a parallel symbol emission;
 //   * per block, code construction and the stored/fixed/dynamic choice
 //     (BlockCoder) are serial per stream because codelen_sym_freqs (Q1) and the
 //     pending bit count (Q3) carry from block to block.
@@ -54,7 +55,7 @@ ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t 
 // word) and among the first Kq = K/4 candidates (high word): longest common
 // prefix, nearest candidate on ties, only if longer than min_match_len - 1 = 3.
 // The reference's running threshold starts at the pending match length instead
-// of 3; lz_parse_stream applies that comparison afterwards, which selects the
+// of 3; lz_macro_position applies that comparison afterwards, which selects the
 // same candidate (the maximum does not depend on the threshold).
 ZD_HD uint64_t lz_match_position(const uint8_t *s, uint32_t len, uint32_t p, const uint16_t *prev,
                                  int K, int Kq) {
@@ -84,72 +85,171 @@ ZD_HD uint64_t lz_match_position(const uint8_t *s, uint32_t len, uint32_t p, con
   return (uint64_t)best | ((uint64_t)snap << 32);
 }
 
-// Lz77.compress zd.ml:1203-1244 + write_block_symbol zd.ml:1118-1123: the lazy
-// parse and the greedy block cut at 65534 source bytes.  match[p] is
-// lz_match_position(p).  Writes the symbol array (literal = byte, backref =
-// dist << 9 | len; the end-of-block symbol is implicit) and one BlockDesc per
-// block, the last one being the final block.  Returns the number of blocks.
-ZD_HD uint32_t lz_parse_stream(const uint8_t *s, uint32_t len, const uint64_t *match, int good_match,
-                               uint32_t *syms, BlockDesc *blocks) {
-  uint32_t nsym = 0, nblk = 0;
-  uint32_t blk_src_start = 0, blk_src_len = 0, blk_sym_start = 0;
-#define ZD_EMIT(sym, n)                                                              \
-  do {                                                                               \
-    if (blk_src_len + (n) > (uint32_t)MAX_BLOCK_SRC_LEN) {                           \
-      BlockDesc b_;                                                                  \
-      b_.src_start = blk_src_start; b_.src_len = blk_src_len;                        \
-      b_.sym_start = blk_sym_start; b_.n_syms = nsym - blk_sym_start;                \
-      blocks[nblk++] = b_;                                                           \
-      blk_src_start += blk_src_len; blk_src_len = 0; blk_sym_start = nsym;           \
-    }                                                                                \
-    syms[nsym++] = (sym);                                                            \
-    blk_src_len += (n);                                                              \
-  } while (0)
+// ---------------------------------------------------------------------------
+// The lazy parse (Lz77.compress zd.ml:1203-1244) in three parallel-friendly
+// pieces.  Between two positions where the reference has NO pending match the
+// parse is a pure function of the position it starts from:
+//   * no match at p: literal s[p], continue at p+1;
+//   * a match at p: it is deferred; while the next position offers a strictly
+//     longer one (found with K candidates, or K/4 once the pending length reaches
+//     good_match, zd.ml:1182-1185) a literal is emitted and the longer match
+//     becomes pending; then the pending match is emitted and the parse continues
+//     right after it.
+// lz_macro_position computes that "macro step" for EVERY position (one lane
+// each); lz_walk_stream follows the steps from position 0 (one lane per stream:
+// one table read per step), marking the visited positions, counting symbols and
+// cutting blocks (write_block_symbol zd.ml:1118-1123); lz_emit_position then
+// writes the symbols of every visited position, all positions in parallel.
 
-  const int64_t max_pos = (int64_t)len - MIN_MATCH_LEN;
-  int64_t i = 0;
-  uint32_t pend = 0;
-  while (i <= max_pos) {
-    const uint64_t m = match[i];
-    const uint32_t prev_len = pend & 0x1FF;
-    const uint32_t pl = prev_len ? prev_len : (uint32_t)(MIN_MATCH_LEN - 1);
-    const uint32_t rem = len - (uint32_t)i;
+struct MacroStep {
+  uint32_t bref;  // the match that ends the step (dist << 9 | len), 0: a lone literal
+  uint32_t step;  // advance (bits 0-15) | literals emitted before the match (bits 16-31)
+};
+ZD_HD uint32_t macro_advance(uint32_t step) { return step & 0xFFFFu; }
+ZD_HD uint32_t macro_lits(uint32_t step) { return step >> 16; }
+
+// get(j) returns lz_match_position(j): best-of-K in the low word, best-of-K/4 in
+// the high word.
+template <typename GetMatch>
+ZD_HD MacroStep lz_macro_position(uint32_t p, uint32_t len, int good_match, GetMatch get) {
+  MacroStep r;
+  r.bref = 0;
+  r.step = 1u | (1u << 16);  // one literal
+  if (len < (uint32_t)MIN_MATCH_LEN || p > len - MIN_MATCH_LEN) return r;  // i > max_pos: literals
+  const uint32_t max_pos = len - MIN_MATCH_LEN;
+  uint32_t pend = (uint32_t)get(p);  // no pending match: threshold 3 < good_match, K candidates
+  if ((pend & 0x1FF) == 0) return r;
+  uint32_t n_lits = 0;
+  uint32_t j = p + 1;
+  while (j <= max_pos) {
+    const uint32_t pl = pend & 0x1FF;
+    const uint32_t rem = len - j;
     const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
     uint32_t b = 0;
     if (pl < maxlen) {
-      // chain_steps / 4 when prev_match_len >= good_match (zd.ml:1182-1185)
+      const uint64_t m = get(j);
       const uint32_t c = pl >= (uint32_t)good_match ? (uint32_t)(m >> 32) : (uint32_t)m;
       if ((c & 0x1FF) > pl) b = c;
     }
-    const uint32_t ml = b & 0x1FF;
-    if (prev_len != 0 && prev_len > ml) {  // previous match wins: emit it, skip past it
-      ZD_EMIT(pend, prev_len);
-      i = i - 1 + prev_len;
-      pend = 0;
-    } else if (ml == 0) {
-      ZD_EMIT((uint32_t)s[i], 1u);
-      i++;
-      pend = 0;
-    } else {  // defer the new, longer match
-      if (prev_len != 0) ZD_EMIT((uint32_t)s[i - 1], 1u);
-      i++;
-      pend = b;
-    }
+    if (b == 0) break;  // previous match wins (zd.ml:1224)
+    n_lits++;           // literal s[j-1], defer the longer match (zd.ml:1236-1240)
+    pend = b;
+    j++;
   }
-  {
-    const uint32_t prev_len = pend & 0x1FF;
-    if (prev_len != 0) {  // pending match at the end (zd.ml:1211-1212)
-      ZD_EMIT(pend, prev_len);
-      i = max_pos + prev_len;
+  r.bref = pend;
+  r.step = (n_lits + (pend & 0x1FF)) | (n_lits << 16);
+  return r;
+}
+
+constexpr uint32_t WALK_TILE = 256;  // positions per symbol-emission tile
+constexpr uint32_t MAX_LIT_RUN = 32;  // literal positions one walk step may cover
+
+// A position with no match is a literal; `run` consecutive such positions
+// (1 <= run <= MAX_LIT_RUN, all without a match) are covered by one walk step.
+ZD_HD uint32_t macro_literal_run(uint32_t run) { return run | (run << 16); }
+
+// One lane per stream, resumable: the walk consumes steps[p] through get(p) for
+// p < stop (what the caller has staged) and at most `budget` steps per call.
+// Outputs: visited bitmap (1 bit per position, every word of the stream written),
+// tile_sym[t] = index of the first symbol emitted at or after position
+// t * WALK_TILE, the block list (greedy cut at 65534 source bytes,
+// zd.ml:1119-1120) and the symbol count.
+struct WalkState {
+  uint64_t acc;   // bits of bitmap word `word` gathered so far
+  uint32_t p, nsym, nblk, blk_src_start, blk_sym_start, word, tile;
+};
+ZD_HD void lz_walk_init(WalkState &w) {
+  w.acc = 0;
+  w.p = w.nsym = w.nblk = w.blk_src_start = w.blk_sym_start = w.word = w.tile = 0;
+}
+ZD_HD void walk_cut(WalkState &w, BlockDesc *blocks, uint32_t at) {
+  BlockDesc b;
+  b.src_start = w.blk_src_start; b.src_len = at - w.blk_src_start;
+  b.sym_start = w.blk_sym_start; b.n_syms = w.nsym - w.blk_sym_start;
+  blocks[w.nblk++] = b;
+  w.blk_src_start = at;
+  w.blk_sym_start = w.nsym;
+}
+// mark positions [a, b) visited
+ZD_HD void walk_mark(WalkState &w, uint64_t *bitmap, uint32_t a, uint32_t b) {
+  while (a < b) {
+    const uint32_t wd = a >> 6;
+    if (wd != w.word) {
+      bitmap[w.word] = w.acc;
+      for (uint32_t k = w.word + 1; k < wd; k++) bitmap[k] = 0;
+      w.acc = 0;
+      w.word = wd;
     }
-    for (int64_t k = i; k < (int64_t)len; k++) ZD_EMIT((uint32_t)s[k], 1u);
+    const uint32_t lo = a & 63;
+    const uint32_t end = ((wd + 1) << 6) < b ? 64u : b - (wd << 6);
+    const uint64_t m = (end >= 64 ? ~0ull : ((1ull << end) - 1)) & ~((1ull << lo) - 1);
+    w.acc |= m;
+    a = (wd << 6) + end;
   }
-  BlockDesc b_;
-  b_.src_start = blk_src_start; b_.src_len = blk_src_len;
-  b_.sym_start = blk_sym_start; b_.n_syms = nsym - blk_sym_start;
-  blocks[nblk++] = b_;
-#undef ZD_EMIT
-  return nblk;
+}
+template <typename GetStep>
+ZD_HD void lz_walk_advance(WalkState &w, uint32_t len, uint32_t stop, int budget, GetStep get,
+                           uint64_t *bitmap, uint32_t *tile_sym, BlockDesc *blocks) {
+  const uint32_t n_tiles = (len + WALK_TILE - 1) / WALK_TILE;
+  const uint32_t lim = stop < len ? stop : len;
+  while (w.p < lim && budget-- > 0) {
+    const uint32_t p = w.p;
+    while (w.tile < n_tiles && w.tile * WALK_TILE <= p) tile_sym[w.tile++] = w.nsym;
+    const uint32_t st = get(p);
+    uint32_t lits = macro_lits(st);
+    const uint32_t adv = macro_advance(st);
+    const uint32_t mlen = adv - lits;  // 0: a run of `lits` literal positions
+    if (mlen == 0) {
+      walk_mark(w, bitmap, p, p + lits);
+      // tiles that start inside the run: one symbol per position before them
+      while (w.tile < n_tiles && w.tile * WALK_TILE < p + lits) {
+        tile_sym[w.tile] = w.nsym + (w.tile * WALK_TILE - p);
+        w.tile++;
+      }
+    } else {
+      walk_mark(w, bitmap, p, p + 1);
+    }
+    uint32_t q = p;
+    // write_block_symbol zd.ml:1118-1123: a cut can only fall where the block
+    // already holds 65534 source bytes
+    while (lits) {
+      const uint32_t room = (uint32_t)MAX_BLOCK_SRC_LEN - (q - w.blk_src_start);
+      const uint32_t take = lits < room ? lits : room;
+      w.nsym += take;
+      q += take;
+      lits -= take;
+      if (lits) walk_cut(w, blocks, q);
+    }
+    if (mlen) {
+      if ((q - w.blk_src_start) + mlen > (uint32_t)MAX_BLOCK_SRC_LEN) walk_cut(w, blocks, q);
+      w.nsym += 1;
+      q += mlen;
+    }
+    w.p = q;
+  }
+}
+// after the last position: flush the bitmap and tile table, close the final
+// block (always present, zd.ml:1216).  Returns the number of blocks.
+ZD_HD uint32_t lz_walk_finish(WalkState &w, uint32_t len, uint64_t *bitmap, uint32_t *tile_sym,
+                              BlockDesc *blocks) {
+  const uint32_t n_words = (len + 63) >> 6, n_tiles = (len + WALK_TILE - 1) / WALK_TILE;
+  while (w.tile < n_tiles) tile_sym[w.tile++] = w.nsym;
+  if (n_words) {
+    bitmap[w.word] = w.acc;
+    for (uint32_t k = w.word + 1; k < n_words; k++) bitmap[k] = 0;
+  }
+  walk_cut(w, blocks, len);
+  return w.nblk;
+}
+
+// Symbols of one visited position written at syms[first..]: a literal position
+// writes its byte; a match position its deferral literals, then its match.
+ZD_HD uint32_t macro_sym_count(MacroStep m) { return m.bref ? macro_lits(m.step) + 1u : 1u; }
+ZD_HD void lz_emit_position(const uint8_t *s, uint32_t p, MacroStep m, uint32_t *syms, uint32_t first) {
+  if (m.bref == 0) { syms[first] = s[p]; return; }
+  const uint32_t lits = macro_lits(m.step);
+  for (uint32_t k = 0; k < lits; k++) syms[first + k] = s[p + k];
+  syms[first + lits] = m.bref;
 }
 
 // ---------------------------------------------------------------------------
