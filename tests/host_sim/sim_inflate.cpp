@@ -56,7 +56,8 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   const bool crc_adler = crc_op == CRC_ADLER32;
   refill(d, L, src);
   for (;;) {
-    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, budget, crc_adler);
+    SoloGroup grp;
+    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, budget, crc_adler, grp);
     // services, in the kernel's order
     for (uint32_t k = 0; k < d.q_count; k++) {
       DeferredCopy c;

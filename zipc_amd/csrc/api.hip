@@ -219,16 +219,15 @@ size_t zipc_hip_zlib_bound(size_t len) { return zipc_hip_deflate_bound(len) + 6;
 
 // ---- batch forms ---------------------------------------------------------------
 
-static int pick_log2L(size_t n_streams) {
-  // spread the batch over the 1024 SIMDs before packing lanes; 16 streams per
-  // wave is the LDS limit (4 waves x 36 KiB per CU)
-  int log2L = 0;
-  while (log2L < 4 && (n_streams >> (log2L + 1)) >= 1024) log2L++;
-  if (const char *e = getenv("ZIPC_HIP_LOG2L")) {  // tuning knob for experiments
+static int pick_log2S(size_t n_streams) {
+  // streams per wave: 4 (one per 16-lane group) once that still leaves >= 1024
+  // waves for the chip's 1024 SIMDs; fewer for small batches
+  int log2S = n_streams >= 4096 ? 2 : n_streams >= 2048 ? 1 : 0;
+  if (const char *e = getenv("ZIPC_HIP_LOG2S")) {  // tuning knob for experiments
     int v = atoi(e);
-    if (v >= 0 && v <= 4) log2L = v;
+    if (v >= 0 && v <= 2) log2S = v;
   }
-  return log2L;
+  return log2S;
 }
 
 static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
@@ -256,13 +255,13 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   if (crc_op < 0 || crc_op > 2 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int log2L = pick_log2L(n_streams);
-  const size_t L = (size_t)1 << log2L;
-  const unsigned grid = (unsigned)((n_streams + L - 1) / L);
-  const size_t lds = (size_t)INFLATE_LDS_BYTES_PER_LANE << log2L;
+  const int log2S = pick_log2S(n_streams);
+  const size_t S = (size_t)1 << log2S;
+  const unsigned grid = (unsigned)((n_streams + S - 1) / S);
+  const size_t lds = (size_t)INFLATE_LDS_BYTES_PER_LANE << log2S;
   ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3(grid), dim3(64), lds,
             (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
-            (StreamResult *)d_results, (uint32_t)n_streams, log2L, crc_op);
+            (StreamResult *)d_results, (uint32_t)n_streams, log2S, crc_op);
   HIP_TRY(ctx, hipGetLastError());
   if (crc_op == ZIPC_HIP_CRC_CRC32)
     return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,

@@ -1,24 +1,28 @@
 // inflate.hip -- batch inflate kernel for gfx950 (CDNA4, wave64).
 //
-// Decomposition: ONE WAVEFRONT PER WORKGROUP carrying L <= 16 independent deflate
-// streams, one per lane (inflate_lane.h).  A deflate stream is a serial
-// dependency chain (the bit position of symbol k+1 depends on symbol k), so
-// throughput comes from streams in flight; 2496 B of LDS per stream (tables +
-// input ring + deferred-copy queue) lets a CU hold 64 of them.
+// Decomposition: ONE WAVEFRONT PER WORKGROUP carrying 4 independent deflate
+// streams, each run by a group of 16 lanes (inflate_lane.h).  A deflate stream is
+// a serial dependency chain (the bit position of symbol k+1 depends on symbol k);
+// the 16 lanes of a group shorten that chain by looking the litlen table up at
+// the 16 next bit offsets at once, so that a run of literals costs one LDS round
+// trip plus a register shuffle per literal.  2496 B of LDS per stream (tables +
+// input ring + deferred-copy queue) lets a CU hold 64 streams = 16 waves, 4 per
+// SIMD, which is what hides the remaining LDS and shuffle latency.
 //
 // The wave alternates two phases:
-//   decode   every lane runs its own stream for up to ROUND_SYMBOLS symbols out
-//            of LDS only (no global loads; literals leave as 8-byte stores);
+//   decode   every group runs its stream for up to ROUND_TURNS turns out of LDS
+//            only (no global loads; literals leave as 8-byte stores);
 //   service  wave-uniform code doing everything that needs global loads, once
-//            per round and for all lanes at the same time, so their latencies
+//            per round and for all streams at the same time, so their latencies
 //            overlap instead of serialising the wave:
-//              1. fill the queued match copies (8 per lane in flight),
+//              1. fill the queued match copies, one per lane (32 per stream in
+//                 flight),
 //              2. copy parked long/overlapping matches (Buf.recopy zd.ml:63-75),
 //              3. copy stored blocks with all 64 lanes (read_uncompressed_block
 //                 zd.ml:671-680), 16 B per lane,
 //              4. per-block Adler-32 with the reference's 5552-byte chunking
 //                 (inflated_block_crc zd.ml:682-690),
-//              5. top up every lane's input ring with coalesced loads.
+//              5. top up every stream's input ring with coalesced loads.
 #include "inflate_lane.h"
 #include "kernels.h"
 #include "wave_ops.h"
@@ -26,26 +30,56 @@
 namespace zd {
 
 static_assert(LDS_BYTES_PER_LANE == INFLATE_LDS_BYTES_PER_LANE, "kernels.h");
-constexpr int ROUND_SYMBOLS = 64;  // symbols a lane may decode between two service points
-constexpr int MAX_L = 16;
+static_assert(SPEC_WINDOW == 16 && QUEUE_ENTRIES == 32, "group layout");
+constexpr int ROUND_TURNS = 24;  // turns a stream may run between two service points
+constexpr int GROUP = 16;        // lanes per stream
+constexpr int MAX_S = 64 / GROUP;
+
+// The 16-lane group of one stream.
+struct WaveGroup {
+  int sub;     // lane index inside the group
+  uint32_t e;  // this lane's speculative litlen lookup (offset = sub)
+  __device__ __forceinline__ bool writer() const { return sub == 0; }
+  __device__ __forceinline__ void lookup(const LaneLds &L, uint64_t bits) {
+    e = L.u16(LDS_LIT_TBL, (int)((bits >> sub) & ((1u << LIT_TBITS) - 1)));
+  }
+  __device__ __forceinline__ uint32_t entry(const LaneLds &, uint64_t, int o) const {
+    return __shfl(e, o, GROUP);
+  }
+  // the lanes whose offset starts a literal store it: byte k of the run goes to out[k]
+  __device__ __forceinline__ void store_literals(const LaneLds &, uint64_t, uint32_t V, uint8_t *out) const {
+    if ((V >> sub) & 1u) out[__popc(V & ((1u << sub) - 1u))] = (uint8_t)(e >> 4);
+  }
+  // the writer lane ran a header step alone: everybody takes over its state
+  __device__ __forceinline__ bool sync(InflateLane &d, bool ok) const {
+#define ZD_B(x) d.x = __shfl(d.x, 0, GROUP)
+    d.bits = __shfl((unsigned long long)d.bits, 0, GROUP);
+    ZD_B(in_word); ZD_B(ring_wr); ZD_B(skip); ZD_B(nbits); ZD_B(out_pos); ZD_B(status); ZD_B(phase);
+    ZD_B(final_block); ZD_B(lit_max_sym); ZD_B(dist_max_sym); ZD_B(blk_out_start); ZD_B(req_src);
+    ZD_B(req_len); ZD_B(hdr_num); ZD_B(hdr_hlit); ZD_B(hdr_hdist); ZD_B(hdr_cl_max);
+#undef ZD_B
+    return __shfl((int)ok, 0, GROUP) != 0;
+  }
+};
 
 // Top up the input rings: for each stream j of the wave, lanes 0..63 load the
 // next (up to 64) words of its compressed input; all loads are issued before the
 // first LDS write so that one memory latency covers the whole wave.
 __device__ __forceinline__ void service_refill(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa,
-                                               int lane, int Lcount) {
-  uint32_t w[MAX_L];
-  uint32_t idx[MAX_L];
+                                               int lane, int S) {
+  uint32_t w[MAX_S];
+  uint32_t idx[MAX_S];
 #pragma unroll
-  for (int j = 0; j < MAX_L; j++) {
+  for (int j = 0; j < MAX_S; j++) {
     w[j] = 0;
     idx[j] = 0xFFFFFFFFu;
-    if (j < Lcount) {
-      const uint32_t wr = __shfl(d.ring_wr, j, 64);
-      const uint32_t rd = __shfl(d.in_word, j, 64);
-      const uint32_t slen = __shfl(d.src_len, j, 64);
-      const unsigned long long so = __shfl((unsigned long long)d.src_off, j, 64);
-      const int ph = __shfl(d.phase, j, 64);
+    if (j < S) {
+      const int src_lane = j * GROUP;
+      const uint32_t wr = __shfl(d.ring_wr, src_lane, 64);
+      const uint32_t rd = __shfl(d.in_word, src_lane, 64);
+      const uint32_t slen = __shfl(d.src_len, src_lane, 64);
+      const unsigned long long so = __shfl((unsigned long long)d.src_off, src_lane, 64);
+      const int ph = __shfl(d.phase, src_lane, 64);
       const uint32_t total = (slen + 3u) >> 2;
       uint32_t lim = rd + (uint32_t)RING_WORDS;
       if (lim > total) lim = total;
@@ -63,11 +97,11 @@ __device__ __forceinline__ void service_refill(InflateLane &d, const LaneLds &L,
     }
   }
 #pragma unroll
-  for (int j = 0; j < MAX_L; j++) {
-    if (j < Lcount && idx[j] != 0xFFFFFFFFu)
+  for (int j = 0; j < MAX_S; j++) {
+    if (j < S && idx[j] != 0xFFFFFFFFu)
       L.r[((idx[j] & (uint32_t)(RING_WORDS - 1)) << L.log2L) + j] = w[j];
   }
-  // publish the new write cursors
+  // publish the new write cursor (every lane of a group computes the same value)
   if (d.phase != PH_DONE) {
     const uint32_t total = d.total_words();
     uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
@@ -78,29 +112,19 @@ __device__ __forceinline__ void service_refill(InflateLane &d, const LaneLds &L,
   }
 }
 
-// Fill the deferred copies of every lane, 8 per lane at a time: all loads of a
-// batch are issued before its stores.  Entries never depend on one another (a
+// Fill the deferred copies: lane s of a group takes entries s and s + 16, all
+// loads are issued before the stores.  Entries never depend on one another (a
 // match reaching into an unfilled hole is parked instead of queued).
-__device__ __forceinline__ void service_resolve(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ da) {
-  uint32_t maxc = d.q_count;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint32_t u = __shfl_xor(maxc, o, 64);
-    maxc = u > maxc ? u : maxc;
-  }
+__device__ __forceinline__ void service_resolve(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ da,
+                                                int sub) {
   uint8_t *dst = da + d.dst_off;
-  for (uint32_t base = 0; base < maxc; base += 8) {
-    DeferredCopy c[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      c[k].len = 0;
-      if (base + k < d.q_count)
-        deferred_load(c[k], dst, L.queue((int)(base + k), 0), L.queue((int)(base + k), 1));
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      if (c[k].len) deferred_store(c[k], dst);
-  }
+  DeferredCopy c0, c1;
+  c0.len = 0;
+  c1.len = 0;
+  if ((uint32_t)sub < d.q_count) deferred_load(c0, dst, L.queue(sub, 0), L.queue(sub, 1));
+  if ((uint32_t)sub + GROUP < d.q_count) deferred_load(c1, dst, L.queue(sub + GROUP, 0), L.queue(sub + GROUP, 1));
+  if (c0.len) deferred_store(c0, dst);
+  if (c1.len) deferred_store(c1, dst);
   d.q_count = 0;
 }
 
@@ -108,19 +132,24 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            StreamResult *__restrict__ results,
-                                                           uint32_t n_streams, int log2L, int crc_op) {
+                                                           uint32_t n_streams, int log2S, int crc_op) {
   extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
   const int lane = threadIdx.x;
-  const int Lcount = 1 << log2L;
-  const uint32_t stream = blockIdx.x * (uint32_t)Lcount + (uint32_t)lane;
-  const bool has_stream = lane < Lcount && stream < n_streams;
+  const int S = 1 << log2S;
+  const int g = lane / GROUP;
+  const uint32_t stream = blockIdx.x * (uint32_t)S + (uint32_t)g;
+  const bool has_stream = g < S && stream < n_streams;
   const bool crc_adler = crc_op == CRC_ADLER32;
 
   LaneLds L;
   L.w = (uint16_t *)lds_raw;
-  L.r = (uint32_t *)(lds_raw + ((size_t)(LDS_U16_PER_LANE * 2) << log2L));
-  L.lane = lane & (Lcount - 1);
-  L.log2L = log2L;
+  L.r = (uint32_t *)(lds_raw + ((size_t)(LDS_U16_PER_LANE * 2) << log2S));
+  L.lane = g & (S - 1);
+  L.log2L = log2S;
+
+  WaveGroup grp;
+  grp.sub = lane % GROUP;
+  grp.e = 0;
 
   Arenas A;
   A.src = src_arena;
@@ -134,22 +163,22 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
     d.phase = PH_DONE;
   }
 
-  service_refill(d, L, src_arena, lane, Lcount);
+  service_refill(d, L, src_arena, lane, S);
 
   for (;;) {
-    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, ROUND_SYMBOLS, crc_adler);
+    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, ROUND_TURNS, crc_adler, grp);
 
     // ---- service point: wave-uniform control flow from here ----
-    if (__ballot(d.q_count != 0)) service_resolve(d, L, dst_arena);
+    if (__ballot(d.q_count != 0)) service_resolve(d, L, dst_arena, grp.sub);
 
     if (__ballot(d.phase == PH_REQ_MATCH)) {
       if (d.phase == PH_REQ_MATCH) {
-        lane_copy_match(dst_arena + d.dst_off, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
+        if (grp.writer()) lane_copy_match(dst_arena + d.dst_off, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
         lane_after_match(d);
       }
     }
 
-    unsigned long long m = __ballot(d.phase == PH_REQ_COPY);
+    unsigned long long m = __ballot(d.phase == PH_REQ_COPY && grp.writer());
     if (m) {
       while (m) {
         const int leader = __ffsll((long long)m) - 1;
@@ -162,7 +191,7 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
       if (d.phase == PH_REQ_COPY) lane_after_copy(d, crc_adler);
     }
 
-    m = __ballot(d.phase == PH_REQ_ADLER);
+    m = __ballot(d.phase == PH_REQ_ADLER && grp.writer());
     if (m) {
       // the block's bytes were stored by other lanes of this wave: make them visible
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -173,16 +202,16 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
         const uint32_t n = __shfl(d.out_pos - d.blk_out_start, leader, 64);
         const uint32_t a = __shfl(d.adler, leader, 64);
         const uint32_t r = wave_adler_update(a, dst_arena + po, n, lane);
-        if (lane == leader) d.adler = r;
+        if (lane / GROUP == leader / GROUP) d.adler = r;
       }
       if (d.phase == PH_REQ_ADLER) lane_after_adler(d);
     }
 
     if (!__ballot(d.phase != PH_DONE)) break;
-    service_refill(d, L, src_arena, lane, Lcount);
+    service_refill(d, L, src_arena, lane, S);
   }
 
-  if (has_stream) {
+  if (has_stream && grp.writer()) {
     StreamResult r;
     r.status = d.status;
     r.out_len = d.status == ST_OK ? d.out_pos : 0;

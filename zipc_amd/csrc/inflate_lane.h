@@ -1,14 +1,23 @@
-// inflate_lane.h -- one deflate stream decoded by ONE lane.
+// inflate_lane.h -- the serial state machine of one deflate stream.
 //
-// This is the lane-serial half of the batch inflate kernel (inflate.hip): a
-// wavefront carries up to 16 independent streams, one per lane.  Everything a
-// lane touches while it decodes symbols lives in LDS -- its decode tables, a
-// 64-word ring of its compressed input, a queue of deferred match copies -- so
-// the symbol loop issues NO global loads: the only vector-memory traffic it
-// generates are the literal stores (8 literals per 8-byte store).  Whatever
-// needs a global load is parked and done by the whole wave at the next service
-// point (inflate.hip), in lockstep, so that one memory latency is paid per
-// round instead of one per match:
+// This is the per-stream half of the batch inflate kernel (inflate.hip).  A
+// wavefront carries 4 independent streams; each stream is run by a GROUP of 16
+// lanes that all hold the same copy of the state below and execute the same
+// code.  What the 16 lanes do differently is one thing: lane s of the group
+// looks up the litlen table at bit offset s of the current window, so that a
+// run of literals is decoded by following the chain of code lengths through
+// the 16 speculative lookups (grp.entry) instead of one dependent LDS read per
+// literal.  Side effects (LDS writes, global stores) are done by lane 0 of the
+// group ("writer").  tests/host_sim drives the same code with a one-lane group
+// whose speculative lookups are plain table reads.
+//
+// Everything the stream touches while it decodes symbols lives in LDS -- its
+// decode tables, a 64-word ring of its compressed input, a queue of deferred
+// match copies -- so the symbol loop issues NO global loads: the only
+// vector-memory traffic it generates are the literal stores (8 literals per
+// 8-byte store).  Whatever needs a global load is parked and done by the whole
+// wave at the next service point (inflate.hip), in lockstep, so that one memory
+// latency is paid per round instead of one per match:
 //   * short non-overlapping matches (len <= 16 <= dist) are queued as holes
 //     {dst_pos, dist, len} and filled later -- legal because a later symbol can
 //     only observe those bytes through another match, and a match whose source
@@ -35,9 +44,9 @@ namespace zd {
 constexpr int LIT_TBITS = 9;   // primary litlen lookup bits
 constexpr int DIST_TBITS = 7;  // primary dist lookup bits (also holds the <=7-bit codelen code)
 
-// Per-lane LDS image, interleaved over the L lanes that share a wave's block so
-// that equal indices of neighbouring lanes sit in neighbouring banks:
-// element i of lane l lives at [(offset + i) * L + l].
+// Per-stream LDS image, interleaved over the L streams that share a wave so that
+// equal indices of neighbouring streams sit in neighbouring banks: element i of
+// stream l lives at [(offset + i) * L + l].
 constexpr int LDS_LIT_TBL = 0;                          // 512 x u16: (sym << 4) | len
 constexpr int LDS_DIST_TBL = LDS_LIT_TBL + 512;         // 128 x u16
 constexpr int LDS_LIT_SYMS = LDS_DIST_TBL + 128;        // 288 x u16 symbols sorted by code
@@ -53,12 +62,13 @@ constexpr int QUEUE_ENTRIES = 32;    // deferred copies, 2 words each
 constexpr int LDS_U32_PER_LANE = RING_WORDS + 2 * QUEUE_ENTRIES;  // 128
 constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 2496
 constexpr uint32_t DEFER_MAX_LEN = 16;
+constexpr int SPEC_WINDOW = 16;  // bit offsets looked up speculatively (= lanes per group)
 
 struct LaneLds {
   uint16_t *w;  // u16 regions of this wave's block
   uint32_t *r;  // u32 regions (ring, queue) of this wave's block
-  int lane;     // my slot, < (1 << log2L)
-  int log2L;
+  int lane;     // my stream's slot in the wave, < (1 << log2L)
+  int log2L;    // log2(streams per wave)
   ZD_HD uint16_t &u16(int off, int i) const { return w[((off + i) << log2L) + lane]; }
   ZD_HD uint32_t &ring(uint32_t word) const { return r[((word & (RING_WORDS - 1)) << log2L) + lane]; }
   ZD_HD uint32_t &queue(int k, int half) const { return r[((RING_WORDS + 2 * k + half) << log2L) + lane]; }
@@ -89,13 +99,11 @@ ZD_HD void store_u32_le(uint8_t *p, uint32_t v) {
 struct InflateLane {
   uint64_t src_off, dst_off;
   uint64_t bits;       // bit buffer, LSB first (src_bits zd.ml:536)
-  uint64_t lit_acc;    // up to 8 literals not yet stored: bytes [out_pos - lit_n, out_pos)
   uint32_t src_len;
   uint32_t in_word;    // next input word to pull from the ring
   uint32_t ring_wr;    // one past the last word staged in the ring
   uint32_t skip;       // bytes to drop from the next pulled word (after a stored block)
   int32_t nbits;       // REAL bits in `bits` (src_bits_len zd.ml:537)
-  uint32_t lit_n;
   uint32_t out_pos;
   uint32_t cap_min;    // min(limit, dst_cap): fast overflow test
   uint32_t limit;      // ?decompressed_size, or 0xFFFFFFFF
@@ -154,21 +162,6 @@ struct InflateLane {
   // decompression size exceeded" (zd.ml:27-29); running out of the caller's
   // dst_cap with no limit given is the boundary's DST_TOO_SMALL.
   ZD_HD void overflow(uint64_t need) { fail(need > limit ? ST_SIZE_EXCEEDED : ST_DST_TOO_SMALL); }
-
-  // store the pending literals (one 8-byte store; the bytes past lit_n lie at or
-  // beyond out_pos, where nothing valid exists yet)
-  ZD_HD void flush_literals(uint8_t *__restrict__ da) {
-    if (lit_n) {
-      uint8_t *o = da + dst_off + (out_pos - lit_n);
-      if ((uint64_t)(out_pos - lit_n) + 8 <= hard_cap) store_u64_le(o, lit_acc);
-      else {
-#pragma unroll 1
-        for (uint32_t i = 0; i < lit_n; i++) o[i] = (uint8_t)(lit_acc >> (8 * i));
-      }
-      lit_acc = 0;
-      lit_n = 0;
-    }
-  }
 };
 
 // Huffman.init_decoder zd.ml:355-391 on lengths[start .. start+n) held in the
@@ -438,27 +431,64 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
 
 enum : int { SYM_BUDGET = 0, SYM_EOB = 1, SYM_STOP = 2 };
 
-// read_block_symbols zd.ml:593-616, at most `budget` symbols.  SYM_STOP: failed,
-// parked on a request, or waiting for input / for the deferred copies.
-ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int budget) {
+// read_block_symbols zd.ml:593-616, at most `budget` turns.  One turn:
+//   1. every lane of the group has looked the litlen table up at its own bit
+//      offset (grp.lookup); the literal chain is followed through those 16
+//      entries with register shuffles: V collects the offsets where a literal
+//      starts, o ends on the first offset that is not a (short-coded) literal;
+//   2. the lanes named by V store their literals themselves, side by side;
+//   3. unless the chain ran off the window, the symbol at offset o is decoded:
+//      straight from the shuffled entry when it has a short code (end of block
+//      or a length), else through read_symbol's canonical walk.
+// SYM_STOP: failed, parked on a request, or waiting for input.
+template <typename Group>
+ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int &budget, Group &grp) {
   uint8_t *dst = A.dst + d.dst_off;
+  const bool writer = grp.writer();
 #pragma unroll 1
-  for (int n = 0; n < budget; n++) {
-    if (!d.input_ready(2)) return SYM_STOP;  // a symbol pulls at most twice
+  while (budget > 0) {
+    budget--;
+    if (!d.input_ready(2)) return SYM_STOP;  // a turn pulls at most twice
     d.pull(L);
-    int sym = read_symbol(d, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
-    if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-    if (sym < LITLEN_EOB) {
-      if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
-      d.lit_acc |= (uint64_t)(uint32_t)sym << (8 * d.lit_n);
-      d.lit_n++;
-      d.out_pos++;
-      if (d.lit_n == 8) {
-        store_u64_le(dst + d.out_pos - 8, d.lit_acc);  // out_pos <= cap_min <= hard_cap
-        d.lit_acc = 0;
-        d.lit_n = 0;
+    grp.lookup(L, d.bits);
+    uint32_t V = 0, e = 0;
+    int o = 0, len = 0;
+    uint32_t n = 0;
+    const uint32_t room = d.cap_min - d.out_pos;
+#pragma unroll 1
+    for (;;) {
+      e = grp.entry(L, d.bits, o);
+      len = (int)(e & 15);
+      if (len == 0 || e >= (256u << 4) || o + len > d.nbits || n >= room) break;
+      V |= 1u << o;
+      n++;
+      o += len;
+      if (o >= SPEC_WINDOW) break;
+    }
+    grp.store_literals(L, d.bits, V, dst + d.out_pos);
+    d.out_pos += n;
+    d.bits >>= o;
+    d.nbits -= o;
+    if (o >= SPEC_WINDOW) continue;
+
+    int sym;
+    if (len != 0 && e >= (256u << 4)) {
+      // short-coded non-literal: the entry is already here
+      if (len > d.nbits) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+      d.bits >>= len;
+      d.nbits -= len;
+      sym = (int)(e >> 4);
+    } else {
+      // a literal that does not fit, a long code, or exhausted input: the plain way
+      d.pull(L);
+      sym = read_symbol(d, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+      if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+      if (sym < LITLEN_EOB) {
+        if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
+        if (writer) dst[d.out_pos] = (uint8_t)sym;
+        d.out_pos++;
+        continue;
       }
-      continue;
     }
     if (sym == LITLEN_EOB) return SYM_EOB;
     if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
@@ -476,13 +506,14 @@ ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int bu
     if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
     if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
     // Buf.recopy zd.ml:615 -- queued, or handed to the wave
-    d.flush_literals(A.dst);
     const uint32_t src_pos = d.out_pos - dist;
     const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
     if (length <= DEFER_MAX_LEN && dist >= length && !hazard && d.q_count < (uint32_t)QUEUE_ENTRIES) {
       if (d.q_count == 0) d.hole_min = d.out_pos;
-      L.queue((int)d.q_count, 0) = d.out_pos;
-      L.queue((int)d.q_count, 1) = dist | (length << 16);
+      if (writer) {
+        L.queue((int)d.q_count, 0) = d.out_pos;
+        L.queue((int)d.q_count, 1) = dist | (length << 16);
+      }
       d.q_count++;
       d.out_pos += length;
     } else {
@@ -495,33 +526,55 @@ ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int bu
   return SYM_BUDGET;
 }
 
-// Runs the lane until it finishes, fails, parks, or has spent `budget` symbols.
-// Pending literals are always stored before returning.
-ZD_HD void lane_step(InflateLane &d, const LaneLds &L, const Arenas &A, int budget, bool crc_adler) {
+// One header action by the group's writer lane (the other lanes take over its
+// state afterwards, grp.sync): false = must wait for input.
+ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
+  if (d.phase == PH_HEADER) return lane_block_header(d, L, sa);
+  const int r = setup_dynamic_lengths(d, L);
+  if (r == 0) return false;
+  if (r < 0) { d.fail(ST_CORRUPTED); return true; }
+  d.phase = PH_SYMBOLS;
+  return true;
+}
+
+// Runs the stream until it finishes, fails, parks, or has spent `budget` turns.
+template <typename Group>
+ZD_HD void lane_step(InflateLane &d, const LaneLds &L, const Arenas &A, int budget, bool crc_adler,
+                     Group &grp) {
 #pragma unroll 1
   while (budget > 0) {
-    if (d.phase == PH_HEADER) {
-      if (!lane_block_header(d, L, A.src)) break;  // waits for input
-      budget -= 8;
-    } else if (d.phase == PH_HDR_LENGTHS) {
-      const int r = setup_dynamic_lengths(d, L);
-      if (r == 0) break;
-      if (r < 0) { d.fail(ST_CORRUPTED); break; }
-      d.phase = PH_SYMBOLS;
-      budget -= 8;
+    if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+      bool ok = true;
+      if (grp.writer()) ok = lane_header_step(d, L, A.src);
+      ok = grp.sync(d, ok);
+      if (!ok) break;  // waits for input
+      budget -= 2;
     } else if (d.phase == PH_SYMBOLS) {
-      const int r = lane_symbols(d, L, A, budget);
+      const int r = lane_symbols(d, L, A, budget, grp);
       if (r != SYM_EOB) break;
       // inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
       if (crc_adler) { d.phase = PH_REQ_ADLER; break; }
       d.phase = d.final_block ? PH_DONE : PH_HEADER;
-      budget -= 8;
+      budget -= 2;
     } else {
       break;
     }
   }
-  d.flush_literals(A.dst);
 }
+
+// the one-lane group of tests/host_sim: every "speculative" lookup is a table read
+struct SoloGroup {
+  ZD_HD bool writer() const { return true; }
+  ZD_HD bool sync(InflateLane &, bool ok) const { return ok; }
+  ZD_HD void lookup(const LaneLds &, uint64_t) {}
+  ZD_HD uint32_t entry(const LaneLds &L, uint64_t bits, int o) const {
+    return L.u16(LDS_LIT_TBL, (int)((bits >> o) & ((1u << LIT_TBITS) - 1)));
+  }
+  ZD_HD void store_literals(const LaneLds &L, uint64_t bits, uint32_t V, uint8_t *out) const {
+    for (int o = 0, k = 0; o < SPEC_WINDOW; o++)
+      if ((V >> o) & 1) out[k++] = (uint8_t)(entry(L, bits, o) >> 4);
+  }
+};
 
 // after the cooperative copy of a stored block
 ZD_HD void lane_after_copy(InflateLane &d, bool crc_adler) {
@@ -568,9 +621,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.src_off = s.src_off;
   d.dst_off = s.dst_off;
   d.bits = 0;
-  d.lit_acc = 0;
   d.nbits = 0;
-  d.lit_n = 0;
   d.in_word = 0;
   d.ring_wr = 0;
   d.skip = 0;
