@@ -36,13 +36,14 @@ def algorithmic_bytes(kernel, N, C):
         "inflate_batch": C + N,            # read compressed, write plain
         "crc32_segments": N,               # one pass over the checked bytes
         "lz_chain": N + 2 * N,             # read source, write 2-byte links
-        "lz_match": N + 2 * N + 8 * N,     # source + links in, 8-byte match pairs out
-        "lz_parse": 8 * N + N + 4 * N,     # match pairs + literals in, <= 4 B/symbol out
+        "lz_match": N + 2 * N + 8 * N,     # source + links in, 8-byte macro steps out
+        "lz_walk": 4 * N + N // 8,         # step words in, visited bitmap out
+        "lz_symbols": N // 8 + 8 * N + N + 4 * N,  # bitmap + macro steps + literals in, <= 4 B/symbol out
         "deflate_emit": 4 * N + C,         # symbols in, compressed out
     }.get(kernel, 0)
 
 
-def cpu_baseline(config_id, bits, level, stream_len, budget_s=12.0):
+def cpu_baseline(config_id, bits, level, stream_len, budget_s=15.0):
     """The oracle (C port of the reference algorithm) on this host, 1 thread, on a
     bounded sample of the same workload."""
     import oracle
@@ -52,7 +53,7 @@ def cpu_baseline(config_id, bits, level, stream_len, budget_s=12.0):
     nbytes = 0
     j = 0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and j < 4096:
+    while time.perf_counter() - t0 < budget_s and j < 65536:
         plain = synth.stream_bytes_np(config_id, j, stream_len, bits).tobytes()
         a = time.perf_counter()
         st, comp, _ = oracle.deflate(plain, level=level, crc_op=oracle.CRC_CRC32)

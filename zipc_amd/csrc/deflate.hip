@@ -476,7 +476,7 @@ __device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t 
   __syncthreads();
 }
 
-__global__ __launch_bounds__(64) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
+__global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
                                                           uint8_t *__restrict__ dst_arena,
                                                           const StreamDesc *__restrict__ descs,
                                                           StreamResult *__restrict__ results,

@@ -133,16 +133,21 @@ struct InflateLane {
   ZD_HD void pull(const LaneLds &L) {
     if (nbits <= 32 && in_word < ring_wr) {
       uint32_t w = L.ring(in_word);
-      const uint32_t base = in_word * 4u;
-      int32_t valid = (int32_t)(src_len - base < 4u ? src_len - base : 4u);
-      if (skip) {
-        w = skip >= 4 ? 0u : w >> (8 * skip);
-        valid -= (int32_t)skip;
-        if (valid < 0) valid = 0;
-        skip = 0;
+      if (skip == 0 && in_word < (src_len >> 2)) {  // a whole word, the usual case
+        bits |= (uint64_t)w << nbits;
+        nbits += 32;
+      } else {
+        const uint32_t base = in_word * 4u;
+        int32_t valid = (int32_t)(src_len - base < 4u ? src_len - base : 4u);
+        if (skip) {
+          w = skip >= 4 ? 0u : w >> (8 * skip);
+          valid -= (int32_t)skip;
+          if (valid < 0) valid = 0;
+          skip = 0;
+        }
+        bits |= (uint64_t)w << nbits;
+        nbits += 8 * valid;
       }
-      bits |= (uint64_t)w << nbits;
-      nbits += 8 * valid;
       in_word++;
     }
   }
@@ -455,16 +460,18 @@ ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int &b
     int o = 0, len = 0;
     uint32_t n = 0;
     const uint32_t room = d.cap_min - d.out_pos;
+    bool go;
 #pragma unroll 1
-    for (;;) {
+    do {
       e = grp.entry(L, d.bits, o);
       len = (int)(e & 15);
-      if (len == 0 || e >= (256u << 4) || o + len > d.nbits || n >= room) break;
-      V |= 1u << o;
-      n++;
-      o += len;
-      if (o >= SPEC_WINDOW) break;
-    }
+      go = (len != 0) & (e < (256u << 4)) & (o + len <= d.nbits) & (n < room);
+      if (go) {
+        V |= 1u << o;
+        n++;
+        o += len;
+      }
+    } while (go & (o < SPEC_WINDOW));
     grp.store_literals(L, d.bits, V, dst + d.out_pos);
     d.out_pos += n;
     d.bits >>= o;
