@@ -37,8 +37,7 @@ def algorithmic_bytes(kernel, N, C):
         "crc32_segments": N,               # one pass over the checked bytes
         "lz_chain": N + 2 * N,             # read source, write 2-byte links
         "lz_match": N + 2 * N + 8 * N,     # source + links in, 8-byte macro steps out
-        "lz_walk": 4 * N + N // 8,         # step words in, visited bitmap out
-        "lz_symbols": N // 8 + 8 * N + N + 4 * N,  # bitmap + macro steps + literals in, <= 4 B/symbol out
+        "lz_parse": 8 * N + N + 4 * N,     # macro steps + literals in, <= 4 B/symbol out
         "deflate_emit": 4 * N + C,         # symbols in, compressed out
     }.get(kernel, 0)
 

@@ -38,6 +38,79 @@ uint32_t adler_update_serial(uint32_t a, const uint8_t *p, uint32_t n) {
 }
 }  // namespace
 
+
+// Host model of lz_parse_kernel (zipc_amd/csrc/deflate.hip): one wave per stream,
+// tiles of 64 positions (one per lane); inside a tile the visited positions are
+// found by pointer doubling + top-down marking instead of a serial walk.
+static uint32_t parse_tiles_model(const uint8_t *s, uint32_t len, const uint32_t *brefs, const uint32_t *steps,
+                                  uint32_t *syms, BlockDesc *blocks) {
+  const int T = 64, X = 576;
+  uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;
+  uint32_t B = 0;
+  while (B < len) {
+    if (entry >= B + T) { B = entry & ~63u; continue; }
+    uint32_t J[7][64], cnt[64], adv[64];  // 2^k hops, k = 0..6: the exit can be 64 hops away
+    bool valid[64];
+    for (int t = 0; t < T; t++) {
+      uint32_t p = B + t;
+      valid[t] = p < len;
+      uint32_t br = valid[t] ? brefs[p] : 0, st = valid[t] ? steps[p] : 0;
+      adv[t] = valid[t] ? (br ? macro_advance(st) : 1u) : 0u;
+      cnt[t] = valid[t] ? (br ? macro_lits(st) + 1u : 1u) : 0u;
+      J[0][t] = valid[t] ? t + adv[t] : t;
+    }
+    for (int k = 1; k < 7; k++)
+      for (int t = 0; t < T; t++) { uint32_t x = J[k - 1][t]; J[k][t] = x < 64 ? J[k - 1][x] : x; }
+    uint8_t M[640];
+    memset(M, 0, sizeof M);
+    M[entry - B] = 1;
+    for (int k = 6; k >= 0; k--) {
+      uint8_t m[64];
+      for (int t = 0; t < T; t++) m[t] = M[t];
+      for (int t = 0; t < T; t++) if (m[t]) M[J[k][t]] = 1;
+    }
+    uint32_t exit_abs = len;
+    for (int x = 64; x < X; x++) if (M[x]) { exit_abs = B + x; break; }
+    // scan + emission
+    uint32_t first[64], run = nsym;
+    for (int t = 0; t < T; t++) { first[t] = run; if (valid[t] && M[t]) run += cnt[t]; }
+    for (int t = 0; t < T; t++) {
+      if (!(valid[t] && M[t])) continue;
+      MacroStep m;
+      m.bref = brefs[B + t];
+      m.step = steps[B + t];
+      lz_emit_position(s, B + t, m, syms, first[t]);
+    }
+    // block cut (write_block_symbol zd.ml:1118-1123)
+    const uint64_t limit = (uint64_t)blk_start + MAX_BLOCK_SRC_LEN;
+    for (int t = 0; t < T; t++) {
+      if (!(valid[t] && M[t])) continue;
+      const uint32_t p = B + t;
+      if ((uint64_t)p + adv[t] <= limit) continue;
+      uint32_t cutpos, symidx;
+      const uint32_t br = brefs[p], lits = br ? macro_lits(steps[p]) : 0;
+      if (br == 0) { cutpos = p; symidx = first[t]; }
+      else if ((uint64_t)p + lits > limit) { uint32_t i = (uint32_t)(limit - p); cutpos = p + i; symidx = first[t] + i; }
+      else { cutpos = p + lits; symidx = first[t] + lits; }
+      BlockDesc b;
+      b.src_start = blk_start; b.src_len = cutpos - blk_start;
+      b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
+      blocks[nblk++] = b;
+      blk_start = cutpos;
+      blk_sym_start = symidx;
+      break;
+    }
+    nsym = run;
+    entry = exit_abs;
+    B += T;
+  }
+  BlockDesc b;
+  b.src_start = blk_start; b.src_len = len - blk_start;
+  b.sym_start = blk_sym_start; b.n_syms = nsym - blk_sym_start;
+  blocks[nblk++] = b;
+  return nblk;
+}
+
 // kinds[] receives the block kinds (0 stored, 1 fixed, 2 dynamic), up to max_kinds
 extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t *dst, uint64_t dst_cap,
                            uint64_t *out_len, uint32_t *adler_out, int *kinds, int max_kinds,
@@ -105,7 +178,9 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       lz_walk_advance(ws, len, stop, 48, gets, bitmap.data(), tile_sym.data(), blocks.data());
     }
     uint32_t nblk = lz_walk_finish(ws, len, bitmap.data(), tile_sym.data(), blocks.data());
-    for (uint32_t t = 0; t * WALK_TILE < len; t++) {
+    const bool use_tiles = getenv("SIM_PARSE_TILES") != nullptr;
+    if (use_tiles) nblk = parse_tiles_model(src, len, brefs.data(), steps.data(), syms.data(), blocks.data());
+    for (uint32_t t = 0; !use_tiles && t * WALK_TILE < len; t++) {
       uint32_t idx = tile_sym[t];
       for (uint32_t p = t * WALK_TILE; p < len && p < (t + 1) * WALK_TILE; p++) {
         if (!((bitmap[p >> 6] >> (p & 63)) & 1)) continue;

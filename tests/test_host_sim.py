@@ -67,6 +67,17 @@ def test_deflate_lane_logic_bytes_equal_oracle(sim, oracle):
             assert kinds == [b.kind for b in blocks][:64], (name, lvl)
 
 
+def test_parse_tiles_model_bytes_equal_oracle(sim, oracle, monkeypatch):
+    """lz_parse_kernel's algorithm (pointer doubling + marking per 64-position
+    tile instead of a serial walk), modelled on the host, gives the same bytes."""
+    monkeypatch.setenv("SIM_PARSE_TILES", "1")
+    for name, data in util.deflate_cases().items():
+        for lvl in (1, 2, 3):
+            st0, c0, a0 = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+            st, c, a, _ = sim_deflate(sim, oracle, data, lvl)
+            assert st == 0 and c == c0 and a == a0, (name, lvl)
+
+
 def test_deflate_lane_logic_fuzz(sim, oracle):
     rnd = random.Random(11)
     for t in range(600):

@@ -16,11 +16,11 @@
 //                            following positions to form the position's "macro
 //                            step" of the lazy parse (deflate_lane.h) -> 8 bytes
 //                            per position.
-//   lz_walk_kernel           one lane per stream: follows the macro steps from
-//                            position 0 (Lz77.compress zd.ml:1203-1244): visited
-//                            bitmap, symbol counts, block cut (zd.ml:1118-1123).
-//   lz_symbols_kernel        one lane per position: visited positions write their
-//                            symbols (block scan for the symbol index).
+//   lz_parse_kernel          one wave per stream: which positions the lazy parse
+//                            visits (Lz77.compress zd.ml:1203-1244), found per
+//                            64-position tile by pointer doubling + marking
+//                            instead of a serial walk; symbol emission and block
+//                            cut (zd.ml:1118-1123).
 //   deflate_emit_kernel      one wave per stream, blocks in order: histogram (LDS
 //                            atomics), Huffman codes + stored/fixed/dynamic choice
 //                            (write_block zd.ml:1094-1104, lane 0), then all 64 lanes
@@ -40,7 +40,7 @@ constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 
 // streams with an out-of-range length are rejected by every kernel and take no scratch
 __host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
   if (src_len > 0xFFFFFFF0ull) src_len = 0;
-  return ((src_len + 255) & ~255ull) + POS_PAD;  // multiple of WALK_TILE and of 64
+  return ((src_len + 255) & ~255ull) + POS_PAD;
 }
 __host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
   if (src_len > 0xFFFFFFF0ull) src_len = 0;
@@ -55,8 +55,6 @@ struct DeflateScratch {
   uint16_t *prev;       // [P] chain links
   uint32_t *bref;       // [P] MacroStep::bref
   uint32_t *step;       // [P] MacroStep::step
-  uint64_t *bitmap;     // [P / 64] visited positions
-  uint32_t *tile_sym;   // [P / 256] first symbol index of each tile
   uint32_t *syms;       // [P]
   BlockDesc *blocks;    // [Bk]
   uint64_t cap_positions, cap_blocks;
@@ -75,8 +73,7 @@ size_t deflate_scratch_bytes(size_t n, size_t /*max_src_len*/, size_t total_src_
   size_t b = 0;
   b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
   if (level != LEVEL_NONE) {
-    b += align_up(P * 2, 256) + 3 * align_up(P * 4, 256) + align_up(P / 8 + 64, 256) +
-         align_up(P / 64 + 64, 256);
+    b += align_up(P * 2, 256) + 3 * align_up(P * 4, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
   }
   return b + 1024;
@@ -91,15 +88,13 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
-  s.prev = nullptr; s.bref = nullptr; s.step = nullptr; s.bitmap = nullptr; s.tile_sym = nullptr;
+  s.prev = nullptr; s.bref = nullptr; s.step = nullptr;
   s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
     s.prev = (uint16_t *)p; p += align_up(P * 2, 256);
     s.bref = (uint32_t *)p; p += align_up(P * 4, 256);
     s.step = (uint32_t *)p; p += align_up(P * 4, 256);
     s.syms = (uint32_t *)p; p += align_up(P * 4, 256);
-    s.bitmap = (uint64_t *)p; p += align_up(P / 8 + 64, 256);
-    s.tile_sym = (uint32_t *)p; p += align_up(P / 64 + 64, 256);
     s.blocks = (BlockDesc *)p; p += align_up(Bk * sizeof(BlockDesc), 256);
   }
   s.cap_positions = P;
@@ -283,137 +278,141 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
   TileMatches get;
   get.sm = sm; get.base = base_pos; get.count = MATCH_THREADS + MATCH_HALO;
   get.s = s; get.prev = prev; get.len = len; get.K = K; get.Kq = Kq;
-  MacroStep m = lz_macro_position(p, len, good_match, get);
-  if (m.bref == 0) {
-    // literal position: let one walk step cover the run of literal positions
-    // that follows (as far as this tile's LDS image shows them)
-    uint32_t run = 1;
-    while (run < MAX_LIT_RUN && p + run < len && t + run < MATCH_THREADS + MATCH_HALO &&
-           ((uint32_t)sm[t + run] & 0x1FF) == 0)
-      run++;
-    m.step = macro_literal_run(run);
-  }
+  const MacroStep m = lz_macro_position(p, len, good_match, get);
   S.bref[base + p] = m.bref;
   S.step[base + p] = m.step;
 }
 
 // ---------------------------------------------------------------------------------
-// One lane per stream, 16 streams per wave.  The step table of each stream is
-// staged through a 64-entry LDS ring that the wave refills with coalesced loads
-// between slices of WALK_SLICE steps, so a step costs an LDS read instead of a
-// dependent global load.
-constexpr int WALK_LANES = 16;
-constexpr int WALK_RING = 64;
-constexpr int WALK_SLICE = 48;
+// The lazy parse proper (Lz77.compress zd.ml:1203-1244 + write_block_symbol
+// zd.ml:1118-1123): which positions does the parse visit, what symbols do they
+// emit, where are blocks cut.  One wave per stream walks the stream in tiles of
+// 64 positions (one per lane).  Inside a tile the serial walk "p -> p + advance"
+// is replaced by pointer doubling: J_k[t] = position reached from t after 2^k
+// steps (shuffles; indices >= 64 are exits into later tiles), then the visited
+// set is marked top-down from the tile's entry position through a 640-byte LDS
+// mark array (k = 6..0: every marked lane marks J_k of itself).  Visited lanes
+// get their symbol index from a wave scan and write their symbols.  The only
+// serial dependency left between tiles is the entry position.
+constexpr int PARSE_TILE = 64;
+constexpr int PARSE_MARKS = 640;  // local indices: 64 positions + exits up to +512, padded
 
-struct WalkRing {
-  const uint32_t *ring;  // [WALK_RING][WALK_LANES]
-  int lane;
-  __device__ __forceinline__ uint32_t operator()(uint32_t q) const {
-    return ring[(q & (WALK_RING - 1)) * WALK_LANES + lane];
-  }
-};
-
-__global__ __launch_bounds__(64) void lz_walk_kernel(const StreamDesc *__restrict__ descs, uint32_t n,
-                                                     DeflateScratch S) {
-  __shared__ uint32_t ring[WALK_RING * WALK_LANES];
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
+                                                      const StreamDesc *__restrict__ descs,
+                                                      DeflateScratch S) {
+  // marks are exchanged between the lanes of the wave: volatile keeps every
+  // access in program order (LDS operations of one wave execute in order)
+  __shared__ uint8_t M_raw[PARSE_MARKS];
+  volatile uint8_t *M = M_raw;
   if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
-  const uint32_t stream = blockIdx.x * WALK_LANES + (uint32_t)lane;
-  bool active = lane < WALK_LANES && stream < n;
-  uint32_t len = 0;
-  uint64_t base = 0, blk_base = 0;
-  if (active) {
-    const StreamDesc sd = descs[stream];
-    if (sd.src_len > 0xFFFFFFF0ull) { S.n_blocks[stream] = 0; active = false; }
-    else {
-      len = (uint32_t)sd.src_len;
-      base = S.pos_base[stream];
-      blk_base = S.blk_base[stream];
-    }
-  }
-  WalkState w;
-  lz_walk_init(w);
-  uint32_t ring_hi = 0;  // steps of positions < ring_hi are staged (those >= w.p are still needed)
-  WalkRing get;
-  get.ring = ring;
-  get.lane = lane;
-  uint64_t *bitmap = S.bitmap + (base >> 6);
-  uint32_t *tile_sym = S.tile_sym + base / WALK_TILE;
-  BlockDesc *blocks = S.blocks + blk_base;
-
-  for (;;) {
-    // ---- refill (wave-uniform): stream j gets positions [max(hi, p), min(p + 64, len))
-    uint32_t v[WALK_LANES], idx[WALK_LANES];
-#pragma unroll
-    for (int j = 0; j < WALK_LANES; j++) {
-      const uint32_t pj = __shfl(w.p, j, 64);
-      const uint32_t hj = __shfl(ring_hi, j, 64);
-      const uint32_t lj = __shfl(len, j, 64);
-      const unsigned long long bj = __shfl((unsigned long long)base, j, 64);
-      const uint32_t start = hj > pj ? hj : pj;
-      uint32_t lim = pj + (uint32_t)WALK_RING;
-      if (lim > lj) lim = lj;
-      const uint32_t my = start + (uint32_t)lane;
-      idx[j] = 0xFFFFFFFFu;
-      v[j] = 0;
-      if (my < lim) { idx[j] = my; v[j] = S.step[bj + my]; }
-    }
-#pragma unroll
-    for (int j = 0; j < WALK_LANES; j++)
-      if (idx[j] != 0xFFFFFFFFu) ring[(idx[j] & (WALK_RING - 1)) * WALK_LANES + j] = v[j];
-    {
-      uint32_t lim = w.p + (uint32_t)WALK_RING;
-      if (lim > len) lim = len;
-      if (lim > ring_hi) ring_hi = lim;
-    }
-    __syncthreads();
-    if (active) lz_walk_advance(w, len, ring_hi, WALK_SLICE, get, bitmap, tile_sym, blocks);
-    __syncthreads();
-    if (!__ballot(active && w.p < len)) break;
-  }
-  if (active) S.n_blocks[stream] = lz_walk_finish(w, len, bitmap, tile_sym, blocks);
-}
-
-// ---------------------------------------------------------------------------------
-__global__ __launch_bounds__(WALK_TILE) void lz_symbols_kernel(const uint8_t *__restrict__ src_arena,
-                                                               const StreamDesc *__restrict__ descs,
-                                                               DeflateScratch S, uint32_t tiles_per_stream) {
-  __shared__ uint32_t wave_tot[WALK_TILE / 64];
-  if (S.error[0]) return;
-  const uint32_t stream = blockIdx.x / tiles_per_stream;
-  const uint32_t tile = blockIdx.x % tiles_per_stream;
   const StreamDesc sd = descs[stream];
-  if (sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len > 0xFFFFFFF0ull) {
+    if (lane == 0) S.n_blocks[stream] = 0;
+    return;
+  }
   const uint32_t len = (uint32_t)sd.src_len;
-  if (tile * WALK_TILE >= len) return;  // uniform per workgroup
+  const uint8_t *s = src_arena + sd.src_off;
   const uint64_t base = S.pos_base[stream];
-  const uint32_t t = threadIdx.x;
-  const uint32_t p = tile * WALK_TILE + t;
-  MacroStep m;
-  m.bref = 0;
-  m.step = 0;
-  uint32_t cnt = 0;
-  if (p < len && ((S.bitmap[(base >> 6) + (p >> 6)] >> (p & 63)) & 1ull)) {
-    m.bref = S.bref[base + p];
-    m.step = S.step[base + p];
-    cnt = macro_sym_count(m);
-  }
-  // exclusive scan of cnt over the 256 threads
-  const int lane = t & 63;
-  uint32_t incl = cnt;
+  const uint32_t *brefs = S.bref + base, *steps = S.step + base;
+  uint32_t *syms = S.syms + base;
+  BlockDesc *blocks = S.blocks + S.blk_base[stream];
+
+  uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
+  uint32_t B = 0;
+  uint32_t br = 0, st = 0;
+  if ((uint32_t)lane < len) { br = brefs[lane]; st = steps[lane]; }
+  while (B < len) {
+    // next tile's table entries are requested before this tile is worked on
+    uint32_t Bn = B + PARSE_TILE;
+    uint32_t br_n = 0, st_n = 0;
+    if (Bn + (uint32_t)lane < len) { br_n = brefs[Bn + lane]; st_n = steps[Bn + lane]; }
+
+    const uint32_t p = B + (uint32_t)lane;
+    const bool valid = p < len;
+    const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
+    const uint32_t lits = br ? macro_lits(st) : 0u;
+    const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
+    uint32_t J[7];
+    J[0] = (uint32_t)lane + adv;  // <= 63 + 512
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t u = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += u;
+    for (int k = 1; k < 7; k++) {
+      const uint32_t x = J[k - 1];
+      const uint32_t y = __shfl(J[k - 1], (int)(x & 63u), 64);
+      J[k] = x < (uint32_t)PARSE_TILE ? y : x;
+    }
+#pragma unroll
+    for (int i = 0; i < PARSE_MARKS / 64; i++) M[lane + 64 * i] = 0;
+    if (lane == 0) M[entry - B] = 1;
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+      const uint8_t m = M[lane];
+      if (m) M[J[k]] = 1;
+    }
+    const bool visited = valid && M[lane] != 0;
+    // the exit of the tile = entry of a later one (none: the stream ends here)
+    uint32_t next_entry = len;
+#pragma unroll 1
+    for (int i = 1; i < PARSE_MARKS / 64 - 0; i++) {
+      const unsigned long long b = __ballot(M[64 * i + lane] != 0);
+      if (b) { next_entry = B + 64u * (uint32_t)i + (uint32_t)(__ffsll((long long)b) - 1); break; }
+    }
+    // symbol indices: exclusive scan of cnt over the visited lanes
+    uint32_t incl = visited ? cnt : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    const uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t first = nsym + incl - (visited ? cnt : 0u);
+    if (visited) {
+      MacroStep m;
+      m.bref = br;
+      m.step = st;
+      lz_emit_position(s, p, m, syms, first);
+    }
+    // block cut: the first visited node that ends past blk_start + 65534
+    const uint64_t limit = (uint64_t)blk_start + MAX_BLOCK_SRC_LEN;
+    const unsigned long long cb = __ballot(visited && (uint64_t)p + adv > limit);
+    if (cb) {
+      const int c = __ffsll((long long)cb) - 1;
+      uint32_t cutpos, symidx;
+      if (br == 0) { cutpos = p; symidx = first; }
+      else if ((uint64_t)p + lits > limit) { const uint32_t i = (uint32_t)(limit - p); cutpos = p + i; symidx = first + i; }
+      else { cutpos = p + lits; symidx = first + lits; }
+      cutpos = __shfl(cutpos, c, 64);
+      symidx = __shfl(symidx, c, 64);
+      if (lane == 0) {
+        BlockDesc b;
+        b.src_start = blk_start; b.src_len = cutpos - blk_start;
+        b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
+        blocks[nblk] = b;
+      }
+      nblk++;
+      blk_start = cutpos;
+      blk_sym_start = symidx;
+    }
+    nsym += total;
+    entry = next_entry;
+    // tiles the parse jumps over entirely are skipped
+    const uint32_t Be = entry & ~63u;
+    if (Be > Bn) {
+      Bn = Be;
+      br_n = 0; st_n = 0;
+      if (Bn + (uint32_t)lane < len) { br_n = brefs[Bn + lane]; st_n = steps[Bn + lane]; }
+    }
+    B = Bn;
+    br = br_n;
+    st = st_n;
   }
-  if (lane == 63) wave_tot[t >> 6] = incl;
-  __syncthreads();
-  uint32_t before = 0;
-  for (uint32_t w = 0; w < (t >> 6); w++) before += wave_tot[w];
-  if (cnt) {
-    const uint32_t first = S.tile_sym[base / WALK_TILE + tile] + before + incl - cnt;
-    lz_emit_position(src_arena + sd.src_off, p, m, S.syms + base, first);
+  if (lane == 0) {
+    BlockDesc b;  // the final block, always present (zd.ml:1216)
+    b.src_start = blk_start; b.src_len = len - blk_start;
+    b.sym_start = blk_sym_start; b.n_syms = nsym - blk_sym_start;
+    blocks[nblk] = b;
+    S.n_blocks[stream] = nblk + 1;
   }
 }
 
@@ -703,10 +702,7 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
   ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)(n * cps)), dim3(MATCH_THREADS), 0, d_src,
             d_descs, S, (uint32_t)cps, K, K / 4, good_match);
-  ZD_LAUNCH(ctx, "lz_walk", lz_walk_kernel, dim3((unsigned)((n + WALK_LANES - 1) / WALK_LANES)), dim3(64), 0,
-            d_descs, (uint32_t)n, S);
-  ZD_LAUNCH(ctx, "lz_symbols", lz_symbols_kernel, dim3((unsigned)(n * cps)), dim3(WALK_TILE), 0, d_src,
-            d_descs, S, (uint32_t)cps);
+  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
             d_results, S, crc_op);
   return hipGetLastError();
