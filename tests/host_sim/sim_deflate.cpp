@@ -61,16 +61,16 @@ static uint32_t parse_tiles_model(const uint8_t *s, uint32_t len, const uint32_t
     }
     for (int k = 1; k < 7; k++)
       for (int t = 0; t < T; t++) { uint32_t x = J[k - 1][t]; J[k][t] = x < 64 ? J[k - 1][x] : x; }
-    uint8_t M[640];
-    memset(M, 0, sizeof M);
-    M[entry - B] = 1;
-    for (int k = 6; k >= 0; k--) {
-      uint8_t m[64];
-      for (int t = 0; t < T; t++) m[t] = M[t];
-      for (int t = 0; t < T; t++) if (m[t]) M[J[k][t]] = 1;
+    bool M[64];
+    uint32_t vv[64];
+    for (int t = 0; t < T; t++) {  // descending search, as the kernel's lanes do
+      uint32_t v = entry - B;
+      for (int k = 6; k >= 0; k--) { uint32_t y = J[k][v]; if (y <= (uint32_t)t) v = y; }
+      vv[t] = v;
+      M[t] = v == (uint32_t)t;
     }
-    uint32_t exit_abs = len;
-    for (int x = 64; x < X; x++) if (M[x]) { exit_abs = B + x; break; }
+    uint32_t exit_abs = B + J[0][vv[63]];
+    if (exit_abs > len) exit_abs = len;
     // scan + emission
     uint32_t first[64], run = nsym;
     for (int t = 0; t < T; t++) { first[t] = run; if (valid[t] && M[t]) run += cnt[t]; }

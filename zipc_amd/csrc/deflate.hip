@@ -289,21 +289,16 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
 // emit, where are blocks cut.  One wave per stream walks the stream in tiles of
 // 64 positions (one per lane).  Inside a tile the serial walk "p -> p + advance"
 // is replaced by pointer doubling: J_k[t] = position reached from t after 2^k
-// steps (shuffles; indices >= 64 are exits into later tiles), then the visited
-// set is marked top-down from the tile's entry position through a 640-byte LDS
-// mark array (k = 6..0: every marked lane marks J_k of itself).  Visited lanes
-// get their symbol index from a wave scan and write their symbols.  The only
-// serial dependency left between tiles is the entry position.
+// steps (shuffles; indices >= 64 are exits into later tiles); then every lane
+// decides whether it is on the path from the tile's entry position by a
+// descending search through those tables.  Visited lanes get their symbol index
+// from a wave scan and write their symbols.  The only serial dependency left
+// between tiles is the entry position.
 constexpr int PARSE_TILE = 64;
-constexpr int PARSE_MARKS = 640;  // local indices: 64 positions + exits up to +512, padded
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
                                                       const StreamDesc *__restrict__ descs,
                                                       DeflateScratch S) {
-  // marks are exchanged between the lanes of the wave: volatile keeps every
-  // access in program order (LDS operations of one wave execute in order)
-  __shared__ uint8_t M_raw[PARSE_MARKS];
-  volatile uint8_t *M = M_raw;
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
@@ -342,22 +337,20 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
       const uint32_t y = __shfl(J[k - 1], (int)(x & 63u), 64);
       J[k] = x < (uint32_t)PARSE_TILE ? y : x;
     }
-#pragma unroll
-    for (int i = 0; i < PARSE_MARKS / 64; i++) M[lane + 64 * i] = 0;
-    if (lane == 0) M[entry - B] = 1;
+    // Is lane t on the path from the entry?  Every lane searches the path for the
+    // largest element <= t, descending through the 2^k-step tables (the path is
+    // strictly increasing): 7 shuffles, no memory.
+    uint32_t v = entry - B;  // < 64: tiles the parse jumps over are skipped below
 #pragma unroll
     for (int k = 6; k >= 0; k--) {
-      const uint8_t m = M[lane];
-      if (m) M[J[k]] = 1;
+      const uint32_t y = __shfl(J[k], (int)v, 64);
+      if (y <= (uint32_t)lane) v = y;
     }
-    const bool visited = valid && M[lane] != 0;
-    // the exit of the tile = entry of a later one (none: the stream ends here)
-    uint32_t next_entry = len;
-#pragma unroll 1
-    for (int i = 1; i < PARSE_MARKS / 64 - 0; i++) {
-      const unsigned long long b = __ballot(M[64 * i + lane] != 0);
-      if (b) { next_entry = B + 64u * (uint32_t)i + (uint32_t)(__ffsll((long long)b) - 1); break; }
-    }
+    const bool visited = valid && v == (uint32_t)lane;
+    // the path leaves the tile after the last visited position (lane 63's answer)
+    const uint32_t last = __shfl(v, 63, 64);
+    uint32_t next_entry = B + __shfl(J[0], (int)last, 64);
+    if (next_entry > len) next_entry = len;
     // symbol indices: exclusive scan of cnt over the visited lanes
     uint32_t incl = visited ? cnt : 0u;
 #pragma unroll
