@@ -12,11 +12,9 @@
 //                            (64 KiB), 1024 positions inserted per round.
 //   lz_match_kernel          one lane per position: best match over the first K and
 //                            the first K/4 chain candidates (find_backref,
-//                            zd.ml:1176-1201), exchanged through LDS with the
-//                            following positions to form the position's "macro
-//                            step" of the lazy parse (deflate_lane.h) -> 8 bytes
-//                            per position.
-//   lz_parse_kernel          one wave per stream: which positions the lazy parse
+//                            zd.ml:1176-1201) -> 8 bytes per position.
+//   lz_parse_kernel          one wave per stream: the "macro step" of every position
+//                            (deflate_lane.h), then which positions the lazy parse
 //                            visits (Lz77.compress zd.ml:1203-1244), found per
 //                            64-position tile by pointer doubling + marking
 //                            instead of a serial walk; symbol emission and block
@@ -53,8 +51,7 @@ struct DeflateScratch {
   uint32_t *n_blocks;   // [n]
   uint32_t *error;      // [1] != 0: scratch too small for the batch (bad total_src_len)
   uint16_t *prev;       // [P] chain links
-  uint32_t *bref;       // [P] MacroStep::bref
-  uint32_t *step;       // [P] MacroStep::step
+  uint64_t *match;      // [P] lz_match_position: best-of-K | best-of-K/4 << 32
   uint32_t *syms;       // [P]
   BlockDesc *blocks;    // [Bk]
   uint64_t cap_positions, cap_blocks;
@@ -73,7 +70,7 @@ size_t deflate_scratch_bytes(size_t n, size_t /*max_src_len*/, size_t total_src_
   size_t b = 0;
   b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
   if (level != LEVEL_NONE) {
-    b += align_up(P * 2, 256) + 3 * align_up(P * 4, 256);
+    b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
   }
   return b + 1024;
@@ -88,12 +85,11 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
-  s.prev = nullptr; s.bref = nullptr; s.step = nullptr;
+  s.prev = nullptr; s.match = nullptr;
   s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
     s.prev = (uint16_t *)p; p += align_up(P * 2, 256);
-    s.bref = (uint32_t *)p; p += align_up(P * 4, 256);
-    s.step = (uint32_t *)p; p += align_up(P * 4, 256);
+    s.match = (uint64_t *)p; p += align_up(P * 8, 256);
     s.syms = (uint32_t *)p; p += align_up(P * 4, 256);
     s.blocks = (BlockDesc *)p; p += align_up(Bk * sizeof(BlockDesc), 256);
   }
@@ -232,55 +228,28 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
 
 // ---------------------------------------------------------------------------------
 constexpr uint32_t MATCH_THREADS = 256;
-constexpr uint32_t MATCH_HALO = 32;  // following positions whose matches are shared through LDS
-
-// match pairs of the tile (+ halo) in LDS; anything further is recomputed
-struct TileMatches {
-  const uint64_t *sm;
-  uint32_t base, count;
-  const uint8_t *s;
-  const uint16_t *prev;
-  uint32_t len;
-  int K, Kq;
-  __device__ __forceinline__ uint64_t operator()(uint32_t j) const {
-    const uint32_t k = j - base;
-    if (k < count) return sm[k];
-    return lz_match_position(s, len, j, prev, K, Kq);
-  }
-};
 
 __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
-                                                                 DeflateScratch S, uint32_t chunks_per_stream,
-                                                                 int K, int Kq, int good_match) {
-  __shared__ uint64_t sm[MATCH_THREADS + MATCH_HALO];
+                                                                 DeflateScratch S, uint32_t n_streams,
+                                                                 uint32_t chunks_per_stream, int K, int Kq) {
   if (S.error[0]) return;
-  const uint32_t stream = blockIdx.x / chunks_per_stream;
-  const uint32_t chunk = blockIdx.x % chunks_per_stream;
+  // XCD-aware order: workgroups b and b + 8 share an XCD (and its L2), so the
+  // grid is cut into 8 contiguous slabs, one per XCD: all tiles of a stream --
+  // which re-read the same 32 KiB window and its chain links -- hit one L2.
+  const uint32_t nb = gridDim.x;
+  const uint32_t per_xcd = (nb + 7) / 8;
+  const uint32_t logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const uint32_t stream = logical / chunks_per_stream;
+  const uint32_t chunk = logical % chunks_per_stream;
+  if (stream >= n_streams) return;  // grid is padded to a multiple of 8
   const StreamDesc sd = descs[stream];
-  if (sd.src_len == 0 || sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
   const uint32_t len = (uint32_t)sd.src_len;
-  const uint32_t base_pos = chunk * MATCH_THREADS;
-  if (base_pos >= len) return;  // uniform per workgroup
-  const uint8_t *s = src_arena + sd.src_off;
+  const uint32_t p = chunk * MATCH_THREADS + threadIdx.x;
+  if (p > len - 4) return;
   const uint64_t base = S.pos_base[stream];
-  const uint16_t *prev = S.prev + base;
-  const uint32_t t = threadIdx.x;
-  const uint32_t p = base_pos + t;
-  const bool has_match = len >= 4;  // positions <= len - 4 have chain links
-  sm[t] = (has_match && p <= len - 4) ? lz_match_position(s, len, p, prev, K, Kq) : 0ull;
-  if (t < MATCH_HALO) {
-    const uint32_t ph = base_pos + MATCH_THREADS + t;
-    sm[MATCH_THREADS + t] = (has_match && ph <= len - 4) ? lz_match_position(s, len, ph, prev, K, Kq) : 0ull;
-  }
-  __syncthreads();
-  if (p >= len) return;
-  TileMatches get;
-  get.sm = sm; get.base = base_pos; get.count = MATCH_THREADS + MATCH_HALO;
-  get.s = s; get.prev = prev; get.len = len; get.K = K; get.Kq = Kq;
-  const MacroStep m = lz_macro_position(p, len, good_match, get);
-  S.bref[base + p] = m.bref;
-  S.step[base + p] = m.step;
+  S.match[base + p] = lz_match_position(src_arena + sd.src_off, len, p, S.prev + base, K, Kq);
 }
 
 // ---------------------------------------------------------------------------------
@@ -298,7 +267,7 @@ constexpr int PARSE_TILE = 64;
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
                                                       const StreamDesc *__restrict__ descs,
-                                                      DeflateScratch S) {
+                                                      DeflateScratch S, int good_match) {
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
@@ -310,22 +279,55 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   const uint32_t len = (uint32_t)sd.src_len;
   const uint8_t *s = src_arena + sd.src_off;
   const uint64_t base = S.pos_base[stream];
-  const uint32_t *brefs = S.bref + base, *steps = S.step + base;
+  const uint64_t *match = S.match + base;
+  const bool has_match = len >= (uint32_t)MIN_MATCH_LEN;
+  const uint32_t max_pos = has_match ? len - MIN_MATCH_LEN : 0;  // positions <= max_pos have a match entry
   uint32_t *syms = S.syms + base;
   BlockDesc *blocks = S.blocks + S.blk_base[stream];
 
   uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
   uint32_t B = 0;
-  uint32_t br = 0, st = 0;
-  if ((uint32_t)lane < len) { br = brefs[lane]; st = steps[lane]; }
+  uint64_t m_cur = 0;
+  if (has_match && (uint32_t)lane <= max_pos) m_cur = match[lane];
   while (B < len) {
     // next tile's table entries are requested before this tile is worked on
     uint32_t Bn = B + PARSE_TILE;
-    uint32_t br_n = 0, st_n = 0;
-    if (Bn + (uint32_t)lane < len) { br_n = brefs[Bn + lane]; st_n = steps[Bn + lane]; }
+    uint64_t m_nxt = 0;
+    if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
 
     const uint32_t p = B + (uint32_t)lane;
     const bool valid = p < len;
+    // macro step of every position of the tile (lz_macro_position, with the
+    // following positions' matches taken from the neighbouring lanes)
+    uint32_t br = 0, st = 1u | (1u << 16);
+    {
+      uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
+      bool chaining = (pend & 0x1FF) != 0;
+      uint32_t n_lits = 0, j = p + 1;
+      while (__ballot(chaining)) {
+        const uint32_t off = j - B;  // >= 1
+        const uint64_t a = __shfl((unsigned long long)m_cur, (int)(off & 63u), 64);
+        const uint64_t b2 = __shfl((unsigned long long)m_nxt, (int)(off & 63u), 64);
+        if (chaining) {
+          if (j > max_pos) chaining = false;
+          else {
+            uint64_t mj = off < 64u ? a : b2;
+            if (off >= 128u) mj = match[j];  // beyond the staged tiles: rare
+            const uint32_t pl = pend & 0x1FF;
+            const uint32_t rem = len - j;
+            const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
+            uint32_t nb = 0;
+            if (pl < maxlen) {
+              const uint32_t c = pl >= (uint32_t)good_match ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+              if ((c & 0x1FF) > pl) nb = c;
+            }
+            if (nb == 0) chaining = false;
+            else { n_lits++; pend = nb; j++; }
+          }
+        }
+      }
+      if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
+    }
     const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
     const uint32_t lits = br ? macro_lits(st) : 0u;
     const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
@@ -393,12 +395,11 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     const uint32_t Be = entry & ~63u;
     if (Be > Bn) {
       Bn = Be;
-      br_n = 0; st_n = 0;
-      if (Bn + (uint32_t)lane < len) { br_n = brefs[Bn + lane]; st_n = steps[Bn + lane]; }
+      m_nxt = 0;
+      if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
     }
     B = Bn;
-    br = br_n;
-    st = st_n;
+    m_cur = m_nxt;
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
@@ -693,9 +694,9 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
   const size_t cps = max_src_len ? (max_src_len + MATCH_THREADS - 1) / MATCH_THREADS : 1;
   if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)(n * cps)), dim3(MATCH_THREADS), 0, d_src,
-            d_descs, S, (uint32_t)cps, K, K / 4, good_match);
-  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S);
+  ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((n * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0, d_src,
+            d_descs, S, (uint32_t)n, (uint32_t)cps, K, K / 4);
+  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
             d_results, S, crc_op);
   return hipGetLastError();
