@@ -41,6 +41,56 @@ def test_checksums_match_oracle(gpu_ctx, oracle):
     assert Adler_32.string(b"\xff" * 4200) == 0xA2045889  # not RFC 1950's a2d65889
 
 
+def _chunk_with_s2(target_s2, n=5552):
+    """n bytes whose position-weighted sum S2 = sum (n - i) b_i equals target_s2"""
+    full = n * (n + 1) // 2
+    v = min(target_s2 // full, 254)
+    b = [v] * n
+    rem = target_s2 - v * full
+    i = 0
+    while rem >= n - i and i < n:
+        w = n - i
+        k = min(rem // w, 255 - b[i])
+        b[i] += k
+        rem -= k * w
+        i += 1
+    while rem > 0:  # weights n-i for i >= current index are all <= rem's reach
+        w = min(rem, n - i)
+        j = n - w
+        if b[j] < 255:
+            b[j] += 1
+            rem -= w
+        else:
+            i += 1
+    return bytes(b)
+
+
+def test_adler_chain_ambiguous_chunks(gpu_ctx, oracle):
+    """Buffers built so that n*s1 + S2 of a 5552-byte chunk lands right at 0 and
+    right at 2^31, where the reference's signed remainder (zipc_deflate.ml:95,196)
+    depends on the sign of the running s2: the parallel chain must replay those
+    chunks exactly."""
+    from zipc_amd.zipc_deflate import Adler_32
+
+    n = 5552
+    for deltas in ([-30000, -1, 0, 1, 30000], [0, 0, 0], [65000, -65000, 5, -5, 0, 1]):
+        for lead in (b"", b"\xff" * n, util.rand_bytes(3 * n, 9)):
+            data = bytearray(lead)
+            for d in deltas:
+                for target in (1 << 31, 40000):
+                    st = oracle.adler32_update(1, bytes(data)) if len(data) % n == 0 else None
+                    s1 = oracle.adler32(bytes(data)) & 0xFFFF if len(data) else 1
+                    want = target + d - n * s1
+                    if want < 0:
+                        want = 0
+                    data += _chunk_with_s2(want, n)
+                    data += b"\xff" * n  # pushes s2 negative (C >= 2^31) before the next crafted chunk
+            data = bytes(data)
+            assert len(data) % n == 0
+            assert Adler_32.string(data) == oracle.adler32(data), (deltas, len(lead))
+            assert Adler_32.string(data + b"xyz") == oracle.adler32(data + b"xyz")
+
+
 def test_deflate_trip_like_reference(gpu_ctx, oracle):  # test/test.ml:28-43,123-126
     from zipc_amd import zipc_deflate as Z
 

@@ -310,15 +310,18 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
   }
   if (want_adler32) {
     const uint64_t n_chunks = len ? len / ADLER_CHUNK + 1 : 0;
-    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (size_t)(n_chunks + 1) * sizeof(uint2)));
+    // chunk sums, followed by the ambiguous-chunk list of adler_chain_kernel
+    const size_t sums_bytes = ((size_t)(n_chunks + 1) * sizeof(uint2) + 255) / 256 * 256;
+    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, sums_bytes + ADLER_AMB_CAP * sizeof(uint32_t)));
     uint2 *sums = (uint2 *)ctx->adler_sums.p;
+    uint32_t *amb = (uint32_t *)((uint8_t *)ctx->adler_sums.p + sums_bytes);
     if (n_chunks) {
       if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
       ZD_LAUNCH(ctx, "adler_chunks", adler_chunks_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
                 (const uint8_t *)d_buf, (uint64_t)len, n_chunks, sums);
     }
-    ZD_LAUNCH(ctx, "adler_chain", adler_chain_kernel, dim3(1), dim3(64), 0, (const uint2 *)sums,
-              (uint64_t)len, n_chunks, d_out + 1);
+    ZD_LAUNCH(ctx, "adler_chain", adler_chain_kernel, dim3(1), dim3(1024), 0, (const uint2 *)sums,
+              (uint64_t)len, n_chunks, amb, ADLER_AMB_CAP, d_out + 1);
     HIP_TRY(ctx, hipGetLastError());
   }
   return ZIPC_HIP_OK;

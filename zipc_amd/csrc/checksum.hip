@@ -76,6 +76,18 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
   uint32_t c = 0;
   int64_t i = lo;
   if (hi > lo) {
+    // whole 16-byte vectors first: one request per 16 bytes instead of four
+    for (; i + 16 <= hi; i += 16) {
+      const u32x4 v = load16_unaligned(p + i);
+      uint32_t u = c ^ v.x;
+      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+      u = c ^ v.y;
+      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+      u = c ^ v.z;
+      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+      u = c ^ v.w;
+      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+    }
     // word loop (src/zipc_deflate.ml:141-150)
     for (; i + 4 <= hi; i += 4) {
       uint32_t u = c ^ load_u32_le(p + i);
@@ -162,18 +174,143 @@ __global__ __launch_bounds__(256) void adler_chunks_kernel(const uint8_t *__rest
   if (lane == 0) sums[chunk] = make_uint2(S1, S2);
 }
 
-// the chunk chain, in order (src/zipc_deflate.ml:196): s1/s2 := signed rem
-__global__ void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks,
-                                   uint32_t *__restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  uint32_t s1, s2;
-  adler_unpack(1u, s1, s2);  // Adler_32.init
-  const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
-  for (uint64_t k = 0; k < n_chunks; k++) {
-    const uint2 s = sums[k];
-    adler_chunk_step(s1, s2, k == 0 ? r : ADLER_CHUNK, s.x, s.y);
+// The chunk chain (src/zipc_deflate.ml:196: s1/s2 := SIGNED rem after every chunk)
+// for hundreds of thousands of chunks, without walking them one by one.
+//   s1 never goes negative, so s1 before chunk k is (1 + sum of S1) mod 65521: a scan.
+//   s2: with x = s2 before the chunk (|x| < 65521) the reference computes
+//   srem32(wrap32(x + C)), C = n * s1 + S2 < 2^32.  Unless C lies within 65521 of 0
+//   or of 2^31 the branch taken depends on C alone: below 2^31 the result is
+//   (x + C) mod p >= 0, above it is congruent to x + C - 225 (2^32 mod 65521 = 225)
+//   with a non-positive representative.  So the residues follow from a second scan
+//   of a_k = C_k - 225 * hi_k; the few chunks whose branch does depend on x
+//   ("ambiguous", about 6e-5 of them on random data) are then replayed exactly, in
+//   order, by one thread, each replay shifting all later residues by a constant.
+constexpr uint32_t CHAIN_THREADS_A = 1024;
+
+__device__ __forceinline__ uint64_t block_excl_scan_mod(uint64_t v, uint64_t *sh, int t) {
+  // exclusive scan of per-thread values (each < 65521) over the 1024 threads, mod p
+  sh[t] = v;
+  __syncthreads();
+  for (int o = 1; o < (int)CHAIN_THREADS_A; o <<= 1) {
+    const uint64_t u = t >= o ? sh[t - o] : 0;
+    __syncthreads();
+    sh[t] = (sh[t] + u) % ADLER_BASE;
+    __syncthreads();
   }
-  out[0] = adler_pack(s1, s2);
+  const uint64_t incl = sh[t];
+  __syncthreads();
+  return (incl + ADLER_BASE - v % ADLER_BASE) % ADLER_BASE;
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n,
+                                                                    uint64_t n_chunks, uint32_t *__restrict__ amb,
+                                                                    uint32_t amb_cap, uint32_t *__restrict__ out) {
+  __shared__ uint64_t sh[CHAIN_THREADS_A];
+  __shared__ uint32_t amb_count;
+  const int t = threadIdx.x;
+  const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
+  const uint64_t per = n_chunks ? (n_chunks + CHAIN_THREADS_A - 1) / CHAIN_THREADS_A : 1;
+  const uint64_t lo = (uint64_t)t * per < n_chunks ? (uint64_t)t * per : n_chunks;
+  const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
+  if (t == 0) amb_count = 0;
+  // pass 1: s1 before every run
+  uint64_t acc = 0;
+  for (uint64_t k = lo; k < hi; k++) acc += sums[k].x;
+  const uint64_t s1_run = (1 + block_excl_scan_mod(acc % ADLER_BASE, sh, t)) % ADLER_BASE;
+  // pass 2: a_k summed per run, ambiguous chunks listed
+  uint64_t s1 = s1_run, a_acc = 0;
+  for (uint64_t k = lo; k < hi; k++) {
+    const uint2 sm = sums[k];
+    const uint32_t len = k == 0 ? r : ADLER_CHUNK;
+    const uint64_t C = (uint64_t)len * s1 + sm.y;  // < 2^32
+    const bool hi_k = C >= 0x80000000ull;
+    const bool ambiguous = C < ADLER_BASE || (C > 0x80000000ull - ADLER_BASE && C < 0x80000000ull + ADLER_BASE);
+    if (ambiguous) {
+      const uint32_t slot = atomicAdd(&amb_count, 1u);
+      if (slot < amb_cap) amb[slot] = (uint32_t)k;
+    }
+    a_acc = (a_acc + C % ADLER_BASE + (hi_k ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
+    s1 = (s1 + sm.x) % ADLER_BASE;
+  }
+  const uint64_t res_run = block_excl_scan_mod(a_acc, sh, t);  // residue of s2 before the run (x0 = 0)
+  __shared__ uint64_t run_s1[CHAIN_THREADS_A], run_res[CHAIN_THREADS_A];
+  run_s1[t] = s1_run;
+  run_res[t] = res_run;
+  __syncthreads();
+  if (t != 0) return;
+
+  // replay, thread 0.  state(k) recomputes (s1, predicted residue, branch of k-1)
+  // for one chunk from its run's start (runs are short).
+  const uint32_t n_amb = amb_count < amb_cap ? amb_count : amb_cap;
+  // insertion sort of the ambiguous indices (atomics gave them out of order)
+  for (uint32_t i = 1; i < n_amb; i++) {
+    const uint32_t v = amb[i];
+    uint32_t j = i;
+    while (j > 0 && amb[j - 1] > v) { amb[j] = amb[j - 1]; j--; }
+    amb[j] = v;
+  }
+  uint64_t delta = 0;          // correction (mod p) of every predicted residue from here on
+  int64_t exact_next = 0;      // exact s2 after the last replayed chunk ...
+  uint64_t exact_at = ~0ull;   // ... valid as the input of chunk `exact_at`
+  uint32_t final_s2 = 0;
+  const bool overflow = amb_count > amb_cap;
+  for (uint32_t i = 0; i <= n_amb; i++) {
+    const uint64_t k = i < n_amb ? amb[i] : n_chunks;  // last turn: the state after all chunks
+    // predicted state before chunk k
+    const uint64_t run = k / per < CHAIN_THREADS_A ? k / per : CHAIN_THREADS_A - 1;
+    uint64_t s1k = run_s1[run], resk = run_res[run];
+    bool prev_hi = false;
+    uint64_t start = run * per;
+    if (start > k) start = k;
+    for (uint64_t q = start; q < k; q++) {
+      const uint2 sm = sums[q];
+      const uint32_t len = q == 0 ? r : ADLER_CHUNK;
+      const uint64_t C = (uint64_t)len * s1k + sm.y;
+      prev_hi = C >= 0x80000000ull;
+      resk = (resk + C % ADLER_BASE + (prev_hi ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
+      s1k = (s1k + sm.x) % ADLER_BASE;
+    }
+    if (start == k && k > 0) {  // k opens its run: the branch of k-1 comes from the previous run
+      const uint64_t prun = (k - 1) / per;
+      uint64_t s1p = run_s1[prun];
+      for (uint64_t q = prun * per; q < k - 1; q++) s1p = (s1p + sums[q].x) % ADLER_BASE;
+      const uint64_t C = (uint64_t)(k - 1 == 0 ? r : ADLER_CHUNK) * s1p + sums[k - 1].y;
+      prev_hi = C >= 0x80000000ull;
+    }
+    int64_t x;
+    if (k == exact_at) x = exact_next;
+    else {
+      const uint64_t rr = (resk + delta) % ADLER_BASE;
+      x = (k > 0 && prev_hi) ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
+    }
+    if (i == n_amb) { final_s2 = (uint32_t)(int32_t)x; break; }
+    const uint2 sm = sums[k];
+    const uint32_t len = k == 0 ? r : ADLER_CHUNK;
+    const uint64_t C = (uint64_t)len * s1k + sm.y;
+    const uint32_t t2 = (uint32_t)((int64_t)C + x);
+    const int32_t outv = (int32_t)t2 % (int32_t)ADLER_BASE;  // the reference's signed rem
+    const uint64_t ro = (uint64_t)(((int64_t)outv % ADLER_BASE + ADLER_BASE) % ADLER_BASE);
+    const bool hi_k = C >= 0x80000000ull;
+    const uint64_t predicted = (resk + delta + C % ADLER_BASE + (hi_k ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
+    delta = (delta + ro + ADLER_BASE - predicted) % ADLER_BASE;
+    exact_next = outv;
+    exact_at = k + 1;
+  }
+  uint64_t s1_all = run_s1[CHAIN_THREADS_A - 1];
+  {
+    uint64_t st = (CHAIN_THREADS_A - 1) * per;
+    if (st > n_chunks) st = n_chunks;
+    for (uint64_t q = st; q < n_chunks; q++) s1_all = (s1_all + sums[q].x) % ADLER_BASE;
+  }
+  if (overflow) {
+    // more ambiguous chunks than the list holds (adversarial input): plain walk
+    uint32_t a1, a2;
+    adler_unpack(1u, a1, a2);
+    for (uint64_t k = 0; k < n_chunks; k++) adler_chunk_step(a1, a2, k == 0 ? r : ADLER_CHUNK, sums[k].x, sums[k].y);
+    out[0] = adler_pack(a1, a2);
+    return;
+  }
+  out[0] = adler_pack((uint32_t)s1_all, final_s2);
 }
 
 }  // namespace zd
