@@ -147,7 +147,21 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
         prev[p] = (q >= 0 && p - q <= 32768) ? (uint16_t)(p - q) : 0;
         head[h] = p;
       }
-      for (uint32_t p = 0; p + 4 <= len; p++) match[p] = lz_match_position(src, len, p, prev.data(), K, K / 4);
+      // the kernel's 4-positions-per-lane form, positions 256 apart
+      for (uint32_t b0 = 0; b0 + 4 <= len; b0 += 1024) {
+        for (uint32_t t = 0; t < 256; t++) {
+          uint32_t pp[4];
+          bool act[4];
+          uint64_t out[4];
+          for (int i = 0; i < 4; i++) { pp[i] = b0 + t + 256 * i; act[i] = pp[i] + 4 <= len; if (!act[i]) pp[i] = 0; }
+          lz_match_positions<4>(src, len, pp, act, prev.data(), K, K / 4, out);
+          for (int i = 0; i < 4; i++) {
+            if (!act[i]) continue;
+            match[pp[i]] = out[i];
+            if ((pp[i] & 63) == 0 && out[i] != lz_match_position(src, len, pp[i], prev.data(), K, K / 4)) return 99;
+          }
+        }
+      }
     }
     // macro step of every position (+ literal runs), then the walk in small
     // resumable slices like the kernel's ring, then the symbol emission

@@ -228,6 +228,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
 
 // ---------------------------------------------------------------------------------
 constexpr uint32_t MATCH_THREADS = 256;
+constexpr int MATCH_NP = 4;  // positions per lane, their chain walks interleaved
+constexpr uint32_t MATCH_TILE = MATCH_THREADS * MATCH_NP;
 
 __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
@@ -246,10 +248,22 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
   const StreamDesc sd = descs[stream];
   if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
   const uint32_t len = (uint32_t)sd.src_len;
-  const uint32_t p = chunk * MATCH_THREADS + threadIdx.x;
-  if (p > len - 4) return;
+  const uint32_t p0 = chunk * MATCH_TILE + threadIdx.x;
+  if (chunk * MATCH_TILE > len - 4) return;
   const uint64_t base = S.pos_base[stream];
-  S.match[base + p] = lz_match_position(src_arena + sd.src_off, len, p, S.prev + base, K, Kq);
+  uint32_t p[MATCH_NP];
+  bool act[MATCH_NP];
+  uint64_t out[MATCH_NP];
+#pragma unroll
+  for (int i = 0; i < MATCH_NP; i++) {
+    p[i] = p0 + MATCH_THREADS * (uint32_t)i;
+    act[i] = p[i] <= len - 4;
+    if (!act[i]) p[i] = 0;
+  }
+  lz_match_positions<MATCH_NP>(src_arena + sd.src_off, len, p, act, S.prev + base, K, Kq, out);
+#pragma unroll
+  for (int i = 0; i < MATCH_NP; i++)
+    if (act[i]) S.match[base + p[i]] = out[i];
 }
 
 // ---------------------------------------------------------------------------------
@@ -692,7 +706,7 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   level_params(level, good_match, K);
   ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S);
   ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
-  const size_t cps = max_src_len ? (max_src_len + MATCH_THREADS - 1) / MATCH_THREADS : 1;
+  const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
   if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
   ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((n * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0, d_src,
             d_descs, S, (uint32_t)n, (uint32_t)cps, K, K / 4);

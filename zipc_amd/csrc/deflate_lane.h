@@ -85,6 +85,83 @@ ZD_HD uint64_t lz_match_position(const uint8_t *s, uint32_t len, uint32_t p, con
   return (uint64_t)best | ((uint64_t)snap << 32);
 }
 
+// lz_match_position for NP positions at once, their chain walks interleaved so
+// that the NP link loads, then the NP source loads, are in flight together (the
+// walk is a chain of dependent loads: one lane alone keeps a single load in
+// flight).  Same result as NP calls of lz_match_position.
+template <int NP>
+ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p, const bool *act,
+                              const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  uint32_t q[NP], best_len[NP], best[NP], snap[NP], maxlen[NP];
+  int steps[NP];
+  bool snapped[NP], done[NP];
+  uint64_t pw[NP];
+  bool any = false;
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    q[i] = p[i];
+    best_len[i] = MIN_MATCH_LEN - 1;
+    best[i] = 0;
+    snap[i] = 0;
+    steps[i] = 0;
+    snapped[i] = false;
+    maxlen[i] = 0;
+    pw[i] = 0;
+    done[i] = true;
+    if (act[i]) {
+      maxlen[i] = len - p[i] < (uint32_t)MAX_MATCH_LEN ? len - p[i] : (uint32_t)MAX_MATCH_LEN;
+      done[i] = !(best_len[i] < maxlen[i]);  // zd.ml:1181
+      if (maxlen[i] >= 8) pw[i] = load_u64_le(s + p[i]);
+    }
+    any |= !done[i];
+  }
+  while (any) {
+    uint32_t d[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) d[i] = done[i] ? 0u : (uint32_t)prev[q[i]];
+    uint64_t a[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      a[i] = 0;
+      if (!done[i]) {
+        if (d[i] == 0 || steps[i] == K) done[i] = true;
+        else {
+          q[i] -= d[i];
+          if (p[i] - q[i] > (uint32_t)MAX_MATCH_DIST) done[i] = true;  // zd.ml:1187
+          else if (maxlen[i] >= 8) a[i] = load_u64_le(s + q[i]);
+        }
+      }
+    }
+    any = false;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      if (!done[i]) {
+        steps[i]++;
+        uint32_t l;
+        if (maxlen[i] >= 8) {
+          const uint64_t x = a[i] ^ pw[i];
+          l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : common_prefix(s, q[i], p[i], maxlen[i]);
+        } else {
+          l = common_prefix(s, q[i], p[i], maxlen[i]);
+        }
+        if (l > best_len[i]) {
+          best_len[i] = l;
+          best[i] = ((p[i] - q[i]) << 9) | l;
+        }
+        if (steps[i] == Kq) { snap[i] = best[i]; snapped[i] = true; }
+        if (l == maxlen[i]) done[i] = true;  // zd.ml:1194
+      }
+      any |= !done[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    if (!snapped[i]) snap[i] = best[i];
+    if (Kq == 0) snap[i] = 0;
+    out[i] = (uint64_t)best[i] | ((uint64_t)snap[i] << 32);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The lazy parse (Lz77.compress zd.ml:1203-1244) in three parallel-friendly
 // pieces.  Between two positions where the reference has NO pending match the
