@@ -11,7 +11,8 @@
 using namespace zd;
 
 extern "C" void sim_chain(const uint8_t *s, uint32_t len, uint16_t *prev, uint32_t seed, int *max_turns) {
-  const uint32_t T = 1024, SWEEP_PERIOD = 16384, SWEEP_MARK = 20000;
+  const uint32_t T = 1024, SWEEP_PERIOD = 16384, SWEEP_MARK = 20000;  // CHAIN_ROUND positions per round
+  const int PLAIN_TURNS = 4;
   const int NEAR = 8;
   *max_turns = 0;
   if (len < 4) return;
@@ -38,18 +39,20 @@ extern "C" void sim_chain(const uint8_t *s, uint32_t len, uint16_t *prev, uint32
       hs[NEAR + t] = (uint16_t)h[t];
     }
     for (uint32_t t = 0; t < T; t++) e_old[t] = active[t] ? head[h[t]] : 0;
-    for (uint32_t t = 0; t < T; t++) {
-      bool has_succ = false;
-      if (active[t]) {
-        for (int k = NEAR; k >= 1; k--) if (hs[NEAR + t - k] == h[t]) near_pred[t] = k;
-        for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + t + k] == h[t];
-      }
-      reader[t] = active[t] && near_pred[t] == 0;
-      writer[t] = active[t] && !has_succ;
-      pending[t] = writer[t];
-    }
+    for (uint32_t t = 0; t < T; t++) { reader[t] = active[t]; writer[t] = active[t]; pending[t] = active[t]; }
     int turns = 0;
     for (;;) {
+      if (turns == PLAIN_TURNS) {
+        for (uint32_t t = 0; t < T; t++) {
+          bool has_succ = false;
+          if (active[t]) {
+            for (int k = NEAR; k >= 1; k--) if (hs[NEAR + t - k] == h[t]) near_pred[t] = k;
+            for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + t + k] == h[t];
+          }
+          reader[t] = active[t] && near_pred[t] == 0;
+          if (has_succ) { writer[t] = 0; pending[t] = 0; }
+        }
+      }
       turns++;
       // all pending threads store; a random one per address lands: apply in random order
       std::vector<uint32_t> order;

@@ -147,15 +147,19 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
 // head holds positions mod 2^16; every 16384 positions entries older than 32768
 // are replaced by a marker that decodes as "none" until the next sweep.
 constexpr uint32_t CHAIN_THREADS = 1024;
+constexpr int CHAIN_PPT = 1;                                // positions per thread and round
+constexpr uint32_t CHAIN_ROUND = CHAIN_THREADS * CHAIN_PPT;  // positions inserted per round
 constexpr uint32_t SWEEP_PERIOD = 16384;
 constexpr uint32_t SWEEP_MARK = 20000;
 constexpr int NEAR = 8;
+constexpr int PLAIN_TURNS = 4;  // peel turns before the neighbour short-cut is worth its LDS reads
+static_assert(SWEEP_PERIOD % CHAIN_ROUND == 0, "sweeps fall on round boundaries");
 
 __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
                                                                  DeflateScratch S) {
   __shared__ uint16_t head[32768];
-  __shared__ uint16_t hs[CHAIN_THREADS + 2 * NEAR];
+  __shared__ uint16_t hs[CHAIN_ROUND + 2 * NEAR];
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x;
   const uint32_t t = threadIdx.x;
@@ -165,9 +169,9 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   const uint8_t *s = src_arena + sd.src_off;
   uint16_t *prev = S.prev + S.pos_base[stream];
   const uint32_t max_pos = len - 4;
-  if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_THREADS + NEAR + t] = 0xFFFF; }
+  if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_ROUND + NEAR + t] = 0xFFFF; }
 
-  for (uint32_t B = 0; B <= max_pos; B += CHAIN_THREADS) {
+  for (uint32_t B = 0; B <= max_pos; B += CHAIN_ROUND) {
     if ((B % SWEEP_PERIOD) == 0) {
       const uint16_t mark = (uint16_t)(B + SWEEP_MARK);
       for (uint32_t i = t; i < 32768; i += CHAIN_THREADS) {
@@ -180,47 +184,89 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
       }
       __syncthreads();
     }
-    const uint32_t p = B + t;
-    const bool active = p <= max_pos;
-    const uint32_t h = active ? hash4(load_u32_le(s + p)) : 0xFFFFu;
-    hs[NEAR + t] = (uint16_t)h;
-    const uint32_t e_old = active ? head[h] : 0;
+    // local index of my i-th position: t + 1024 * i (coalesced loads and stores)
+    uint32_t h[CHAIN_PPT], e_old[CHAIN_PPT];
+    bool active[CHAIN_PPT];
+#pragma unroll
+    for (int i = 0; i < CHAIN_PPT; i++) {
+      const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
+      const uint32_t p = B + li;
+      active[i] = p <= max_pos;
+      h[i] = active[i] ? hash4(load_u32_le(s + p)) : 0xFFFFu;
+      hs[NEAR + li] = (uint16_t)h[i];
+      e_old[i] = active[i] ? head[h[i]] : 0;
+    }
     __syncthreads();
 
-    uint32_t near_pred = 0;
-    bool has_succ = false;
-    if (active) {
+    // The peel starts with every position both reading and writing (exact on its
+    // own).  Only if it is still running after PLAIN_TURNS turns -- runs, short
+    // periods -- are the neighbour hashes consulted: a position with an equal hash
+    // within 8 to its left takes that one as predecessor and stops reading, and
+    // one with an equal hash within 8 to its right stops writing (it is never the
+    // predecessor of a position that still reads, nor the group's last).
+    uint32_t near_pred[CHAIN_PPT];
+    bool reader[CHAIN_PPT], writer[CHAIN_PPT], pending[CHAIN_PPT], notmax[CHAIN_PPT];
+    int pred_local[CHAIN_PPT];
+    bool any_pending = false;
 #pragma unroll
-      for (int k = NEAR; k >= 1; k--)
-        if (hs[NEAR + t - k] == h) near_pred = (uint32_t)k;  // ends with the nearest
-#pragma unroll
-      for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + t + k] == h;
+    for (int i = 0; i < CHAIN_PPT; i++) {
+      near_pred[i] = 0;
+      reader[i] = active[i];
+      writer[i] = active[i];
+      pending[i] = active[i];
+      notmax[i] = false;
+      pred_local[i] = -1;
     }
-    const bool reader = active && near_pred == 0;
-    const bool writer = active && !has_succ;
-    bool pending = writer, notmax = false;
-    int pred_local = -1;
-    for (;;) {
-      if (pending) head[h] = (uint16_t)p;
+    for (int turn = 0;; turn++) {
+      if (turn == PLAIN_TURNS) {
+#pragma unroll
+        for (int i = 0; i < CHAIN_PPT; i++) {
+          const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
+          bool has_succ = false;
+          if (active[i]) {
+#pragma unroll
+            for (int k = NEAR; k >= 1; k--)
+              if (hs[NEAR + li - k] == h[i]) near_pred[i] = (uint32_t)k;  // ends with the nearest
+#pragma unroll
+            for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + li + k] == h[i];
+          }
+          reader[i] = active[i] && near_pred[i] == 0;
+          if (has_succ) { writer[i] = false; pending[i] = false; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < CHAIN_PPT; i++)
+        if (pending[i]) head[h[i]] = (uint16_t)(B + t + CHAIN_THREADS * (uint32_t)i);
       __syncthreads();
-      if (reader || writer) {
-        const uint32_t r_local = ((uint32_t)head[h] - B) & 0xFFFFu;
-        if (r_local == t) pending = false;
-        else if (r_local < t) { if (reader && (int)r_local > pred_local) pred_local = (int)r_local; }
-        else notmax = true;
+      any_pending = false;
+#pragma unroll
+      for (int i = 0; i < CHAIN_PPT; i++) {
+        if (reader[i] || writer[i]) {
+          const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
+          const uint32_t r_local = ((uint32_t)head[h[i]] - B) & 0xFFFFu;
+          if (r_local == li) pending[i] = false;
+          else if (r_local < li) { if (reader[i] && (int)r_local > pred_local[i]) pred_local[i] = (int)r_local; }
+          else notmax[i] = true;
+        }
+        any_pending |= pending[i];
       }
-      if (!__syncthreads_or(pending ? 1 : 0)) break;
+      if (!__syncthreads_or(any_pending ? 1 : 0)) break;
     }
-    if (writer && !notmax) head[h] = (uint16_t)p;
-    if (active) {
-      uint32_t d;
-      if (near_pred) d = near_pred;
-      else if (pred_local >= 0) d = t - (uint32_t)pred_local;
-      else {
-        d = (p - e_old) & 0xFFFFu;
-        if (d > 32768) d = 0;
+#pragma unroll
+    for (int i = 0; i < CHAIN_PPT; i++) {
+      const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
+      const uint32_t p = B + li;
+      if (writer[i] && !notmax[i]) head[h[i]] = (uint16_t)p;
+      if (active[i]) {
+        uint32_t d;
+        if (near_pred[i]) d = near_pred[i];
+        else if (pred_local[i] >= 0) d = li - (uint32_t)pred_local[i];
+        else {
+          d = (p - e_old[i]) & 0xFFFFu;
+          if (d > 32768) d = 0;
+        }
+        prev[p] = (uint16_t)d;
       }
-      prev[p] = (uint16_t)d;
     }
     __syncthreads();
   }
