@@ -477,6 +477,15 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
 // staging row, and the completed bytes are flushed with coalesced stores.
 constexpr int STAGE_WORDS = 104;  // 7 carried bits + 64 x 48 bits = 3079 bits < 104 words
 
+// The emit kernel runs one wave per workgroup: LDS operations of one wave execute
+// in order, so lanes only need the COMPILER to keep LDS accesses in program order
+// around an exchange -- not __syncthreads(), whose s_waitcnt vmcnt(0) would also
+// wait for every global store of the previous tile.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 struct BitOut {
   uint8_t *dst;        // stream output base
   uint32_t out_pos;    // bytes already in global memory
@@ -509,7 +518,7 @@ __device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t 
     if (mid) atomicOr(&stage[wi + 1], mid);
     if (sh && nbits + (int)sh > 64) atomicOr(&stage[wi + 2], (uint32_t)(value >> (64 - sh)));
   }
-  __syncthreads();
+  wave_sync();
   const uint32_t full_bytes = total >> 3;
   const uint32_t full_words = full_bytes >> 2;
   uint8_t *o = bo.dst + bo.out_pos;
@@ -518,15 +527,15 @@ __device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t 
   if ((uint32_t)lane < tail) o[4 * full_words + lane] = (uint8_t)(stage[full_words] >> (8 * lane));
   const uint32_t rem_bits = total & 7u;
   const uint32_t last = (stage[full_bytes >> 2] >> (8 * (full_bytes & 3u))) & ((1u << rem_bits) - 1u);
-  __syncthreads();
+  wave_sync();
   // reset the staging row for the next tile
   for (int w = lane; w < STAGE_WORDS; w += 64) stage[w] = 0;
-  __syncthreads();
+  wave_sync();
   if (lane == 0) stage[0] = last;
   bo.out_pos += full_bytes;
   bo.acc = last;
   bo.acc_bits = (int)rem_bits;
-  __syncthreads();
+  wave_sync();
 }
 
 __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   for (int i = lane; i < 288; i += 64) dyn_lit[i] = 0;
   for (int i = lane; i < STAGE_WORDS; i += 64) stage[i] = 0;
   if (lane == 0) huff_fixed_encoders(fix_lit, fix_dist);
-  __syncthreads();
+  wave_sync();
 
   BitOut bo;
   bo.dst = dst_arena + sd.dst_off;
@@ -582,16 +591,26 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     // symbol histograms (write_lit_symbol / write_backref_symbol zd.ml:1125-1136)
     for (int i = lane; i < 288; i += 64) lit_freq[i] = 0;
     if (lane < 32) dist_freq[lane] = 0;
-    __syncthreads();
-    for (uint32_t k = (uint32_t)lane; k < bd.n_syms; k += 64) {
-      const uint32_t sref = syms[bd.sym_start + k];
-      if ((sref >> 9) == 0) atomicAdd(&lit_freq[sref], 1u);
-      else {
-        atomicAdd(&lit_freq[length_to_sym((int)(sref & 0x1FF))], 1u);
-        atomicAdd(&dist_freq[dist_to_sym((int)(sref >> 9))], 1u);
+    wave_sync();
+    // 4 tiles of symbols per turn: the loads are issued together
+    for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 256) {
+      uint32_t sref[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+        sref[u] = k < bd.n_syms ? syms[bd.sym_start + k] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (sref[u] == 0xFFFFFFFFu) continue;
+        if ((sref[u] >> 9) == 0) atomicAdd(&lit_freq[sref[u]], 1u);
+        else {
+          atomicAdd(&lit_freq[length_to_sym((int)(sref[u] & 0x1FF))], 1u);
+          atomicAdd(&dist_freq[dist_to_sym((int)(sref[u] >> 9))], 1u);
+        }
       }
     }
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
       lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
       coder_make_dynamic(c);
@@ -606,7 +625,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       sh_info[5] = (int)(bits & 0xFFFFFFFFu);
       sh_info[6] = (int)(bits >> 32);
     }
-    __syncthreads();
+    wave_sync();
     const int kind = sh_info[0];
     c.codelen_syms_len = sh_info[1];
     c.hlit = sh_info[2];
@@ -636,7 +655,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       bo.out_pos = (uint32_t)need;
       bo.acc = 0;
       bo.acc_bits = 0;
-      __syncthreads();
+      wave_sync();
       continue;
     }
 
@@ -649,7 +668,18 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     const uint32_t *hd = kind == 1 ? fix_dist : dyn_dist;
     const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
     const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
+    // symbols of the next tile are requested before the current tile is packed
+    auto fetch = [&](uint32_t base) -> uint32_t {
+      const uint32_t idx = base + (uint32_t)lane;
+      if (idx > n_hdr && idx < n_items) {
+        const uint32_t k = idx - 1 - n_hdr;
+        return k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
+      }
+      return 0u;
+    };
+    uint32_t sref_cur = fetch(0);
     for (uint32_t base = 0; base < n_items; base += 64) {
+      const uint32_t sref_next = base + 64 < n_items ? fetch(base + 64) : 0u;
       const uint32_t idx = base + (uint32_t)lane;
       uint64_t value = 0;
       int nbits = 0;
@@ -662,12 +692,11 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
           dyn_header_item(c, (int)idx - 1, v, nbits);
           value = v;
         } else {
-          const uint32_t k = idx - 1 - n_hdr;
-          const uint32_t sref = k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
-          symbol_bits(sref, hl, hd, value, nbits);
+          symbol_bits(sref_cur, hl, hd, value, nbits);
         }
       }
       pack_tile(bo, stage, value, nbits, lane);
+      sref_cur = sref_next;
     }
   }
 
