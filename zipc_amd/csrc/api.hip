@@ -312,7 +312,7 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
     const uint64_t n_chunks = len ? len / ADLER_CHUNK + 1 : 0;
     // chunk sums, followed by the ambiguous-chunk list of adler_chain_kernel
     const size_t sums_bytes = ((size_t)(n_chunks + 1) * sizeof(uint2) + 255) / 256 * 256;
-    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, sums_bytes + ADLER_AMB_CAP * sizeof(uint32_t)));
+    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, sums_bytes + ADLER_AMB_CAP * 16));
     uint2 *sums = (uint2 *)ctx->adler_sums.p;
     uint32_t *amb = (uint32_t *)((uint8_t *)ctx->adler_sums.p + sums_bytes);
     if (n_chunks) {

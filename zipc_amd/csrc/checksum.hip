@@ -202,11 +202,24 @@ __device__ __forceinline__ uint64_t block_excl_scan_mod(uint64_t v, uint64_t *sh
   return (incl + ADLER_BASE - v % ADLER_BASE) % ADLER_BASE;
 }
 
+// what pass 2 already knows about an ambiguous chunk, kept for the replay
+struct AmbRecord {
+  uint32_t k;          // chunk index
+  uint32_t s1;         // s1 before the chunk
+  uint32_t a_partial;  // sum of a_j over the chunks of its run before it (mod p)
+  uint32_t prev_hi;    // branch of chunk k-1 as C_{k-1} alone decides it
+};
+static_assert(sizeof(AmbRecord) == 16, "kernels.h sizes the list with 16 bytes per entry");
+
 __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n,
-                                                                    uint64_t n_chunks, uint32_t *__restrict__ amb,
+                                                                    uint64_t n_chunks, uint32_t *__restrict__ amb_raw,
                                                                     uint32_t amb_cap, uint32_t *__restrict__ out) {
   __shared__ uint64_t sh[CHAIN_THREADS_A];
+  __shared__ uint64_t run_res[CHAIN_THREADS_A];
+  __shared__ uint32_t run_last_hi[CHAIN_THREADS_A];
+  __shared__ uint64_t run_a[CHAIN_THREADS_A];
   __shared__ uint32_t amb_count;
+  AmbRecord *amb = (AmbRecord *)amb_raw;
   const int t = threadIdx.x;
   const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
   const uint64_t per = n_chunks ? (n_chunks + CHAIN_THREADS_A - 1) / CHAIN_THREADS_A : 1;
@@ -217,8 +230,9 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
   uint64_t acc = 0;
   for (uint64_t k = lo; k < hi; k++) acc += sums[k].x;
   const uint64_t s1_run = (1 + block_excl_scan_mod(acc % ADLER_BASE, sh, t)) % ADLER_BASE;
-  // pass 2: a_k summed per run, ambiguous chunks listed
+  // pass 2: a_k summed per run, ambiguous chunks recorded with what is known here
   uint64_t s1 = s1_run, a_acc = 0;
+  uint32_t last_hi = 0xFFFFFFFFu;  // branch of the previous chunk (unknown for the first of the run)
   for (uint64_t k = lo; k < hi; k++) {
     const uint2 sm = sums[k];
     const uint32_t len = k == 0 ? r : ADLER_CHUNK;
@@ -227,66 +241,68 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
     const bool ambiguous = C < ADLER_BASE || (C > 0x80000000ull - ADLER_BASE && C < 0x80000000ull + ADLER_BASE);
     if (ambiguous) {
       const uint32_t slot = atomicAdd(&amb_count, 1u);
-      if (slot < amb_cap) amb[slot] = (uint32_t)k;
+      if (slot < amb_cap) {
+        AmbRecord rec;
+        rec.k = (uint32_t)k;
+        rec.s1 = (uint32_t)s1;
+        rec.a_partial = (uint32_t)a_acc;
+        rec.prev_hi = last_hi;
+        amb[slot] = rec;
+      }
     }
     a_acc = (a_acc + C % ADLER_BASE + (hi_k ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
     s1 = (s1 + sm.x) % ADLER_BASE;
+    last_hi = hi_k ? 1u : 0u;
   }
+  run_last_hi[t] = last_hi;
+  run_a[t] = a_acc;
   const uint64_t res_run = block_excl_scan_mod(a_acc, sh, t);  // residue of s2 before the run (x0 = 0)
-  __shared__ uint64_t run_s1[CHAIN_THREADS_A], run_res[CHAIN_THREADS_A];
-  run_s1[t] = s1_run;
   run_res[t] = res_run;
+  sh[t] = s1;  // s1 after the run
   __syncthreads();
   if (t != 0) return;
 
-  // replay, thread 0.  state(k) recomputes (s1, predicted residue, branch of k-1)
-  // for one chunk from its run's start (runs are short).
-  const uint32_t n_amb = amb_count < amb_cap ? amb_count : amb_cap;
-  // insertion sort of the ambiguous indices (atomics gave them out of order)
-  for (uint32_t i = 1; i < n_amb; i++) {
-    const uint32_t v = amb[i];
+  // ---- replay of the ambiguous chunks, in order, by one thread
+  const uint32_t n_amb = amb_count;
+  if (n_amb > amb_cap || n_amb > 4096) {
+    // adversarial input: more ambiguous chunks than worth sorting -- plain walk
+    uint32_t a1, a2;
+    adler_unpack(1u, a1, a2);
+    for (uint64_t k = 0; k < n_chunks; k++) adler_chunk_step(a1, a2, k == 0 ? r : ADLER_CHUNK, sums[k].x, sums[k].y);
+    out[0] = adler_pack(a1, a2);
+    return;
+  }
+  for (uint32_t i = 1; i < n_amb; i++) {  // insertion sort by chunk index
+    const AmbRecord v = amb[i];
     uint32_t j = i;
-    while (j > 0 && amb[j - 1] > v) { amb[j] = amb[j - 1]; j--; }
+    while (j > 0 && amb[j - 1].k > v.k) { amb[j] = amb[j - 1]; j--; }
     amb[j] = v;
   }
+  // branch of the chunk before position k when k opens a run: last chunk of the
+  // nearest earlier non-empty run
+  auto prev_branch = [&](uint64_t k, uint32_t rec_prev) -> bool {
+    if (rec_prev != 0xFFFFFFFFu) return rec_prev != 0;
+    if (k == 0) return false;
+    int64_t run = (int64_t)((k - 1) / per);
+    while (run >= 0 && run_last_hi[run] == 0xFFFFFFFFu) run--;
+    return run >= 0 && run_last_hi[run] != 0;
+  };
   uint64_t delta = 0;          // correction (mod p) of every predicted residue from here on
   int64_t exact_next = 0;      // exact s2 after the last replayed chunk ...
   uint64_t exact_at = ~0ull;   // ... valid as the input of chunk `exact_at`
-  uint32_t final_s2 = 0;
-  const bool overflow = amb_count > amb_cap;
-  for (uint32_t i = 0; i <= n_amb; i++) {
-    const uint64_t k = i < n_amb ? amb[i] : n_chunks;  // last turn: the state after all chunks
-    // predicted state before chunk k
-    const uint64_t run = k / per < CHAIN_THREADS_A ? k / per : CHAIN_THREADS_A - 1;
-    uint64_t s1k = run_s1[run], resk = run_res[run];
-    bool prev_hi = false;
-    uint64_t start = run * per;
-    if (start > k) start = k;
-    for (uint64_t q = start; q < k; q++) {
-      const uint2 sm = sums[q];
-      const uint32_t len = q == 0 ? r : ADLER_CHUNK;
-      const uint64_t C = (uint64_t)len * s1k + sm.y;
-      prev_hi = C >= 0x80000000ull;
-      resk = (resk + C % ADLER_BASE + (prev_hi ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
-      s1k = (s1k + sm.x) % ADLER_BASE;
-    }
-    if (start == k && k > 0) {  // k opens its run: the branch of k-1 comes from the previous run
-      const uint64_t prun = (k - 1) / per;
-      uint64_t s1p = run_s1[prun];
-      for (uint64_t q = prun * per; q < k - 1; q++) s1p = (s1p + sums[q].x) % ADLER_BASE;
-      const uint64_t C = (uint64_t)(k - 1 == 0 ? r : ADLER_CHUNK) * s1p + sums[k - 1].y;
-      prev_hi = C >= 0x80000000ull;
-    }
+  for (uint32_t i = 0; i < n_amb; i++) {
+    const AmbRecord rec = amb[i];
+    const uint64_t k = rec.k;
+    const uint64_t resk = (run_res[k / per] + rec.a_partial) % ADLER_BASE;
     int64_t x;
     if (k == exact_at) x = exact_next;
     else {
       const uint64_t rr = (resk + delta) % ADLER_BASE;
-      x = (k > 0 && prev_hi) ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
+      x = prev_branch(k, rec.prev_hi) ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
     }
-    if (i == n_amb) { final_s2 = (uint32_t)(int32_t)x; break; }
     const uint2 sm = sums[k];
     const uint32_t len = k == 0 ? r : ADLER_CHUNK;
-    const uint64_t C = (uint64_t)len * s1k + sm.y;
+    const uint64_t C = (uint64_t)len * rec.s1 + sm.y;
     const uint32_t t2 = (uint32_t)((int64_t)C + x);
     const int32_t outv = (int32_t)t2 % (int32_t)ADLER_BASE;  // the reference's signed rem
     const uint64_t ro = (uint64_t)(((int64_t)outv % ADLER_BASE + ADLER_BASE) % ADLER_BASE);
@@ -296,20 +312,18 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
     exact_next = outv;
     exact_at = k + 1;
   }
-  uint64_t s1_all = run_s1[CHAIN_THREADS_A - 1];
-  {
-    uint64_t st = (CHAIN_THREADS_A - 1) * per;
-    if (st > n_chunks) st = n_chunks;
-    for (uint64_t q = st; q < n_chunks; q++) s1_all = (s1_all + sums[q].x) % ADLER_BASE;
+  // state after the last chunk
+  uint32_t final_s2;
+  if (exact_at == n_chunks) final_s2 = (uint32_t)(int32_t)exact_next;
+  else {
+    const uint64_t last_run = n_chunks ? (n_chunks - 1) / per : 0;
+    const uint64_t total_res = n_chunks ? (run_res[last_run] + run_a[last_run]) % ADLER_BASE : 0;
+    const uint64_t rr = (total_res + delta) % ADLER_BASE;
+    const bool ph = n_chunks ? prev_branch(n_chunks, 0xFFFFFFFFu) : false;
+    final_s2 = (uint32_t)(int32_t)(ph ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr);
   }
-  if (overflow) {
-    // more ambiguous chunks than the list holds (adversarial input): plain walk
-    uint32_t a1, a2;
-    adler_unpack(1u, a1, a2);
-    for (uint64_t k = 0; k < n_chunks; k++) adler_chunk_step(a1, a2, k == 0 ? r : ADLER_CHUNK, sums[k].x, sums[k].y);
-    out[0] = adler_pack(a1, a2);
-    return;
-  }
+  const uint64_t lr = n_chunks ? (n_chunks - 1) / per : 0;
+  const uint64_t s1_all = n_chunks ? sh[lr] : 1;
   out[0] = adler_pack((uint32_t)s1_all, final_s2);
 }
 

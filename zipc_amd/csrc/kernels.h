@@ -33,7 +33,7 @@ __global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ des
                                     uint32_t *__restrict__ single_out);
 __global__ void adler_chunks_kernel(const uint8_t *__restrict__ p, uint64_t n, uint64_t n_chunks,
                                     uint2 *__restrict__ sums);
-constexpr uint32_t ADLER_AMB_CAP = 65536;  // ambiguous-chunk list of adler_chain_kernel
+constexpr uint32_t ADLER_AMB_CAP = 8192;  // ambiguous-chunk records (16 bytes each) of adler_chain_kernel
 __global__ void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks,
                                    uint32_t *__restrict__ amb, uint32_t amb_cap,
                                    uint32_t *__restrict__ out);
