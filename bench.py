@@ -42,6 +42,22 @@ def algorithmic_bytes(kernel, N, C):
     }.get(kernel, 0)
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*hbm_traffic.json,
+    made by tools/pmc_report.py --hbm-json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command), or None."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["kernels"][kernel]["bytes"], os.path.basename(files[-1])
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(config_id, bits, level, stream_len, budget_s=15.0):
     """The oracle (C port of the reference algorithm) on this host, 1 thread, on a
     bounded sample of the same workload."""
@@ -178,6 +194,7 @@ def main():
     dom_ms = kernels[dom]
     alg = algorithmic_bytes(dom, N, C)
     achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic(dom)
 
     if rank == 0:
         line = {
@@ -202,8 +219,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes": alg, "launch_ms": dom_ms,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes": alg, "launch_ms": dom_ms,
             },
             "deflate_gib_s": N / GIB * psteps / t_def,
             "inflate_gib_s": N / GIB * psteps / t_inf,
