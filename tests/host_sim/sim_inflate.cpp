@@ -23,19 +23,94 @@ static uint32_t adler_update_serial(uint32_t a, const uint8_t *p, uint32_t n) {
   return adler_pack(s1, s2);
 }
 
-// ring refill as inflate.hip's service_refill does it (one stream)
+// ring refill as inflate.hip does it (one stream): words past the end are zero
 static void refill(InflateLane &d, const LaneLds &L, const uint8_t *src) {
   if (d.phase == PH_DONE) return;
-  uint32_t total = d.total_words();
-  uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
-  if (lim > total) lim = total;
+  const uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
   uint32_t end = d.ring_wr + 64u < lim ? d.ring_wr + 64u : lim;
   for (uint32_t w = d.ring_wr; w < end; w++) {
     uint32_t v = 0;
-    for (uint32_t b = 0; b < 4 && w * 4 + b < d.src_len; b++) v |= (uint32_t)src[w * 4 + b] << (8 * b);
-    L.ring(w) = v;
+    for (uint32_t b = 0; b < 4 && (uint64_t)w * 4 + b < d.src_len; b++) v |= (uint32_t)src[(uint64_t)w * 4 + b] << (8 * b);
+    L.ring_put(w, v);
   }
-  if (end > d.ring_wr) d.ring_wr = end;
+  d.ring_wr = end;
+}
+
+// Host model of inflate.hip's wide turn: the 64 lanes are emulated with arrays,
+// every step is the kernel's step.  Returns true when the chain stopped inside
+// the window (the caller then decodes one symbol the plain way).
+static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
+  WideSym sp[64];
+  bool ok[64];
+  uint32_t end[64];
+  uint32_t J[6][64];
+  for (int s = 0; s < 64; s++) {
+    const uint32_t p = d.boff + (uint32_t)s;
+    const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
+    const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
+    sp[s] = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - s, L);
+    ok[s] = sp[s].ok && s != 63;
+    end[s] = (uint32_t)s + sp[s].tot;
+    J[0][s] = ok[s] ? (end[s] < 63u ? end[s] : 63u) : (uint32_t)s;
+  }
+  for (int k = 1; k < 6; k++)
+    for (int t = 0; t < 64; t++) J[k][t] = J[k - 1][J[k - 1][t]];
+  bool visited[64];
+  for (int t = 0; t < 64; t++) {
+    uint32_t v = 0;
+    for (int k = 5; k >= 0; k--) { const uint32_t y = J[k][v]; if (y <= (uint32_t)t) v = y; }
+    visited[t] = v == (uint32_t)t;
+  }
+  uint32_t outoff[64], incl[64], mrank[64], run = 0, mr = 0;
+  int first_match = -1;
+  for (int t = 0; t < 64; t++) {
+    outoff[t] = run;
+    mrank[t] = mr;
+    if (visited[t] && ok[t]) {
+      run += sp[t].outlen;
+      if (sp[t].is_match) { if (first_match < 0) first_match = t; mr++; }
+    }
+    incl[t] = run;
+  }
+  const uint32_t INF = 0xFFFFFFFFu;
+  const uint32_t room = d.cap_min - d.out_pos;
+  const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
+  const uint32_t first_match_dst = first_match >= 0 ? d.out_pos + outoff[first_match] : INF;
+  int c = -1;
+  for (int t = 0; t < 64 && c < 0; t++) {
+    if (!visited[t]) continue;
+    if (!ok[t]) { c = t; break; }
+    bool late = outoff[t] + sp[t].outlen > room;
+    if (sp[t].is_match) {
+      const uint32_t dstp = d.out_pos + outoff[t];
+      const uint32_t h0 = d.q_count ? d.hole_min : INF, h1 = mrank[t] ? first_match_dst : INF;
+      const uint32_t hole = h0 < h1 ? h0 : h1;
+      late = late || sp[t].value > dstp || mrank[t] >= qfree || dstp - sp[t].value + sp[t].outlen > hole;
+    }
+    if (late) c = t;
+  }
+  if (c < 0) abort();  // the path always ends in a stop or in the sink
+  uint32_t n_match = 0;
+  int last = -1;
+  for (int t = 0; t < c; t++) {
+    if (!(visited[t] && ok[t])) continue;
+    if (!sp[t].is_match) dst[d.out_pos + outoff[t]] = (uint8_t)sp[t].value;
+    else {
+      L.queue((int)(d.q_count + mrank[t]), 0) = d.out_pos + outoff[t];
+      L.queue((int)(d.q_count + mrank[t]), 1) = sp[t].value | (sp[t].outlen << 16);
+      n_match++;
+    }
+    last = t;
+  }
+  uint32_t consumed = (uint32_t)c;
+  if (last >= 0) {
+    d.out_pos += incl[last];
+    if (c == 63) consumed = end[last];
+  }
+  if (d.q_count == 0 && n_match) d.hole_min = first_match_dst;
+  d.q_count += n_match;
+  d.advance(consumed);
+  return c < 63;
 }
 
 extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, uint64_t dst_cap,
@@ -44,7 +119,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   static uint16_t w[LDS_U16_PER_LANE];
   static uint32_t r[LDS_U32_PER_LANE];
   LaneLds L;
-  L.w = w; L.r = r; L.lane = 0; L.log2L = 0;
+  L.w = w; L.r = r;
   StreamDesc s;
   memset(&s, 0, sizeof s);
   s.src_off = 0; s.src_len = src_len; s.dst_off = 0; s.dst_cap = dst_cap;
@@ -54,10 +129,30 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   InflateLane d;
   lane_init(d, s);
   const bool crc_adler = crc_op == CRC_ADLER32;
+  const bool wide = getenv("SIM_INFLATE_WIDE") != nullptr;
   refill(d, L, src);
   for (;;) {
-    SoloGroup grp;
-    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, budget, crc_adler, grp);
+    // decode phase: the kernel's round
+    for (int turn = 0; turn < budget; turn++) {
+      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+        if (!lane_header_step(d, L, src)) break;
+        if (d.phase == PH_SYMBOLS)
+          for (int lane = 0; lane < 64; lane++) build_wide_tables(d, L, lane);
+      } else if (d.phase == PH_SYMBOLS) {
+        bool stopped = true;
+        if (wide) {
+          if (!d.input_ready(TURN_WORDS)) break;
+          stopped = wide_turn_model(d, L, dst);
+        }
+        if (stopped) {
+          const int rr = lane_one_symbol(d, L, A, true);
+          if (rr == SYM_EOB) lane_end_of_block(d, crc_adler);
+          else if (rr == SYM_STOP) break;
+        }
+      } else {
+        break;
+      }
+    }
     // services, in the kernel's order
     for (uint32_t k = 0; k < d.q_count; k++) {
       DeferredCopy c;

@@ -58,6 +58,34 @@ def test_inflate_lane_accept_reject_fuzz(sim, oracle):
     assert seen.get(0, 0) > 50 and seen.get(1, 0) > 50
 
 
+def test_inflate_wide_turn_model(sim, oracle, monkeypatch):
+    """The kernel's wide turn (64 speculative symbol decodes, chain by pointer
+    doubling, parallel commit), modelled on the host: same bytes, same accept /
+    reject, on the golden streams and on damaged ones."""
+    monkeypatch.setenv("SIM_INFLATE_WIDE", "1")
+    seen = {}
+    for i, s in enumerate(util.zlib_streams()):
+        st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
+        for budget in (8, 3):
+            st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=budget)
+            assert (st, d, a) == (st0, d0, a0), s["name"]
+        lim = max(0, s["plain_len"] - 1)
+        assert sim_inflate(sim, s["raw"], lim, limit=lim)[0] == oracle.inflate(s["raw"], decompressed_size=lim)[0]
+        if len(s["raw"]) > 40000:
+            continue
+        cap = s["plain_len"] * 2 + 1000
+        for r in util.corrupt_variants(s["raw"], i, 40):
+            st0, d0, a0 = oracle.inflate(r, decompressed_size=cap, crc_op=oracle.CRC_ADLER32)
+            st, d, a = sim_inflate(sim, r, cap, limit=cap, crc_op=2)
+            assert st == st0 and d == d0 and (st != 0 or a == a0), s["name"]
+            seen[st] = seen.get(st, 0) + 1
+    assert seen.get(0, 0) > 30 and seen.get(1, 0) > 30
+    for name, data in util.deflate_cases(small=True).items():
+        for lvl in (0, 2):
+            c = oracle.deflate(data, level=lvl)[1]
+            assert sim_inflate(sim, c, len(data), limit=len(data))[:2] == (0, data), name
+
+
 def test_deflate_lane_logic_bytes_equal_oracle(sim, oracle):
     for name, data in util.deflate_cases().items():
         for lvl in (0, 1, 2, 3):

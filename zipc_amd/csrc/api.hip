@@ -219,17 +219,6 @@ size_t zipc_hip_zlib_bound(size_t len) { return zipc_hip_deflate_bound(len) + 6;
 
 // ---- batch forms ---------------------------------------------------------------
 
-static int pick_log2S(size_t n_streams) {
-  // streams per wave: 4 (one per 16-lane group) once that still leaves >= 1024
-  // waves for the chip's 1024 SIMDs; fewer for small batches
-  int log2S = n_streams >= 4096 ? 2 : n_streams >= 2048 ? 1 : 0;
-  if (const char *e = getenv("ZIPC_HIP_LOG2S")) {  // tuning knob for experiments
-    int v = atoi(e);
-    if (v >= 0 && v <= 2) log2S = v;
-  }
-  return log2S;
-}
-
 static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
                       StreamResult *d_results, size_t n_ranges, uint64_t single_off,
                       uint64_t single_len, size_t max_len, uint32_t *d_single_out) {
@@ -255,13 +244,10 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   if (crc_op < 0 || crc_op > 2 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const int log2S = pick_log2S(n_streams);
-  const size_t S = (size_t)1 << log2S;
-  const unsigned grid = (unsigned)((n_streams + S - 1) / S);
-  const size_t lds = (size_t)INFLATE_LDS_BYTES_PER_LANE << log2S;
-  ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3(grid), dim3(64), lds,
+  // one wave per stream
+  ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)n_streams), dim3(64), 0,
             (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
-            (StreamResult *)d_results, (uint32_t)n_streams, log2S, crc_op);
+            (StreamResult *)d_results, (uint32_t)n_streams, 0, crc_op);
   HIP_TRY(ctx, hipGetLastError());
   if (crc_op == ZIPC_HIP_CRC_CRC32)
     return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,

@@ -1,28 +1,38 @@
 // inflate.hip -- batch inflate kernel for gfx950 (CDNA4, wave64).
 //
-// Decomposition: ONE WAVEFRONT PER WORKGROUP carrying 4 independent deflate
-// streams, each run by a group of 16 lanes (inflate_lane.h).  A deflate stream is
-// a serial dependency chain (the bit position of symbol k+1 depends on symbol k);
-// the 16 lanes of a group shorten that chain by looking the litlen table up at
-// the 16 next bit offsets at once, so that a run of literals costs one LDS round
-// trip plus a register shuffle per literal.  2496 B of LDS per stream (tables +
-// input ring + deferred-copy queue) lets a CU hold 64 streams = 16 waves, 4 per
-// SIMD, which is what hides the remaining LDS and shuffle latency.
+// Decomposition: ONE WAVEFRONT PER STREAM (one 64-thread workgroup each).  A
+// deflate stream is a serial chain -- the bit position of symbol k+1 depends on
+// symbol k -- so the wave shortens the chain instead of running many of them:
 //
-// The wave alternates two phases:
-//   decode   every group runs its stream for up to ROUND_TURNS turns out of LDS
-//            only (no global loads; literals leave as 8-byte stores);
-//   service  wave-uniform code doing everything that needs global loads, once
-//            per round and for all streams at the same time, so their latencies
-//            overlap instead of serialising the wave:
-//              1. fill the queued match copies, one per lane (32 per stream in
-//                 flight),
-//              2. copy parked long/overlapping matches (Buf.recopy zd.ml:63-75),
-//              3. copy stored blocks with all 64 lanes (read_uncompressed_block
-//                 zd.ml:671-680), 16 B per lane,
-//              4. per-block Adler-32 with the reference's 5552-byte chunking
-//                 (inflated_block_crc zd.ml:682-690),
-//              5. top up every stream's input ring with coalesced loads.
+//   wide turn   lane s decodes the whole symbol (literal, or length + distance
+//               with their extra bits) that WOULD start s bits after the
+//               stream's position: 64 speculative decodes, each three words of
+//               the input ring and two table lookups, branch free
+//               (wide_decode, inflate_lane.h).  The offsets where symbols
+//               really start form a path 0 -> 0 + bits(0) -> ...; it is found
+//               without walking it: J_k[s] = offset reached from s after 2^k
+//               symbols (5 rounds of ds_bpermute, offsets kept as bpermute
+//               addresses so a round is one instruction), then every lane
+//               finds by a descending search whether it lies on the path.
+//               Lane 63 is the path's sink.  An exclusive wave scan (DPP) of
+//               the output lengths over the lanes on the path gives every
+//               symbol its output position: literal lanes store their byte,
+//               match lanes append {dst, dist, len} to the deferred-copy queue
+//               in LDS.  About 8 symbols are committed per turn on 4-bit data.
+//   plain step  whatever a wide turn must not commit (long codes, end of block,
+//               matches that cannot be deferred, hazards, the last bytes of the
+//               input) stops the path; lane_one_symbol (inflate_lane.h) decodes
+//               that one symbol with all the reference's checks.
+//   service     everything that needs global loads, by all 64 lanes: fill the
+//               queued match copies (32 in flight), copy long/overlapping
+//               matches, copy stored blocks 16 B per lane
+//               (read_uncompressed_block zd.ml:671-680), per-block Adler-32 with
+//               the reference's 5552-byte chunking (inflated_block_crc
+//               zd.ml:682-690), refill the input ring with one coalesced load.
+//
+// The stream state is wave-uniform; it is pinned to scalar registers with
+// readfirstlane so that the control flow around the turns is scalar branches,
+// not exec-mask arithmetic.  LDS: 5072 B per stream (tables + ring + queue).
 #include "inflate_lane.h"
 #include "kernels.h"
 #include "wave_ops.h"
@@ -30,188 +40,209 @@
 namespace zd {
 
 static_assert(LDS_BYTES_PER_LANE == INFLATE_LDS_BYTES_PER_LANE, "kernels.h");
-static_assert(SPEC_WINDOW == 16 && QUEUE_ENTRIES == 32, "group layout");
-constexpr int ROUND_TURNS = 24;  // turns a stream may run between two service points
-constexpr int GROUP = 16;        // lanes per stream
-constexpr int MAX_S = 64 / GROUP;
+static_assert(SPEC_WINDOW == 64 && QUEUE_ENTRIES <= 64, "one lane per offset / per queue entry");
+constexpr int ROUND_TURNS = 12;  // wide turns between two service points
 
-// The 16-lane group of one stream.
-struct WaveGroup {
-  int sub;     // lane index inside the group
-  uint32_t e;  // this lane's speculative litlen lookup (offset = sub)
-  __device__ __forceinline__ bool writer() const { return sub == 0; }
-  __device__ __forceinline__ void lookup(const LaneLds &L, uint64_t bits) {
-    e = L.u16(LDS_LIT_TBL, (int)((bits >> sub) & ((1u << LIT_TBITS) - 1)));
-  }
-  __device__ __forceinline__ uint32_t entry(const LaneLds &, uint64_t, int o) const {
-    return __shfl(e, o, GROUP);
-  }
-  // the lanes whose offset starts a literal store it: byte k of the run goes to out[k]
-  __device__ __forceinline__ void store_literals(const LaneLds &, uint64_t, uint32_t V, uint8_t *out) const {
-    if ((V >> sub) & 1u) out[__popc(V & ((1u << sub) - 1u))] = (uint8_t)(e >> 4);
-  }
-  // the writer lane ran a header step alone: everybody takes over its state
-  __device__ __forceinline__ bool sync(InflateLane &d, bool ok) const {
-#define ZD_B(x) d.x = __shfl(d.x, 0, GROUP)
-    d.bits = __shfl((unsigned long long)d.bits, 0, GROUP);
-    ZD_B(in_word); ZD_B(ring_wr); ZD_B(skip); ZD_B(nbits); ZD_B(out_pos); ZD_B(status); ZD_B(phase);
-    ZD_B(final_block); ZD_B(lit_max_sym); ZD_B(dist_max_sym); ZD_B(blk_out_start); ZD_B(req_src);
-    ZD_B(req_len); ZD_B(hdr_num); ZD_B(hdr_hlit); ZD_B(hdr_hdist); ZD_B(hdr_cl_max);
-#undef ZD_B
-    return __shfl((int)ok, 0, GROUP) != 0;
-  }
-};
-
-// Top up the input rings: for each stream j of the wave, lanes 0..63 load the
-// next (up to 64) words of its compressed input; all loads are issued before the
-// first LDS write so that one memory latency covers the whole wave.
-__device__ __forceinline__ void service_refill(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa,
-                                               int lane, int S) {
-  uint32_t w[MAX_S];
-  uint32_t idx[MAX_S];
-#pragma unroll
-  for (int j = 0; j < MAX_S; j++) {
-    w[j] = 0;
-    idx[j] = 0xFFFFFFFFu;
-    if (j < S) {
-      const int src_lane = j * GROUP;
-      const uint32_t wr = __shfl(d.ring_wr, src_lane, 64);
-      const uint32_t rd = __shfl(d.in_word, src_lane, 64);
-      const uint32_t slen = __shfl(d.src_len, src_lane, 64);
-      const unsigned long long so = __shfl((unsigned long long)d.src_off, src_lane, 64);
-      const int ph = __shfl(d.phase, src_lane, 64);
-      const uint32_t total = (slen + 3u) >> 2;
-      uint32_t lim = rd + (uint32_t)RING_WORDS;
-      if (lim > total) lim = total;
-      const uint32_t my = wr + (uint32_t)lane;
-      if (ph != PH_DONE && my < lim) {
-        idx[j] = my;
-        const uint8_t *p = sa + so + (uint64_t)my * 4u;
-        if (my * 4u + 4u <= slen) w[j] = load_u32_le(p);
-        else {
-          uint32_t v = 0;
-          for (uint32_t b = 0; my * 4u + b < slen; b++) v |= (uint32_t)p[b] << (8 * b);
-          w[j] = v;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < MAX_S; j++) {
-    if (j < S && idx[j] != 0xFFFFFFFFu)
-      L.r[((idx[j] & (uint32_t)(RING_WORDS - 1)) << L.log2L) + j] = w[j];
-  }
-  // publish the new write cursor (every lane of a group computes the same value)
-  if (d.phase != PH_DONE) {
-    const uint32_t total = d.total_words();
-    uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
-    if (lim > total) lim = total;
-    uint32_t nw = d.ring_wr + 64u;
-    if (nw > lim) nw = lim;
-    if (nw > d.ring_wr) d.ring_wr = nw;
-  }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni(uint64_t v) {
+  return ((uint64_t)uni((uint32_t)(v >> 32)) << 32) | uni((uint32_t)v);
 }
 
-// Fill the deferred copies: lane s of a group takes entries s and s + 16, all
-// loads are issued before the stores.  Entries never depend on one another (a
-// match reaching into an unfilled hole is parked instead of queued).
-__device__ __forceinline__ void service_resolve(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ da,
-                                                int sub) {
-  uint8_t *dst = da + d.dst_off;
-  DeferredCopy c0, c1;
-  c0.len = 0;
-  c1.len = 0;
-  if ((uint32_t)sub < d.q_count) deferred_load(c0, dst, L.queue(sub, 0), L.queue(sub, 1));
-  if ((uint32_t)sub + GROUP < d.q_count) deferred_load(c1, dst, L.queue(sub + GROUP, 0), L.queue(sub + GROUP, 1));
-  if (c0.len) deferred_store(c0, dst);
-  if (c1.len) deferred_store(c1, dst);
-  d.q_count = 0;
+// every field of the (wave-uniform) state back into scalar registers
+__device__ __forceinline__ void uniformize(InflateLane &d) {
+#define ZD_U(x) d.x = uni(d.x)
+  ZD_U(src_off); ZD_U(dst_off); ZD_U(src_len); ZD_U(in_word); ZD_U(boff); ZD_U(ring_wr);
+  ZD_U(out_pos); ZD_U(cap_min); ZD_U(limit); ZD_U(hard_cap); ZD_U(status);
+  ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
+  ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
+  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(adler);
+#undef ZD_U
+}
+
+// value of lane `addr / 4`
+__device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v);
+}
+
+// inclusive wave scan: Kogge-Stone inside the rows of 16 on DPP row shifts,
+// then the row totals broadcast down (row_bcast:15 to rows 1 and 3,
+// row_bcast:31 to rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return x;
+}
+
+// One wide turn.  Returns true when the path stopped inside the window: the
+// symbol at the new position is then for lane_one_symbol.
+__device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
+  // the symbol that would start at my offset
+  const uint32_t p = d.boff + (uint32_t)lane;
+  const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
+  const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
+  const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - lane, L);
+  const bool ok = sp.ok && lane != 63;  // lane 63 is the sink: the next turn starts there
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  const uint32_t end = (uint32_t)lane + sp.tot;
+  // J[k]: offset reached after 2^k symbols, as a bpermute address; a lane that
+  // stops the path points to itself
+  uint32_t J[6];
+  J[0] = ok ? (end < 63u ? end : 63u) * 4u : lane4;
+#pragma unroll
+  for (int k = 1; k < 6; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+  // am I on the path from offset 0?  largest path element <= lane, descending
+  uint32_t v = 0;
+#pragma unroll
+  for (int k = 5; k >= 0; k--) {
+    const uint32_t y = lane_value(v, J[k]);
+    if (y <= lane4) v = y;
+  }
+  const bool visited = v == lane4;
+  const bool commit0 = visited && ok;
+  const bool match0 = commit0 && sp.is_match;
+  // output offsets: exclusive scan of the produced bytes over the path
+  const uint32_t mine = commit0 ? sp.outlen : 0u;
+  const uint32_t incl = wave_scan_incl(mine);
+  const uint32_t outoff = incl - mine;
+  const unsigned long long match_mask = __ballot(match0);
+  const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_mask >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)match_mask, 0u));
+  const int first_match = match_mask ? __ffsll((long long)match_mask) - 1 : 0;
+  const uint32_t INF = 0xFFFFFFFFu;
+  const uint32_t first_match_dst =
+      match_mask ? d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, first_match) : INF;
+  // symbols that would overflow, reach before the start, overfill the queue or
+  // read an unfilled hole end the turn in front of them
+  const uint32_t room = d.cap_min - d.out_pos;
+  const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
+  const uint32_t dstp = d.out_pos + outoff;
+  const uint32_t h0 = d.q_count ? d.hole_min : INF;
+  const uint32_t h1 = mrank ? first_match_dst : INF;  // a match lane behind the first one
+  const uint32_t hole = h0 < h1 ? h0 : h1;
+  const bool late = (commit0 && outoff + sp.outlen > room) ||
+                    (match0 && (sp.value > dstp || mrank >= qfree || dstp - sp.value + sp.outlen > hole));
+  const unsigned long long cut_mask = __ballot((visited && !ok) || late);
+  const int c = __ffsll((long long)cut_mask) - 1;  // the path always ends in a stop or in the sink
+  const bool commit = commit0 && lane < c;
+  if (commit) {
+    if (sp.is_match) {
+      L.queue((int)(d.q_count + mrank), 0) = dstp;
+      L.queue((int)(d.q_count + mrank), 1) = sp.value | (sp.outlen << 16);
+    } else {
+      dst[dstp] = (uint8_t)sp.value;
+    }
+  }
+  const unsigned long long commit_mask = __ballot(commit);
+  const uint32_t n_match = (uint32_t)__popcll(__ballot(commit && sp.is_match));
+  uint32_t consumed = (uint32_t)c;
+  if (commit_mask) {
+    const int last = 63 - __clzll((long long)commit_mask);
+    d.out_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, last);
+    if (c == 63) consumed = (uint32_t)__builtin_amdgcn_readlane((int)end, last);  // may leave the window
+  }
+  if (d.q_count == 0 && n_match) d.hole_min = first_match_dst;
+  d.q_count += n_match;
+  d.advance(consumed);
+  return c < 63;
 }
 
 __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            StreamResult *__restrict__ results,
-                                                           uint32_t n_streams, int log2S, int crc_op) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+                                                           uint32_t n_streams, int /*log2S*/, int crc_op) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const int lane = threadIdx.x;
-  const int S = 1 << log2S;
-  const int g = lane / GROUP;
-  const uint32_t stream = blockIdx.x * (uint32_t)S + (uint32_t)g;
-  const bool has_stream = g < S && stream < n_streams;
+  const uint32_t stream = blockIdx.x;
+  if (stream >= n_streams) return;
   const bool crc_adler = crc_op == CRC_ADLER32;
+  const bool writer = lane == 0;
 
   LaneLds L;
   L.w = (uint16_t *)lds_raw;
-  L.r = (uint32_t *)(lds_raw + ((size_t)(LDS_U16_PER_LANE * 2) << log2S));
-  L.lane = g & (S - 1);
-  L.log2L = log2S;
-
-  WaveGroup grp;
-  grp.sub = lane % GROUP;
-  grp.e = 0;
+  L.r = (uint32_t *)(lds_raw + LDS_U16_PER_LANE * 2);
 
   Arenas A;
   A.src = src_arena;
   A.dst = dst_arena;
   InflateLane d;
-  if (has_stream) {
-    lane_init(d, descs[stream]);
-  } else {
-    StreamDesc none = {};
-    lane_init(d, none);
-    d.phase = PH_DONE;
-  }
-
-  service_refill(d, L, src_arena, lane, S);
+  lane_init(d, descs[stream]);
+  uint8_t *dst = dst_arena + d.dst_off;
+  const uint8_t *src = src_arena + d.src_off;
 
   for (;;) {
-    if (d.phase <= PH_SYMBOLS) lane_step(d, L, A, ROUND_TURNS, crc_adler, grp);
+    // ---- refill the input ring: lane t stages word ring_wr + t (zero past the end)
+    if (d.phase != PH_DONE) {
+      const uint32_t lim = d.in_word + (uint32_t)RING_WORDS;
+      const uint32_t my = d.ring_wr + (uint32_t)lane;
+      if (my < lim) {
+        const uint64_t at = (uint64_t)my * 4u;
+        const uint8_t *p = src + at;
+        uint32_t wv = 0;
+        if (at + 4u <= d.src_len) wv = load_u32_le(p);
+        else
+          for (uint32_t b = 0; at + b < d.src_len; b++) wv |= (uint32_t)p[b] << (8 * b);
+        L.ring_put(my, wv);
+      }
+      uint32_t nw = d.ring_wr + 64u;
+      if (nw > lim) nw = lim;
+      d.ring_wr = nw;
+    }
+    uniformize(d);
 
-    // ---- service point: wave-uniform control flow from here ----
-    if (__ballot(d.q_count != 0)) service_resolve(d, L, dst_arena, grp.sub);
-
-    if (__ballot(d.phase == PH_REQ_MATCH)) {
-      if (d.phase == PH_REQ_MATCH) {
-        if (grp.writer()) lane_copy_match(dst_arena + d.dst_off, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
-        lane_after_match(d);
+    // ---- decode
+    for (int turn = 0; turn < ROUND_TURNS; turn++) {
+      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+        bool ok = true;
+        if (writer) ok = lane_header_step(d, L, src_arena);
+        uniformize(d);  // lane 0 is the first active lane: everybody takes its state
+        if (!uni((uint32_t)ok)) break;  // waits for input
+        if (d.phase == PH_SYMBOLS) build_wide_tables(d, L, lane);
+      } else if (d.phase == PH_SYMBOLS) {
+        if (!d.input_ready(TURN_WORDS)) break;
+        const bool stopped = wide_turn(d, L, dst, lane);
+        if (stopped) {
+          const int r = lane_one_symbol(d, L, A, writer);
+          uniformize(d);
+          const int ru = uni(r);
+          if (ru == SYM_EOB) lane_end_of_block(d, crc_adler);
+          else if (ru == SYM_STOP) break;
+        }
+      } else {
+        break;
       }
     }
 
-    unsigned long long m = __ballot(d.phase == PH_REQ_COPY && grp.writer());
-    if (m) {
-      while (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const unsigned long long so = __shfl((unsigned long long)(d.src_off + d.req_src), leader, 64);
-        const unsigned long long oo = __shfl((unsigned long long)(d.dst_off + d.out_pos), leader, 64);
-        const uint32_t len = __shfl(d.req_len, leader, 64);
-        wave_copy(dst_arena + oo, src_arena + so, len, lane);
-      }
-      if (d.phase == PH_REQ_COPY) lane_after_copy(d, crc_adler);
+    // ---- services
+    if (d.q_count) {  // fill the queued copies: entry `lane`, all loads before the stores
+      DeferredCopy c0;
+      c0.len = 0;
+      if ((uint32_t)lane < d.q_count) deferred_load(c0, dst, L.queue(lane, 0), L.queue(lane, 1));
+      if (c0.len) deferred_store(c0, dst);
+      d.q_count = 0;
     }
-
-    m = __ballot(d.phase == PH_REQ_ADLER && grp.writer());
-    if (m) {
+    if (d.phase == PH_REQ_MATCH) {
+      if (writer) lane_copy_match(dst, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
+      lane_after_match(d);
+    } else if (d.phase == PH_REQ_COPY) {
+      wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
+      lane_after_copy(d, crc_adler);
+    }
+    if (d.phase == PH_REQ_ADLER) {
       // the block's bytes were stored by other lanes of this wave: make them visible
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      while (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        const unsigned long long po = __shfl((unsigned long long)(d.dst_off + d.blk_out_start), leader, 64);
-        const uint32_t n = __shfl(d.out_pos - d.blk_out_start, leader, 64);
-        const uint32_t a = __shfl(d.adler, leader, 64);
-        const uint32_t r = wave_adler_update(a, dst_arena + po, n, lane);
-        if (lane / GROUP == leader / GROUP) d.adler = r;
-      }
-      if (d.phase == PH_REQ_ADLER) lane_after_adler(d);
+      d.adler = wave_adler_update(d.adler, dst + d.blk_out_start, d.out_pos - d.blk_out_start, lane);
+      lane_after_adler(d);
     }
-
-    if (!__ballot(d.phase != PH_DONE)) break;
-    service_refill(d, L, src_arena, lane, S);
+    if (d.phase == PH_DONE && d.q_count == 0) break;
   }
 
-  if (has_stream && grp.writer()) {
+  if (writer) {
     StreamResult r;
     r.status = d.status;
     r.out_len = d.status == ST_OK ? d.out_pos : 0;

@@ -1,23 +1,24 @@
-// inflate_lane.h -- the serial state machine of one deflate stream.
+// inflate_lane.h -- the state machine of one deflate stream.
 //
-// This is the per-stream half of the batch inflate kernel (inflate.hip).  A
-// wavefront carries 4 independent streams; each stream is run by a GROUP of 16
-// lanes that all hold the same copy of the state below and execute the same
-// code.  What the 16 lanes do differently is one thing: lane s of the group
-// looks up the litlen table at bit offset s of the current window, so that a
-// run of literals is decoded by following the chain of code lengths through
-// the 16 speculative lookups (grp.entry) instead of one dependent LDS read per
-// literal.  Side effects (LDS writes, global stores) are done by lane 0 of the
-// group ("writer").  tests/host_sim drives the same code with a one-lane group
-// whose speculative lookups are plain table reads.
+// This is the per-stream half of the batch inflate kernel (inflate.hip), where
+// ONE WAVEFRONT runs ONE STREAM: all 64 lanes hold the same copy of the state
+// below and execute the same code (the kernel keeps it in scalar registers).
+// What the lanes do differently is the speculative decode of inflate.hip's "wide
+// turn": lane s decodes the symbol that would start s bits after the stream's
+// position (wide_decode), the chain of real symbol starts is then found by
+// pointer doubling, and every symbol on it is committed in parallel.  Whatever
+// the wide turn cannot commit -- long codes, end of block, matches that must not
+// be deferred, the tail of the input -- is decoded one symbol at a time by
+// lane_one_symbol, which is also all that tests/host_sim's plain model needs.
 //
 // Everything the stream touches while it decodes symbols lives in LDS -- its
 // decode tables, a 64-word ring of its compressed input, a queue of deferred
-// match copies -- so the symbol loop issues NO global loads: the only
-// vector-memory traffic it generates are the literal stores (8 literals per
-// 8-byte store).  Whatever needs a global load is parked and done by the whole
-// wave at the next service point (inflate.hip), in lockstep, so that one memory
-// latency is paid per round instead of one per match:
+// match copies -- so decoding issues NO global loads: the only vector-memory
+// traffic it generates are the literal stores.  The stream position is a word
+// index into the input plus a bit offset; there is no shifted bit buffer to
+// maintain, every reader takes its bits straight from the ring.  Whatever needs
+// a global load is parked and done at the next service point (inflate.hip) by
+// all 64 lanes:
 //   * short non-overlapping matches (len <= 16 <= dist) are queued as holes
 //     {dst_pos, dist, len} and filled later -- legal because a later symbol can
 //     only observe those bytes through another match, and a match whose source
@@ -44,9 +45,7 @@ namespace zd {
 constexpr int LIT_TBITS = 9;   // primary litlen lookup bits
 constexpr int DIST_TBITS = 7;  // primary dist lookup bits (also holds the <=7-bit codelen code)
 
-// Per-stream LDS image, interleaved over the L streams that share a wave so that
-// equal indices of neighbouring streams sit in neighbouring banks: element i of
-// stream l lives at [(offset + i) * L + l].
+// Per-stream LDS image.  u16 regions first:
 constexpr int LDS_LIT_TBL = 0;                          // 512 x u16: (sym << 4) | len
 constexpr int LDS_DIST_TBL = LDS_LIT_TBL + 512;         // 128 x u16
 constexpr int LDS_LIT_SYMS = LDS_DIST_TBL + 128;        // 288 x u16 symbols sorted by code
@@ -57,21 +56,36 @@ constexpr int LDS_U16_PER_LANE = LDS_DIST_COUNTS + 16;  // 992
 // While a dynamic header is read the litlen table is not built yet: its region
 // holds the distribution-sort cursors [0,16) and the 316 code lengths [16,336).
 constexpr int LDS_LENGTHS = LDS_LIT_TBL + 16;
-constexpr int RING_WORDS = 64;       // input ring, 32-bit words
-constexpr int QUEUE_ENTRIES = 32;    // deferred copies, 2 words each
-constexpr int LDS_U32_PER_LANE = RING_WORDS + 2 * QUEUE_ENTRIES;  // 128
-constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 2496
+// then the u32 regions:
+constexpr int RING_WORDS = 64;     // input ring, 32-bit words, slot = word index & 63
+constexpr int RING_MIRROR = 4;     // slots 64..67 repeat slots 0..3: readers take 3 consecutive words
+constexpr int QUEUE_ENTRIES = 32;  // deferred copies, 2 words each
+constexpr int LDS_RING = 0;
+constexpr int LDS_QUEUE = LDS_RING + RING_WORDS + RING_MIRROR;
+constexpr int LDS_WIDE_LIT = LDS_QUEUE + 2 * QUEUE_ENTRIES;  // 512 x u32, see wide_lit_entry
+constexpr int LDS_WIDE_DIST = LDS_WIDE_LIT + 512;            // 128 x u32, see wide_dist_entry
+constexpr int LDS_U32_PER_LANE = LDS_WIDE_DIST + 128;        // 772
+constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 5072
 constexpr uint32_t DEFER_MAX_LEN = 16;
-constexpr int SPEC_WINDOW = 16;  // bit offsets looked up speculatively (= lanes per group)
+constexpr int SPEC_WINDOW = 64;    // bit offsets decoded speculatively (= lanes of the wave)
+constexpr int SPEC_SYM_BITS = 48;  // longest symbol: 15 + 5 + 15 + 13 bits
+constexpr int TURN_WORDS = 5;      // words a wide turn may touch: (31 + 63) / 32 + 3
+constexpr int HEADER_WORDS = 6;    // words a block header step may touch: (31 + 3 + 71) / 32 + 3
 
 struct LaneLds {
-  uint16_t *w;  // u16 regions of this wave's block
-  uint32_t *r;  // u32 regions (ring, queue) of this wave's block
-  int lane;     // my stream's slot in the wave, < (1 << log2L)
-  int log2L;    // log2(streams per wave)
-  ZD_HD uint16_t &u16(int off, int i) const { return w[((off + i) << log2L) + lane]; }
-  ZD_HD uint32_t &ring(uint32_t word) const { return r[((word & (RING_WORDS - 1)) << log2L) + lane]; }
-  ZD_HD uint32_t &queue(int k, int half) const { return r[((RING_WORDS + 2 * k + half) << log2L) + lane]; }
+  uint16_t *w;  // u16 regions of this stream's block
+  uint32_t *r;  // u32 regions
+  ZD_HD uint16_t &u16(int off, int i) const { return w[off + i]; }
+  ZD_HD uint32_t &slot(int s) const { return r[LDS_RING + s]; }
+  ZD_HD uint32_t &queue(int k, int half) const { return r[LDS_QUEUE + 2 * k + half]; }
+  ZD_HD uint32_t &wide_lit(int i) const { return r[LDS_WIDE_LIT + i]; }
+  ZD_HD uint32_t &wide_dist(int i) const { return r[LDS_WIDE_DIST + i]; }
+  // stage input word `word` (and its mirror)
+  ZD_HD void ring_put(uint32_t word, uint32_t v) const {
+    const int s = (int)(word & (uint32_t)(RING_WORDS - 1));
+    r[LDS_RING + s] = v;
+    if (s < RING_MIRROR) r[LDS_RING + RING_WORDS + s] = v;
+  }
 };
 
 enum : int {
@@ -96,14 +110,29 @@ ZD_HD void store_u32_le(uint8_t *p, uint32_t v) {
   *(u32u *)p = v;
 }
 
+// bits [sh, sh + 32) of hi:lo, sh taken modulo 32 (v_alignbit_b32)
+ZD_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
+// `width` bits of v from bit `off` on; off, width < 32 (v_bfe_u32)
+ZD_HD uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ubfe(v, off, width);
+#else
+  return (v >> off) & ((1u << width) - 1u);
+#endif
+}
+
 struct InflateLane {
   uint64_t src_off, dst_off;
-  uint64_t bits;       // bit buffer, LSB first (src_bits zd.ml:536)
   uint32_t src_len;
-  uint32_t in_word;    // next input word to pull from the ring
+  uint32_t in_word;    // stream position: input word ...
+  uint32_t boff;       // ... and bit in it, < 32 (src_pos / src_bits of zd.ml:534-537)
   uint32_t ring_wr;    // one past the last word staged in the ring
-  uint32_t skip;       // bytes to drop from the next pulled word (after a stored block)
-  int32_t nbits;       // REAL bits in `bits` (src_bits_len zd.ml:537)
   uint32_t out_pos;
   uint32_t cap_min;    // min(limit, dst_cap): fast overflow test
   uint32_t limit;      // ?decompressed_size, or 0xFFFFFFFF
@@ -121,46 +150,40 @@ struct InflateLane {
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
 
   ZD_HD uint32_t total_words() const { return (src_len + 3u) >> 2; }
-  // enough staged input for `words` more pulls, or nothing left to stage
-  ZD_HD bool input_ready(uint32_t words) const {
-    return ring_wr - in_word >= words || ring_wr >= total_words();
-  }
+  // `words` words from the position on are staged.  The refill stages zero
+  // words past the end of the input, so this always comes true.
+  ZD_HD bool input_ready(uint32_t words) const { return ring_wr - in_word >= words; }
 
-  // read_bits' refill (zd.ml:570-575), a word at a time out of the LDS ring.
-  // nbits only ever counts REAL bits (bytes past the end are masked to zero and
-  // not counted), so "count > nbits" with nothing left to pull is the
-  // reference's "src_pos > src_max" exhaustion test.
-  ZD_HD void pull(const LaneLds &L) {
-    if (nbits <= 32 && in_word < ring_wr) {
-      uint32_t w = L.ring(in_word);
-      if (skip == 0 && in_word < (src_len >> 2)) {  // a whole word, the usual case
-        bits |= (uint64_t)w << nbits;
-        nbits += 32;
-      } else {
-        const uint32_t base = in_word * 4u;
-        int32_t valid = (int32_t)(src_len - base < 4u ? src_len - base : 4u);
-        if (skip) {
-          w = skip >= 4 ? 0u : w >> (8 * skip);
-          valid -= (int32_t)skip;
-          if (valid < 0) valid = 0;
-          skip = 0;
-        }
-        bits |= (uint64_t)w << nbits;
-        nbits += 8 * valid;
-      }
-      in_word++;
-    }
+  // REAL bits from the position to the end of the input, clamped to 2^24.
+  // "count > bits_left" is the reference's "src_pos > src_max" exhaustion test
+  // of read_bits (zd.ml:570-575): bytes past the end read as zero here and are
+  // never counted.
+  ZD_HD uint32_t bits_left() const {
+    const uint32_t total = total_words();
+    if (in_word >= total) return 0;
+    uint32_t wl = total - in_word;
+    if (wl > (1u << 19)) wl = 1u << 19;
+    const uint32_t pad = (total * 4u - src_len) * 8u;  // bits of the last word past the end
+    const uint32_t have = wl * 32u - pad;
+    return have > boff ? have - boff : 0;
   }
-  ZD_HD bool take(int n, uint32_t &v) {  // false = input exhausted
-    if (n > nbits) return false;
-    v = (uint32_t)(bits & ((1ull << n) - 1));
-    bits >>= n;
-    nbits -= n;
-    return true;
+  // the next 64 bits (3 words staged)
+  ZD_HD uint64_t peek64(const LaneLds &L) const {
+    const int s = (int)(in_word & (uint32_t)(RING_WORDS - 1));
+    const uint32_t w0 = L.slot(s), w1 = L.slot(s + 1), w2 = L.slot(s + 2);
+    return ((uint64_t)funnel32(w2, w1, boff) << 32) | funnel32(w1, w0, boff);
   }
+  ZD_HD void advance(uint32_t n) {
+    const uint32_t p = boff + n;
+    in_word += p >> 5;
+    boff = p & 31u;
+  }
+  // read_bits zd.ml:564-582, n <= 16; false = input exhausted
   ZD_HD bool read_bits(const LaneLds &L, int n, uint32_t &v) {
-    pull(L);
-    return take(n, v);
+    if ((uint32_t)n > bits_left()) return false;
+    v = (uint32_t)peek64(L) & ((1u << n) - 1u);
+    advance((uint32_t)n);
+    return true;
   }
 
   // overflow of the output: the reference's fixed Buf fails with "Expected
@@ -168,6 +191,26 @@ struct InflateLane {
   // dst_cap with no limit given is the boundary's DST_TOO_SMALL.
   ZD_HD void overflow(uint64_t need) { fail(need > limit ? ST_SIZE_EXCEEDED : ST_DST_TOO_SMALL); }
 };
+
+// A symbol being decoded out of a 64-bit peek: `used` of `avail` real bits.
+struct BitCursor {
+  uint64_t x;
+  int used, avail;
+  ZD_HD bool take(int n, uint32_t &v) {  // false = input exhausted
+    if (used + n > avail) return false;
+    v = (uint32_t)(x >> used) & ((1u << n) - 1u);
+    used += n;
+    return true;
+  }
+};
+ZD_HD BitCursor cursor_at(const InflateLane &d, const LaneLds &L) {
+  BitCursor c;
+  c.x = d.peek64(L);
+  c.used = 0;
+  const uint32_t left = d.bits_left();
+  c.avail = left > 64u ? 64 : (int)left;
+  return c;
+}
 
 // Huffman.init_decoder zd.ml:355-391 on lengths[start .. start+n) held in the
 // lane's lengths scratch; fills counts/syms regions.  scratch_off: 16 free u16
@@ -243,25 +286,23 @@ ZD_HD void build_table(const LaneLds &L, int tbl_off, int tbits, int counts_off,
 // reference's canonical walk over counts/symbols, one code bit at a time.
 // Returns -1 for "Corrupted data stream" (input exhausted, or the walk leaves
 // the 15-bit range: the reference's counts.(16) Invalid_argument).
-ZD_HD int read_symbol(InflateLane &d, const LaneLds &L, int tbl_off, int tbits, int counts_off,
+ZD_HD int read_symbol(BitCursor &c, const LaneLds &L, int tbl_off, int tbits, int counts_off,
                       int syms_off) {
-  uint32_t e = L.u16(tbl_off, (int)(d.bits & ((1u << tbits) - 1)));
+  const uint32_t e = L.u16(tbl_off, (int)((uint32_t)(c.x >> c.used) & ((1u << tbits) - 1)));
   int len = e & 15;
   if (len != 0) {
-    if (len > d.nbits) return -1;
-    d.bits >>= len;
-    d.nbits -= len;
+    if (c.used + len > c.avail) return -1;
+    c.used += len;
     return (int)(e >> 4);
   }
   int base = 0, offs = 0;
 #pragma unroll 1
   for (len = 1; len <= 15; len++) {
-    if (len > d.nbits) return -1;
-    offs = 2 * offs + (int)((d.bits >> (len - 1)) & 1);
+    if (c.used + len > c.avail) return -1;
+    offs = 2 * offs + (int)((c.x >> (c.used + len - 1)) & 1);
     int count = L.u16(counts_off, len);
     if (offs < count) {
-      d.bits >>= len;
-      d.nbits -= len;
+      c.used += len;
       return L.u16(syms_off, base + offs);
     }
     base += count;
@@ -295,7 +336,7 @@ ZD_HD void setup_fixed(InflateLane &d, const LaneLds &L) {
 }
 
 // read_dynamic_codes zd.ml:638-643 + read_codelen_code zd.ml:624-636: the fixed
-// part of a dynamic header (at most 71 bits: the caller made 3 words ready).
+// part of a dynamic header (at most 71 bits: the caller made HEADER_WORDS ready).
 ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
   uint32_t v;
   if (!d.read_bits(L, 5, v)) return false;
@@ -332,30 +373,31 @@ ZD_HD int setup_dynamic_lengths(InflateLane &d, const LaneLds &L) {
   uint32_t v;
 #pragma unroll 1
   while (num < total) {
-    if (!d.input_ready(1)) { d.hdr_num = num; return 0; }  // <= 14 bits per turn
-    d.pull(L);
-    int sym = read_symbol(d, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+    if (!d.input_ready(3)) { d.hdr_num = num; return 0; }  // <= 14 bits per turn
+    BitCursor c = cursor_at(d, L);
+    int sym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
     if (sym < 0 || sym > d.hdr_cl_max) return -1;  // zd.ml:649
     int repeat;
     switch (sym) {
     case 16:
       if (num == 0) return -1;  // zd.ml:653
-      if (!d.take(2, v)) return -1;
+      if (!c.take(2, v)) return -1;
       repeat = 3 + (int)v;
       sym = L.u16(LDS_LENGTHS, num - 1);
       break;
     case 17:
-      if (!d.take(3, v)) return -1;
+      if (!c.take(3, v)) return -1;
       repeat = 3 + (int)v;
       sym = 0;
       break;
     case 18:
-      if (!d.take(7, v)) return -1;
+      if (!c.take(7, v)) return -1;
       repeat = 11 + (int)v;
       sym = 0;
       break;
     default: repeat = 1; break;
     }
+    d.advance((uint32_t)c.used);
     if (repeat > total - num) return -1;  // zd.ml:659 (may span litlen/dist)
 #pragma unroll 1
     while (repeat > 0) { repeat--; L.u16(LDS_LENGTHS, num) = (uint16_t)sym; num++; }
@@ -389,7 +431,7 @@ ZD_HD void lane_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t l
 // can be decoded, or a stored block can be copied.  Returns false when the lane
 // must wait for input (nothing consumed).
 ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
-  if (!d.input_ready(3)) return false;  // 3 + 14 + 57 header bits at most
+  if (!d.input_ready(HEADER_WORDS)) return false;  // 3 + 14 + 57 header bits at most
   uint32_t v;
   const uint8_t *src = sa + d.src_off;
   if (!d.read_bits(L, 1, v)) { d.fail(ST_CORRUPTED); return true; }
@@ -399,11 +441,9 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
   switch (v) {
   case 0: {  // read_uncompressed_block zd.ml:671-680
     // the reference buffers < 8 bits, so its src_pos is the byte after the
-    // last one touched: ceil(consumed_bits / 8)
-    const uint64_t pulled = (uint64_t)d.in_word * 4u < d.src_len ? (uint64_t)d.in_word * 4u : d.src_len;
-    const uint64_t consumed_bits = pulled * 8u - (uint64_t)d.nbits;
-    uint32_t pos = (uint32_t)((consumed_bits + 7u) >> 3);
-    if (d.src_len - pos < 4) { d.fail(ST_CORRUPTED); return true; }
+    // last one touched
+    uint32_t pos = d.in_word * 4u + ((d.boff + 7u) >> 3);
+    if (pos > d.src_len || d.src_len - pos < 4) { d.fail(ST_CORRUPTED); return true; }
     const uint32_t length = src[pos] | ((uint32_t)src[pos + 1] << 8);
     const uint32_t inv = src[pos + 2] | ((uint32_t)src[pos + 3] << 8);
     if (length != ((~inv) & 0xFFFFu)) { d.fail(ST_CORRUPTED); return true; }
@@ -412,13 +452,11 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
     if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return true; }
     d.req_src = pos;
     d.req_len = length;
-    // input resumes at the byte after the block: word-aligned pull + byte skip
+    // input resumes at the byte after the block
     const uint32_t next = pos + length;
     d.in_word = next >> 2;
-    d.skip = next & 3u;
+    d.boff = (next & 3u) * 8u;
     if (d.ring_wr < d.in_word) d.ring_wr = d.in_word;  // ring holds nothing useful
-    d.bits = 0;
-    d.nbits = 0;
     d.phase = PH_REQ_COPY;
     return true;
   }
@@ -434,107 +472,58 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
   }
 }
 
-enum : int { SYM_BUDGET = 0, SYM_EOB = 1, SYM_STOP = 2 };
+enum : int { SYM_OK = 0, SYM_EOB = 1, SYM_STOP = 2 };
 
-// read_block_symbols zd.ml:593-616, at most `budget` turns.  One turn:
-//   1. every lane of the group has looked the litlen table up at its own bit
-//      offset (grp.lookup); the literal chain is followed through those 16
-//      entries with register shuffles: V collects the offsets where a literal
-//      starts, o ends on the first offset that is not a (short-coded) literal;
-//   2. the lanes named by V store their literals themselves, side by side;
-//   3. unless the chain ran off the window, the symbol at offset o is decoded:
-//      straight from the shuffled entry when it has a short code (end of block
-//      or a length), else through read_symbol's canonical walk.
-// SYM_STOP: failed, parked on a request, or waiting for input.
-template <typename Group>
-ZD_HD int lane_symbols(InflateLane &d, const LaneLds &L, const Arenas &A, int &budget, Group &grp) {
+// Exactly one symbol of read_block_symbols (zd.ml:593-616), decoded the plain
+// way.  SYM_STOP: failed, parked on a request, or waiting for input.
+ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer) {
   uint8_t *dst = A.dst + d.dst_off;
-  const bool writer = grp.writer();
-#pragma unroll 1
-  while (budget > 0) {
-    budget--;
-    if (!d.input_ready(2)) return SYM_STOP;  // a turn pulls at most twice
-    d.pull(L);
-    grp.lookup(L, d.bits);
-    uint32_t V = 0, e = 0;
-    int o = 0, len = 0;
-    uint32_t n = 0;
-    const uint32_t room = d.cap_min - d.out_pos;
-    bool go;
-#pragma unroll 1
-    do {
-      e = grp.entry(L, d.bits, o);
-      len = (int)(e & 15);
-      go = (len != 0) & (e < (256u << 4)) & (o + len <= d.nbits) & (n < room);
-      if (go) {
-        V |= 1u << o;
-        n++;
-        o += len;
-      }
-    } while (go & (o < SPEC_WINDOW));
-    grp.store_literals(L, d.bits, V, dst + d.out_pos);
-    d.out_pos += n;
-    d.bits >>= o;
-    d.nbits -= o;
-    if (o >= SPEC_WINDOW) continue;
-
-    int sym;
-    if (len != 0 && e >= (256u << 4)) {
-      // short-coded non-literal: the entry is already here
-      if (len > d.nbits) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-      d.bits >>= len;
-      d.nbits -= len;
-      sym = (int)(e >> 4);
-    } else {
-      // a literal that does not fit, a long code, or exhausted input: the plain way
-      d.pull(L);
-      sym = read_symbol(d, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
-      if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-      if (sym < LITLEN_EOB) {
-        if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
-        if (writer) dst[d.out_pos] = (uint8_t)sym;
-        d.out_pos++;
-        continue;
-      }
-    }
-    if (sym == LITLEN_EOB) return SYM_EOB;
-    if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-    uint32_t vbase, vextra, v = 0;
-    length_sym_value(sym, vbase, vextra);
-    if (vextra != 0 && !d.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-    const uint32_t length = vbase + v;
-    d.pull(L);
-    int dsym = read_symbol(d, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-    if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-    dist_sym_value(dsym, vbase, vextra);
-    v = 0;
-    if (vextra != 0 && !d.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-    const uint32_t dist = vbase + v;
-    if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
-    if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
-    // Buf.recopy zd.ml:615 -- queued, or handed to the wave
-    const uint32_t src_pos = d.out_pos - dist;
-    const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
-    if (length <= DEFER_MAX_LEN && dist >= length && !hazard && d.q_count < (uint32_t)QUEUE_ENTRIES) {
-      if (d.q_count == 0) d.hole_min = d.out_pos;
-      if (writer) {
-        L.queue((int)d.q_count, 0) = d.out_pos;
-        L.queue((int)d.q_count, 1) = dist | (length << 16);
-      }
-      d.q_count++;
-      d.out_pos += length;
-    } else {
-      d.req_dist = dist;
-      d.req_len = length;
-      d.phase = PH_REQ_MATCH;
-      return SYM_STOP;
-    }
+  if (!d.input_ready(3)) return SYM_STOP;
+  BitCursor c = cursor_at(d, L);
+  int sym = read_symbol(c, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+  if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  if (sym < LITLEN_EOB) {
+    if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
+    if (writer) dst[d.out_pos] = (uint8_t)sym;
+    d.out_pos++;
+    d.advance((uint32_t)c.used);
+    return SYM_OK;
   }
-  return SYM_BUDGET;
+  if (sym == LITLEN_EOB) { d.advance((uint32_t)c.used); return SYM_EOB; }
+  if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  uint32_t vbase, vextra, v = 0;
+  length_sym_value(sym, vbase, vextra);
+  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  const uint32_t length = vbase + v;
+  int dsym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+  if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  dist_sym_value(dsym, vbase, vextra);
+  v = 0;
+  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  const uint32_t dist = vbase + v;
+  if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
+  if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
+  d.advance((uint32_t)c.used);
+  // Buf.recopy zd.ml:615 -- queued, or handed to the wave
+  const uint32_t src_pos = d.out_pos - dist;
+  const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
+  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+    if (d.q_count == 0) d.hole_min = d.out_pos;
+    if (writer) {
+      L.queue((int)d.q_count, 0) = d.out_pos;
+      L.queue((int)d.q_count, 1) = dist | (length << 16);
+    }
+    d.q_count++;
+    d.out_pos += length;
+    return SYM_OK;
+  }
+  d.req_dist = dist;
+  d.req_len = length;
+  d.phase = PH_REQ_MATCH;
+  return SYM_STOP;
 }
 
-// One header action by the group's writer lane (the other lanes take over its
-// state afterwards, grp.sync): false = must wait for input.
+// One header action: false = must wait for input.
 ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
   if (d.phase == PH_HEADER) return lane_block_header(d, L, sa);
   const int r = setup_dynamic_lengths(d, L);
@@ -544,44 +533,77 @@ ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__r
   return true;
 }
 
-// Runs the stream until it finishes, fails, parks, or has spent `budget` turns.
-template <typename Group>
-ZD_HD void lane_step(InflateLane &d, const LaneLds &L, const Arenas &A, int budget, bool crc_adler,
-                     Group &grp) {
-#pragma unroll 1
-  while (budget > 0) {
-    if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
-      bool ok = true;
-      if (grp.writer()) ok = lane_header_step(d, L, A.src);
-      ok = grp.sync(d, ok);
-      if (!ok) break;  // waits for input
-      budget -= 2;
-    } else if (d.phase == PH_SYMBOLS) {
-      const int r = lane_symbols(d, L, A, budget, grp);
-      if (r != SYM_EOB) break;
-      // inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
-      if (crc_adler) { d.phase = PH_REQ_ADLER; break; }
-      d.phase = d.final_block ? PH_DONE : PH_HEADER;
-      budget -= 2;
-    } else {
-      break;
-    }
-  }
+// end of block: inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
+ZD_HD void lane_end_of_block(InflateLane &d, bool crc_adler) {
+  if (crc_adler) d.phase = PH_REQ_ADLER;
+  else d.phase = d.final_block ? PH_DONE : PH_HEADER;
 }
 
-// the one-lane group of tests/host_sim: every "speculative" lookup is a table read
-struct SoloGroup {
-  ZD_HD bool writer() const { return true; }
-  ZD_HD bool sync(InflateLane &, bool ok) const { return ok; }
-  ZD_HD void lookup(const LaneLds &, uint64_t) {}
-  ZD_HD uint32_t entry(const LaneLds &L, uint64_t bits, int o) const {
-    return L.u16(LDS_LIT_TBL, (int)((bits >> o) & ((1u << LIT_TBITS) - 1)));
-  }
-  ZD_HD void store_literals(const LaneLds &L, uint64_t bits, uint32_t V, uint8_t *out) const {
-    for (int o = 0, k = 0; o < SPEC_WINDOW; o++)
-      if ((V >> o) & 1) out[k++] = (uint8_t)(entry(L, bits, o) >> 4);
-  }
+// ---- the wide turn's tables and per-lane decode
+//
+// The wide tables restate the primary tables with everything a speculative
+// lane needs in one word, and with every check that does not depend on the
+// stream position already made: an entry is 0 ("stop") unless the wide turn may
+// commit the symbol -- a literal, or a length symbol 257..267 (length <= 16 =
+// DEFER_MAX_LEN) in the block's alphabet; long codes, end of block, invalid and
+// longer length symbols stop the chain and are left to lane_one_symbol, which
+// owns every error and edge decision.
+//   litlen: [3:0] code bits  [5:4] kind (1 literal, 2 length)  [8:6] extra bits
+//           [17:9] literal byte / base length  [23:18] code + extra bits
+//   dist:   [3:0] code bits  [7:4] extra bits  [23:8] base distance
+//           [31:24] code + extra bits
+ZD_HD uint32_t wide_lit_entry(uint32_t e16, int lit_max_sym) {
+  const uint32_t len = e16 & 15u, sym = e16 >> 4;
+  if (len == 0) return 0;
+  if (sym < (uint32_t)LITLEN_EOB) return len | (1u << 4) | (sym << 9) | (len << 18);
+  if (sym == (uint32_t)LITLEN_EOB || (int)sym > lit_max_sym || sym > 267u) return 0;
+  uint32_t base, extra;
+  length_sym_value((int)sym, base, extra);
+  return len | (2u << 4) | (extra << 6) | (base << 9) | ((len + extra) << 18);
+}
+ZD_HD uint32_t wide_dist_entry(uint32_t e16, int dist_max_sym) {
+  const uint32_t len = e16 & 15u, sym = e16 >> 4;
+  if (len == 0 || (int)sym > dist_max_sym || sym > (uint32_t)DIST_SYM_MAX) return 0;
+  uint32_t base, extra;
+  dist_sym_value((int)sym, base, extra);
+  return len | (extra << 4) | (base << 8) | ((len + extra) << 24);
+}
+// lane `lane` of 64 restates its share of both tables
+ZD_HD void build_wide_tables(const InflateLane &d, const LaneLds &L, int lane) {
+#pragma unroll 1
+  for (int i = lane; i < (1 << LIT_TBITS); i += 64) L.wide_lit(i) = wide_lit_entry(L.u16(LDS_LIT_TBL, i), d.lit_max_sym);
+#pragma unroll 1
+  for (int i = lane; i < (1 << DIST_TBITS); i += 64) L.wide_dist(i) = wide_dist_entry(L.u16(LDS_DIST_TBL, i), d.dist_max_sym);
+}
+
+// What lane s of the wide turn finds s bits after the position: xlo/xhi = the
+// next 64 bits from there, avail = real bits from there on.  Branch free: the
+// distance lookup of a literal lane reads a valid (ignored) entry.
+struct WideSym {
+  bool ok;          // the turn may commit it
+  bool is_match;
+  uint32_t tot;     // bits of the whole symbol
+  uint32_t outlen;  // bytes it produces
+  uint32_t value;   // literal byte, or distance
 };
+ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, int avail, const LaneLds &L) {
+  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  const uint32_t len = e & 15u, kind = (e >> 4) & 3u, extra = (e >> 6) & 7u, base = (e >> 9) & 511u;
+  const uint32_t b1 = e >> 18;
+  const uint32_t length = base + bit_field(xlo, len, extra);
+  const uint32_t x2 = funnel32(xhi, xlo, b1);  // b1 <= 14
+  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  const uint32_t len2 = e2 & 15u, dextra = (e2 >> 4) & 15u, dbase = (e2 >> 8) & 0xFFFFu;
+  const uint32_t dist = dbase + bit_field(x2, len2, dextra);
+  const bool is_lit = kind == 1u;
+  WideSym r;
+  r.is_match = kind == 2u && e2 != 0u && dist >= length;
+  r.tot = b1 + (is_lit ? 0u : e2 >> 24);
+  r.ok = (is_lit || r.is_match) && (int)r.tot <= avail;
+  r.outlen = is_lit ? 1u : length;
+  r.value = is_lit ? base : dist;
+  return r;
+}
 
 // after the cooperative copy of a stored block
 ZD_HD void lane_after_copy(InflateLane &d, bool crc_adler) {
@@ -627,11 +649,9 @@ ZD_HD void deferred_store(const DeferredCopy &c, uint8_t *dst) {
 ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.src_off = s.src_off;
   d.dst_off = s.dst_off;
-  d.bits = 0;
-  d.nbits = 0;
   d.in_word = 0;
+  d.boff = 0;
   d.ring_wr = 0;
-  d.skip = 0;
   d.out_pos = 0;
   d.status = ST_OK;
   d.phase = PH_HEADER;
