@@ -39,6 +39,8 @@ static void refill(InflateLane &d, const LaneLds &L, const uint8_t *src) {
 // Host model of inflate.hip's wide turn: the 64 lanes are emulated with arrays,
 // every step is the kernel's step.  Returns true when the chain stopped inside
 // the window (the caller then decodes one symbol the plain way).
+// counters for tools/sim_turn_stats.py: turns, committed symbols, matches, bits, and why turns ended
+extern "C" { uint64_t sim_stats[16]; }
 static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   WideSym sp[64];
   bool ok[64];
@@ -48,17 +50,18 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     const uint32_t p = d.boff + (uint32_t)s;
     const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
     const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
-    sp[s] = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - s, L);
+    sp[s] = wide_decode<true>(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - s, L);
     ok[s] = sp[s].ok && s != 63;
     end[s] = (uint32_t)s + sp[s].tot;
     J[0][s] = ok[s] ? (end[s] < 63u ? end[s] : 63u) : (uint32_t)s;
   }
-  for (int k = 1; k < 6; k++)
+  const int levels = d.levels;
+  for (int k = 1; k < levels; k++)
     for (int t = 0; t < 64; t++) J[k][t] = J[k - 1][J[k - 1][t]];
   bool visited[64];
   for (int t = 0; t < 64; t++) {
     uint32_t v = 0;
-    for (int k = 5; k >= 0; k--) { const uint32_t y = J[k][v]; if (y <= (uint32_t)t) v = y; }
+    for (int k = levels - 1; k >= 0; k--) { const uint32_t y = J[k][v]; if (y <= (uint32_t)t) v = y; }
     visited[t] = v == (uint32_t)t;
   }
   uint32_t outoff[64], incl[64], mrank[64], run = 0, mr = 0;
@@ -90,6 +93,10 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     if (late) c = t;
   }
   if (c < 0) abort();  // the path always ends in a stop or in the sink
+  sim_stats[0]++;
+  if (c == 63) sim_stats[4]++;            // ran to the sink
+  else if (!ok[c]) sim_stats[5]++;        // a stop entry / end of input
+  else sim_stats[6]++;                    // late: room, queue, hazard
   uint32_t n_match = 0;
   int last = -1;
   for (int t = 0; t < c; t++) {
@@ -101,7 +108,9 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
       n_match++;
     }
     last = t;
+    sim_stats[1]++;
   }
+  sim_stats[2] += n_match;
   uint32_t consumed = (uint32_t)c;
   if (last >= 0) {
     d.out_pos += incl[last];
@@ -110,6 +119,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   if (d.q_count == 0 && n_match) d.hole_min = first_match_dst;
   d.q_count += n_match;
   d.advance(consumed);
+  sim_stats[3] += consumed;
   return c < 63;
 }
 
@@ -136,8 +146,14 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
     for (int turn = 0; turn < budget; turn++) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
         if (!lane_header_step(d, L, src)) break;
-        if (d.phase == PH_SYMBOLS)
-          for (int lane = 0; lane < 64; lane++) build_wide_tables(d, L, lane);
+        if (d.phase == PH_SYMBOLS) {
+          uint32_t shortest = 15;
+          for (int lane = 0; lane < 64; lane++) {
+            const uint32_t m = build_wide_tables(d, L, lane);
+            if (m < shortest) shortest = m;
+          }
+          d.levels = levels_for(shortest);
+        }
       } else if (d.phase == PH_SYMBOLS) {
         bool stopped = true;
         if (wide) {

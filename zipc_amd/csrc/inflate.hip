@@ -56,9 +56,21 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(out_pos); ZD_U(cap_min); ZD_U(limit); ZD_U(hard_cap); ZD_U(status);
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
-  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(adler);
+  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(adler); ZD_U(levels);
 #undef ZD_U
 }
+
+__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t u = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = u < v ? u : v;
+  }
+  return uni(v);
+}
+
+// lanes where p holds, as a mask (the compiler keeps p as a mask already)
+__device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // value of lane `addr / 4`
 __device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
@@ -80,25 +92,31 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 
 // One wide turn.  Returns true when the path stopped inside the window: the
 // symbol at the new position is then for lane_one_symbol.
+//
+// LEVELS: the path has at most 63 / (shortest code of the block) symbols, so
+// 2^LEVELS - 1 hops of doubling are enough (InflateLane::levels).
+// PLENTY: the input does not end within the turn's reach, no lane can run out of bits.
+template <int LEVELS, bool PLENTY>
 __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
   // the symbol that would start at my offset
   const uint32_t p = d.boff + (uint32_t)lane;
   const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
   const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
-  const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - lane, L);
+  const WideSym sp = wide_decode<!PLENTY>(funnel32(w1, w0, p), funnel32(w2, w1, p),
+                                          PLENTY ? 0 : (int)d.bits_left() - lane, L);
   const bool ok = sp.ok && lane != 63;  // lane 63 is the sink: the next turn starts there
   const uint32_t lane4 = (uint32_t)lane * 4u;
   const uint32_t end = (uint32_t)lane + sp.tot;
   // J[k]: offset reached after 2^k symbols, as a bpermute address; a lane that
   // stops the path points to itself
-  uint32_t J[6];
+  uint32_t J[LEVELS];
   J[0] = ok ? (end < 63u ? end : 63u) * 4u : lane4;
 #pragma unroll
-  for (int k = 1; k < 6; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+  for (int k = 1; k < LEVELS; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
   // am I on the path from offset 0?  largest path element <= lane, descending
   uint32_t v = 0;
 #pragma unroll
-  for (int k = 5; k >= 0; k--) {
+  for (int k = LEVELS - 1; k >= 0; k--) {
     const uint32_t y = lane_value(v, J[k]);
     if (y <= lane4) v = y;
   }
@@ -109,7 +127,7 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const uint32_t mine = commit0 ? sp.outlen : 0u;
   const uint32_t incl = wave_scan_incl(mine);
   const uint32_t outoff = incl - mine;
-  const unsigned long long match_mask = __ballot(match0);
+  const unsigned long long match_mask = wave_mask(match0);
   const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_mask >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)match_mask, 0u));
   const int first_match = match_mask ? __ffsll((long long)match_mask) - 1 : 0;
@@ -126,7 +144,7 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const uint32_t hole = h0 < h1 ? h0 : h1;
   const bool late = (commit0 && outoff + sp.outlen > room) ||
                     (match0 && (sp.value > dstp || mrank >= qfree || dstp - sp.value + sp.outlen > hole));
-  const unsigned long long cut_mask = __ballot((visited && !ok) || late);
+  const unsigned long long cut_mask = wave_mask((visited && !ok) || late);
   const int c = __ffsll((long long)cut_mask) - 1;  // the path always ends in a stop or in the sink
   const bool commit = commit0 && lane < c;
   if (commit) {
@@ -137,8 +155,8 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
       dst[dstp] = (uint8_t)sp.value;
     }
   }
-  const unsigned long long commit_mask = __ballot(commit);
-  const uint32_t n_match = (uint32_t)__popcll(__ballot(commit && sp.is_match));
+  const unsigned long long commit_mask = wave_mask(commit);
+  const uint32_t n_match = (uint32_t)__popcll(wave_mask(commit && sp.is_match));
   uint32_t consumed = (uint32_t)c;
   if (commit_mask) {
     const int last = 63 - __clzll((long long)commit_mask);
@@ -151,7 +169,25 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   return c < 63;
 }
 
-__global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
+// Wide turns until one stops, the round's turns are used up or the staged input
+// runs low.  Only the position and the output/queue counters change in here; the
+// rest of the state stays put in its scalar registers.
+template <int LEVELS>
+__device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane,
+                                           int &turn) {
+  const uint32_t total = d.total_words();
+  const uint32_t plenty_below = total > 8u ? total - 8u : 0u;  // 8 words > 31 + 63 + 48 bits + the peek
+  bool stopped = false;
+  while (turn < ROUND_TURNS && d.input_ready(TURN_WORDS)) {
+    turn++;
+    stopped = d.in_word < plenty_below ? wide_turn<LEVELS, true>(d, L, dst, lane)
+                                       : wide_turn<LEVELS, false>(d, L, dst, lane);
+    if (stopped) break;
+  }
+  return stopped;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            StreamResult *__restrict__ results,
@@ -196,16 +232,23 @@ __global__ __launch_bounds__(64) void inflate_batch_kernel(const uint8_t *__rest
     uniformize(d);
 
     // ---- decode
-    for (int turn = 0; turn < ROUND_TURNS; turn++) {
+    for (int turn = 0; turn < ROUND_TURNS;) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+        turn++;
         bool ok = true;
         if (writer) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
         if (!uni((uint32_t)ok)) break;  // waits for input
-        if (d.phase == PH_SYMBOLS) build_wide_tables(d, L, lane);
+        if (d.phase == PH_SYMBOLS) {
+          const uint32_t shortest = build_wide_tables(d, L, lane);
+          d.levels = levels_for(wave_min(shortest));
+        }
       } else if (d.phase == PH_SYMBOLS) {
         if (!d.input_ready(TURN_WORDS)) break;
-        const bool stopped = wide_turn(d, L, dst, lane);
+        bool stopped;
+        if (d.levels == 4) stopped = wide_turns<4>(d, L, dst, lane, turn);
+        else if (d.levels == 5) stopped = wide_turns<5>(d, L, dst, lane, turn);
+        else stopped = wide_turns<6>(d, L, dst, lane, turn);
         if (stopped) {
           const int r = lane_one_symbol(d, L, A, writer);
           uniformize(d);

@@ -146,6 +146,7 @@ struct InflateLane {
   uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position
   int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max;  // dynamic header in progress
   uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
+  int32_t levels;      // doubling levels the block's wide turns need (levels_for)
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
 
@@ -568,13 +569,23 @@ ZD_HD uint32_t wide_dist_entry(uint32_t e16, int dist_max_sym) {
   dist_sym_value((int)sym, base, extra);
   return len | (extra << 4) | (base << 8) | ((len + extra) << 24);
 }
-// lane `lane` of 64 restates its share of both tables
-ZD_HD void build_wide_tables(const InflateLane &d, const LaneLds &L, int lane) {
+// lane `lane` of 64 restates its share of both tables; returns the bits of the
+// shortest symbol it saw that a wide turn may commit
+ZD_HD uint32_t build_wide_tables(const InflateLane &d, const LaneLds &L, int lane) {
+  uint32_t shortest = 15;
 #pragma unroll 1
-  for (int i = lane; i < (1 << LIT_TBITS); i += 64) L.wide_lit(i) = wide_lit_entry(L.u16(LDS_LIT_TBL, i), d.lit_max_sym);
+  for (int i = lane; i < (1 << LIT_TBITS); i += 64) {
+    const uint32_t e = wide_lit_entry(L.u16(LDS_LIT_TBL, i), d.lit_max_sym);
+    L.wide_lit(i) = e;
+    if (e != 0 && (e & 15u) < shortest) shortest = e & 15u;
+  }
 #pragma unroll 1
   for (int i = lane; i < (1 << DIST_TBITS); i += 64) L.wide_dist(i) = wide_dist_entry(L.u16(LDS_DIST_TBL, i), d.dist_max_sym);
+  return shortest;
 }
+// A window of 63 offsets holds at most 63 / shortest symbols; the wide turn's
+// descending search over J[0 .. levels) reaches 2^levels - 1 hops.
+ZD_HD int levels_for(uint32_t shortest) { return shortest >= 4 ? 4 : shortest >= 2 ? 5 : 6; }
 
 // What lane s of the wide turn finds s bits after the position: xlo/xhi = the
 // next 64 bits from there, avail = real bits from there on.  Branch free: the
@@ -586,6 +597,7 @@ struct WideSym {
   uint32_t outlen;  // bytes it produces
   uint32_t value;   // literal byte, or distance
 };
+template <bool CHECK_AVAIL>
 ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, int avail, const LaneLds &L) {
   const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
   const uint32_t len = e & 15u, kind = (e >> 4) & 3u, extra = (e >> 6) & 7u, base = (e >> 9) & 511u;
@@ -599,7 +611,7 @@ ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, int avail, const LaneLds &
   WideSym r;
   r.is_match = kind == 2u && e2 != 0u && dist >= length;
   r.tot = b1 + (is_lit ? 0u : e2 >> 24);
-  r.ok = (is_lit || r.is_match) && (int)r.tot <= avail;
+  r.ok = (is_lit || r.is_match) && (!CHECK_AVAIL || (int)r.tot <= avail);
   r.outlen = is_lit ? 1u : length;
   r.value = is_lit ? base : dist;
   return r;
@@ -663,6 +675,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.hole_min = 0;
   d.hdr_num = d.hdr_hlit = d.hdr_hdist = d.hdr_cl_max = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
+  d.levels = 6;
   if (s.src_len > 0xFFFFFFF0ull || s.dst_cap > 0xFFFFFFF0ull) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;
     d.fail(ST_INVALID_ARG);
