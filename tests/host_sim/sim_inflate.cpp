@@ -50,9 +50,9 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     const uint32_t p = d.boff + (uint32_t)s;
     const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
     const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
-    sp[s] = wide_decode<true>(funnel32(w1, w0, p), funnel32(w2, w1, p), (int)d.bits_left() - s, L);
-    ok[s] = sp[s].ok && s != 63;
-    end[s] = (uint32_t)s + sp[s].tot;
+    sp[s] = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), L);
+    ok[s] = (sp[s].is_lit() || sp[s].is_match()) && (int)sp[s].tot() <= (int)d.bits_left() - s && s != 63;
+    end[s] = (uint32_t)s + sp[s].tot();
     J[0][s] = ok[s] ? (end[s] < 63u ? end[s] : 63u) : (uint32_t)s;
   }
   const int levels = d.levels;
@@ -70,8 +70,8 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     outoff[t] = run;
     mrank[t] = mr;
     if (visited[t] && ok[t]) {
-      run += sp[t].outlen;
-      if (sp[t].is_match) { if (first_match < 0) first_match = t; mr++; }
+      run += sp[t].outlen();
+      if (sp[t].is_match()) { if (first_match < 0) first_match = t; mr++; }
     }
     incl[t] = run;
   }
@@ -83,12 +83,12 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   for (int t = 0; t < 64 && c < 0; t++) {
     if (!visited[t]) continue;
     if (!ok[t]) { c = t; break; }
-    bool late = outoff[t] + sp[t].outlen > room;
-    if (sp[t].is_match) {
+    bool late = outoff[t] + sp[t].outlen() > room;
+    if (sp[t].is_match()) {
       const uint32_t dstp = d.out_pos + outoff[t];
       const uint32_t h0 = d.q_count ? d.hole_min : INF, h1 = mrank[t] ? first_match_dst : INF;
       const uint32_t hole = h0 < h1 ? h0 : h1;
-      late = late || sp[t].value > dstp || mrank[t] >= qfree || dstp - sp[t].value + sp[t].outlen > hole;
+      late = late || sp[t].dist > dstp || mrank[t] >= qfree || dstp - sp[t].dist + sp[t].length > hole;
     }
     if (late) c = t;
   }
@@ -101,10 +101,10 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   int last = -1;
   for (int t = 0; t < c; t++) {
     if (!(visited[t] && ok[t])) continue;
-    if (!sp[t].is_match) dst[d.out_pos + outoff[t]] = (uint8_t)sp[t].value;
+    if (!sp[t].is_match()) dst[d.out_pos + outoff[t]] = (uint8_t)sp[t].lit;
     else {
       L.queue((int)(d.q_count + mrank[t]), 0) = d.out_pos + outoff[t];
-      L.queue((int)(d.q_count + mrank[t]), 1) = sp[t].value | (sp[t].outlen << 16);
+      L.queue((int)(d.q_count + mrank[t]), 1) = sp[t].dist | (sp[t].length << 16);
       n_match++;
     }
     last = t;

@@ -69,8 +69,9 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
   return uni(v);
 }
 
-// lanes where p holds, as a mask (the compiler keeps p as a mask already)
+// lanes where p holds, as a mask -- and back
 __device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
 // value of lane `addr / 4`
 __device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
@@ -98,19 +99,25 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
 // PLENTY: the input does not end within the turn's reach, no lane can run out of bits.
 template <int LEVELS, bool PLENTY>
 __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
+  typedef unsigned long long mask_t;  // one bit per lane; the predicates of the turn are kept as masks
   // the symbol that would start at my offset
   const uint32_t p = d.boff + (uint32_t)lane;
   const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
   const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
-  const WideSym sp = wide_decode<!PLENTY>(funnel32(w1, w0, p), funnel32(w2, w1, p),
-                                          PLENTY ? 0 : (int)d.bits_left() - lane, L);
-  const bool ok = sp.ok && lane != 63;  // lane 63 is the sink: the next turn starts there
+  const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), L);
+  const bool is_lit = sp.kind == 1u;
+  const mask_t lit_m = wave_mask(is_lit);
+  const mask_t match_m = wave_mask(sp.kind == 2u) & wave_mask(sp.e2 != 0u) & wave_mask(sp.dist >= sp.length);
+  const uint32_t tot = sp.b1 + (is_lit ? 0u : sp.t2);
+  const uint32_t outlen = is_lit ? 1u : sp.length;
+  mask_t ok_m = (lit_m | match_m) & ~(1ull << 63);  // lane 63 is the sink: the next turn starts there
+  if (!PLENTY) ok_m &= wave_mask((int)tot <= (int)d.bits_left() - lane);
   const uint32_t lane4 = (uint32_t)lane * 4u;
-  const uint32_t end = (uint32_t)lane + sp.tot;
+  const uint32_t end = (uint32_t)lane + tot;
   // J[k]: offset reached after 2^k symbols, as a bpermute address; a lane that
   // stops the path points to itself
   uint32_t J[LEVELS];
-  J[0] = ok ? (end < 63u ? end : 63u) * 4u : lane4;
+  J[0] = lane_in(ok_m) ? (end < 63u ? end : 63u) * 4u : lane4;
 #pragma unroll
   for (int k = 1; k < LEVELS; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
   // am I on the path from offset 0?  largest path element <= lane, descending
@@ -120,51 +127,48 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
     const uint32_t y = lane_value(v, J[k]);
     if (y <= lane4) v = y;
   }
-  const bool visited = v == lane4;
-  const bool commit0 = visited && ok;
-  const bool match0 = commit0 && sp.is_match;
+  const mask_t visited_m = wave_mask(v == lane4);
+  const mask_t commit0_m = visited_m & ok_m;
+  const mask_t match0_m = commit0_m & match_m;
   // output offsets: exclusive scan of the produced bytes over the path
-  const uint32_t mine = commit0 ? sp.outlen : 0u;
+  const uint32_t mine = lane_in(commit0_m) ? outlen : 0u;
   const uint32_t incl = wave_scan_incl(mine);
   const uint32_t outoff = incl - mine;
-  const unsigned long long match_mask = wave_mask(match0);
-  const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(match_mask >> 32),
-                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)match_mask, 0u));
-  const int first_match = match_mask ? __ffsll((long long)match_mask) - 1 : 0;
+  const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(match0_m >> 32),
+                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)match0_m, 0u));
   const uint32_t INF = 0xFFFFFFFFu;
   const uint32_t first_match_dst =
-      match_mask ? d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, first_match) : INF;
+      match0_m ? d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, __ffsll((long long)match0_m) - 1) : INF;
   // symbols that would overflow, reach before the start, overfill the queue or
-  // read an unfilled hole end the turn in front of them
+  // read an unfilled hole end the turn in front of them; the holes are the
+  // queued copies and, behind the turn's first match, that match
   const uint32_t room = d.cap_min - d.out_pos;
   const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
   const uint32_t dstp = d.out_pos + outoff;
+  const uint32_t src_end = dstp - sp.dist + sp.length;
   const uint32_t h0 = d.q_count ? d.hole_min : INF;
-  const uint32_t h1 = mrank ? first_match_dst : INF;  // a match lane behind the first one
-  const uint32_t hole = h0 < h1 ? h0 : h1;
-  const bool late = (commit0 && outoff + sp.outlen > room) ||
-                    (match0 && (sp.value > dstp || mrank >= qfree || dstp - sp.value + sp.outlen > hole));
-  const unsigned long long cut_mask = wave_mask((visited && !ok) || late);
-  const int c = __ffsll((long long)cut_mask) - 1;  // the path always ends in a stop or in the sink
-  const bool commit = commit0 && lane < c;
-  if (commit) {
-    if (sp.is_match) {
-      L.queue((int)(d.q_count + mrank), 0) = dstp;
-      L.queue((int)(d.q_count + mrank), 1) = sp.value | (sp.outlen << 16);
-    } else {
-      dst[dstp] = (uint8_t)sp.value;
-    }
+  const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;
+  const mask_t first_m = match0_m & (0ull - match0_m);
+  const mask_t late_m = (commit0_m & wave_mask(outoff + outlen > room)) |
+                        (match0_m & (wave_mask(sp.dist > dstp) | wave_mask(mrank >= qfree) |
+                                     (first_m & wave_mask(src_end > h0)) | (~first_m & wave_mask(src_end > h1))));
+  const mask_t cut_m = (visited_m & ~ok_m) | late_m;
+  const int c = __ffsll((long long)cut_m) - 1;  // the path always ends in a stop or in the sink
+  const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
+  const mask_t commit_match_m = commit_m & match_m;
+  if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
+  if (lane_in(commit_match_m)) {
+    L.queue((int)(d.q_count + mrank), 0) = dstp;
+    L.queue((int)(d.q_count + mrank), 1) = sp.dist | (sp.length << 16);
   }
-  const unsigned long long commit_mask = wave_mask(commit);
-  const uint32_t n_match = (uint32_t)__popcll(wave_mask(commit && sp.is_match));
   uint32_t consumed = (uint32_t)c;
-  if (commit_mask) {
-    const int last = 63 - __clzll((long long)commit_mask);
+  if (commit_m) {
+    const int last = 63 - __clzll((long long)commit_m);
     d.out_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, last);
     if (c == 63) consumed = (uint32_t)__builtin_amdgcn_readlane((int)end, last);  // may leave the window
   }
-  if (d.q_count == 0 && n_match) d.hole_min = first_match_dst;
-  d.q_count += n_match;
+  if (d.q_count == 0 && commit_match_m) d.hole_min = first_match_dst;
+  d.q_count += (uint32_t)__popcll(commit_match_m);
   d.advance(consumed);
   return c < 63;
 }

@@ -588,32 +588,34 @@ ZD_HD uint32_t build_wide_tables(const InflateLane &d, const LaneLds &L, int lan
 ZD_HD int levels_for(uint32_t shortest) { return shortest >= 4 ? 4 : shortest >= 2 ? 5 : 6; }
 
 // What lane s of the wide turn finds s bits after the position: xlo/xhi = the
-// next 64 bits from there, avail = real bits from there on.  Branch free: the
-// distance lookup of a literal lane reads a valid (ignored) entry.
+// next 64 bits from there.  Branch free: the distance lookup of a literal lane
+// reads a valid (ignored) entry.
 struct WideSym {
-  bool ok;          // the turn may commit it
-  bool is_match;
-  uint32_t tot;     // bits of the whole symbol
-  uint32_t outlen;  // bytes it produces
-  uint32_t value;   // literal byte, or distance
+  uint32_t kind;    // 0 stop, 1 literal, 2 length symbol
+  uint32_t e2;      // distance entry, 0 = stop
+  uint32_t lit;     // literal byte (kind 1)
+  uint32_t length;  // match length (kind 2)
+  uint32_t dist;    // match distance (kind 2, e2 != 0)
+  uint32_t b1, t2;  // bits of the litlen part, of the distance part
+  // the predicates the turn forms out of these (as wave masks in the kernel)
+  ZD_HD bool is_lit() const { return kind == 1u; }
+  ZD_HD bool is_match() const { return kind == 2u && e2 != 0u && dist >= length; }  // may be deferred
+  ZD_HD uint32_t tot() const { return b1 + (kind == 1u ? 0u : t2); }
+  ZD_HD uint32_t outlen() const { return kind == 1u ? 1u : length; }
 };
-template <bool CHECK_AVAIL>
-ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, int avail, const LaneLds &L) {
-  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
-  const uint32_t len = e & 15u, kind = (e >> 4) & 3u, extra = (e >> 6) & 7u, base = (e >> 9) & 511u;
-  const uint32_t b1 = e >> 18;
-  const uint32_t length = base + bit_field(xlo, len, extra);
-  const uint32_t x2 = funnel32(xhi, xlo, b1);  // b1 <= 14
-  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
-  const uint32_t len2 = e2 & 15u, dextra = (e2 >> 4) & 15u, dbase = (e2 >> 8) & 0xFFFFu;
-  const uint32_t dist = dbase + bit_field(x2, len2, dextra);
-  const bool is_lit = kind == 1u;
+ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, const LaneLds &L) {
   WideSym r;
-  r.is_match = kind == 2u && e2 != 0u && dist >= length;
-  r.tot = b1 + (is_lit ? 0u : e2 >> 24);
-  r.ok = (is_lit || r.is_match) && (!CHECK_AVAIL || (int)r.tot <= avail);
-  r.outlen = is_lit ? 1u : length;
-  r.value = is_lit ? base : dist;
+  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  const uint32_t len = e & 15u, extra = (e >> 6) & 7u, base = (e >> 9) & 511u;
+  r.kind = (e >> 4) & 3u;
+  r.b1 = e >> 18;
+  r.lit = base;
+  r.length = base + bit_field(xlo, len, extra);
+  const uint32_t x2 = funnel32(xhi, xlo, r.b1);  // b1 <= 14
+  r.e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  const uint32_t len2 = r.e2 & 15u, dextra = (r.e2 >> 4) & 15u, dbase = (r.e2 >> 8) & 0xFFFFu;
+  r.dist = dbase + bit_field(x2, len2, dextra);
+  r.t2 = r.e2 >> 24;
   return r;
 }
 
