@@ -312,6 +312,77 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
     if (act[i]) S.match[base + p[i]] = out[i];
 }
 
+// The same search for longer streams, out of LDS: a workgroup takes a tile of
+// 16 Ki positions and first stages everything their chain walks can touch -- the
+// 32 KiB window in front of the tile, the tile itself and the 258 bytes behind it,
+// with the chain links of those positions: 48 KiB + 96 KiB of the CU's 160 KiB.
+// The walks are chains of dependent, data-dependent 2- and 8-byte reads; from
+// global memory they are bound by the rate at which the vector memory pipeline
+// takes divergent addresses, out of LDS a wave's 64 addresses go in a few clocks.
+constexpr uint32_t MATCHW_THREADS = 1024;
+constexpr uint32_t MATCHW_TILE = 16384;
+constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
+constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
+constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
+static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
+static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
+
+__global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
+                                                                         const StreamDesc *__restrict__ descs,
+                                                                         DeflateScratch S, uint32_t n_streams,
+                                                                         uint32_t tiles_per_stream, int K, int Kq) {
+  __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
+  __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
+  if (S.error[0]) return;
+  // XCD-aware order as in lz_match_kernel: the tiles of a stream re-read each
+  // other's windows, so they go to one XCD's L2
+  const uint32_t nb = gridDim.x;
+  const uint32_t per_xcd = (nb + 7) / 8;
+  const uint32_t logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+  const uint32_t stream = logical / tiles_per_stream;
+  const uint32_t tile = logical % tiles_per_stream;
+  if (stream >= n_streams) return;  // grid is padded to a multiple of 8
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint64_t t0_64 = (uint64_t)tile * MATCHW_TILE;
+  if (t0_64 > len - 4) return;
+  const uint32_t t0 = (uint32_t)t0_64;
+  const uint32_t w0 = t0 > MAX_MATCH_DIST ? t0 - MAX_MATCH_DIST : 0;  // first staged position
+  const uint64_t base = S.pos_base[stream];
+  const uint8_t *s = src_arena + sd.src_off;
+  const uint32_t tid = threadIdx.x;
+  {  // stage source bytes [w0, t0 + tile + 264) (zero past the end) and links [w0, t0 + tile)
+    const uint64_t want = (uint64_t)t0 + MATCHW_TILE + 264;
+    const uint32_t src_end = want < len ? (uint32_t)want : len;
+    const uint32_t n_src = (src_end - w0 + 15u) & ~15u;
+    for (uint32_t o = tid * 16u; o < n_src; o += MATCHW_THREADS * 16u) {
+      u32x4 v;
+      if ((uint64_t)w0 + o + 16u <= len) v = load16_unaligned(s + w0 + o);
+      else {
+        uint8_t b[16];
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) b[i] = (uint64_t)w0 + o + i < len ? s[w0 + o + i] : (uint8_t)0;
+        __builtin_memcpy(&v, b, 16);
+      }
+      *(u32x4 *)(win_src + o) = v;
+    }
+    const uint32_t link_end = (uint64_t)t0 + MATCHW_TILE < len ? t0 + MATCHW_TILE : len;
+    const uint32_t n_links = (link_end - w0 + 7u) & ~7u;  // the scratch is padded past len
+    const uint16_t *pv = S.prev + base + w0;
+    for (uint32_t o = tid * 8u; o < n_links; o += MATCHW_THREADS * 8u) *(u32x4 *)(win_prev + o) = *(const u32x4 *)(pv + o);
+  }
+  __syncthreads();
+  const uint8_t *ws = win_src - w0;       // indexed by stream position
+  const uint16_t *wp = win_prev - w0;
+  // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on
+  const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
+  const uint64_t wbeg = (uint64_t)t0 + (tid / 64u) * per_wave;
+  const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
+  if (wbeg < wend)  // wave-uniform: lz_match_run is entered by whole waves
+    lz_match_run(ws, len, (uint32_t)wbeg + (tid & 63u), (uint32_t)wend, 64u, wp, K, Kq, S.match + base);
+}
+
 // ---------------------------------------------------------------------------------
 // The lazy parse proper (Lz77.compress zd.ml:1203-1244 + write_block_symbol
 // zd.ml:1118-1123): which positions does the parse visit, what symbols do they
@@ -781,10 +852,17 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   level_params(level, good_match, K);
   ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S);
   ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
-  const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
-  if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((n * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0, d_src,
-            d_descs, S, (uint32_t)n, (uint32_t)cps, K, K / 4);
+  if (max_src_len <= MATCHW_SMALL) {  // short streams: a whole-CU window per tile would sit mostly idle
+    const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
+    if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((n * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
+              d_src, d_descs, S, (uint32_t)n, (uint32_t)cps, K, K / 4);
+  } else {
+    const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
+    if (n * tps > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * tps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
+              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, K, K / 4);
+  }
   ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
             d_results, S, crc_op);

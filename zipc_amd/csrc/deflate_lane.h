@@ -162,6 +162,67 @@ ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p,
   }
 }
 
+// lz_match_position for the positions pbeg, pbeg + stride, ... < pend, one after
+// the other, as ONE loop: an iteration is either a chain step of the current
+// position or its last step plus the start of the next position.  The lanes of
+// a wave run this with different positions at their own pace, so a wave iterates
+// max-over-lanes of the SUM of the chain lengths of a lane's positions -- not the
+// sum over positions of the max over lanes that walking position groups in
+// lockstep costs (chain lengths vary a lot between neighbouring positions).
+// out is indexed by position.  Same results as lz_match_position.
+ZD_HD void lz_match_run(const uint8_t *s, uint32_t len, uint32_t pbeg, uint32_t pend, uint32_t stride,
+                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  bool alive = pbeg < pend;
+  uint32_t p = alive ? pbeg : 0u, q = p, best_len = MIN_MATCH_LEN - 1, best = 0, snap = 0, maxlen, steps = 0;
+  bool snapped = false;
+  uint64_t pw = 0;
+  maxlen = len - p < (uint32_t)MAX_MATCH_LEN ? len - p : (uint32_t)MAX_MATCH_LEN;
+  if (alive && maxlen >= 8) pw = load_u64_le(s + p);
+  // On the GPU the loop is left by the whole wave at once (the exit test is
+  // wave-uniform): that keeps it ONE loop whose iterations mix positions, instead
+  // of a loop per position that the lanes would have to leave together.
+  for (;;) {
+    if (alive) {
+      bool finish = true;
+      const uint32_t d = prev[q];
+      if (d != 0 && steps != (uint32_t)K && best_len < maxlen && p - (q - d) <= (uint32_t)MAX_MATCH_DIST) {
+        q -= d;  // zd.ml:1181,1187
+        steps++;
+        uint32_t l;
+        if (maxlen >= 8) {
+          const uint64_t x = load_u64_le(s + q) ^ pw;
+          l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : common_prefix(s, q, p, maxlen);
+        } else {
+          l = common_prefix(s, q, p, maxlen);
+        }
+        if (l > best_len) {
+          best_len = l;
+          best = ((p - q) << 9) | l;
+        }
+        if (steps == (uint32_t)Kq) { snap = best; snapped = true; }
+        finish = l == maxlen;  // zd.ml:1194
+      }
+      if (finish) {
+        if (!snapped) snap = best;
+        if (Kq == 0) snap = 0;
+        out[p] = (uint64_t)best | ((uint64_t)snap << 32);
+        p += stride;
+        alive = p < pend;
+        if (alive) {
+          q = p; best_len = MIN_MATCH_LEN - 1; best = 0; snap = 0; steps = 0; snapped = false;
+          maxlen = len - p < (uint32_t)MAX_MATCH_LEN ? len - p : (uint32_t)MAX_MATCH_LEN;
+          if (maxlen >= 8) pw = load_u64_le(s + p);
+        }
+      }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+#else
+    if (!alive) break;
+#endif
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The lazy parse (Lz77.compress zd.ml:1203-1244) in three parallel-friendly
 // pieces.  Between two positions where the reference has NO pending match the
