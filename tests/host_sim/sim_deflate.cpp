@@ -165,14 +165,19 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
     }
     // the window kernel's form: a lane runs every 64th position of 1 Ki positions
     if (len >= 4) {
-      std::vector<uint64_t> match2(len + 8, 0);
+      std::vector<uint64_t> match2(len + 8, 0), match3(len + 8, 0);
+      std::vector<uint8_t> padded(len + 16, 0xA5);  // the word-read form over-reads
+      memcpy(padded.data(), src, len);
       for (uint32_t wbeg = 0; wbeg + 4 <= len; wbeg += 1024) {
         const uint32_t wend = wbeg + 1024 < len - 3 ? wbeg + 1024 : len - 3;
-        for (uint32_t lane = 0; lane < 64; lane++)
-          if (wbeg + lane < wend) lz_match_run(src, len, wbeg + lane, wend, 64, prev.data(), K, K / 4, match2.data());
+        for (uint32_t lane = 0; lane < 64; lane++) {
+          const uint32_t pb[2] = {wbeg + lane, wbeg + lane + 64};
+          lz_match_runs<2, true>(padded.data(), len, pb, wend, 128, prev.data(), K, K / 4, match2.data());
+          lz_match_runs<1, false>(src, len, pb, wend, 64, prev.data(), K, K / 4, match3.data());
+        }
       }
       for (uint32_t p = 0; p + 4 <= len; p++)
-        if (match2[p] != match[p]) return 98;
+        if (match2[p] != match[p] || match3[p] != match[p]) return 98;
     }
     // macro step of every position (+ literal runs), then the walk in small
     // resumable slices like the kernel's ring, then the symbol emission

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
 // takes divergent addresses, out of LDS a wave's 64 addresses go in a few clocks.
 constexpr uint32_t MATCHW_THREADS = 1024;
 constexpr uint32_t MATCHW_TILE = 16384;
+constexpr int MATCHW_NP = 2;  // runs per lane
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
@@ -352,35 +353,58 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint64_t base = S.pos_base[stream];
   const uint8_t *s = src_arena + sd.src_off;
   const uint32_t tid = threadIdx.x;
-  {  // stage source bytes [w0, t0 + tile + 264) (zero past the end) and links [w0, t0 + tile)
+  {  // stage source bytes [w0, t0 + tile + 264) and links [w0, t0 + tile): every
+     // thread first issues all its 16-byte loads, then stores them
     const uint64_t want = (uint64_t)t0 + MATCHW_TILE + 264;
     const uint32_t src_end = want < len ? (uint32_t)want : len;
-    const uint32_t n_src = (src_end - w0 + 15u) & ~15u;
-    for (uint32_t o = tid * 16u; o < n_src; o += MATCHW_THREADS * 16u) {
-      u32x4 v;
-      if ((uint64_t)w0 + o + 16u <= len) v = load16_unaligned(s + w0 + o);
-      else {
-        uint8_t b[16];
-#pragma unroll
-        for (uint32_t i = 0; i < 16; i++) b[i] = (uint64_t)w0 + o + i < len ? s[w0 + o + i] : (uint8_t)0;
-        __builtin_memcpy(&v, b, 16);
-      }
-      *(u32x4 *)(win_src + o) = v;
-    }
+    const uint32_t n_src = (src_end - w0) & ~15u;  // whole 16-byte units; the rest below
     const uint32_t link_end = (uint64_t)t0 + MATCHW_TILE < len ? t0 + MATCHW_TILE : len;
     const uint32_t n_links = (link_end - w0 + 7u) & ~7u;  // the scratch is padded past len
     const uint16_t *pv = S.prev + base + w0;
-    for (uint32_t o = tid * 8u; o < n_links; o += MATCHW_THREADS * 8u) *(u32x4 *)(win_prev + o) = *(const u32x4 *)(pv + o);
+    constexpr int SRC_ROUNDS = (MATCHW_SRC_BYTES / 16 + MATCHW_THREADS - 1) / MATCHW_THREADS;
+    constexpr int LINK_ROUNDS = (MATCHW_LINKS / 8 + MATCHW_THREADS - 1) / MATCHW_THREADS;
+    u32x4 vs[SRC_ROUNDS], vl[LINK_ROUNDS];
+    const uint32_t last_src = n_src ? n_src - 16u : 0u;
+    if (n_src == 0) {  // a stream shorter than one unit in a batch of long ones
+#pragma unroll
+      for (int j = 0; j < SRC_ROUNDS; j++) vs[j] = u32x4{0, 0, 0, 0};
+    } else
+#pragma unroll
+    for (int j = 0; j < SRC_ROUNDS; j++) {
+      const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
+      vs[j] = load16_unaligned(s + w0 + (o < n_src ? o : last_src));  // unconditional: all in flight together
+    }
+#pragma unroll
+    for (int j = 0; j < LINK_ROUNDS; j++) {
+      const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
+      vl[j] = *(const u32x4 *)(pv + (o < n_links ? o : n_links - 8u));
+    }
+#pragma unroll
+    for (int j = 0; j < SRC_ROUNDS; j++) {
+      const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
+      if (o < n_src) *(u32x4 *)(win_src + o) = vs[j];
+    }
+#pragma unroll
+    for (int j = 0; j < LINK_ROUNDS; j++) {
+      const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
+      if (o < n_links) *(u32x4 *)(win_prev + o) = vl[j];
+    }
+    if (tid < ((src_end - w0) & 15u)) win_src[n_src + tid] = s[w0 + n_src + tid];
   }
   __syncthreads();
   const uint8_t *ws = win_src - w0;       // indexed by stream position
   const uint16_t *wp = win_prev - w0;
-  // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on
+  // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
+  // as MATCHW_NP interleaved runs
   const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
   const uint64_t wbeg = (uint64_t)t0 + (tid / 64u) * per_wave;
   const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
-  if (wbeg < wend)  // wave-uniform: lz_match_run is entered by whole waves
-    lz_match_run(ws, len, (uint32_t)wbeg + (tid & 63u), (uint32_t)wend, 64u, wp, K, Kq, S.match + base);
+  if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
+    uint32_t pbeg[MATCHW_NP];
+#pragma unroll
+    for (int i = 0; i < MATCHW_NP; i++) pbeg[i] = (uint32_t)wbeg + (tid & 63u) + 64u * (uint32_t)i;
+    lz_match_runs<MATCHW_NP, true>(ws, len, pbeg, (uint32_t)wend, 64u * MATCHW_NP, wp, K, Kq, S.match + base);
+  }
 }
 
 // ---------------------------------------------------------------------------------

@@ -162,58 +162,79 @@ ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p,
   }
 }
 
-// lz_match_position for the positions pbeg, pbeg + stride, ... < pend, one after
-// the other, as ONE loop: an iteration is either a chain step of the current
-// position or its last step plus the start of the next position.  The lanes of
-// a wave run this with different positions at their own pace, so a wave iterates
-// max-over-lanes of the SUM of the chain lengths of a lane's positions -- not the
-// sum over positions of the max over lanes that walking position groups in
-// lockstep costs (chain lengths vary a lot between neighbouring positions).
-// out is indexed by position.  Same results as lz_match_position.
-ZD_HD void lz_match_run(const uint8_t *s, uint32_t len, uint32_t pbeg, uint32_t pend, uint32_t stride,
-                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
-  bool alive = pbeg < pend;
-  uint32_t p = alive ? pbeg : 0u, q = p, best_len = MIN_MATCH_LEN - 1, best = 0, snap = 0, maxlen, steps = 0;
-  bool snapped = false;
-  uint64_t pw = 0;
-  maxlen = len - p < (uint32_t)MAX_MATCH_LEN ? len - p : (uint32_t)MAX_MATCH_LEN;
-  if (alive && maxlen >= 8) pw = load_u64_le(s + p);
+// lz_match_position for runs of positions -- a run is pbeg, pbeg + stride, ...
+// < pend, one position after the other -- as ONE loop: an iteration is either a
+// chain step of a run's current position or its last step plus the start of the
+// run's next position.  The lanes of a wave work on different positions at
+// their own pace, so a wave iterates max-over-lanes of the SUM of the chain
+// lengths of a lane's positions -- not the sum over positions of the max over
+// lanes that walking position groups in lockstep costs (chain lengths vary a lot
+// between neighbouring positions).  NP independent runs per lane are stepped in
+// the same iteration: a step is a chain of dependent reads, NP of them overlap.
+// The common path of a step is branch free; long matches (first 8 bytes equal)
+// and the last 7 positions of the stream take common_prefix.
+// WORDS: read candidates with load_u64_words (s is 4-byte aligned and may be
+// over-read by 11 bytes) -- the LDS window.  out is indexed by position.  Same
+// results as lz_match_position.
+struct MatchRun {
+  uint32_t p, q, best_len, best, snap, maxlen, steps;
+  bool alive, snapped;
+  uint64_t pw;
+};
+template <bool WORDS>
+ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend) {
+  r.alive = p < pend;
+  r.p = r.alive ? p : 0u;
+  r.q = r.p;
+  r.best_len = MIN_MATCH_LEN - 1;
+  r.best = 0; r.snap = 0; r.steps = 0; r.snapped = false;
+  r.maxlen = len - r.p < (uint32_t)MAX_MATCH_LEN ? len - r.p : (uint32_t)MAX_MATCH_LEN;
+  r.pw = 0;
+  if (WORDS) r.pw = load_u64_words(s, r.p);
+  else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
+}
+template <bool WORDS>
+ZD_HD void match_run_step(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t pend, uint32_t stride,
+                          const uint16_t *prev, uint32_t K, uint32_t Kq, uint64_t *out) {
+  if (!r.alive) return;
+  const uint32_t d = prev[r.q];
+  const uint32_t qn = r.q - d;
+  const bool walk = d != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
+  const uint32_t qc = walk ? qn : r.p;
+  uint64_t x = 0;
+  if (WORDS) x = load_u64_words(s, qc) ^ r.pw;
+  else if (r.maxlen >= 8) x = load_u64_le(s + qc) ^ r.pw;
+  uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+  if (walk && (x == 0 || r.maxlen < 8)) l = common_prefix(s, qc, r.p, r.maxlen);
+  r.q = qc;
+  r.steps += walk ? 1u : 0u;
+  if (walk && l > r.best_len) {
+    r.best_len = l;
+    r.best = ((r.p - qc) << 9) | l;
+  }
+  if (walk && r.steps == Kq) { r.snap = r.best; r.snapped = true; }
+  if (!walk || l == r.maxlen) {  // zd.ml:1194: nothing later can be longer
+    if (!r.snapped) r.snap = r.best;
+    if (Kq == 0) r.snap = 0;
+    out[r.p] = (uint64_t)r.best | ((uint64_t)r.snap << 32);
+    match_run_start<WORDS>(r, s, len, r.p + stride, pend);
+  }
+}
+template <int NP, bool WORDS>
+ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, uint32_t pend, uint32_t stride,
+                         const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  MatchRun r[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) match_run_start<WORDS>(r[i], s, len, pbeg[i], pend);
   // On the GPU the loop is left by the whole wave at once (the exit test is
   // wave-uniform): that keeps it ONE loop whose iterations mix positions, instead
   // of a loop per position that the lanes would have to leave together.
   for (;;) {
-    if (alive) {
-      bool finish = true;
-      const uint32_t d = prev[q];
-      if (d != 0 && steps != (uint32_t)K && best_len < maxlen && p - (q - d) <= (uint32_t)MAX_MATCH_DIST) {
-        q -= d;  // zd.ml:1181,1187
-        steps++;
-        uint32_t l;
-        if (maxlen >= 8) {
-          const uint64_t x = load_u64_le(s + q) ^ pw;
-          l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : common_prefix(s, q, p, maxlen);
-        } else {
-          l = common_prefix(s, q, p, maxlen);
-        }
-        if (l > best_len) {
-          best_len = l;
-          best = ((p - q) << 9) | l;
-        }
-        if (steps == (uint32_t)Kq) { snap = best; snapped = true; }
-        finish = l == maxlen;  // zd.ml:1194
-      }
-      if (finish) {
-        if (!snapped) snap = best;
-        if (Kq == 0) snap = 0;
-        out[p] = (uint64_t)best | ((uint64_t)snap << 32);
-        p += stride;
-        alive = p < pend;
-        if (alive) {
-          q = p; best_len = MIN_MATCH_LEN - 1; best = 0; snap = 0; steps = 0; snapped = false;
-          maxlen = len - p < (uint32_t)MAX_MATCH_LEN ? len - p : (uint32_t)MAX_MATCH_LEN;
-          if (maxlen >= 8) pw = load_u64_le(s + p);
-        }
-      }
+    bool alive = false;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      match_run_step<WORDS>(r[i], s, len, pend, stride, prev, (uint32_t)K, (uint32_t)Kq, out);
+      alive |= r[i].alive;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;

@@ -110,23 +110,6 @@ ZD_HD void store_u32_le(uint8_t *p, uint32_t v) {
   *(u32u *)p = v;
 }
 
-// bits [sh, sh + 32) of hi:lo, sh taken modulo 32 (v_alignbit_b32)
-ZD_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_alignbit(hi, lo, sh);
-#else
-  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
-#endif
-}
-// `width` bits of v from bit `off` on; off, width < 32 (v_bfe_u32)
-ZD_HD uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __builtin_amdgcn_ubfe(v, off, width);
-#else
-  return (v >> off) & ((1u << width) - 1u);
-#endif
-}
-
 struct InflateLane {
   uint64_t src_off, dst_off;
   uint32_t src_len;

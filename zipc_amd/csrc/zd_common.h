@@ -127,6 +127,32 @@ ZD_HD void store_u64_le(uint8_t *p, uint64_t v) {
   *(u64u *)p = v;
 }
 
+// bits [sh, sh + 32) of hi:lo, sh taken modulo 32 (v_alignbit_b32)
+ZD_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+  return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
+// `width` bits of v from bit `off` on; off, width < 32 (v_bfe_u32)
+ZD_HD uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_ubfe(v, off, width);
+#else
+  return (v >> off) & ((1u << width) - 1u);
+#endif
+}
+
+// 8 bytes at s + pos read as three ALIGNED words (s 4-byte aligned; touches up
+// to 11 bytes past pos & ~3): the form for LDS, where a misaligned 8-byte read
+// stalls the pipe (SQ_LDS_UNALIGNED_STALL)
+ZD_HD uint64_t load_u64_words(const uint8_t *s, uint32_t pos) {
+  const uint32_t *w = (const uint32_t *)(s + (pos & ~3u));
+  const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], sh = (pos & 3u) * 8u;
+  return ((uint64_t)funnel32(d2, d1, sh) << 32) | funnel32(d1, d0, sh);
+}
+
 // low `len` bits of v, reversed
 ZD_HD uint32_t bitrev(uint32_t v, int len) {
 #if defined(__clang__)
