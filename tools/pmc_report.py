@@ -26,7 +26,7 @@ for k, v in agg.items():
     if hbm_out is None:
         print(k, "dispatches", {c: len(disp[k][c]) for c in mean}, {c: round(x) for c, x in mean.items()})
     else:
-        name = k.replace("zd::", "").replace("_kernel", "")
+        name = k.replace("zd::", "").replace("_kernel", "").replace("_window", "")
         fetch = mean.get("FETCH_SIZE", 0.0) * 1024
         write = mean.get("WRITE_SIZE", 0.0) * 1024
         out[name] = {"fetch_bytes": fetch, "write_bytes": write, "bytes": fetch + write}
