@@ -509,12 +509,7 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     uint32_t next_entry = B + __shfl(J[0], (int)last, 64);
     if (next_entry > len) next_entry = len;
     // symbol indices: exclusive scan of cnt over the visited lanes
-    uint32_t incl = visited ? cnt : 0u;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
+    const uint32_t incl = wave_scan_incl(visited ? cnt : 0u);
     const uint32_t total = __shfl(incl, 63, 64);
     const uint32_t first = nsym + incl - (visited ? cnt : 0u);
     if (visited) {
@@ -588,14 +583,7 @@ struct BitOut {
   int acc_bits;        // dst_bits_len (zd.ml:785)
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    uint32_t u = __shfl_up(v, o, 64);
-    if (lane >= o) v += u;
-  }
-  return v;
-}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) { return wave_scan_incl(v); }
 
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
@@ -642,7 +630,6 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   __shared__ uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], fix_lit[288], fix_dist[32];
   __shared__ uint32_t codelen_syms[320], heap[580];
   __shared__ uint32_t stage[STAGE_WORDS];
-  __shared__ int sh_info[8];
 
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
@@ -676,6 +663,10 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   bo.acc_bits = 0;
   uint32_t adler = 1;  // Adler_32.init
   uint32_t status = ST_OK;
+#ifdef ZD_EMIT_PHASES  // timing-only build: the results carry cycle counts instead (tools/exp_emit_phases.py)
+  uint64_t ph_hist = 0, ph_code = 0;
+  const uint64_t ph_begin = __builtin_readcyclecounter();
+#endif
 
   for (uint32_t b = 0; b < nblk && status == ST_OK; b++) {
     const BlockDesc bd = blocks[b];
@@ -683,6 +674,9 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     // deflated_block_src_crc zd.ml:1081-1086 (Adler: one update call per block)
     if (crc_op == CRC_ADLER32) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane);
 
+#ifdef ZD_EMIT_PHASES
+    const uint64_t ph0 = __builtin_readcyclecounter();
+#endif
     // symbol histograms (write_lit_symbol / write_backref_symbol zd.ml:1125-1136)
     for (int i = lane; i < 288; i += 64) lit_freq[i] = 0;
     if (lane < 32) dist_freq[lane] = 0;
@@ -706,27 +700,23 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       }
     }
     wave_sync();
-    if (lane == 0) {
-      lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
-      coder_make_dynamic(c);
-      uint64_t flen, dlen;
-      const int kind = coder_choose(c, bd.src_len, bo.acc_bits, flen, dlen);
-      sh_info[0] = kind;
-      sh_info[1] = c.codelen_syms_len;
-      sh_info[2] = c.hlit;
-      sh_info[3] = c.hdist;
-      sh_info[4] = c.hclen;
-      const uint64_t bits = kind == 1 ? flen : dlen;
-      sh_info[5] = (int)(bits & 0xFFFFFFFFu);
-      sh_info[6] = (int)(bits >> 32);
-    }
+    // Code construction is a serial algorithm (the reference's heap, ties and all):
+    // every lane runs it redundantly on the same LDS data, which makes it
+    // wave-uniform -- scalar registers and scalar ALU instead of one live lane.
+#ifdef ZD_EMIT_PHASES
+    const uint64_t ph1 = __builtin_readcyclecounter();
+#endif
+    lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
+    coder_make_dynamic(c);
+    uint64_t flen, dlen;
+    const int kind = coder_choose(c, bd.src_len, bo.acc_bits, flen, dlen);
+    const uint64_t block_bits = kind == 1 ? flen : dlen;
     wave_sync();
-    const int kind = sh_info[0];
-    c.codelen_syms_len = sh_info[1];
-    c.hlit = sh_info[2];
-    c.hdist = sh_info[3];
-    c.hclen = sh_info[4];
-    const uint64_t block_bits = (uint64_t)(uint32_t)sh_info[5] | ((uint64_t)(uint32_t)sh_info[6] << 32);
+#ifdef ZD_EMIT_PHASES
+    const uint64_t ph2 = __builtin_readcyclecounter();
+    ph_hist += ph1 - ph0;
+    ph_code += ph2 - ph1;
+#endif
 
     if (kind == 0) {
       // write_non_compressed_block zd.ml:873-877
@@ -807,6 +797,10 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     r.status = status;
     r.out_len = status == ST_OK ? bo.out_pos : 0;
     r.checksum = (crc_op == CRC_ADLER32 && status == ST_OK) ? adler : 0u;  // CRC-32: checksum pass
+#ifdef ZD_EMIT_PHASES
+    r.checksum = (uint32_t)((__builtin_readcyclecounter() - ph_begin) >> 4);
+    r.out_len = (ph_hist >> 4) | ((ph_code >> 4) << 32);
+#endif
     results[stream] = r;
   }
 }

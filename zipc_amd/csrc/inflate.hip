@@ -78,19 +78,6 @@ __device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v);
 }
 
-// inclusive wave scan: Kogge-Stone inside the rows of 16 on DPP row shifts,
-// then the row totals broadcast down (row_bcast:15 to rows 1 and 3,
-// row_bcast:31 to rows 2 and 3)
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
-  return x;
-}
-
 // One wide turn.  Returns true when the path stopped inside the window: the
 // symbol at the new position is then for lane_one_symbol.
 //

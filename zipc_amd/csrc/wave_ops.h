@@ -24,6 +24,19 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
   if ((uint32_t)lane < (len & 15u)) dst[body + lane] = src[body + lane];
 }
 
+// inclusive wave scan: Kogge-Stone inside the rows of 16 on DPP row shifts,
+// then the row totals broadcast down (row_bcast:15 to rows 1 and 3,
+// row_bcast:31 to rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
+  return x;
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
