@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Phase times inside inflate_batch_kernel, from a timing-only build of the library
+(-DZD_INFLATE_PHASES: the per-stream results carry s_memtime deltas instead of lengths).
+Compressed input is produced with the default library; ZIPC_HIP_PHASE_LIB is the timing build."""
+import ctypes, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+import zipc_amd
+from zipc_amd import batch, synth, _lib
+n = int(os.environ.get("N_STREAMS", "16384")); L = 65536; bits = int(os.environ.get("BITS", "4"))
+dev = torch.device("cuda", 0); ctx = zipc_amd.Context(0)
+src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
+descs = batch.uniform_layout(n, L, batch.deflate_bound(L))
+comp = torch.zeros(n * int(descs["dst_off"][1]) + 256, dtype=torch.uint8, device=dev)
+out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
+d_descs = batch.to_device(descs, dev); d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, 2, 0)
+res = batch.results_from_device(d_res)
+d_idescs = batch.to_device(batch.compact_descs(res, descs, L), dev)
+# second library instance: the timing build
+P = ctypes.CDLL(os.environ["ZIPC_HIP_PHASE_LIB"])
+P.zipc_hip_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int]
+h = ctypes.c_void_p(); assert P.zipc_hip_create(ctypes.byref(h), 0) == 0
+P.zipc_hip_inflate_batch.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+d_ires = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+for _ in range(2):
+    assert P.zipc_hip_inflate_batch(h, comp.data_ptr(), out.data_ptr(), d_idescs.data_ptr(), d_ires.data_ptr(), n, L, 0) == 0
+P.zipc_hip_synchronize.argtypes = [ctypes.c_void_p]; P.zipc_hip_synchronize(h)
+r = batch.results_from_device(d_ires)
+tot = r["status"].astype(np.float64) * 64; hdr = r["checksum"].astype(np.float64) * 64
+wide = (r["out_len"] & 0xFFFFFFFF).astype(np.float64) * 64; plain = (r["out_len"] >> 32).astype(np.float64) * 64
+print("per stream, clocks: total %.0f  headers %.0f (%.1f%%)  wide turns %.0f (%.1f%%)  plain steps %.0f (%.1f%%)  services+rest %.0f (%.1f%%)"
+      % (tot.mean(), hdr.mean(), 100 * hdr.mean() / tot.mean(), wide.mean(), 100 * wide.mean() / tot.mean(), plain.mean(),
+         100 * plain.mean() / tot.mean(), (tot - hdr - wide - plain).mean(), 100 * (tot - hdr - wide - plain).mean() / tot.mean()))

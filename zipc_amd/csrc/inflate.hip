@@ -202,6 +202,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   uint8_t *dst = dst_arena + d.dst_off;
   const uint8_t *src = src_arena + d.src_off;
 
+#ifdef ZD_INFLATE_PHASES  // timing-only build: the results carry cycle counts (tools/exp_inflate_phases.py)
+  uint64_t ph_hdr = 0, ph_wide = 0, ph_plain = 0, ph_t;
+  const uint64_t ph_begin = __builtin_readcyclecounter();
+#define ZD_PH(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; } while (0)
+#define ZD_PH_START() ph_t = __builtin_readcyclecounter()
+#else
+#define ZD_PH(acc) do {} while (0)
+#define ZD_PH_START() do {} while (0)
+#endif
   for (;;) {
     // ---- refill the input ring: lane t stages word ring_wr + t (zero past the end)
     if (d.phase != PH_DONE) {
@@ -226,6 +235,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     for (int turn = 0; turn < ROUND_TURNS;) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
         turn++;
+        ZD_PH_START();
         bool ok = true;
         if (writer) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
@@ -234,16 +244,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
         }
+        ZD_PH(ph_hdr);
       } else if (d.phase == PH_SYMBOLS) {
         if (!d.input_ready(TURN_WORDS)) break;
+        ZD_PH_START();
         bool stopped;
         if (d.levels == 4) stopped = wide_turns<4>(d, L, dst, lane, turn);
         else if (d.levels == 5) stopped = wide_turns<5>(d, L, dst, lane, turn);
         else stopped = wide_turns<6>(d, L, dst, lane, turn);
+        ZD_PH(ph_wide);
         if (stopped) {
           const int r = lane_one_symbol(d, L, A, writer);
           uniformize(d);
           const int ru = uni(r);
+          ZD_PH(ph_plain);
           if (ru == SYM_EOB) lane_end_of_block(d, crc_adler);
           else if (ru == SYM_STOP) break;
         }
@@ -283,6 +297,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     // CRC-32 is filled in by the checksum pass over the produced bytes
     // (chaining per block is exact for CRC-32); Adler-32 is final here.
     r.checksum = (crc_adler && d.status == ST_OK) ? d.adler : 0u;
+#ifdef ZD_INFLATE_PHASES
+    r.status = (uint32_t)((__builtin_readcyclecounter() - ph_begin) >> 6);
+    r.checksum = (uint32_t)(ph_hdr >> 6);
+    r.out_len = (ph_wide >> 6) | ((ph_plain >> 6) << 32);
+#endif
     results[stream] = r;
   }
 }
