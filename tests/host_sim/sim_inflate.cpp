@@ -79,6 +79,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   const uint32_t room = d.cap_min - d.out_pos;
   const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
   const uint32_t first_match_dst = first_match >= 0 ? d.out_pos + outoff[first_match] : INF;
+  const uint32_t qbase = d.q_count ? d.hole_min : first_match_dst;
   int c = -1;
   for (int t = 0; t < 64 && c < 0; t++) {
     if (!visited[t]) continue;
@@ -88,7 +89,8 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
       const uint32_t dstp = d.out_pos + outoff[t];
       const uint32_t h0 = d.q_count ? d.hole_min : INF, h1 = mrank[t] ? first_match_dst : INF;
       const uint32_t hole = h0 < h1 ? h0 : h1;
-      late = late || sp[t].dist > dstp || mrank[t] >= qfree || dstp - sp[t].dist + sp[t].length > hole;
+      late = late || sp[t].dist > dstp || mrank[t] >= qfree || dstp - qbase > QUEUE_REL_MAX ||
+             dstp - sp[t].dist + sp[t].length > hole;
     }
     if (late) c = t;
   }
@@ -103,8 +105,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     if (!(visited[t] && ok[t])) continue;
     if (!sp[t].is_match()) dst[d.out_pos + outoff[t]] = (uint8_t)sp[t].lit;
     else {
-      L.queue((int)(d.q_count + mrank[t]), 0) = d.out_pos + outoff[t];
-      L.queue((int)(d.q_count + mrank[t]), 1) = sp[t].dist | (sp[t].length << 16);
+      L.queue((int)(d.q_count + mrank[t])) = queue_pack(d.out_pos + outoff[t] - qbase, sp[t].dist, sp[t].length);
       n_match++;
     }
     last = t;
@@ -172,7 +173,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
     // services, in the kernel's order
     for (uint32_t k = 0; k < d.q_count; k++) {
       DeferredCopy c;
-      deferred_load(c, dst, L.queue((int)k, 0), L.queue((int)k, 1));
+      deferred_load(c, dst, d.hole_min, L.queue((int)k));
       deferred_store(c, dst);
     }
     d.q_count = 0;

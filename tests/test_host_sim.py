@@ -66,7 +66,7 @@ def test_inflate_wide_turn_model(sim, oracle, monkeypatch):
     seen = {}
     for i, s in enumerate(util.zlib_streams()):
         st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
-        for budget in (8, 3):
+        for budget in (24, 3, 400):
             st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=budget)
             assert (st, d, a) == (st0, d0, a0), s["name"]
         lim = max(0, s["plain_len"] - 1)

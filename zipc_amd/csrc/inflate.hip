@@ -24,7 +24,7 @@
 //               input) stops the path; lane_one_symbol (inflate_lane.h) decodes
 //               that one symbol with all the reference's checks.
 //   service     everything that needs global loads, by all 64 lanes: fill the
-//               queued match copies (32 in flight), copy long/overlapping
+//               queued match copies (up to 64 in flight), copy long/overlapping
 //               matches, copy stored blocks 16 B per lane
 //               (read_uncompressed_block zd.ml:671-680), per-block Adler-32 with
 //               the reference's 5552-byte chunking (inflated_block_crc
@@ -41,7 +41,7 @@ namespace zd {
 
 static_assert(LDS_BYTES_PER_LANE == INFLATE_LDS_BYTES_PER_LANE, "kernels.h");
 static_assert(SPEC_WINDOW == 64 && QUEUE_ENTRIES <= 64, "one lane per offset / per queue entry");
-constexpr int ROUND_TURNS = 12;  // wide turns between two service points
+constexpr int ROUND_TURNS = 24;  // wide turns between two service points
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ int32_t uni(int32_t v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -136,18 +136,17 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const uint32_t h0 = d.q_count ? d.hole_min : INF;
   const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;
   const mask_t first_m = match0_m & (0ull - match0_m);
+  const uint32_t qbase = d.q_count ? d.hole_min : first_match_dst;  // what queued destinations are relative to
   const mask_t late_m = (commit0_m & wave_mask(outoff + outlen > room)) |
                         (match0_m & (wave_mask(sp.dist > dstp) | wave_mask(mrank >= qfree) |
+                                     wave_mask(dstp - qbase > QUEUE_REL_MAX) |
                                      (first_m & wave_mask(src_end > h0)) | (~first_m & wave_mask(src_end > h1))));
   const mask_t cut_m = (visited_m & ~ok_m) | late_m;
   const int c = __ffsll((long long)cut_m) - 1;  // the path always ends in a stop or in the sink
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
   if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
-  if (lane_in(commit_match_m)) {
-    L.queue((int)(d.q_count + mrank), 0) = dstp;
-    L.queue((int)(d.q_count + mrank), 1) = sp.dist | (sp.length << 16);
-  }
+  if (lane_in(commit_match_m)) L.queue((int)(d.q_count + mrank)) = queue_pack(dstp - qbase, sp.dist, sp.length);
   uint32_t consumed = (uint32_t)c;
   if (commit_m) {
     const int last = 63 - __clzll((long long)commit_m);
@@ -270,7 +269,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     if (d.q_count) {  // fill the queued copies: entry `lane`, all loads before the stores
       DeferredCopy c0;
       c0.len = 0;
-      if ((uint32_t)lane < d.q_count) deferred_load(c0, dst, L.queue(lane, 0), L.queue(lane, 1));
+      if ((uint32_t)lane < d.q_count) deferred_load(c0, dst, d.hole_min, L.queue(lane));
       if (c0.len) deferred_store(c0, dst);
       d.q_count = 0;
     }

@@ -59,14 +59,20 @@ constexpr int LDS_LENGTHS = LDS_LIT_TBL + 16;
 // then the u32 regions:
 constexpr int RING_WORDS = 64;     // input ring, 32-bit words, slot = word index & 63
 constexpr int RING_MIRROR = 4;     // slots 64..67 repeat slots 0..3: readers take 3 consecutive words
-constexpr int QUEUE_ENTRIES = 32;  // deferred copies, 2 words each
+constexpr int QUEUE_ENTRIES = 64;  // deferred copies, one packed word each (queue_pack)
 constexpr int LDS_RING = 0;
 constexpr int LDS_QUEUE = LDS_RING + RING_WORDS + RING_MIRROR;
-constexpr int LDS_WIDE_LIT = LDS_QUEUE + 2 * QUEUE_ENTRIES;  // 512 x u32, see wide_lit_entry
+constexpr int LDS_WIDE_LIT = LDS_QUEUE + QUEUE_ENTRIES;       // 512 x u32, see wide_lit_entry
 constexpr int LDS_WIDE_DIST = LDS_WIDE_LIT + 512;            // 128 x u32, see wide_dist_entry
 constexpr int LDS_U32_PER_LANE = LDS_WIDE_DIST + 128;        // 772
 constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 5072
 constexpr uint32_t DEFER_MAX_LEN = 16;
+// A queued copy is one word: its destination relative to the first queued copy's
+// (InflateLane::hole_min), distance and length.
+constexpr uint32_t QUEUE_REL_MAX = 8191;
+ZD_HD uint32_t queue_pack(uint32_t dst_rel, uint32_t dist, uint32_t len) {  // dist <= 32768, 3 <= len <= 16
+  return (dist - 1u) | ((len - 3u) << 15) | (dst_rel << 19);
+}
 constexpr int SPEC_WINDOW = 64;    // bit offsets decoded speculatively (= lanes of the wave)
 constexpr int SPEC_SYM_BITS = 48;  // longest symbol: 15 + 5 + 15 + 13 bits
 constexpr int TURN_WORDS = 5;      // words a wide turn may touch: (31 + 63) / 32 + 3
@@ -77,7 +83,7 @@ struct LaneLds {
   uint32_t *r;  // u32 regions
   ZD_HD uint16_t &u16(int off, int i) const { return w[off + i]; }
   ZD_HD uint32_t &slot(int s) const { return r[LDS_RING + s]; }
-  ZD_HD uint32_t &queue(int k, int half) const { return r[LDS_QUEUE + 2 * k + half]; }
+  ZD_HD uint32_t &queue(int k) const { return r[LDS_QUEUE + k]; }
   ZD_HD uint32_t &wide_lit(int i) const { return r[LDS_WIDE_LIT + i]; }
   ZD_HD uint32_t &wide_dist(int i) const { return r[LDS_WIDE_DIST + i]; }
   // stage input word `word` (and its mirror)
@@ -491,12 +497,10 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
   // Buf.recopy zd.ml:615 -- queued, or handed to the wave
   const uint32_t src_pos = d.out_pos - dist;
   const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
-  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+  const bool in_reach = d.q_count == 0 || d.out_pos - d.hole_min <= QUEUE_REL_MAX;
+  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
     if (d.q_count == 0) d.hole_min = d.out_pos;
-    if (writer) {
-      L.queue((int)d.q_count, 0) = d.out_pos;
-      L.queue((int)d.q_count, 1) = dist | (length << 16);
-    }
+    if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
     d.q_count++;
     d.out_pos += length;
     return SYM_OK;
@@ -627,8 +631,8 @@ struct DeferredCopy {
   uint64_t a, b;
   uint32_t dst_pos, len;
 };
-ZD_HD void deferred_load(DeferredCopy &c, const uint8_t *dst, uint32_t dst_pos, uint32_t dist_len) {
-  const uint32_t dist = dist_len & 0xFFFFu, len = dist_len >> 16;
+ZD_HD void deferred_load(DeferredCopy &c, const uint8_t *dst, uint32_t base, uint32_t packed) {
+  const uint32_t dist = (packed & 0x7FFFu) + 1u, len = ((packed >> 15) & 15u) + 3u, dst_pos = base + (packed >> 19);
   const uint8_t *s = dst + dst_pos - dist;
   c.dst_pos = dst_pos;
   c.len = len;
