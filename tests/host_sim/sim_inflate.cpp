@@ -3,6 +3,7 @@
 // drives one lane (L = 1), doing the wave-cooperative services (stored-block
 // copy, per-block Adler-32) serially.  Lets the decoder logic be checked
 // against the oracle on the CPU-only build box; the product never loads this.
+#include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
 #include "../../zipc_amd/csrc/inflate_lane.h"
@@ -94,7 +95,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     }
     if (late) c = t;
   }
-  if (c < 0) abort();  // the path always ends in a stop or in the sink
+  if (c < 0) c = 63;  // no stop on the path: it ran into the sink (whose own hop the levels need not cover)
   sim_stats[0]++;
   if (c == 63) sim_stats[4]++;            // ran to the sink
   else if (!ok[c]) sim_stats[5]++;        // a stop entry / end of input
@@ -147,6 +148,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
     for (int turn = 0; turn < budget; turn++) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
         if (!lane_header_step(d, L, src)) break;
+        if (d.phase == PH_TABLES) lane_finish_tables(d, L);
         if (d.phase == PH_SYMBOLS) {
           uint32_t shortest = 15;
           for (int lane = 0; lane < 64; lane++) {

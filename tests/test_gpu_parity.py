@@ -225,6 +225,37 @@ def test_inflate_batch_ragged_with_errors(gpu_ctx, oracle):
         assert n_ok > 40 and n_ok < len(streams)
 
 
+def test_inflate_header_fuzz_equals_oracle(gpu_ctx, oracle):
+    """accept/reject and output of damaged and random dynamic headers: the kernel
+    builds its decode tables wave-parallel, the oracle the reference's way"""
+    import torch
+
+    from zipc_amd import batch
+
+    streams = util.header_fuzz_streams(77, 500, 1500)
+    cap = 1 << 16
+    dev = torch.device("cuda", 0)
+    src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+    dst_off = (np.arange(len(streams), dtype=np.uint64) * (cap + 256))
+    descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, [cap] * len(streams), limit=[cap] * len(streams))
+    src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+    dst = torch.zeros(len(streams) * (cap + 256) + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(len(streams) * 16, dtype=torch.uint8, device=dev)
+    batch.inflate_batch(gpu_ctx, src, dst, batch.to_device(descs, dev), d_res, len(streams), cap, 2)
+    res = batch.results_from_device(d_res)
+    out = dst.cpu().numpy()
+    kinds = {}
+    for i, s in enumerate(streams):
+        st0, d0, c0 = oracle.inflate(s, decompressed_size=cap, crc_op=2)
+        kinds[st0] = kinds.get(st0, 0) + 1
+        assert res["status"][i] == st0, (i, st0, int(res["status"][i]))
+        if st0 == 0:
+            o = int(dst_off[i])
+            assert res["out_len"][i] == len(d0) and out[o:o + len(d0)].tobytes() == d0, i
+            assert res["checksum"][i] == c0, i
+    assert kinds.get(0, 0) > 500 and kinds.get(1, 0) > 500, kinds
+
+
 def test_deflate_batch_ragged_equals_oracle(gpu_ctx, oracle):
     import torch
 

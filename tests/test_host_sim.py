@@ -155,3 +155,17 @@ def test_crc_combination_rule(sim, oracle):
         raw_b = oracle.crc32_update(0, b)
         st_a = oracle.crc32_update(0xFFFFFFFF, a)
         assert sim.sim_crc_advance(st_a, raw_b, len(b)) == oracle.crc32_update(0xFFFFFFFF, a + b)
+
+
+def test_inflate_models_header_fuzz(sim, oracle, monkeypatch):
+    """random complete / perturbed Huffman codes in dynamic headers: plain and wide model vs oracle"""
+    streams = util.header_fuzz_streams(78, 150, 450)
+    for wide in (False, True):
+        if wide:
+            monkeypatch.setenv("SIM_INFLATE_WIDE", "1")
+        for s in streams:
+            st0, d0, c0 = oracle.inflate(s, decompressed_size=1 << 16, crc_op=2)
+            st, d, a = sim_inflate(sim, s, 1 << 16, limit=1 << 16, crc_op=2, budget=24)
+            assert st == st0
+            if st0 == 0:
+                assert d == d0 and a == c0

@@ -104,3 +104,166 @@ def corrupt_variants(raw, seed, count):
                     b[r.randrange(len(b))] = r.randrange(256)
         out.append(bytes(b))
     return out
+
+
+class _Bits:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, v, n):  # LSB first (extra bits, header fields)
+        for i in range(n):
+            self.bits.append((v >> i) & 1)
+
+    def code(self, c, n):  # Huffman codes go MSB first
+        for i in range(n - 1, -1, -1):
+            self.bits.append((c >> i) & 1)
+
+    def bytes(self):
+        b = bytearray((len(self.bits) + 7) // 8)
+        for i, v in enumerate(self.bits):
+            b[i >> 3] |= v << (i & 7)
+        return bytes(b)
+
+
+def _random_code_lengths(r, n_used, max_len):
+    """lengths of a random complete prefix code over n_used symbols (n_used >= 2)"""
+    lens = [1, 1]
+    while len(lens) < n_used:
+        cands = [i for i, l in enumerate(lens) if l < max_len]
+        i = r.choice(cands)
+        l = lens.pop(i) + 1
+        lens += [l, l]
+    r.shuffle(lens)
+    return lens
+
+
+def _canonical(lengths):
+    codes, code = {}, 0
+    for l in range(1, 16):
+        for sym, sl in enumerate(lengths):
+            if sl == l:
+                codes[sym] = code
+                code += 1
+        code <<= 1
+    return codes
+
+
+def random_dynamic_stream(r, damage):
+    """one final dynamic block with a random complete litlen / dist / codelen code,
+    a few literals and matches; damage > 0 perturbs that many code lengths (the
+    stream then is usually, not always, rejected)"""
+    n_lit = r.choice([1, 2, 5, 20, 60, 200])
+    used = set(r.sample(range(256), n_lit)) | {256} | set(r.sample(range(257, 286), r.choice([0, 1, 3, 10])))
+    used = sorted(used)
+    ll = [0] * 286
+    for sym, l in zip(used, _random_code_lengths(r, max(len(used), 2), 15) if len(used) > 1 else [1]):
+        ll[sym] = l
+    n_dist = r.choice([1, 1, 2, 6, 30])
+    dl = [0] * 30
+    dsyms = sorted(r.sample(range(30), n_dist))
+    if n_dist == 1:
+        dl[dsyms[0]] = 1
+    else:
+        for sym, l in zip(dsyms, _random_code_lengths(r, n_dist, 15)):
+            dl[sym] = l
+    for _ in range(damage):
+        which = r.choice([ll, dl])
+        which[r.randrange(len(which))] = r.randrange(16)
+    hlit = max(257, max([i for i, l in enumerate(ll) if l] + [256]) + 1)
+    hdist = max(1, max([i for i, l in enumerate(dl) if l] + [0]) + 1)
+    seq = ll[:hlit] + dl[:hdist]
+    # code-length alphabet: plain lengths, zero runs as 17/18, repeats as 16 now and then
+    items, i = [], 0
+    while i < len(seq):
+        run = 1
+        while i + run < len(seq) and seq[i + run] == seq[i]:
+            run += 1
+        if seq[i] == 0 and run >= 3 and r.random() < 0.8:
+            n = min(run, 138)
+            items.append((17, n - 3, 3) if n <= 10 else (18, n - 11, 7))
+            i += n
+        elif run >= 4 and r.random() < 0.6:
+            items.append((seq[i], 0, 0))
+            n = min(run - 1, 6)
+            items.append((16, n - 3, 2))
+            i += 1 + n
+        else:
+            items.append((seq[i], 0, 0))
+            i += 1
+    cl_used = sorted({it[0] for it in items})
+    cl = [0] * 19
+    if len(cl_used) == 1:
+        cl[cl_used[0]] = 1
+    else:
+        for sym, l in zip(cl_used, _random_code_lengths(r, len(cl_used), 7)):
+            cl[sym] = l
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    hclen = max(4, max(i for i, s in enumerate(order) if cl[s]) + 1)
+    w = _Bits()
+    w.put(1, 1); w.put(2, 2); w.put(hlit - 257, 5); w.put(hdist - 1, 5); w.put(hclen - 4, 4)
+    for s_ in order[:hclen]:
+        w.put(cl[s_], 3)
+    clc = _canonical(cl)
+    for sym, extra, nb in items:
+        w.code(clc[sym], cl[sym]); w.put(extra, nb)
+    lc, dc = _canonical(ll), _canonical(dl)
+    lits = [s_ for s_ in used if s_ < 256 and ll[s_]]
+    lens_ = [s_ for s_ in used if s_ > 256 and ll[s_]]
+    produced = 0
+    lbase = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+    lext = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
+    dbase = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    dext = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
+    for _ in range(r.randrange(1, 120)):
+        if lens_ and lits and produced > 0 and r.random() < 0.3:
+            ok_d = [d for d in range(30) if dl[d] and dbase[d] <= produced]
+            if ok_d:
+                ls = r.choice(lens_); d = r.choice(ok_d)
+                w.code(lc[ls], ll[ls]); e = r.randrange(1 << lext[ls - 257]); w.put(e, lext[ls - 257])
+                de = r.randrange(1 << dext[d])
+                while dbase[d] + de > produced:
+                    de = r.randrange(1 << dext[d]) if dbase[d] + de > produced and dext[d] else 0
+                    if dbase[d] + de <= produced:
+                        break
+                    de = 0
+                w.code(dc[d], dl[d]); w.put(de, dext[d])
+                produced += lbase[ls - 257] + e
+                continue
+        if lits:
+            s_ = r.choice(lits)
+            w.code(lc[s_], ll[s_])
+            produced += 1
+    w.code(lc[256], ll[256]) if ll[256] else None
+    w.put(0, 7)
+    return w.bytes()
+
+
+def header_fuzz_streams(seed, n_random, n_flips):
+    """deflate streams that stress the dynamic block header (read_dynamic_block
+    zd.ml:623-669, Huffman.init_decoder zd.ml:355-391): random bits behind a
+    "final, dynamic" block start with small code-length-code lengths (so that a fair
+    share survives the first decoder and reaches the next checks), and single bit
+    flips inside the header of valid dynamic streams."""
+    r = random.Random(seed)
+    out = []
+    for _ in range(n_random):
+        bits = [1, 0, 1]  # BFINAL = 1, BTYPE = 2
+        def put(v, n):
+            for i in range(n):
+                bits.append((v >> i) & 1)
+        put(r.randrange(32), 5); put(r.randrange(32), 5)
+        hclen = r.randrange(16); put(hclen, 4)
+        for _ in range(hclen + 4):
+            put(r.choice([0, 0, 1, 2, 2, 3, 3, 3, 4, 4, 5, 7]), 3)
+        while len(bits) < 8 * 96:
+            bits.append(r.randrange(2))
+        b = bytearray(len(bits) // 8)
+        for i, v in enumerate(bits):
+            b[i >> 3] |= v << (i & 7)
+        out.append(bytes(b))
+    for k in range(n_flips):  # valid random codes, and the same with a few lengths perturbed
+        try:
+            out.append(random_dynamic_stream(r, 0 if k % 2 == 0 else r.randrange(1, 3)))
+        except (KeyError, IndexError, ValueError):
+            pass  # a perturbed table the writer itself cannot encode with
+    return out

@@ -56,7 +56,7 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(out_pos); ZD_U(cap_min); ZD_U(limit); ZD_U(hard_cap); ZD_U(status);
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
-  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(adler); ZD_U(levels);
+  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
 #undef ZD_U
 }
 
@@ -76,6 +76,109 @@ __device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin
 // value of lane `addr / 4`
 __device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
   return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v);
+}
+
+// ---- phase PH_TABLES by the whole wave (serial form: lane_finish_tables)
+//
+// Huffman.init_decoder zd.ml:355-391 on lengths[start .. start + n): the counts
+// per length are an LDS histogram, the verdicts depend on the counts alone, and
+// the symbols sorted by (length, symbol) get their slot from a ballot per length
+// present in each group of 64 symbols.  Same arrays as init_decoder.
+__device__ __forceinline__ bool wave_init_decoder(const LaneLds &L, int counts_off, int syms_off, int scratch_off,
+                                                  int start, int n, int32_t &max_sym, int lane) {
+  if (lane < 16) L.u16(counts_off, lane) = 0;
+  int my_max = -1;
+  for (int i = lane; i < n; i += 64) {
+    const int len = L.u16(LDS_LENGTHS, start + i);
+    if (len != 0) {
+      my_max = i;
+      // counts are u16: add into the containing word (no carry: counts <= 288)
+      const int at = counts_off + len;
+      atomicAdd((uint32_t *)(L.w + (at & ~1)), (at & 1) ? 0x10000u : 1u);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int u = __shfl_xor(my_max, o, 64);
+    my_max = u > my_max ? u : my_max;
+  }
+  max_sym = uni(my_max);
+  int available = 1, num_codes = 0;
+  bool ok = true;
+#pragma unroll 1
+  for (int i = 0; i < 16; i++) {  // every lane, same values
+    const int used = L.u16(counts_off, i);
+    if (used > available) ok = false;  // over-subscribed zd.ml:371
+    available = 2 * (available - used);
+    if (lane == 0) L.u16(scratch_off, i) = (uint16_t)num_codes;
+    num_codes += used;
+  }
+  if (!uni((uint32_t)ok)) return false;
+  if ((num_codes > 1 && available > 0) || (num_codes == 1 && L.u16(counts_off, 1) != 1)) return false;  // zd.ml:377-378
+#pragma unroll 1
+  for (int c = 0; c < n; c += 64) {
+    const int i = c + lane;
+    const int len = i < n ? (int)L.u16(LDS_LENGTHS, start + i) : 0;
+    unsigned long long todo = wave_mask(len != 0);
+#pragma unroll 1
+    while (todo) {
+      const int l = __builtin_amdgcn_readlane(len, __ffsll((long long)todo) - 1);
+      const unsigned long long m = wave_mask(len == l);
+      const uint32_t first = L.u16(scratch_off, l);
+      if (len == l)
+        L.u16(syms_off, (int)(first + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)))) = (uint16_t)i;
+      if (lane == 0) L.u16(scratch_off, l) = (uint16_t)(first + (uint32_t)__popcll(m));
+      todo &= ~m;
+    }
+  }
+  if (num_codes == 1 && lane == 0) {  // zd.ml:389-390: phantom code 1 -> too-large symbol
+    L.u16(counts_off, 1) = 2;
+    L.u16(syms_off, 1) = (uint16_t)(max_sym + 1);
+  }
+  return true;
+}
+
+// build_table: every entry walks the canonical code for its own index -- the
+// reference's read_symbol (zd.ml:584-591) on the entry's bits
+__device__ __forceinline__ void wave_build_table(const LaneLds &L, int tbl_off, int tbits, int counts_off, int syms_off,
+                                                 int lane) {
+#pragma unroll 1
+  for (int e = lane; e < (1 << tbits); e += 64) {
+    int base = 0, offs = 0;
+    uint32_t ent = 0;
+#pragma unroll 1
+    for (int len = 1; len <= tbits; len++) {
+      offs = 2 * offs + ((e >> (len - 1)) & 1);
+      const int count = L.u16(counts_off, len);
+      if (offs < count) { ent = ((uint32_t)L.u16(syms_off, base + offs) << 4) | (uint32_t)len; break; }
+      base += count;
+      offs -= count;
+    }
+    L.u16(tbl_off, e) = (uint16_t)ent;
+  }
+}
+
+__device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds &L, int lane) {
+  if (d.hdr_fixed) {  // fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349
+    if (lane < 16) {
+      L.u16(LDS_LIT_COUNTS, lane) = lane == 7 ? 24 : lane == 8 ? 152 : lane == 9 ? 112 : 0;
+      L.u16(LDS_DIST_COUNTS, lane) = lane == 5 ? 32 : 0;
+    }
+    for (int i = lane; i < 288; i += 64)
+      L.u16(LDS_LIT_SYMS, i) = (uint16_t)(i < 24 ? 256 + i : i < 168 ? i - 24 : i < 176 ? 112 + i : i - 32);
+    if (lane < 32) L.u16(LDS_DIST_SYMS, lane) = (uint16_t)lane;
+    d.lit_max_sym = LITLEN_SYM_MAX;  // 286 and 287 are unused
+    d.dist_max_sym = DIST_SYM_MAX;   // 30 and 31 are unused
+  } else {
+    if (!wave_init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, d.hdr_hlit, d.lit_max_sym, lane) ||
+        !wave_init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, d.hdr_hlit, d.hdr_hdist, d.dist_max_sym, lane)) {
+      d.fail(ST_CORRUPTED);
+      return;
+    }
+  }
+  wave_build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS, lane);
+  wave_build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS, lane);
+  d.phase = PH_SYMBOLS;
 }
 
 // One wide turn.  Returns true when the path stopped inside the window: the
@@ -141,8 +244,10 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
                         (match0_m & (wave_mask(sp.dist > dstp) | wave_mask(mrank >= qfree) |
                                      wave_mask(dstp - qbase > QUEUE_REL_MAX) |
                                      (first_m & wave_mask(src_end > h0)) | (~first_m & wave_mask(src_end > h1))));
-  const mask_t cut_m = (visited_m & ~ok_m) | late_m;
-  const int c = __ffsll((long long)cut_m) - 1;  // the path always ends in a stop or in the sink
+  // the path ends in a stop, or it runs into the sink (bit 63: the sink's own hop
+  // need not be covered by LEVELS)
+  const mask_t cut_m = (visited_m & ~ok_m) | late_m | (1ull << 63);
+  const int c = __ffsll((long long)cut_m) - 1;
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
   if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
@@ -239,6 +344,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         if (writer) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
         if (!uni((uint32_t)ok)) break;  // waits for input
+        if (d.phase == PH_TABLES) wave_finish_tables(d, L, lane);
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));

@@ -101,7 +101,8 @@ enum : int {
   PH_REQ_COPY = 3,     // stored block validated: waiting for the cooperative copy
   PH_REQ_MATCH = 4,    // a match that cannot be deferred: waiting for the lockstep copy
   PH_REQ_ADLER = 5,    // block finished: waiting for the cooperative Adler-32 update
-  PH_DONE = 6
+  PH_DONE = 6,
+  PH_TABLES = 7        // code lengths known (hdr_fixed, or the lengths scratch): decode tables to be built
 };
 
 // Arena base pointers stay kernel arguments (so every access is a global_*
@@ -134,6 +135,7 @@ struct InflateLane {
   uint32_t req_src, req_len, req_dist;
   uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position
   int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max;  // dynamic header in progress
+  int32_t hdr_fixed;   // PH_TABLES: 1 = the fixed codes
   uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
   int32_t levels;      // doubling levels the block's wide turns need (levels_for)
 
@@ -394,12 +396,7 @@ ZD_HD int setup_dynamic_lengths(InflateLane &d, const LaneLds &L) {
   }
   d.hdr_num = num;
   if (L.u16(LDS_LENGTHS, 256) == 0) return -1;  // zd.ml:662
-  if (!init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, d.hdr_hlit, d.lit_max_sym)) return -1;
-  if (!init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, d.hdr_hlit, d.hdr_hdist, d.dist_max_sym))
-    return -1;
-  build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
-  build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-  return 1;
+  return 1;  // the two decoders (zd.ml:663-666) are built in phase PH_TABLES
 }
 
 // Buf.recopy zd.ml:63-75 into global memory.  Far matches move 8 bytes at a
@@ -451,8 +448,8 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
     return true;
   }
   case 1:
-    setup_fixed(d, L);
-    d.phase = PH_SYMBOLS;
+    d.hdr_fixed = 1;
+    d.phase = PH_TABLES;
     return true;
   case 2:
     if (!setup_dynamic_begin(d, L)) { d.fail(ST_CORRUPTED); return true; }
@@ -517,8 +514,25 @@ ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__r
   const int r = setup_dynamic_lengths(d, L);
   if (r == 0) return false;
   if (r < 0) { d.fail(ST_CORRUPTED); return true; }
-  d.phase = PH_SYMBOLS;
+  d.hdr_fixed = 0;
+  d.phase = PH_TABLES;
   return true;
+}
+
+// Phase PH_TABLES, serial form (the kernel has a wave-parallel one with the same
+// results, inflate.hip): the block's two decoders and their primary tables.
+ZD_HD void lane_finish_tables(InflateLane &d, const LaneLds &L) {
+  if (d.hdr_fixed) setup_fixed(d, L);
+  else {
+    if (!init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, d.hdr_hlit, d.lit_max_sym) ||
+        !init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, d.hdr_hlit, d.hdr_hdist, d.dist_max_sym)) {
+      d.fail(ST_CORRUPTED);
+      return;
+    }
+    build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+    build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+  }
+  d.phase = PH_SYMBOLS;
 }
 
 // end of block: inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
@@ -570,8 +584,10 @@ ZD_HD uint32_t build_wide_tables(const InflateLane &d, const LaneLds &L, int lan
   for (int i = lane; i < (1 << DIST_TBITS); i += 64) L.wide_dist(i) = wide_dist_entry(L.u16(LDS_DIST_TBL, i), d.dist_max_sym);
   return shortest;
 }
-// A window of 63 offsets holds at most 63 / shortest symbols; the wide turn's
-// descending search over J[0 .. levels) reaches 2^levels - 1 hops.
+// The offsets 0..62 hold at most 62 / shortest + 1 symbol starts; the wide turn's
+// descending search over J[0 .. levels) reaches 2^levels - 1 hops from offset 0.
+// (The hop from the last start into the sink, lane 63, is not counted: a path
+// without a stop ends there by construction.)
 ZD_HD int levels_for(uint32_t shortest) { return shortest >= 4 ? 4 : shortest >= 2 ? 5 : 6; }
 
 // What lane s of the wide turn finds s bits after the position: xlo/xhi = the
@@ -663,6 +679,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.q_count = 0;
   d.hole_min = 0;
   d.hdr_num = d.hdr_hlit = d.hdr_hdist = d.hdr_cl_max = 0;
+  d.hdr_fixed = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
   d.levels = 6;
   if (s.src_len > 0xFFFFFFF0ull || s.dst_cap > 0xFFFFFFF0ull) {
