@@ -621,6 +621,215 @@ __device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t 
   wave_sync();
 }
 
+// ---- the block coder by the whole wave (serial forms: deflate_lane.h, which the
+// host model runs).  What is order sensitive in the reference -- the heap that
+// builds the tree, with its tie behaviour, and the run-length scan of the code
+// lengths -- stays a serial algorithm that every lane runs redundantly (wave-
+// uniform, hence on the scalar unit); the loops over symbols around them are
+// spread over the lanes.
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Huffman.lengths_of_freqs zd.ml:404-473 (huff_lengths_of_freqs)
+__device__ __forceinline__ void wave_lengths_of_freqs(uint32_t *heap, uint32_t *e, const uint32_t *freqs, int max_sym,
+                                                      int max_code_len, int lane) {
+  uint32_t freq_cap = 65535;
+  for (;;) {
+    int max = 0;
+#pragma unroll 1
+    for (int c = 0; c <= max_sym; c += 64) {  // leaves, in symbol order
+      const int sym = c + lane;
+      uint32_t f = sym <= max_sym ? freqs[sym] : 0u;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
+      if (f != 0) {
+        if (f > freq_cap) f = freq_cap;
+        const int at = max + 1 + (int)lanes_below(m);
+        heap[at] = (f << 10) | (uint32_t)(max_sym + 1 + at);
+      }
+      max += __popcll(m);
+    }
+    if (max < 2) {  // trivial_codeword_lengths zd.ml:462-466
+      for (int sym = lane; sym <= max_sym; sym += 64) e[sym] = freqs[sym] == 0 ? 0u : 1u;
+      return;
+    }
+    wave_sync();
+#pragma unroll 1
+    for (int i = max / 2; i >= 1; i--) huff_heapdown(heap, max, i);
+#pragma unroll 1
+    for (int m = max; m > 1; m--) {  // make_huffman_tree zd.ml:432-445
+      const int new_max = m - 1;
+      const uint32_t p = heap[1];
+      heap[1] = heap[m];
+      huff_heapdown(heap, new_max, 1);
+      const uint32_t q = heap[1];
+      const uint32_t f = (p >> 10) + (q >> 10);
+      heap[1] = (f << 10) | (uint32_t)m;
+      heap[p & 0x3FF] = (uint32_t)m;
+      heap[q & 0x3FF] = (uint32_t)m;
+      huff_heapdown(heap, new_max, 1);
+    }
+    wave_sync();
+    bool overflow = false;  // code_lengths_of_tree zd.ml:446-461: every leaf climbs to the root
+    int rank = 0;
+#pragma unroll 1
+    for (int c = 0; c <= max_sym; c += 64) {
+      const int sym = c + lane;
+      const bool nz = sym <= max_sym && freqs[sym] != 0;
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(nz);
+      uint32_t l = 0;
+      if (nz) {
+        uint32_t p = heap[max_sym + 1 + rank + 1 + (int)lanes_below(m)];
+        l = 1;
+        while (p != 2) { l++; p = heap[p]; }
+      }
+      if (sym <= max_sym) e[sym] = l;
+      overflow |= l > (uint32_t)max_code_len;
+      rank += __popcll(m);
+    }
+    if (__builtin_amdgcn_ballot_w64(overflow) == 0) return;
+    freq_cap >>= 1;  // flatten and retry zd.ml:470-473
+    wave_sync();
+  }
+}
+
+// Huffman.init_with_lengths zd.ml:477-506 (huff_init_with_lengths); scratch: 32 words
+__device__ __forceinline__ void wave_init_with_lengths(uint32_t *e, int max_sym, uint32_t *scratch, int lane) {
+  uint32_t *count = scratch, *next = scratch + 16;
+  if (lane < 16) count[lane] = 0;
+  wave_sync();
+  for (int sym = lane; sym <= max_sym; sym += 64) atomicAdd(&count[e[sym] & 0x1F], 1u);
+  wave_sync();
+  uint32_t code = 0;
+#pragma unroll 1
+  for (int l = 1; l <= 15; l++) {  // every lane, same values
+    code = (code + (l == 1 ? 0u : count[l - 1])) << 1;
+    if (lane == 0) next[l] = code;
+  }
+  wave_sync();
+#pragma unroll 1
+  for (int c = 0; c <= max_sym; c += 64) {
+    const int sym = c + lane;
+    const uint32_t l = sym <= max_sym ? e[sym] & 0x1F : 0u;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(l != 0);
+#pragma unroll 1
+    while (todo) {
+      const uint32_t cur = (uint32_t)__builtin_amdgcn_readlane((int)l, __ffsll((long long)todo) - 1);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(l == cur);
+      const uint32_t first = next[cur];
+      if (l == cur) e[sym] = (bitrev(first + lanes_below(m), (int)cur) << 5) | cur;
+      wave_sync();
+      if (lane == 0) next[cur] = first + (uint32_t)__popcll(m);
+      wave_sync();
+      todo &= ~m;
+    }
+  }
+}
+
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+  return v;
+}
+
+// bit_length_of_block_symbols zd.ml:1049-1064 (coder_symbols_bits)
+__device__ __forceinline__ uint64_t wave_symbols_bits(const BlockCoder &c, const uint32_t *hlit, const uint32_t *hdist,
+                                                      int lane) {
+  uint64_t acc = 0;
+  for (int sym = lane; sym <= LITLEN_SYM_MAX; sym += 64)
+    acc += (uint64_t)c.lit_freq[sym] * ((hlit[sym] & 0x1F) + (uint32_t)length_extra_bits(sym));
+  if (lane <= DIST_SYM_MAX) acc += (uint64_t)c.dist_freq[lane] * ((hdist[lane] & 0x1F) + (uint32_t)dist_extra_bits(lane));
+  return wave_sum64(acc);
+}
+
+// make_dynamic_huffman + make_dynamic_huffman_encoding zd.ml:953-1043 (coder_make_dynamic)
+__device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scratch, int lane) {
+  wave_lengths_of_freqs(c.heap, c.dyn_lit, c.lit_freq, LITLEN_SYM_MAX, 15, lane);
+  wave_sync();
+  wave_init_with_lengths(c.dyn_lit, LITLEN_SYM_MAX, scratch, lane);
+  wave_lengths_of_freqs(c.heap, c.dyn_dist, c.dist_freq, DIST_SYM_MAX, 15, lane);
+  wave_sync();
+  wave_init_with_lengths(c.dyn_dist, DIST_SYM_MAX, scratch, lane);
+  wave_sync();
+  // gather_dynamic_huffman_code_lengths zd.ml:963-988
+  int litlen_count = 0;
+#pragma unroll 1
+  for (int cbase = 0; cbase <= LITLEN_SYM_MAX; cbase += 64) {
+    const int sym = cbase + lane;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(sym <= LITLEN_SYM_MAX && (c.dyn_lit[sym] & 0x1F) != 0);
+    if (m) litlen_count = cbase + 64 - __clzll((long long)m);
+  }
+  const unsigned long long dm = __builtin_amdgcn_ballot_w64(lane <= DIST_SYM_MAX && (c.dyn_dist[lane] & 0x1F) != 0);
+  int dist_count = dm ? 64 - __clzll((long long)dm) : 0;
+  if (dist_count == 0) {  // HDIST 0 means 1: symbol 0 gets length 1, code 0 (zd.ml:974-979)
+    if (lane == 0) c.dyn_dist[0] = 1;
+    dist_count = 1;
+    wave_sync();
+  }
+  c.hlit = litlen_count - 257;
+  c.hdist = dist_count - 1;
+  uint32_t *l = c.codelen_syms;
+  for (int i = lane; i < litlen_count; i += 64) l[i] = c.dyn_lit[i] & 0x1F;
+  if (lane < dist_count) l[litlen_count + lane] = c.dyn_dist[lane] & 0x1F;
+  wave_sync();
+  // compute_codelen_syms zd.ml:989-1030 (in place: the encoding never expands)
+  const int len_max = litlen_count + dist_count - 1;
+  int k = 0, i = 0;
+#pragma unroll 1
+  while (i <= len_max) {
+    if (l[i] == 0) {
+      const int mx = len_max < i + 138 - 1 ? len_max : i + 138 - 1;
+      int j = i + 1;
+      while (j <= mx && l[j] == 0) j++;
+      const int zcount = j - i;
+      if (zcount < 3) { l[k] = 0; c.codelen_freq[0]++; i = i + 1; }
+      else if (zcount <= 10) { l[k] = ((uint32_t)(zcount - 3) << 8) | 17; c.codelen_freq[17]++; i = j; }
+      else { l[k] = ((uint32_t)(zcount - 11) << 8) | 18; c.codelen_freq[18]++; i = j; }
+      k++;
+    } else {
+      const uint32_t sym = l[i];
+      const int mx = len_max < i + 6 ? len_max : i + 6;
+      int j = i + 1;
+      while (j <= mx && l[j] == sym) j++;
+      const int scount = j - i;
+      l[k] = sym;
+      c.codelen_freq[sym]++;
+      if (scount <= 3) { k++; i = i + 1; }
+      else {
+        l[k + 1] = ((uint32_t)(scount - 3 - 1) << 8) | 16;
+        c.codelen_freq[16]++;
+        k += 2;
+        i = j;
+      }
+    }
+  }
+  c.codelen_syms_len = k;
+  wave_sync();
+  wave_lengths_of_freqs(c.heap, c.dyn_codelen, c.codelen_freq, CODELEN_SYM_MAX, 7, lane);
+  wave_sync();
+  wave_init_with_lengths(c.dyn_codelen, CODELEN_SYM_MAX, scratch, lane);
+  wave_sync();
+  int o = CODELEN_SYM_MAX;  // codelen_length_count zd.ml:1032-1036
+  while (o > 0 && (c.dyn_codelen[k_codelen_order[o]] & 0x1F) == 0) o--;
+  c.hclen = (o + 1) - 4;
+}
+
+// write_block's three estimates and its choice (coder_choose)
+__device__ __forceinline__ int wave_choose(const BlockCoder &c, uint32_t block_src_len, int pending_bits, uint64_t &flen,
+                                           uint64_t &dlen, int lane) {
+  const uint64_t nlen = 3 + (uint64_t)(8 - ((pending_bits + 3) % 8)) + (4 + (uint64_t)block_src_len) * 8;
+  flen = 3 + wave_symbols_bits(c, c.fix_lit, c.fix_dist, lane);
+  uint64_t acc = 0;
+  if (lane <= CODELEN_SYM_MAX) {
+    const uint32_t rb = lane == 16 ? 2 : lane == 17 ? 3 : lane == 18 ? 7 : 0;
+    acc = (uint64_t)c.codelen_freq[lane] * ((c.dyn_codelen[lane] & 0x1F) + rb);
+  }
+  dlen = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4) + wave_sum64(acc) + wave_symbols_bits(c, c.dyn_lit, c.dyn_dist, lane);
+  if (nlen <= dlen && nlen <= flen) return 0;
+  if (flen <= dlen) return 1;
+  return 2;
+}
+
 __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
                                                           uint8_t *__restrict__ dst_arena,
                                                           const StreamDesc *__restrict__ descs,
@@ -630,6 +839,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   __shared__ uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], fix_lit[288], fix_dist[32];
   __shared__ uint32_t codelen_syms[320], heap[580];
   __shared__ uint32_t stage[STAGE_WORDS];
+  __shared__ uint32_t coder_scratch[32];
 
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
@@ -653,7 +863,12 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   for (int i = lane; i < 32; i += 64) { codelen_freq[i] = 0; dyn_dist[i] = 0; dyn_codelen[i] = 0; }
   for (int i = lane; i < 288; i += 64) dyn_lit[i] = 0;
   for (int i = lane; i < STAGE_WORDS; i += 64) stage[i] = 0;
-  if (lane == 0) huff_fixed_encoders(fix_lit, fix_dist);
+  // fixed_litlen_encoder / fixed_dist_encoder zd.ml:514-527
+  for (int i = lane; i < 288; i += 64) fix_lit[i] = i <= 143 ? 8u : i <= 255 ? 9u : i <= 279 ? 7u : 8u;
+  if (lane < 32) fix_dist[lane] = 5;
+  wave_sync();
+  wave_init_with_lengths(fix_lit, 287, coder_scratch, lane);
+  wave_init_with_lengths(fix_dist, 31, coder_scratch, lane);
   wave_sync();
 
   BitOut bo;
@@ -700,16 +915,14 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       }
     }
     wave_sync();
-    // Code construction is a serial algorithm (the reference's heap, ties and all):
-    // every lane runs it redundantly on the same LDS data, which makes it
-    // wave-uniform -- scalar registers and scalar ALU instead of one live lane.
 #ifdef ZD_EMIT_PHASES
     const uint64_t ph1 = __builtin_readcyclecounter();
 #endif
-    lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
-    coder_make_dynamic(c);
+    if (lane == 0) lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
+    wave_sync();
+    wave_make_dynamic(c, coder_scratch, lane);
     uint64_t flen, dlen;
-    const int kind = coder_choose(c, bd.src_len, bo.acc_bits, flen, dlen);
+    const int kind = wave_choose(c, bd.src_len, bo.acc_bits, flen, dlen, lane);
     const uint64_t block_bits = kind == 1 ? flen : dlen;
     wave_sync();
 #ifdef ZD_EMIT_PHASES
