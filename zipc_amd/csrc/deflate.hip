@@ -459,21 +459,37 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
       uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
       bool chaining = (pend & 0x1FF) != 0;
       uint32_t n_lits = 0, j = p + 1;
-      while (__ballot(chaining)) {
+      const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
+      const uint32_t nxt_lo = (uint32_t)m_nxt, nxt_hi = (uint32_t)(m_nxt >> 32);
+      while (__builtin_amdgcn_ballot_w64(chaining)) {
+        // every chaining lane looks at the same distance ahead: lane + 1 + n_lits
         const uint32_t off = j - B;  // >= 1
-        const uint64_t a = __shfl((unsigned long long)m_cur, (int)(off & 63u), 64);
-        const uint64_t b2 = __shfl((unsigned long long)m_nxt, (int)(off & 63u), 64);
+        const uint32_t addr = (off & 63u) * 4u;
+        const bool in_cur = off < 64u;
+        // best-of-K of position j; best-of-K/4 only if a pending match is that long
+        // (all lanes take part in every shuffle: a lane is also somebody's source)
+        const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
+        uint32_t mj_lo = in_cur ? a_lo : b_lo;
+        uint32_t mj_hi = 0;
+        const bool want_hi = chaining && (pend & 0x1FF) >= (uint32_t)good_match;
+        if (__builtin_amdgcn_ballot_w64(want_hi)) {
+          const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
+          mj_hi = in_cur ? a_hi : b_hi;
+        }
         if (chaining) {
           if (j > max_pos) chaining = false;
           else {
-            uint64_t mj = off < 64u ? a : b2;
-            if (off >= 128u) mj = match[j];  // beyond the staged tiles: rare
+            if (off >= 128u) {  // beyond the staged tiles: rare
+              const uint64_t mj = match[j];
+              mj_lo = (uint32_t)mj;
+              mj_hi = (uint32_t)(mj >> 32);
+            }
             const uint32_t pl = pend & 0x1FF;
             const uint32_t rem = len - j;
             const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
             uint32_t nb = 0;
             if (pl < maxlen) {
-              const uint32_t c = pl >= (uint32_t)good_match ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+              const uint32_t c = want_hi ? mj_hi : mj_lo;
               if ((c & 0x1FF) > pl) nb = c;
             }
             if (nb == 0) chaining = false;
@@ -486,27 +502,27 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
     const uint32_t lits = br ? macro_lits(st) : 0u;
     const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
+    // J[k]: position reached after 2^k steps as a ds_bpermute address; a step that
+    // leaves the tile points to itself, so the tables need no range tests
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const uint32_t j0 = (uint32_t)lane + adv;  // <= 63 + 512
     uint32_t J[7];
-    J[0] = (uint32_t)lane + adv;  // <= 63 + 512
+    J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
 #pragma unroll
-    for (int k = 1; k < 7; k++) {
-      const uint32_t x = J[k - 1];
-      const uint32_t y = __shfl(J[k - 1], (int)(x & 63u), 64);
-      J[k] = x < (uint32_t)PARSE_TILE ? y : x;
-    }
+    for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
     // Is lane t on the path from the entry?  Every lane searches the path for the
     // largest element <= t, descending through the 2^k-step tables (the path is
     // strictly increasing): 7 shuffles, no memory.
-    uint32_t v = entry - B;  // < 64: tiles the parse jumps over are skipped below
+    uint32_t v = (entry - B) * 4u;  // < 64: tiles the parse jumps over are skipped below
 #pragma unroll
     for (int k = 6; k >= 0; k--) {
-      const uint32_t y = __shfl(J[k], (int)v, 64);
-      if (y <= (uint32_t)lane) v = y;
+      const uint32_t y = lane_value(v, J[k]);
+      if (y <= lane4) v = y;
     }
-    const bool visited = valid && v == (uint32_t)lane;
+    const bool visited = valid && v == lane4;
     // the path leaves the tile after the last visited position (lane 63's answer)
-    const uint32_t last = __shfl(v, 63, 64);
-    uint32_t next_entry = B + __shfl(J[0], (int)last, 64);
+    const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    uint32_t next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
     if (next_entry > len) next_entry = len;
     // symbol indices: exclusive scan of cnt over the visited lanes
     const uint32_t incl = wave_scan_incl(visited ? cnt : 0u);

@@ -73,10 +73,6 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
 __device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ bool lane_in(unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
 
-// value of lane `addr / 4`
-__device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v);
-}
 
 // ---- phase PH_TABLES by the whole wave (serial form: lane_finish_tables)
 //

@@ -37,6 +37,11 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
   return x;
 }
 
+// value of lane `addr / 4`
+__device__ __forceinline__ uint32_t lane_value(uint32_t addr, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)addr, (int)v);
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
