@@ -443,12 +443,17 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
   uint32_t B = 0;
   uint64_t m_cur = 0;
+  uint32_t lit_cur = 0;  // my position's source byte
   if (has_match && (uint32_t)lane <= max_pos) m_cur = match[lane];
+  if ((uint32_t)lane < len) lit_cur = s[lane];
   while (B < len) {
-    // next tile's table entries are requested before this tile is worked on
+    // next tile's table entries and source bytes are requested before this tile is
+    // worked on: nothing below waits for memory
     uint32_t Bn = B + PARSE_TILE;
     uint64_t m_nxt = 0;
+    uint32_t lit_nxt = 0;
     if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
+    if (Bn + (uint32_t)lane < len) lit_nxt = s[Bn + lane];
 
     const uint32_t p = B + (uint32_t)lane;
     const bool valid = p < len;
@@ -528,11 +533,19 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     const uint32_t incl = wave_scan_incl(visited ? cnt : 0u);
     const uint32_t total = __shfl(incl, 63, 64);
     const uint32_t first = nsym + incl - (visited ? cnt : 0u);
-    if (visited) {
-      MacroStep m;
-      m.bref = br;
-      m.step = st;
-      lz_emit_position(s, p, m, syms, first);
+    // symbols (lz_emit_position): a literal position writes its byte, a match
+    // position its deferral literals -- the bytes of the next positions, taken
+    // from their lanes -- then its match
+    {
+      const bool lit_run = visited && br != 0 && lits != 0;
+      uint32_t k = 0;
+      while (__builtin_amdgcn_ballot_w64(lit_run && k < lits)) {  // rarely more than one turn
+        const uint32_t at = (uint32_t)lane + k;
+        const uint32_t a = lane_value((at & 63u) * 4u, lit_cur), b2 = lane_value((at & 63u) * 4u, lit_nxt);
+        if (lit_run && k < lits) syms[first + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
+        k++;
+      }
+      if (visited) syms[first + (br ? lits : 0u)] = br ? br : lit_cur;
     }
     // block cut: the first visited node that ends past blk_start + 65534
     const uint64_t limit = (uint64_t)blk_start + MAX_BLOCK_SRC_LEN;
@@ -562,10 +575,13 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     if (Be > Bn) {
       Bn = Be;
       m_nxt = 0;
+      lit_nxt = 0;
       if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
+      if (Bn + (uint32_t)lane < len) lit_nxt = s[Bn + lane];
     }
     B = Bn;
     m_cur = m_nxt;
+    lit_cur = lit_nxt;
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
