@@ -140,6 +140,24 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
                            void *dst, size_t dst_cap, size_t *out_len,
                            uint32_t *adler);
 
+/* Many independent streams held in HOST memory through the batch kernels in one
+ * go: stream i is src[i][0 .. src_len[i]) -> dst[i] (capacity dst_cap[i]);
+ * results[i] (host memory, declared below) gets its status, length and checksum.
+ * This is what a caller that handles the members of an archive together uses
+ * instead of n calls of the single-stream forms -- Zipc.File.deflate_of_binary_string
+ * / to_binary_string over all members (src/zipc.ml:180-186,208-231).  limit may
+ * be NULL (no ?decompressed_size for any stream); a stream whose output does not
+ * fit reports ZIPC_HIP_ERR_DST_TOO_SMALL (or the reference's size message when a
+ * limit is given) in its own result.  The call itself fails only for bad
+ * arguments or HIP errors. */
+struct zipc_hip_stream_result_s;
+int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
+                          int level, int crc_op, void *const *dst, const size_t *dst_cap,
+                          struct zipc_hip_stream_result_s *results);
+int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
+                          const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
+                          struct zipc_hip_stream_result_s *results);
+
 /* ---- batch forms (device-resident) ----------------------------------------- */
 
 /* One independent stream: bytes [src_off, src_off+src_len) of the source arena
@@ -156,7 +174,7 @@ typedef struct {
 } zipc_hip_stream_desc;
 #define ZIPC_HIP_STREAM_HAS_LIMIT 1u
 
-typedef struct {
+typedef struct zipc_hip_stream_result_s {
   uint32_t status;   /* ZIPC_HIP_OK or an error code */
   uint32_t checksum; /* per crc_op, finished (0 for NOP) */
   uint64_t out_len;  /* bytes produced at dst_off */

@@ -9,10 +9,10 @@ import util  # noqa: F401  (sets sys.path through conftest)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "zipc_hip.h")).read()
+def declared_symbols(header="zipc_hip.h", prefix="zipc_hip_"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(zipc_hip_[a-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(" + prefix + r"[a-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +24,19 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(s[0] for s in _lib.SYMBOLS) == names  # the Python binding covers the whole header
+
+
+def test_host_library_exports_every_declared_symbol():
+    """include/zipc_host.h (the host layer: Zipc member glue + ZIP container)"""
+    from zipc_amd import zipc_host
+
+    L = zipc_host.lib()
+    names = declared_symbols("zipc_host.h", "zipc_host_")
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+    assert sorted(s[0] for s in zipc_host.SYMBOLS) == names
+    assert C.sizeof(zipc_host.MemberRec) == 88 and C.sizeof(zipc_host.MemberOpts) == 24
 
 
 def test_abi_version_and_struct_layout():

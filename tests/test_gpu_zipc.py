@@ -1,0 +1,192 @@
+"""SURVEY 8(f) rows 1-2 on the GPU: the host layer's codec-backed operations
+(File.deflate_of_binary_string, stored_of_binary_string, to_binary_string[_no_crc_check],
+and the batch forms) against the container oracle + deflate oracle, through the C
+interface of include/zipc_host.h.  Reads like the reference's test_crunched_trip
+(test/test.ml:57-118)."""
+import io
+import os
+import random
+import shutil
+import struct
+import subprocess
+import zipfile
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+from oracle import zipc_container as zc
+from test_zipc_container import FIXTURE, assert_zip_docs, fixture_bytes, py_file, same_members
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def host(gpu_ctx):
+    from zipc_amd import zipc_host
+
+    zipc_host.lib()
+    return zipc_host
+
+
+def oracle_recode(z, oracle, level=None):
+    z2 = dict(z)
+    for p, m in z.items():
+        f = m["kind"]
+        if f is None or not zc.file_can_extract(f):
+            continue
+        s, e = zc.file_to_binary_string(f, oracle)
+        assert e is None
+        nf, e = zc.file_deflate_of_binary_string(s, oracle, level)
+        assert e is None
+        z2[p], _ = zc.member_make(p, nf, mode=m["mode"], mtime=m["mtime"])
+    return z2
+
+
+def test_crunched_trip_like_reference(host, oracle):  # test/test.ml:57-118
+    s = fixture_bytes()
+    a = host.Archive.of_binary_string(s)
+    z, _ = zc.of_binary_string(s)
+    same_members(a, z)
+    # unzip: every file member, CRC checked
+    for i, m in enumerate(a.members()):
+        if m["is_dir"]:
+            continue
+        data, crc = a.member_to_binary_string(i)
+        want, e = zc.file_to_binary_string(z[m["path"]]["kind"], oracle)
+        assert e is None and data == want and crc == m["decompressed_crc_32"]
+    # redeflate_recode: File.to_binary_string |> File.deflate_of_binary_string (default level), same mtime/mode
+    b = host.Archive()
+    for i, m in enumerate(a.members()):
+        if m["is_dir"]:
+            b.add_dir(m["path"], mtime=m["mtime"], mode=m["mode"])
+        else:
+            b.add_file_deflate(m["path"], a.member_to_binary_string(i)[0], mtime=m["mtime"], mode=m["mode"])
+    enc = b.to_binary_string()
+    z2 = oracle_recode(z, oracle)
+    assert enc == zc.to_binary_string(z2)[0]  # compressed bytes included: the GPU deflate is the reference's
+    z3, e = zc.of_binary_string(enc)
+    assert e is None
+    assert_zip_docs(z3, True, oracle)
+    with zipfile.ZipFile(io.BytesIO(enc)) as zf:
+        assert zf.testzip() is None
+
+
+def test_stored_and_deflate_members_at_every_level(host, oracle):
+    r = random.Random(11)
+    datas = [b"", b"a", b"hello hello hello hello", bytes(r.randrange(256) for _ in range(5000)),
+             bytes(r.choice(b"ab") for _ in range(70000)), bytes(r.choice(b"0123456789abcdef") for _ in range(140000))]
+    for level in (None, 0, 1, 2, 3):
+        a = host.Archive()
+        z = {}
+        for k, d in enumerate(datas):
+            p = b"m/%d.bin" % k
+            a.add_file_deflate(p, d, level=level, mtime=1697900810 + k)
+            f, e = zc.file_deflate_of_binary_string(d, oracle, level)
+            assert e is None
+            z[p], _ = zc.member_make(p, f, mtime=1697900810 + k)
+            ps = b"s/%d.bin" % k
+            a.add_file_stored(ps, d, mode=0o600)
+            z[ps], _ = zc.member_make(ps, zc.file_stored_of_binary_string(d, oracle)[0], mode=0o600)
+        same_members(a, z)
+        enc = a.to_binary_string()
+        assert enc == zc.to_binary_string(z)[0], level
+        back = host.Archive.of_binary_string(enc)
+        for i, m in enumerate(back.members()):
+            data, crc = back.member_to_binary_string(i)
+            assert data == datas[int(m["path"].split(b"/")[1].split(b".")[0])] and crc == zlib.crc32(data)
+            assert back.member_to_binary_string(i, check_crc=False) == (data, crc)
+
+
+def test_batch_forms_equal_single_member_forms(host, oracle):
+    r = random.Random(12)
+    files = []
+    for k in range(97):
+        n = r.choice([0, 1, 100, 4096, 65534, 65535, 65536, 70000, 200000]) if k < 20 else r.randrange(0, 30000)
+        bits = r.choice([1, 2, 4, 8])
+        files.append((b"batch/%03d" % k, bytes(r.randrange(1 << bits) for _ in range(n))))
+    for level in (None, 2, 0):
+        a, b = host.Archive(), host.Archive()
+        a.add_files_deflate(files, level=level)  # one launch of the batch kernels
+        for p, d in files:
+            b.add_file_deflate(p, d, level=level)
+        assert a.to_binary_string() == b.to_binary_string()
+        z = {}
+        for p, d in files[:12]:
+            z[p] = zc.member_make(p, zc.file_deflate_of_binary_string(d, oracle, level)[0])[0]
+        for m in a.members()[:12]:
+            f = z[m["path"]]["kind"]
+            assert (m["compressed_size"], m["decompressed_crc_32"]) == (f["compressed_size"], f["decompressed_crc_32"])
+        got = a.extract_all()  # every member inflated + CRC-checked as one batch
+        assert [p for p, _ in got] == sorted(p for p, _ in files)
+        assert dict(got) == dict(files)
+    with zipfile.ZipFile(io.BytesIO(a.to_binary_string())) as zf:
+        assert zf.testzip() is None and len(zf.infolist()) == len(files)
+
+
+def test_member_errors_are_the_references(host, oracle):
+    r13 = random.Random(13)
+    data = bytes(r13.choice(b"abcdefgh") for _ in range(20000))
+    f = py_file(data, zc.DEFLATE)
+    good = zc.member_make(b"ok", f)[0]
+    wrong_crc = dict(f, decompressed_crc_32=f["decompressed_crc_32"] ^ 0x1234)
+    damaged = dict(f, compressed_bytes=f["compressed_bytes"][:50] + b"\xff\xff\xff" + f["compressed_bytes"][53:])
+    too_long = dict(f, decompressed_size=f["decompressed_size"] - 1)
+    encrypted = dict(f, gp_flags=f["gp_flags"] | 1)
+    bz2 = dict(f, compression=zc.BZIP2)
+    other = dict(f, compression=99)
+    z = {b"ok": good}
+    for name, ff in ((b"wrong_crc", wrong_crc), (b"damaged", damaged), (b"too_long", too_long),
+                     (b"encrypted", encrypted), (b"bz2", bz2), (b"other", other)):
+        z[name] = zc.member_make(name, ff)[0]
+    a = host.Archive.of_binary_string(zc.to_binary_string(z)[0])
+    seen = {}
+    for i, m in enumerate(a.members()):
+        want, e = zc.file_to_binary_string(z[m["path"]]["kind"], oracle)
+        if e is None:
+            assert a.member_to_binary_string(i)[0] == want
+        else:
+            with pytest.raises(host.ZipcError) as ei:
+                a.member_to_binary_string(i)
+            assert ei.value.code == host.ERROR and ei.value.msg == e, m["path"]
+            seen[m["path"]] = e
+    assert seen[b"wrong_crc"].startswith("Checksum mismatch, expected ")
+    assert seen[b"damaged"] in ("deflate: Corrupted data stream", "deflate: Expected decompression size exceeded") or \
+        seen[b"damaged"].startswith("Checksum mismatch")
+    assert seen[b"too_long"] == "deflate: Expected decompression size exceeded"
+    assert seen[b"encrypted"] == "Encrypted file not supported"
+    assert seen[b"bz2"] == "Compression bz2 not supported" and seen[b"other"] == "Compression 0099 not supported"
+    # to_binary_string_no_crc_check returns the bytes and the CRC it found
+    i = a.find(b"wrong_crc")
+    got, crc = a.member_to_binary_string(i, check_crc=False)
+    assert got == data and crc == zlib.crc32(data)
+    # the batch form reports the same per member
+    for p, r in a.extract_all():
+        want, e = zc.file_to_binary_string(z[p]["kind"], oracle)
+        if e is None:
+            assert r == want
+        else:
+            assert isinstance(r, host.ZipcError) and r.msg == e, p
+
+
+@pytest.mark.skipif(shutil.which("unzip") is None, reason="Info-ZIP unzip not installed")
+def test_config4_like_archive_validates_with_unzip(host, tmp_path):
+    """BASELINE config C4 in small: members of 3-bit symbols compressed as one batch at level
+    `Default, assembled into a ZIP on the host, checked by Info-ZIP and zipfile"""
+    from zipc_amd import synth
+
+    n, size = 256, 1 << 18
+    files = [(b"m/%05d.bin" % j, synth.stream_bytes_np(4, j, size, 3).tobytes()) for j in range(n)]
+    a = host.Archive()
+    a.add_files_deflate(files, level=2)
+    enc = a.to_binary_string()
+    ratio = sum(m["compressed_size"] for m in a.members()) / (n * size)
+    assert 0.40 < ratio < 0.46  # ~0.43
+    p = tmp_path / "c4.zip"
+    p.write_bytes(enc)
+    r = subprocess.run(["unzip", "-tq", str(p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    with zipfile.ZipFile(io.BytesIO(enc)) as zf:
+        assert zf.read("m/00017.bin") == files[17][1]
+    assert dict(host.Archive.of_binary_string(enc).extract_all()) == dict(files)

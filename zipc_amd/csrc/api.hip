@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
 #include "ctx.h"
 
 using namespace zd;
@@ -392,6 +393,72 @@ int zipc_hip_deflate(zipc_hip_ctx *ctx, const void *src, size_t len, int level, 
                      size_t dst_cap, size_t *out_len, uint32_t *checksum) {
   if (level < 0 || level > 3) return ZIPC_HIP_ERR_INVALID_ARG;
   return one_stream(ctx, false, src, len, 0, 0, level, crc_op, dst, dst_cap, out_len, checksum);
+}
+
+// n host-resident streams through the batch kernels: arenas are the context's
+// staging buffers, streams packed at 256-byte aligned offsets
+static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void *const *src, const size_t *src_len,
+                        const size_t *limit, int level, int crc_op, void *const *dst, const size_t *dst_cap,
+                        zipc_hip_stream_result *results) {
+  if (!ctx || (n && (!src || !src_len || !dst || !dst_cap || !results))) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (n == 0) return ZIPC_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<StreamDesc> descs(n);
+  uint64_t so = 0, dof = 0;
+  size_t max_src = 0, max_cap = 0, total_src = 0;
+  for (size_t i = 0; i < n; i++) {
+    if ((!src[i] && src_len[i]) || (!dst[i] && dst_cap[i])) return ZIPC_HIP_ERR_INVALID_ARG;
+    StreamDesc &d = descs[i];
+    memset(&d, 0, sizeof d);
+    d.src_off = so; d.src_len = src_len[i]; d.dst_off = dof; d.dst_cap = dst_cap[i];
+    if (limit) { d.limit = limit[i]; d.flags = STREAM_HAS_LIMIT; }
+    so += (src_len[i] + 255) / 256 * 256 + 256;
+    dof += (dst_cap[i] + 255) / 256 * 256 + 256;
+    max_src = src_len[i] > max_src ? src_len[i] : max_src;
+    max_cap = dst_cap[i] > max_cap ? dst_cap[i] : max_cap;
+    total_src += src_len[i];
+  }
+  HIP_TRY(ctx, ctx->ensure(ctx->io_src, so + 64));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dof + 64));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_desc, n * sizeof(StreamDesc)));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
+  for (size_t i = 0; i < n; i++)
+    if (src_len[i])
+      HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->io_src.p + descs[i].src_off, src[i], src_len[i],
+                                  hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice,
+                              ctx->stream));
+  int st;
+  if (is_inflate)
+    st = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
+                                (zipc_hip_stream_result *)ctx->io_res.p, n, max_cap, crc_op);
+  else
+    st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
+                                (zipc_hip_stream_result *)ctx->io_res.p, n, max_src, total_src, level, crc_op);
+  if (st) return st;
+  static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
+  HIP_TRY(ctx, hipMemcpyAsync(results, ctx->io_res.p, n * sizeof(StreamResult), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (size_t i = 0; i < n; i++) {
+    if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
+    if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; continue; }
+    if (results[i].out_len)
+      HIP_TRY(ctx, hipMemcpyAsync(dst[i], (const uint8_t *)ctx->io_dst.p + descs[i].dst_off, results[i].out_len,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return ZIPC_HIP_OK;
+}
+
+int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len, int level,
+                          int crc_op, void *const *dst, const size_t *dst_cap, zipc_hip_stream_result *results) {
+  return many_streams(ctx, false, n, src, src_len, nullptr, level, crc_op, dst, dst_cap, results);
+}
+int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
+                          const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
+                          zipc_hip_stream_result *results) {
+  return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, dst, dst_cap, results);
 }
 
 // zlib_decompress src/zipc_deflate.ml:720-740 (start = 0): header checks on the

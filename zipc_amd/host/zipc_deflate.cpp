@@ -1,0 +1,262 @@
+// zipc_deflate.cpp -- Zipc_deflate's functions over the C ABI (see zipc_deflate.hpp).
+#include "zipc_deflate.hpp"
+
+#include <cstdio>
+#include <mutex>
+
+namespace zipc_deflate {
+
+zipc_hip_ctx *context() {
+  static zipc_hip_ctx *ctx = nullptr;
+  static std::once_flag once;
+  static int status = 0;
+  std::call_once(once, [] { status = zipc_hip_create(&ctx, 0); });
+  if (!ctx) throw std::runtime_error(std::string("zipc_hip_create: ") + zipc_hip_strerror(status));
+  return ctx;
+}
+
+static std::string message(int status) { return zipc_hip_strerror(status); }
+// statuses the reference cannot produce (no device, HIP failure, bad argument)
+static bool is_library_failure(int status) { return status >= ZIPC_HIP_ERR_HIP; }
+static void throw_if_library_failure(int status) {
+  if (is_library_failure(status)) throw std::runtime_error(std::string("zipc_hip: ") + message(status));
+}
+
+std::string crc_error(uint32 expect, uint32 found) {
+  char b[96];
+  snprintf(b, sizeof b, "Checksum mismatch, expected %x found %x)", expect, found);
+  return b;
+}
+static std::string hex(uint32 v) {
+  char b[16];
+  snprintf(b, sizeof b, "%x", v);
+  return b;
+}
+
+Result<Unit> Crc_32::check(t expect, t found) {
+  return equal(expect, found) ? Result<Unit>::Ok(Unit{}) : Result<Unit>::Error(crc_error(expect, found));
+}
+std::string Crc_32::pp(t crc) { return hex(crc); }
+Crc_32::t Crc_32::string(const std::string &s, std::size_t start, std::size_t len) {
+  const auto r = range(s, start, len);
+  uint32 v = 0;
+  const int st = zipc_hip_crc32(context(), s.data() + r.first, r.second, &v);
+  if (st) throw std::runtime_error(std::string("zipc_hip_crc32: ") + message(st));
+  return v;
+}
+Result<Unit> Adler_32::check(t expect, t found) {
+  return equal(expect, found) ? Result<Unit>::Ok(Unit{}) : Result<Unit>::Error(crc_error(expect, found));
+}
+std::string Adler_32::pp(t crc) { return hex(crc); }
+Adler_32::t Adler_32::string(const std::string &s, std::size_t start, std::size_t len) {
+  const auto r = range(s, start, len);
+  uint32 v = 0;
+  const int st = zipc_hip_adler32(context(), s.data() + r.first, r.second, &v);
+  if (st) throw std::runtime_error(std::string("zipc_hip_adler32: ") + message(st));
+  return v;
+}
+
+// inflate_and_crc zipc_deflate.ml:692-709 through zipc_hip_inflate.  Without
+// ?decompressed_size the reference's buffer starts at 3 * len (at least 1024,
+// zipc_deflate.ml:19,552-555) and grows without bound: here the call is repeated
+// with a doubled buffer while the library answers DST_TOO_SMALL.
+static int inflate_raw(const char *p, std::size_t n, std::optional<std::size_t> decompressed_size, int crc_op,
+                       std::string &out, uint32 &checksum) {
+  std::size_t cap = decompressed_size ? *decompressed_size : (3 * n < 1024 ? 1024 : 3 * n);
+  for (;;) {
+    out.resize(cap);
+    std::size_t out_len = 0;
+    const int st = zipc_hip_inflate(context(), p, n, decompressed_size ? 1 : 0, decompressed_size ? *decompressed_size : 0,
+                                    crc_op, cap ? &out[0] : nullptr, cap, &out_len, &checksum);
+    if (st == ZIPC_HIP_ERR_DST_TOO_SMALL && !decompressed_size) {
+      cap = cap < 1024 ? 2048 : cap * 2;
+      continue;
+    }
+    throw_if_library_failure(st);
+    out.resize(st == ZIPC_HIP_OK ? out_len : 0);
+    return st;
+  }
+}
+
+Result<std::string> inflate(const std::string &s, std::optional<std::size_t> decompressed_size, std::size_t start,
+                            std::size_t len) {
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = inflate_raw(s.data() + r.first, r.second, decompressed_size, ZIPC_HIP_CRC_NOP, out, c);
+  if (st) return Result<std::string>::Error(message(st));
+  return Result<std::string>::Ok(std::move(out));
+}
+Result<std::pair<std::string, Crc_32::t>> inflate_and_crc_32(const std::string &s,
+                                                             std::optional<std::size_t> decompressed_size,
+                                                             std::size_t start, std::size_t len) {
+  typedef Result<std::pair<std::string, Crc_32::t>> R;
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = inflate_raw(s.data() + r.first, r.second, decompressed_size, ZIPC_HIP_CRC_CRC32, out, c);
+  if (st) return R::Error(message(st));
+  return R::Ok({std::move(out), c});
+}
+Result<std::pair<std::string, Adler_32::t>> inflate_and_adler_32(const std::string &s,
+                                                                 std::optional<std::size_t> decompressed_size,
+                                                                 std::size_t start, std::size_t len) {
+  typedef Result<std::pair<std::string, Adler_32::t>> R;
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = inflate_raw(s.data() + r.first, r.second, decompressed_size, ZIPC_HIP_CRC_ADLER32, out, c);
+  if (st) return R::Error(message(st));
+  return R::Ok({std::move(out), c});
+}
+
+ZlibResult zlib_decompress(const std::string &s, std::optional<std::size_t> decompressed_size, std::size_t start,
+                           std::size_t len) {
+  const auto r = range(s, start, len);
+  ZlibResult z;
+  std::size_t cap = decompressed_size ? *decompressed_size : (3 * r.second < 1024 ? 1024 : 3 * r.second);
+  for (;;) {
+    z.value.resize(cap);
+    std::size_t out_len = 0;
+    uint32 adler = 0, expect = 0, found = 0;
+    const int st = zipc_hip_zlib_decompress(context(), s.data() + r.first, r.second, decompressed_size ? 1 : 0,
+                                            decompressed_size ? *decompressed_size : 0, cap ? &z.value[0] : nullptr, cap,
+                                            &out_len, &adler, &expect, &found);
+    if (st == ZIPC_HIP_ERR_DST_TOO_SMALL && !decompressed_size) {
+      cap = cap < 1024 ? 2048 : cap * 2;
+      continue;
+    }
+    throw_if_library_failure(st);
+    if (st == ZIPC_HIP_OK) {
+      z.ok = true;
+      z.value.resize(out_len);
+      z.adler = adler;
+      return z;
+    }
+    z.value.clear();
+    if (st == ZIPC_HIP_ERR_CHECKSUM) {
+      z.error.mismatch = std::make_pair(expect, found);
+      z.error.message = crc_error(expect, found);
+    } else if (st == ZIPC_HIP_ERR_ZLIB_METHOD) {  // failwithf "Unknown compression method (%d)" cm, zipc_deflate.ml:728
+      char b[64];
+      snprintf(b, sizeof b, "Unknown compression method (%d)", (int)((unsigned char)s[r.first] & 0x0F));
+      z.error.message = b;
+    } else {
+      z.error.message = message(st);
+    }
+    return z;
+  }
+}
+
+static int level_of(std::optional<level> l) { return l ? (int)*l : ZIPC_HIP_LEVEL_BEST; }  // Q2
+
+static int deflate_raw(const char *p, std::size_t n, std::optional<level> lvl, int crc_op, std::string &out,
+                       uint32 &checksum) {
+  const std::size_t cap = zipc_hip_deflate_bound(n);
+  out.resize(cap);
+  std::size_t out_len = 0;
+  const int st = zipc_hip_deflate(context(), p, n, level_of(lvl), crc_op, &out[0], cap, &out_len, &checksum);
+  throw_if_library_failure(st);
+  out.resize(st == ZIPC_HIP_OK ? out_len : 0);
+  return st;
+}
+
+Result<std::string> deflate(const std::string &s, std::optional<level> lvl, std::size_t start, std::size_t len) {
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = deflate_raw(s.data() + r.first, r.second, lvl, ZIPC_HIP_CRC_NOP, out, c);
+  if (st) return Result<std::string>::Error(message(st));
+  return Result<std::string>::Ok(std::move(out));
+}
+Result<std::pair<Crc_32::t, std::string>> crc_32_and_deflate(const std::string &s, std::optional<level> lvl,
+                                                             std::size_t start, std::size_t len) {
+  typedef Result<std::pair<Crc_32::t, std::string>> R;
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = deflate_raw(s.data() + r.first, r.second, lvl, ZIPC_HIP_CRC_CRC32, out, c);
+  if (st) return R::Error(message(st));
+  return R::Ok({c, std::move(out)});
+}
+Result<std::pair<Adler_32::t, std::string>> adler_32_and_deflate(const std::string &s, std::optional<level> lvl,
+                                                                 std::size_t start, std::size_t len) {
+  typedef Result<std::pair<Adler_32::t, std::string>> R;
+  const auto r = range(s, start, len);
+  std::string out;
+  uint32 c = 0;
+  const int st = deflate_raw(s.data() + r.first, r.second, lvl, ZIPC_HIP_CRC_ADLER32, out, c);
+  if (st) return R::Error(message(st));
+  return R::Ok({c, std::move(out)});
+}
+Result<std::string> zlib_compress(const std::string &s, std::optional<level> lvl, std::size_t start,
+                                  std::size_t len) {
+  const auto r = range(s, start, len);
+  const std::size_t cap = zipc_hip_zlib_bound(r.second);
+  std::string out(cap, '\0');
+  std::size_t out_len = 0;
+  uint32 adler = 0;
+  const int st = zipc_hip_zlib_compress(context(), s.data() + r.first, r.second, level_of(lvl), &out[0], cap, &out_len,
+                                        &adler);
+  throw_if_library_failure(st);
+  if (st) return Result<std::string>::Error(message(st));
+  out.resize(out_len);
+  return Result<std::string>::Ok(std::move(out));
+}
+
+std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &items, std::optional<level> lvl) {
+  const std::size_t n = items.size();
+  std::vector<ManyResult> out(n);
+  std::vector<const void *> src(n);
+  std::vector<void *> dst(n);
+  std::vector<std::size_t> len(n), cap(n);
+  for (std::size_t i = 0; i < n; i++) {
+    src[i] = items[i].data;
+    len[i] = items[i].len;
+    cap[i] = zipc_hip_deflate_bound(items[i].len);
+    out[i].value.resize(cap[i]);
+    dst[i] = &out[i].value[0];
+  }
+  std::vector<zipc_hip_stream_result> res(n);
+  const int st = zipc_hip_deflate_many(context(), n, src.data(), len.data(), level_of(lvl), ZIPC_HIP_CRC_CRC32, dst.data(),
+                                       cap.data(), res.data());
+  if (st) throw std::runtime_error(std::string("zipc_hip_deflate_many: ") + message(st));
+  for (std::size_t i = 0; i < n; i++) {
+    throw_if_library_failure((int)res[i].status);
+    out[i].ok = res[i].status == ZIPC_HIP_OK;
+    out[i].value.resize(out[i].ok ? res[i].out_len : 0);
+    out[i].checksum = res[i].checksum;
+    if (!out[i].ok) out[i].error = message((int)res[i].status);
+  }
+  return out;
+}
+
+std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &items) {
+  const std::size_t n = items.size();
+  std::vector<ManyResult> out(n);
+  std::vector<const void *> src(n);
+  std::vector<void *> dst(n);
+  std::vector<std::size_t> len(n), cap(n), limit(n);
+  for (std::size_t i = 0; i < n; i++) {
+    if (!items[i].decompressed_size) throw std::invalid_argument("inflate_and_crc_32_many: decompressed_size missing");
+    src[i] = items[i].data;
+    len[i] = items[i].len;
+    cap[i] = limit[i] = *items[i].decompressed_size;
+    out[i].value.resize(cap[i]);
+    dst[i] = cap[i] ? &out[i].value[0] : nullptr;
+  }
+  std::vector<zipc_hip_stream_result> res(n);
+  const int st = zipc_hip_inflate_many(context(), n, src.data(), len.data(), limit.data(), ZIPC_HIP_CRC_CRC32, dst.data(),
+                                       cap.data(), res.data());
+  if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many: ") + message(st));
+  for (std::size_t i = 0; i < n; i++) {
+    throw_if_library_failure((int)res[i].status);
+    out[i].ok = res[i].status == ZIPC_HIP_OK;
+    out[i].value.resize(out[i].ok ? res[i].out_len : 0);
+    out[i].checksum = res[i].checksum;
+    if (!out[i].ok) out[i].error = message((int)res[i].status);
+  }
+  return out;
+}
+
+}  // namespace zipc_deflate
