@@ -147,7 +147,7 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
   }
   // CRC merge constants (zd_common.h), computed with the same GF(2) routines the
   // kernels use
-  uint32_t x = gf2_xpow8n(256);
+  uint32_t x = gf2_xpow8n(CRC_PIECE_BYTES);
   for (int k = 0; k < 8; k++) { ctx->crc_consts.xpiece[k] = x; x = gf2_mul(x, x); }
   ctx->crc_consts.xseg = gf2_xpow8n(CRC_SEG_BYTES);
   *out = ctx;

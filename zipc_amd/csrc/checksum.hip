@@ -2,11 +2,17 @@
 //
 // CRC-32 (Crc_32.string_update, src/zipc_deflate.ml:137-156): the reference's
 // slice-by-4 table walk is a serial chain over the bytes.  Here a range is cut
-// into 64 KiB segments (one 256-thread workgroup each) and every thread walks a
-// 256-byte piece with the same 4x256 tables held in LDS; pieces and segments
+// into 32 KiB segments (one 256-thread workgroup each) and every thread walks a
+// 128-byte piece with the same 4x256 tables held in LDS; pieces and segments
 // are merged with the CRC combination rule (zd_common.h: gf2_mul), the range
 // being RIGHT-aligned on the piece grid so that all pieces have equal length
-// (leading zero bytes do not change a raw CRC).  Chaining across the
+// (leading zero bytes do not change a raw CRC).  A segment goes through LDS on
+// its way to the threads: it is read from memory as coalesced 16-byte units
+// (every byte fetched once) and written so that piece t starts at 144 t -- 16
+// bytes of padding per piece make the threads' 16-byte reads of their own
+// pieces conflict free.  (Threads reading their pieces straight from memory,
+// 64 lanes x 16 B at a 256 B stride, re-fetched every line several times: the
+// lines in flight on a CU did not fit the caches.)  Chaining across the
 // reference's per-block update calls is exact for CRC-32, so the fused forms
 // (inflate_and_crc_32, crc_32_and_deflate) run this once over the whole
 // produced / consumed range of each stream.
@@ -20,9 +26,10 @@
 
 namespace zd {
 
-constexpr uint32_t CRC_PIECE = 256;                // bytes per thread
+constexpr uint32_t CRC_PIECE = CRC_PIECE_BYTES;      // bytes per thread
 constexpr uint32_t CRC_THREADS = 256;
-constexpr uint32_t CRC_SEG = CRC_PIECE * CRC_THREADS;  // 64 KiB per workgroup
+constexpr uint32_t CRC_SEG = CRC_PIECE * CRC_THREADS;  // 32 KiB per workgroup
+constexpr uint32_t CRC_PIECE_STRIDE = CRC_PIECE + 16;  // of a piece in LDS
 static_assert(CRC_SEG == CRC_SEG_BYTES, "kernels.h");
 
 __device__ __forceinline__ void get_range(int mode, uint32_t i, const StreamDesc *descs,
@@ -57,6 +64,7 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
     const StreamResult *__restrict__ results, uint64_t single_off, uint64_t single_len,
     uint32_t segs_per_range, CrcConsts K, uint32_t *__restrict__ partials) {
   __shared__ uint32_t T[4][256];
+  __shared__ __attribute__((aligned(16))) uint8_t stage[CRC_THREADS * CRC_PIECE_STRIDE];
   __shared__ uint32_t wave_part[CRC_THREADS / 64];
   const int t = threadIdx.x;
   const uint32_t range = blockIdx.x / segs_per_range;
@@ -67,33 +75,61 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
   if (seg >= nseg) return;  // uniform per workgroup
   build_crc_tables(T, t);
 
-  // right-aligned piece grid: `pad` virtual zero bytes in front of the range
+  // right-aligned piece grid: `pad` virtual zero bytes in front of the range;
+  // seg0 = range position of the segment's first byte (negative inside the pad)
   const uint64_t pad = nseg * CRC_SEG - len;
-  const int64_t p0 = (int64_t)((uint64_t)seg * CRC_SEG + (uint64_t)t * CRC_PIECE) - (int64_t)pad;
-  const int64_t lo = p0 < 0 ? 0 : p0;
-  const int64_t hi = p0 + (int64_t)CRC_PIECE;  // <= len by construction
+  const int64_t seg0 = (int64_t)((uint64_t)seg * CRC_SEG) - (int64_t)pad;
   const uint8_t *p = base + off;
+  constexpr int UNITS = CRC_SEG / 16 / CRC_THREADS;  // 16-byte units per thread
+  u32x4 v[UNITS];
+  if (len >= 16) {
+    // unit u = i * 256 + t: consecutive threads, consecutive 16 bytes; all loads in flight together
+#pragma unroll
+    for (int i = 0; i < UNITS; i++) {
+      const int64_t q = seg0 + (int64_t)((uint32_t)i * CRC_THREADS + (uint32_t)t) * 16;
+      v[i] = load16_unaligned(p + (q > 0 ? q : 0));  // q + 16 <= len by construction
+    }
+#pragma unroll
+    for (int i = 0; i < UNITS; i++) {
+      const int64_t q = seg0 + (int64_t)((uint32_t)i * CRC_THREADS + (uint32_t)t) * 16;
+      if (q < 0) {  // only in the first segment of a range: pad bytes are zero
+        uint8_t b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = q + k >= 0 ? p[q + k] : (uint8_t)0;
+        __builtin_memcpy(&v[i], b, 16);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < UNITS; i++) {
+      const int64_t q = seg0 + (int64_t)((uint32_t)i * CRC_THREADS + (uint32_t)t) * 16;
+      uint8_t b[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) b[k] = (q + k >= 0 && q + k < (int64_t)len) ? p[q + k] : (uint8_t)0;
+      __builtin_memcpy(&v[i], b, 16);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < UNITS; i++) {
+    const uint32_t u = (uint32_t)i * CRC_THREADS + (uint32_t)t;
+    *(u32x4 *)(stage + (u / (CRC_PIECE / 16)) * CRC_PIECE_STRIDE + (u % (CRC_PIECE / 16)) * 16) = v[i];
+  }
+  __syncthreads();
+  // my piece (Crc_32.string_update's word loop, src/zipc_deflate.ml:141-150; leading
+  // zero bytes leave c = 0)
   uint32_t c = 0;
-  int64_t i = lo;
-  if (hi > lo) {
-    // whole 16-byte vectors first: one request per 16 bytes instead of four
-    for (; i + 16 <= hi; i += 16) {
-      const u32x4 v = load16_unaligned(p + i);
-      uint32_t u = c ^ v.x;
-      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
-      u = c ^ v.y;
-      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
-      u = c ^ v.z;
-      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
-      u = c ^ v.w;
-      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
-    }
-    // word loop (src/zipc_deflate.ml:141-150)
-    for (; i + 4 <= hi; i += 4) {
-      uint32_t u = c ^ load_u32_le(p + i);
-      c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
-    }
-    for (; i < hi; i++) c = (c >> 8) ^ T[0][(c ^ p[i]) & 0xFF];  // byte tail (:151-155)
+  const u32x4 *mine = (const u32x4 *)(stage + (uint32_t)t * CRC_PIECE_STRIDE);
+#pragma unroll
+  for (int j = 0; j < (int)(CRC_PIECE / 16); j++) {
+    const u32x4 w = mine[j];
+    uint32_t u = c ^ w.x;
+    c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+    u = c ^ w.y;
+    c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+    u = c ^ w.z;
+    c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+    u = c ^ w.w;
+    c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
   }
   // merge the 256 equal-length pieces: tree over lanes, then over waves
 #pragma unroll
@@ -128,6 +164,9 @@ __global__ __launch_bounds__(256) void crc32_finish_kernel(
   uint32_t raw = 0;
   if (nseg <= 1) {
     raw = nseg ? P[0] : 0;
+  } else if (nseg <= 16) {  // short ranges (the batch forms' streams): Horner by the one thread that stores
+    if (t == 0)
+      for (uint32_t j = 0; j < (uint32_t)nseg; j++) raw = gf2_mul(raw, K.xseg) ^ P[j];
   } else {
     // right-aligned grid of 256 runs of R partials each
     const uint64_t R = (nseg + 255) / 256;

@@ -14,7 +14,8 @@ __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      int log2L, int crc_op);
 
 // ---- checksum.hip
-constexpr uint32_t CRC_SEG_BYTES = 65536;
+constexpr uint32_t CRC_PIECE_BYTES = 128;  // bytes per thread of crc32_segments_kernel
+constexpr uint32_t CRC_SEG_BYTES = 32768;   // per workgroup (256 threads)
 enum : int { RANGE_INFLATE_OUT = 0, RANGE_DEFLATE_SRC = 1, RANGE_SINGLE = 2 };
 struct CrcConsts {
   uint32_t xpiece[8];
