@@ -297,18 +297,39 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
   }
   if (want_adler32) {
     const uint64_t n_chunks = len ? len / ADLER_CHUNK + 1 : 0;
-    // chunk sums, followed by the ambiguous-chunk list of adler_chain_kernel
+    // chunk sums, then the ambiguous-chunk list and the per-run arrays of the chain kernels
     const size_t sums_bytes = ((size_t)(n_chunks + 1) * sizeof(uint2) + 255) / 256 * 256;
-    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, sums_bytes + ADLER_AMB_CAP * 16));
+    AdlerRuns R;
+    R.n_runs = 1024;  // one thread per run; at least ~8 chunks per run
+    while (R.n_runs < ADLER_MAX_RUNS && (uint64_t)R.n_runs * 8 < n_chunks) R.n_runs *= 2;
+    const size_t run_bytes = (size_t)R.n_runs * sizeof(uint32_t);
+    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, sums_bytes + ADLER_AMB_CAP * 16 + 5 * run_bytes + 256));
     uint2 *sums = (uint2 *)ctx->adler_sums.p;
-    uint32_t *amb = (uint32_t *)((uint8_t *)ctx->adler_sums.p + sums_bytes);
+    uint8_t *q = (uint8_t *)ctx->adler_sums.p + sums_bytes;
+    uint32_t *amb = (uint32_t *)q; q += ADLER_AMB_CAP * 16;
+    R.sum = (uint32_t *)q; q += run_bytes;
+    R.s1_before = (uint32_t *)q; q += run_bytes;
+    R.s1_after = (uint32_t *)q; q += run_bytes;
+    R.last_hi = (uint32_t *)q; q += run_bytes;
+    R.res_before = (uint32_t *)q; q += run_bytes;
+    R.amb_count = (uint32_t *)q;
     if (n_chunks) {
       if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
       ZD_LAUNCH(ctx, "adler_chunks", adler_chunks_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
                 (const uint8_t *)d_buf, (uint64_t)len, n_chunks, sums);
     }
-    ZD_LAUNCH(ctx, "adler_chain", adler_chain_kernel, dim3(1), dim3(1024), 0, (const uint2 *)sums,
-              (uint64_t)len, n_chunks, amb, ADLER_AMB_CAP, d_out + 1);
+    const uint64_t per = n_chunks ? (n_chunks + R.n_runs - 1) / R.n_runs : 1;
+    HIP_TRY(ctx, hipMemsetAsync(R.amb_count, 0, sizeof(uint32_t), ctx->stream));
+    ZD_LAUNCH(ctx, "adler_runs_s1", adler_runs_s1_kernel, dim3(R.n_runs / 256), dim3(256), 0, (const uint2 *)sums,
+              n_chunks, per, R);
+    ZD_LAUNCH(ctx, "adler_scan_runs", adler_scan_runs_kernel, dim3(1), dim3(1024), 0, (const uint32_t *)R.sum,
+              R.s1_before, R.n_runs, 1u);
+    ZD_LAUNCH(ctx, "adler_runs_a", adler_runs_a_kernel, dim3(R.n_runs / 256), dim3(256), 0, (const uint2 *)sums,
+              (uint64_t)len, n_chunks, per, R, amb, ADLER_AMB_CAP);
+    ZD_LAUNCH(ctx, "adler_scan_runs", adler_scan_runs_kernel, dim3(1), dim3(1024), 0, (const uint32_t *)R.sum,
+              R.res_before, R.n_runs, 0u);
+    ZD_LAUNCH(ctx, "adler_replay", adler_replay_kernel, dim3(1), dim3(1024), 0, (const uint2 *)sums, (uint64_t)len,
+              n_chunks, per, R, amb, ADLER_AMB_CAP, d_out + 1);
     HIP_TRY(ctx, hipGetLastError());
   }
   return ZIPC_HIP_OK;

@@ -20,7 +20,8 @@
 // Adler-32 (Adler_32.string_update, src/zipc_deflate.ml:175-198): one wave per
 // 5552-byte chunk of the reference's chunk grid (FIRST chunk = len mod 5552)
 // reduces (S1, S2); the chunk chain with the signed 32-bit remainder
-// (src/zipc_deflate.ml:95,196) is then applied in order by adler_chain_kernel.
+// (src/zipc_deflate.ml:95,196) is then applied in order by the adler_runs / adler_scan /
+// adler_replay kernels.
 #include "kernels.h"
 #include "wave_ops.h"
 
@@ -250,27 +251,52 @@ struct AmbRecord {
 };
 static_assert(sizeof(AmbRecord) == 16, "kernels.h sizes the list with 16 bytes per entry");
 
-__global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n,
-                                                                    uint64_t n_chunks, uint32_t *__restrict__ amb_raw,
-                                                                    uint32_t amb_cap, uint32_t *__restrict__ out) {
-  __shared__ uint64_t sh[CHAIN_THREADS_A];
-  __shared__ uint64_t run_res[CHAIN_THREADS_A];
-  __shared__ uint32_t run_last_hi[CHAIN_THREADS_A];
-  __shared__ uint64_t run_a[CHAIN_THREADS_A];
-  __shared__ uint32_t amb_count;
-  AmbRecord *amb = (AmbRecord *)amb_raw;
-  const int t = threadIdx.x;
-  const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
-  const uint64_t per = n_chunks ? (n_chunks + CHAIN_THREADS_A - 1) / CHAIN_THREADS_A : 1;
-  const uint64_t lo = (uint64_t)t * per < n_chunks ? (uint64_t)t * per : n_chunks;
+// The chain runs as five small launches over R runs of `per` consecutive chunks
+// (R a multiple of 1024, up to 64 Ki: a thread per run, hundreds of workgroups):
+//   adler_runs_s1    sum of S1 per run
+//   adler_scan_runs  exclusive scan (mod p) of the run sums by one workgroup -> s1 before each run
+//   adler_runs_a     a_k summed per run from that s1; ambiguous chunks recorded
+//   adler_scan_runs  scan of the a sums -> residue of s2 before each run
+//   adler_replay     one thread: ambiguous chunks replayed in order, final value
+// AdlerRuns: the per-run arrays in device scratch.
+__global__ __launch_bounds__(256) void adler_runs_s1_kernel(const uint2 *__restrict__ sums, uint64_t n_chunks,
+                                                            uint64_t per, AdlerRuns R) {
+  const uint64_t run = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (run >= R.n_runs) return;
+  const uint64_t lo = run * per < n_chunks ? run * per : n_chunks;
   const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
-  if (t == 0) amb_count = 0;
-  // pass 1: s1 before every run
   uint64_t acc = 0;
   for (uint64_t k = lo; k < hi; k++) acc += sums[k].x;
-  const uint64_t s1_run = (1 + block_excl_scan_mod(acc % ADLER_BASE, sh, t)) % ADLER_BASE;
-  // pass 2: a_k summed per run, ambiguous chunks recorded with what is known here
-  uint64_t s1 = s1_run, a_acc = 0;
+  R.sum[run] = (uint32_t)(acc % ADLER_BASE);
+}
+
+// out[run] = (first + exclusive prefix of in[0 .. run)) mod p; total[0] = the same over all runs
+__global__ __launch_bounds__(CHAIN_THREADS_A) void adler_scan_runs_kernel(const uint32_t *__restrict__ in,
+                                                                          uint32_t *__restrict__ out,
+                                                                          uint32_t n_runs, uint32_t first) {
+  __shared__ uint64_t sh[CHAIN_THREADS_A];
+  const int t = threadIdx.x;
+  const uint32_t each = n_runs / CHAIN_THREADS_A;  // n_runs is a multiple of 1024
+  uint64_t acc = 0;
+  for (uint32_t j = 0; j < each; j++) acc += in[(uint32_t)t * each + j];
+  uint64_t pre = (first + block_excl_scan_mod(acc % ADLER_BASE, sh, t)) % ADLER_BASE;
+  for (uint32_t j = 0; j < each; j++) {
+    const uint32_t v = in[(uint32_t)t * each + j];
+    out[(uint32_t)t * each + j] = (uint32_t)pre;
+    pre = (pre + v) % ADLER_BASE;
+  }
+}
+
+__global__ __launch_bounds__(256) void adler_runs_a_kernel(const uint2 *__restrict__ sums, uint64_t n,
+                                                           uint64_t n_chunks, uint64_t per, AdlerRuns R,
+                                                           uint32_t *__restrict__ amb_raw, uint32_t amb_cap) {
+  AmbRecord *amb = (AmbRecord *)amb_raw;
+  const uint64_t run = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (run >= R.n_runs) return;
+  const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
+  const uint64_t lo = run * per < n_chunks ? run * per : n_chunks;
+  const uint64_t hi = lo + per < n_chunks ? lo + per : n_chunks;
+  uint64_t s1 = R.s1_before[run], a_acc = 0;
   uint32_t last_hi = 0xFFFFFFFFu;  // branch of the previous chunk (unknown for the first of the run)
   for (uint64_t k = lo; k < hi; k++) {
     const uint2 sm = sums[k];
@@ -279,7 +305,7 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
     const bool hi_k = C >= 0x80000000ull;
     const bool ambiguous = C < ADLER_BASE || (C > 0x80000000ull - ADLER_BASE && C < 0x80000000ull + ADLER_BASE);
     if (ambiguous) {
-      const uint32_t slot = atomicAdd(&amb_count, 1u);
+      const uint32_t slot = atomicAdd(R.amb_count, 1u);
       if (slot < amb_cap) {
         AmbRecord rec;
         rec.k = (uint32_t)k;
@@ -293,53 +319,75 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
     s1 = (s1 + sm.x) % ADLER_BASE;
     last_hi = hi_k ? 1u : 0u;
   }
-  run_last_hi[t] = last_hi;
-  run_a[t] = a_acc;
-  const uint64_t res_run = block_excl_scan_mod(a_acc, sh, t);  // residue of s2 before the run (x0 = 0)
-  run_res[t] = res_run;
-  sh[t] = s1;  // s1 after the run
-  __syncthreads();
-  if (t != 0) return;
+  R.sum[run] = (uint32_t)a_acc;       // the run's a sum (the S1 sums are no longer needed)
+  R.last_hi[run] = last_hi;
+  R.s1_after[run] = (uint32_t)s1;
+}
 
-  // ---- replay of the ambiguous chunks, in order, by one thread
-  const uint32_t n_amb = amb_count;
-  if (n_amb > amb_cap || n_amb > 4096) {
+constexpr uint32_t REPLAY_MAX = 4096;  // ambiguous chunks replayed out of LDS; more: plain walk
+__global__ __launch_bounds__(CHAIN_THREADS_A) void adler_replay_kernel(const uint2 *__restrict__ sums, uint64_t n,
+                                                                       uint64_t n_chunks, uint64_t per, AdlerRuns R,
+                                                                       uint32_t *__restrict__ amb_raw,
+                                                                       uint32_t amb_cap, uint32_t *__restrict__ out) {
+  // everything the serial replay reads is gathered into LDS by the whole
+  // workgroup first: one thread walking global memory pays a full memory latency
+  // per access
+  __shared__ uint32_t keys[REPLAY_MAX];
+  __shared__ AmbRecord recs[REPLAY_MAX];  // sorted by chunk index
+  __shared__ uint2 rec_sums[REPLAY_MAX];
+  __shared__ uint32_t rec_res[REPLAY_MAX];
+  __shared__ uint8_t rec_prev[REPLAY_MAX];
+  const AmbRecord *amb = (const AmbRecord *)amb_raw;
+  const int t = threadIdx.x;
+  const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
+  const uint32_t *run_res = R.res_before, *run_a = R.sum, *run_last_hi = R.last_hi;
+  const uint32_t n_amb = R.amb_count[0];
+  if (n_amb > amb_cap || n_amb > REPLAY_MAX) {
     // adversarial input: more ambiguous chunks than worth sorting -- plain walk
+    if (t != 0) return;
     uint32_t a1, a2;
     adler_unpack(1u, a1, a2);
     for (uint64_t k = 0; k < n_chunks; k++) adler_chunk_step(a1, a2, k == 0 ? r : ADLER_CHUNK, sums[k].x, sums[k].y);
     out[0] = adler_pack(a1, a2);
     return;
   }
-  for (uint32_t i = 1; i < n_amb; i++) {  // insertion sort by chunk index
-    const AmbRecord v = amb[i];
-    uint32_t j = i;
-    while (j > 0 && amb[j - 1].k > v.k) { amb[j] = amb[j - 1]; j--; }
-    amb[j] = v;
-  }
   // branch of the chunk before position k when k opens a run: last chunk of the
   // nearest earlier non-empty run
-  auto prev_branch = [&](uint64_t k, uint32_t rec_prev) -> bool {
-    if (rec_prev != 0xFFFFFFFFu) return rec_prev != 0;
+  auto prev_branch = [&](uint64_t k, uint32_t rec_prev_hi) -> bool {
+    if (rec_prev_hi != 0xFFFFFFFFu) return rec_prev_hi != 0;
     if (k == 0) return false;
     int64_t run = (int64_t)((k - 1) / per);
     while (run >= 0 && run_last_hi[run] == 0xFFFFFFFFu) run--;
     return run >= 0 && run_last_hi[run] != 0;
   };
+  for (uint32_t i = (uint32_t)t; i < n_amb; i += CHAIN_THREADS_A) keys[i] = amb[i].k;
+  __syncthreads();
+  for (uint32_t i = (uint32_t)t; i < n_amb; i += CHAIN_THREADS_A) {  // rank sort (chunk indices are distinct)
+    const AmbRecord rec = amb[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < n_amb; j++) rank += keys[j] < rec.k ? 1u : 0u;
+    recs[rank] = rec;
+    rec_sums[rank] = sums[rec.k];
+    rec_res[rank] = run_res[rec.k / per];
+    rec_prev[rank] = prev_branch(rec.k, rec.prev_hi) ? 1 : 0;
+  }
+  __syncthreads();
+  if (t != 0) return;
+  // ---- replay of the ambiguous chunks, in order, by one thread
   uint64_t delta = 0;          // correction (mod p) of every predicted residue from here on
   int64_t exact_next = 0;      // exact s2 after the last replayed chunk ...
   uint64_t exact_at = ~0ull;   // ... valid as the input of chunk `exact_at`
   for (uint32_t i = 0; i < n_amb; i++) {
-    const AmbRecord rec = amb[i];
+    const AmbRecord rec = recs[i];
     const uint64_t k = rec.k;
-    const uint64_t resk = (run_res[k / per] + rec.a_partial) % ADLER_BASE;
+    const uint64_t resk = ((uint64_t)rec_res[i] + rec.a_partial) % ADLER_BASE;
     int64_t x;
     if (k == exact_at) x = exact_next;
     else {
       const uint64_t rr = (resk + delta) % ADLER_BASE;
-      x = prev_branch(k, rec.prev_hi) ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
+      x = rec_prev[i] ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
     }
-    const uint2 sm = sums[k];
+    const uint2 sm = rec_sums[i];
     const uint32_t len = k == 0 ? r : ADLER_CHUNK;
     const uint64_t C = (uint64_t)len * rec.s1 + sm.y;
     const uint32_t t2 = (uint32_t)((int64_t)C + x);
@@ -356,13 +404,13 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_chain_kernel(const uint
   if (exact_at == n_chunks) final_s2 = (uint32_t)(int32_t)exact_next;
   else {
     const uint64_t last_run = n_chunks ? (n_chunks - 1) / per : 0;
-    const uint64_t total_res = n_chunks ? (run_res[last_run] + run_a[last_run]) % ADLER_BASE : 0;
+    const uint64_t total_res = n_chunks ? ((uint64_t)run_res[last_run] + run_a[last_run]) % ADLER_BASE : 0;
     const uint64_t rr = (total_res + delta) % ADLER_BASE;
     const bool ph = n_chunks ? prev_branch(n_chunks, 0xFFFFFFFFu) : false;
     final_s2 = (uint32_t)(int32_t)(ph ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr);
   }
   const uint64_t lr = n_chunks ? (n_chunks - 1) / per : 0;
-  const uint64_t s1_all = n_chunks ? sh[lr] : 1;
+  const uint64_t s1_all = n_chunks ? R.s1_after[lr] : 1;
   out[0] = adler_pack((uint32_t)s1_all, final_s2);
 }
 

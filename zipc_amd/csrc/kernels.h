@@ -34,9 +34,25 @@ __global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ des
                                     uint32_t *__restrict__ single_out);
 __global__ void adler_chunks_kernel(const uint8_t *__restrict__ p, uint64_t n, uint64_t n_chunks,
                                     uint2 *__restrict__ sums);
-constexpr uint32_t ADLER_AMB_CAP = 8192;  // ambiguous-chunk records (16 bytes each) of adler_chain_kernel
-__global__ void adler_chain_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks,
-                                   uint32_t *__restrict__ amb, uint32_t amb_cap,
-                                   uint32_t *__restrict__ out);
+constexpr uint32_t ADLER_AMB_CAP = 8192;  // ambiguous-chunk records (16 bytes each)
+constexpr uint32_t ADLER_MAX_RUNS = 65536;
+// per-run arrays of the Adler chain (device scratch, n_runs entries each)
+struct AdlerRuns {
+  uint32_t n_runs;       // a multiple of 1024
+  uint32_t *sum;         // S1 sum of the run, later its a sum (mod p)
+  uint32_t *s1_before;   // s1 before the run
+  uint32_t *s1_after;
+  uint32_t *last_hi;     // branch of the run's last chunk, 0xFFFFFFFF for an empty run
+  uint32_t *res_before;  // residue of s2 before the run
+  uint32_t *amb_count;   // [1]
+};
+__global__ void adler_runs_s1_kernel(const uint2 *__restrict__ sums, uint64_t n_chunks, uint64_t per, AdlerRuns R);
+__global__ void adler_scan_runs_kernel(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n_runs,
+                                       uint32_t first);
+__global__ void adler_runs_a_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks, uint64_t per,
+                                    AdlerRuns R, uint32_t *__restrict__ amb, uint32_t amb_cap);
+__global__ void adler_replay_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks, uint64_t per,
+                                    AdlerRuns R, uint32_t *__restrict__ amb, uint32_t amb_cap,
+                                    uint32_t *__restrict__ out);
 
 }  // namespace zd
