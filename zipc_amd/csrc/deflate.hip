@@ -160,6 +160,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
                                                                  DeflateScratch S) {
   __shared__ uint16_t head[32768];
   __shared__ uint16_t hs[CHAIN_ROUND + 2 * NEAR];
+  __shared__ uint32_t peel_more[2];
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x;
   const uint32_t t = threadIdx.x;
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   uint16_t *prev = S.prev + S.pos_base[stream];
   const uint32_t max_pos = len - 4;
   if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_ROUND + NEAR + t] = 0xFFFF; }
+  if (t < 2) peel_more[t] = 0;
 
   for (uint32_t B = 0; B <= max_pos; B += CHAIN_ROUND) {
     if ((B % SWEEP_PERIOD) == 0) {
@@ -250,7 +252,14 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
         }
         any_pending |= pending[i];
       }
-      if (!__syncthreads_or(any_pending ? 1 : 0)) break;
+      // does anybody still peel?  One flag per turn parity: set by the waves that do,
+      // read behind the barrier that also keeps this turn's read-backs ahead of the
+      // next turn's stores, cleared for the turn after next.
+      if (__builtin_amdgcn_ballot_w64(any_pending) && (t & 63u) == 0) peel_more[turn & 1] = 1;
+      __syncthreads();
+      const uint32_t more = peel_more[turn & 1];
+      if (t == 0) peel_more[(turn + 1) & 1] = 0;
+      if (!more) break;
     }
 #pragma unroll
     for (int i = 0; i < CHAIN_PPT; i++) {
