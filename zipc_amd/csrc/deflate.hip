@@ -606,7 +606,8 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
 // symbols) are taken 64 at a time: each lane turns one item into (value, nbits),
 // an inclusive wave scan gives its bit offset, lanes OR their bits into the LDS
 // staging row, and the completed bytes are flushed with coalesced stores.
-constexpr int STAGE_WORDS = 104;  // 7 carried bits + 64 x 48 bits = 3079 bits < 104 words
+constexpr int PACK_TILES = 2;  // tiles of 64 items packed between two flushes of the staging row
+constexpr int STAGE_WORDS = (7 + PACK_TILES * 64 * 48 + 31) / 32 + 7;  // 7 carried bits + 48 bits per item
 
 // The emit kernel runs one wave per workgroup: LDS operations of one wave execute
 // in order, so lanes only need the COMPILER to keep LDS accesses in program order
@@ -624,24 +625,29 @@ struct BitOut {
   int acc_bits;        // dst_bits_len (zd.ml:785)
 };
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int /*lane*/) { return wave_scan_incl(v); }
-
 __device__ __forceinline__ void store_u32_unaligned(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 
-// pack one tile: lane holds (value, nbits) (nbits = 0 for idle lanes)
-__device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t value, int nbits, int lane) {
+// pack PACK_TILES tiles: lane holds (value, nbits) of one item per tile (nbits = 0
+// for idle lanes); tile u's items follow tile u-1's in the bit stream
+__device__ __forceinline__ void pack_tiles(BitOut &bo, uint32_t *stage, const uint64_t *value, const int *nbits,
+                                           int lane) {
   // stage[] is zero except stage[0] = pending bits
-  const uint32_t incl = wave_incl_scan((uint32_t)nbits, lane);
-  const uint32_t total = __shfl(incl, 63, 64) + (uint32_t)bo.acc_bits;
-  if (nbits) {
-    const uint32_t o = incl - (uint32_t)nbits + (uint32_t)bo.acc_bits;
-    const uint32_t wi = o >> 5, sh = o & 31;
-    const uint64_t lo = value << sh;
-    atomicOr(&stage[wi], (uint32_t)lo);
-    const uint32_t mid = (uint32_t)(lo >> 32);
-    if (mid) atomicOr(&stage[wi + 1], mid);
-    if (sh && nbits + (int)sh > 64) atomicOr(&stage[wi + 2], (uint32_t)(value >> (64 - sh)));
+  uint32_t at = (uint32_t)bo.acc_bits;  // bit offset of the tile in the staging row
+#pragma unroll
+  for (int u = 0; u < PACK_TILES; u++) {
+    const uint32_t incl = wave_scan_incl((uint32_t)nbits[u]);
+    if (nbits[u]) {
+      const uint32_t o = at + incl - (uint32_t)nbits[u];
+      const uint32_t wi = o >> 5, sh = o & 31;
+      const uint64_t lo = value[u] << sh;
+      atomicOr(&stage[wi], (uint32_t)lo);
+      const uint32_t mid = (uint32_t)(lo >> 32);
+      if (mid) atomicOr(&stage[wi + 1], mid);
+      if (sh && nbits[u] + (int)sh > 64) atomicOr(&stage[wi + 2], (uint32_t)(value[u] >> (64 - sh)));
+    }
+    at += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   }
+  const uint32_t total = at;
   wave_sync();
   const uint32_t full_bytes = total >> 3;
   const uint32_t full_words = full_bytes >> 2;
@@ -652,8 +658,8 @@ __device__ __forceinline__ void pack_tile(BitOut &bo, uint32_t *stage, uint64_t 
   const uint32_t rem_bits = total & 7u;
   const uint32_t last = (stage[full_bytes >> 2] >> (8 * (full_bytes & 3u))) & ((1u << rem_bits) - 1u);
   wave_sync();
-  // reset the staging row for the next tile
-  for (int w = lane; w < STAGE_WORDS; w += 64) stage[w] = 0;
+  // reset the part of the staging row that was used
+  for (uint32_t w = (uint32_t)lane; w <= (total >> 5) + 1 && w < (uint32_t)STAGE_WORDS; w += 64) stage[w] = 0;
   wave_sync();
   if (lane == 0) stage[0] = last;
   bo.out_pos += full_bytes;
@@ -1007,35 +1013,42 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     const uint32_t *hd = kind == 1 ? fix_dist : dyn_dist;
     const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
     const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
-    // symbols of the next tile are requested before the current tile is packed
-    auto fetch = [&](uint32_t base) -> uint32_t {
-      const uint32_t idx = base + (uint32_t)lane;
+    // symbols of the next tiles are requested before the current ones are packed
+    auto fetch = [&](uint32_t idx) -> uint32_t {
       if (idx > n_hdr && idx < n_items) {
         const uint32_t k = idx - 1 - n_hdr;
         return k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
       }
       return 0u;
     };
-    uint32_t sref_cur = fetch(0);
-    for (uint32_t base = 0; base < n_items; base += 64) {
-      const uint32_t sref_next = base + 64 < n_items ? fetch(base + 64) : 0u;
-      const uint32_t idx = base + (uint32_t)lane;
-      uint64_t value = 0;
-      int nbits = 0;
-      if (idx < n_items) {
-        if (idx == 0) {
-          value = (final ? 1u : 0u) | ((uint32_t)kind << 1);
-          nbits = 3;
-        } else if (idx <= n_hdr) {
-          uint32_t v;
-          dyn_header_item(c, (int)idx - 1, v, nbits);
-          value = v;
-        } else {
-          symbol_bits(sref_cur, hl, hd, value, nbits);
+    uint32_t sref_cur[PACK_TILES], sref_next[PACK_TILES];
+#pragma unroll
+    for (int u = 0; u < PACK_TILES; u++) sref_cur[u] = fetch((uint32_t)(64 * u + lane));
+    for (uint32_t base = 0; base < n_items; base += 64 * PACK_TILES) {
+      uint64_t value[PACK_TILES];
+      int nbits[PACK_TILES];
+#pragma unroll
+      for (int u = 0; u < PACK_TILES; u++) {
+        sref_next[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
+        const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
+        value[u] = 0;
+        nbits[u] = 0;
+        if (idx < n_items) {
+          if (idx == 0) {
+            value[u] = (final ? 1u : 0u) | ((uint32_t)kind << 1);
+            nbits[u] = 3;
+          } else if (idx <= n_hdr) {
+            uint32_t v;
+            dyn_header_item(c, (int)idx - 1, v, nbits[u]);
+            value[u] = v;
+          } else {
+            symbol_bits(sref_cur[u], hl, hd, value[u], nbits[u]);
+          }
         }
       }
-      pack_tile(bo, stage, value, nbits, lane);
-      sref_cur = sref_next;
+      pack_tiles(bo, stage, value, nbits, lane);
+#pragma unroll
+      for (int u = 0; u < PACK_TILES; u++) sref_cur[u] = sref_next[u];
     }
   }
 
