@@ -190,3 +190,69 @@ def test_config4_like_archive_validates_with_unzip(host, tmp_path):
     with zipfile.ZipFile(io.BytesIO(enc)) as zf:
         assert zf.read("m/00017.bin") == files[17][1]
     assert dict(host.Archive.of_binary_string(enc).extract_all()) == dict(files)
+
+
+def test_command_line_like_the_reference_tool(host, oracle, tmp_path):
+    """zipc-hip (zipc_amd/host/zipc_tool.cpp, after test/zipc_tool.ml): crc, compress / decompress,
+    zip, list, unzip -t / extract, recode -- each checked against the oracle or an independent tool"""
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "zipc_amd", "bin", "zipc-hip")
+    assert os.path.exists(tool), "run `make -C zipc_amd/host`"
+
+    def run(*args, stdin=None):
+        r = subprocess.run([tool, *args], input=stdin, capture_output=True)
+        assert r.returncode == 0, (args, r.stderr.decode())
+        return r.stdout
+
+    r = random.Random(21)
+    tree = tmp_path / "tree"
+    (tree / "sub" / "deep").mkdir(parents=True)
+    files = {"a.txt": b"hello zipc\n" * 500, "sub/b.bin": bytes(r.randrange(256) for _ in range(30000)),
+             "sub/deep/c.dat": bytes(r.choice(b"acgt") for _ in range(200000)), "sub/empty": b""}
+    for p, d in files.items():
+        (tree / p).write_bytes(d)
+    # crc / adler
+    assert run("crc", str(tree / "a.txt")).strip() == b"%x" % zlib.crc32(files["a.txt"])
+    assert run("crc", "-a", stdin=files["sub/b.bin"]).strip() == b"%x" % oracle.adler32(files["sub/b.bin"])
+    # compress (default level = `Best like the reference) / decompress, raw and zlib
+    comp = run("compress", str(tree / "sub/deep/c.dat"))
+    assert comp == oracle.deflate(files["sub/deep/c.dat"], level=oracle.LEVEL_BEST)[1]
+    assert run("decompress", stdin=comp) == files["sub/deep/c.dat"]
+    z = run("compress", "--zlib", "--level", "fast", stdin=files["a.txt"])
+    assert zlib.decompress(z) == files["a.txt"] and run("decompress", "--zlib", stdin=z) == files["a.txt"]
+    # zip -> Info-ZIP / zipfile read it; list; unzip -t; extract
+    arc = tmp_path / "t.zip"
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        run("zip", "--level", "default", "-o", str(arc), "tree")
+    finally:
+        os.chdir(cwd)
+    with zipfile.ZipFile(arc) as zf:
+        assert zf.testzip() is None
+        assert {i.filename for i in zf.infolist() if not i.is_dir()} == {"tree/" + p for p in files}
+        assert zf.read("tree/sub/b.bin") == files["sub/b.bin"]
+    if shutil.which("unzip"):
+        assert subprocess.run(["unzip", "-tq", str(arc)], capture_output=True).returncode == 0
+    zo, e = zc.of_binary_string(arc.read_bytes())
+    assert e is None
+    assert run("list", "-l", str(arc)).decode().splitlines() == [zc.member_to_string(zo[p], True) for p in sorted(zo)]
+    assert run("list", "-s", str(arc)).split() == sorted(zo)
+    assert b"No errors detected" in run("unzip", "-t", str(arc))
+    out = tmp_path / "out"
+    run("unzip", "-d", str(out), str(arc))
+    for p, d in files.items():
+        assert (out / "tree" / p).read_bytes() == d
+    # recode at another level: same members, same bytes back
+    rec = tmp_path / "r.zip"
+    run("recode", "--level", "fast", "-o", str(rec), str(arc))
+    with zipfile.ZipFile(rec) as zf:
+        assert zf.testzip() is None and zf.read("tree/a.txt") == files["a.txt"]
+    assert os.path.getsize(rec) != os.path.getsize(arc)
+    # a damaged archive member is reported by unzip -t
+    b = bytearray(arc.read_bytes())
+    off = zo[b"tree/sub/deep/c.dat"]["kind"]["start"]
+    b[off + 100] ^= 0x55
+    bad = tmp_path / "bad.zip"
+    bad.write_bytes(bytes(b))
+    rr = subprocess.run([tool, "unzip", "-t", str(bad)], capture_output=True)
+    assert rr.returncode == 1 and b"tree/sub/deep/c.dat" in rr.stderr
