@@ -256,3 +256,20 @@ def test_command_line_like_the_reference_tool(host, oracle, tmp_path):
     bad.write_bytes(bytes(b))
     rr = subprocess.run([tool, "unzip", "-t", str(bad)], capture_output=True)
     assert rr.returncode == 1 and b"tree/sub/deep/c.dat" in rr.stderr
+
+
+def test_real_files_at_every_level_equal_oracle(host, oracle):
+    """text, source code, an ELF shared object and an already compressed file: what real
+    archives hold (long matches, all 286 symbols in use, multi-block members with Q1
+    active, stored/fixed/dynamic decisions) -- compressed bytes equal the oracle's"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = ["DESIGN.md", "SURVEY.md", "include/zipc_hip.h", "zipc_amd/csrc/deflate.hip", "oracle/libzd_oracle.so",
+             "tests/golden/zip-docs.zip", "tests/golden/zlib_streams.json"]
+    files = [(n.encode(), open(os.path.join(root, n), "rb").read()) for n in names]
+    assert sum(len(d) for _, d in files) > 500000
+    for level in (1, 2, 3):
+        a = host.Archive()
+        a.add_files_deflate(files, level=level)
+        z = {p: zc.member_make(p, zc.file_deflate_of_binary_string(d, oracle, level)[0])[0] for p, d in files}
+        assert a.to_binary_string() == zc.to_binary_string(z)[0], level
+        assert dict(a.extract_all()) == dict(files)
