@@ -404,7 +404,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint8_t *ws = win_src - w0;       // indexed by stream position
   const uint16_t *wp = win_prev - w0;
   // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
-  // as MATCHW_NP interleaved runs
+  // as MATCHW_NP interleaved runs.  (Handing positions out as lanes finish -- a
+  // wave-uniform counter, ballot + mbcnt -- was measured: -2 % on C2, +7 % on the
+  // long chains of C4; the fixed schedule stays.)
   const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
   const uint64_t wbeg = (uint64_t)t0 + (tid / 64u) * per_wave;
   const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;

@@ -184,7 +184,7 @@ struct MatchRun {
 template <bool WORDS>
 ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend) {
   r.alive = p < pend;
-  r.p = r.alive ? p : 0u;
+  r.p = r.alive ? p : (pend ? pend - 1u : 0u);  // a finished run parks on a valid position
   r.q = r.p;
   r.best_len = MIN_MATCH_LEN - 1;
   r.best = 0; r.snap = 0; r.steps = 0; r.snapped = false;
@@ -193,10 +193,13 @@ ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t
   if (WORDS) r.pw = load_u64_words(s, r.p);
   else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
 }
+// One iteration of a run: a chain step of its current position.  Returns true when
+// the position is finished (its result has been written to out[p]); the caller
+// starts the run's next position.
 template <bool WORDS>
-ZD_HD void match_run_step(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t pend, uint32_t stride,
-                          const uint16_t *prev, uint32_t K, uint32_t Kq, uint64_t *out) {
-  if (!r.alive) return;
+ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
+                          uint64_t *out) {
+  if (!r.alive) return false;
   const uint32_t d = prev[r.q];
   const uint32_t qn = r.q - d;
   const bool walk = d != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
@@ -217,9 +220,12 @@ ZD_HD void match_run_step(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t 
     if (!r.snapped) r.snap = r.best;
     if (Kq == 0) r.snap = 0;
     out[r.p] = (uint64_t)r.best | ((uint64_t)r.snap << 32);
-    match_run_start<WORDS>(r, s, len, r.p + stride, pend);
+    return true;
   }
+  return false;
 }
+// Runs with a fixed schedule: run i takes pbeg[i], pbeg[i] + stride, ...  (The
+// window kernel hands positions out as lanes finish instead, deflate.hip.)
 template <int NP, bool WORDS>
 ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, uint32_t pend, uint32_t stride,
                          const uint16_t *prev, int K, int Kq, uint64_t *out) {
@@ -233,7 +239,8 @@ ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, u
     bool alive = false;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      match_run_step<WORDS>(r[i], s, len, pend, stride, prev, (uint32_t)K, (uint32_t)Kq, out);
+      if (match_run_step<WORDS>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out))
+        match_run_start<WORDS>(r[i], s, len, r[i].p + stride, pend);
       alive |= r[i].alive;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
