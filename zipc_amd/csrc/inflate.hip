@@ -191,9 +191,9 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const int slot = (int)(d.in_word & (uint32_t)(RING_WORDS - 1)) + (int)(p >> 5);
   const uint32_t w0 = L.slot(slot), w1 = L.slot(slot + 1), w2 = L.slot(slot + 2);
   const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), L);
-  const bool is_lit = sp.kind == 1u;
+  const bool is_lit = (int32_t)sp.e < 0;
   const mask_t lit_m = wave_mask(is_lit);
-  const mask_t match_m = wave_mask(sp.kind == 2u) & wave_mask(sp.e2 != 0u) & wave_mask(sp.dist >= sp.length);
+  const mask_t match_m = wave_mask((int32_t)sp.e >= 0x40000000) & wave_mask(sp.dist >= sp.length);
   const uint32_t tot = sp.b1 + (is_lit ? 0u : sp.t2);
   const uint32_t outlen = is_lit ? 1u : sp.length;
   mask_t ok_m = (lit_m | match_m) & ~(1ull << 63);  // lane 63 is the sink: the next turn starts there
@@ -291,8 +291,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const bool writer = lane == 0;
 
   LaneLds L;
-  L.w = (uint16_t *)lds_raw;
-  L.r = (uint32_t *)(lds_raw + LDS_U16_PER_LANE * 2);
+  L.r = (uint32_t *)lds_raw;  // the input ring first: its reads encode their offsets
+  L.w = (uint16_t *)(lds_raw + LDS_U32_PER_LANE * 4);
+  static_assert(LDS_U32_PER_LANE * 4 % 16 == 0, "u16 regions stay aligned");
 
   Arenas A;
   A.src = src_arena;

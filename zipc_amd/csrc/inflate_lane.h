@@ -550,25 +550,26 @@ ZD_HD void lane_end_of_block(InflateLane &d, bool crc_adler) {
 // DEFER_MAX_LEN) in the block's alphabet; long codes, end of block, invalid and
 // longer length symbols stop the chain and are left to lane_one_symbol, which
 // owns every error and edge decision.
-//   litlen: [3:0] code bits  [5:4] kind (1 literal, 2 length)  [8:6] extra bits
-//           [17:9] literal byte / base length  [23:18] code + extra bits
-//   dist:   [3:0] code bits  [7:4] extra bits  [23:8] base distance
-//           [31:24] code + extra bits
+//   litlen: [4:0] code bits (bit 4 clear: the word is its own bit-field offset operand)
+//           [7:5] extra bits  [16:8] literal byte / base length  [22:17] code + extra bits
+//           [30] length symbol  [31] literal
+//   dist:   [4:0] code bits  [8:5] extra bits  [24:9] base distance  [29:25] code + extra bits
+//           (an invalid code is 0: it decodes to distance 0, which no length is <= to)
 ZD_HD uint32_t wide_lit_entry(uint32_t e16, int lit_max_sym) {
   const uint32_t len = e16 & 15u, sym = e16 >> 4;
   if (len == 0) return 0;
-  if (sym < (uint32_t)LITLEN_EOB) return len | (1u << 4) | (sym << 9) | (len << 18);
+  if (sym < (uint32_t)LITLEN_EOB) return len | (sym << 8) | (len << 17) | (1u << 31);
   if (sym == (uint32_t)LITLEN_EOB || (int)sym > lit_max_sym || sym > 267u) return 0;
   uint32_t base, extra;
   length_sym_value((int)sym, base, extra);
-  return len | (2u << 4) | (extra << 6) | (base << 9) | ((len + extra) << 18);
+  return len | (extra << 5) | (base << 8) | ((len + extra) << 17) | (1u << 30);
 }
 ZD_HD uint32_t wide_dist_entry(uint32_t e16, int dist_max_sym) {
   const uint32_t len = e16 & 15u, sym = e16 >> 4;
   if (len == 0 || (int)sym > dist_max_sym || sym > (uint32_t)DIST_SYM_MAX) return 0;
   uint32_t base, extra;
   dist_sym_value((int)sym, base, extra);
-  return len | (extra << 4) | (base << 8) | ((len + extra) << 24);
+  return len | (extra << 5) | (base << 9) | ((len + extra) << 25);
 }
 // lane `lane` of 64 restates its share of both tables; returns the bits of the
 // shortest symbol it saw that a wide turn may commit
@@ -594,31 +595,29 @@ ZD_HD int levels_for(uint32_t shortest) { return shortest >= 4 ? 4 : shortest >=
 // next 64 bits from there.  Branch free: the distance lookup of a literal lane
 // reads a valid (ignored) entry.
 struct WideSym {
-  uint32_t kind;    // 0 stop, 1 literal, 2 length symbol
-  uint32_t e2;      // distance entry, 0 = stop
-  uint32_t lit;     // literal byte (kind 1)
-  uint32_t length;  // match length (kind 2)
-  uint32_t dist;    // match distance (kind 2, e2 != 0)
+  uint32_t e;       // litlen entry: 0 stop, bit 31 literal, bit 30 length symbol
+  uint32_t lit;     // literal byte (literal)
+  uint32_t length;  // match length (length symbol)
+  uint32_t dist;    // match distance (length symbol; 0 when the distance code is not committable)
   uint32_t b1, t2;  // bits of the litlen part, of the distance part
   // the predicates the turn forms out of these (as wave masks in the kernel)
-  ZD_HD bool is_lit() const { return kind == 1u; }
-  ZD_HD bool is_match() const { return kind == 2u && e2 != 0u && dist >= length; }  // may be deferred
-  ZD_HD uint32_t tot() const { return b1 + (kind == 1u ? 0u : t2); }
-  ZD_HD uint32_t outlen() const { return kind == 1u ? 1u : length; }
+  ZD_HD bool is_lit() const { return (int32_t)e < 0; }
+  ZD_HD bool is_len() const { return (int32_t)e >= 0x40000000; }
+  ZD_HD bool is_match() const { return is_len() && dist >= length; }  // may be deferred
+  ZD_HD uint32_t tot() const { return b1 + (is_lit() ? 0u : t2); }
+  ZD_HD uint32_t outlen() const { return is_lit() ? 1u : length; }
 };
 ZD_HD WideSym wide_decode(uint32_t xlo, uint32_t xhi, const LaneLds &L) {
   WideSym r;
   const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
-  const uint32_t len = e & 15u, extra = (e >> 6) & 7u, base = (e >> 9) & 511u;
-  r.kind = (e >> 4) & 3u;
-  r.b1 = e >> 18;
-  r.lit = base;
-  r.length = base + bit_field(xlo, len, extra);
+  r.e = e;
+  r.b1 = (e >> 17) & 63u;
+  r.lit = (e >> 8) & 511u;
+  r.length = r.lit + bit_field(xlo, e, (e >> 5) & 7u);  // offset operand: the entry's low 5 bits = code bits
   const uint32_t x2 = funnel32(xhi, xlo, r.b1);  // b1 <= 14
-  r.e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
-  const uint32_t len2 = r.e2 & 15u, dextra = (r.e2 >> 4) & 15u, dbase = (r.e2 >> 8) & 0xFFFFu;
-  r.dist = dbase + bit_field(x2, len2, dextra);
-  r.t2 = r.e2 >> 24;
+  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  r.dist = ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
+  r.t2 = e2 >> 25;
   return r;
 }
 

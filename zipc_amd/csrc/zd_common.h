@@ -135,12 +135,12 @@ ZD_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {
   return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
 #endif
 }
-// `width` bits of v from bit `off` on; off, width < 32 (v_bfe_u32)
+// `width` bits of v from bit `off` on (v_bfe_u32: off and width are the operands' low 5 bits)
 ZD_HD uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_ubfe(v, off, width);
 #else
-  return (v >> off) & ((1u << width) - 1u);
+  return (v >> (off & 31u)) & ((1u << (width & 31u)) - 1u);  // operands taken modulo 32 like the instruction
 #endif
 }
 
