@@ -32,7 +32,7 @@
 //
 // The stream state is wave-uniform; it is pinned to scalar registers with
 // readfirstlane so that the control flow around the turns is scalar branches,
-// not exec-mask arithmetic.  LDS: 5072 B per stream (tables + ring + queue).
+// not exec-mask arithmetic.  LDS: 5088 B per stream (tables + ring + queue).
 #include "inflate_lane.h"
 #include "kernels.h"
 #include "wave_ops.h"
@@ -68,6 +68,9 @@ __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
   }
   return uni(v);
 }
+
+// a - b if a > b, else 0 (v_sub_u32 ... clamp)
+__device__ __forceinline__ uint32_t over(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
 
 // lanes where p holds, as a mask -- and back
 __device__ __forceinline__ unsigned long long wave_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -223,23 +226,27 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const uint32_t mrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(match0_m >> 32),
                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)match0_m, 0u));
   const uint32_t INF = 0xFFFFFFFFu;
-  const uint32_t first_match_dst =
-      match0_m ? d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, __ffsll((long long)match0_m) - 1) : INF;
+  // (scalar work is the scarce resource of this kernel: one scalar instruction
+  // issues per clock and CU, against four vector ones -- so what follows prefers
+  // vector arithmetic and selects to mask algebra and branches)
+  const uint32_t fm_off = (uint32_t)__builtin_amdgcn_readlane((int)outoff, (__ffsll((long long)match0_m) - 1) & 63);
+  const uint32_t first_match_dst = match0_m ? d.out_pos + fm_off : INF;
   // symbols that would overflow, reach before the start, overfill the queue or
   // read an unfilled hole end the turn in front of them; the holes are the
-  // queued copies and, behind the turn's first match, that match
+  // queued copies and, behind the turn's first match, that match.  over(a, b) > 0
+  // exactly when a > b; the conditions are OR-ed as numbers and tested once.
   const uint32_t room = d.cap_min - d.out_pos;
   const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
   const uint32_t dstp = d.out_pos + outoff;
   const uint32_t src_end = dstp - sp.dist + sp.length;
   const uint32_t h0 = d.q_count ? d.hole_min : INF;
   const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;
-  const mask_t first_m = match0_m & (0ull - match0_m);
   const uint32_t qbase = d.q_count ? d.hole_min : first_match_dst;  // what queued destinations are relative to
-  const mask_t late_m = (commit0_m & wave_mask(outoff + outlen > room)) |
-                        (match0_m & (wave_mask(sp.dist > dstp) | wave_mask(mrank >= qfree) |
-                                     wave_mask(dstp - qbase > QUEUE_REL_MAX) |
-                                     (first_m & wave_mask(src_end > h0)) | (~first_m & wave_mask(src_end > h1))));
+  const uint32_t hole = mrank == 0 ? h0 : h1;  // the turn's first match only sees the queued copies
+  const uint32_t bad_match = over(sp.dist, dstp) | over(mrank + 1u, qfree) | over(dstp - qbase, QUEUE_REL_MAX) |
+                             over(src_end, hole);
+  const uint32_t bad = over(outoff + outlen, room) | (lane_in(match0_m) ? bad_match : 0u);
+  const mask_t late_m = commit0_m & wave_mask(bad != 0u);
   // the path ends in a stop, or it runs into the sink (bit 63: the sink's own hop
   // need not be covered by LEVELS)
   const mask_t cut_m = (visited_m & ~ok_m) | late_m | (1ull << 63);
@@ -247,14 +254,14 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
   if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
-  if (lane_in(commit_match_m)) L.queue((int)(d.q_count + mrank)) = queue_pack(dstp - qbase, sp.dist, sp.length);
-  uint32_t consumed = (uint32_t)c;
-  if (commit_m) {
-    const int last = 63 - __clzll((long long)commit_m);
-    d.out_pos += (uint32_t)__builtin_amdgcn_readlane((int)incl, last);
-    if (c == 63) consumed = (uint32_t)__builtin_amdgcn_readlane((int)end, last);  // may leave the window
-  }
-  if (d.q_count == 0 && commit_match_m) d.hole_min = first_match_dst;
+  // every lane writes a queue word: the ones without a committed match into the spare slot
+  L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - qbase, sp.dist, sp.length);
+  const int last = (63 - __clzll((long long)commit_m)) & 63;
+  const uint32_t n_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, last);
+  const uint32_t end_last = (uint32_t)__builtin_amdgcn_readlane((int)end, last);
+  d.out_pos += commit_m ? n_out : 0u;
+  const uint32_t consumed = (c == 63 && commit_m) ? end_last : (uint32_t)c;  // the last symbol may leave the window
+  d.hole_min = (d.q_count == 0 && commit_match_m) ? first_match_dst : d.hole_min;
   d.q_count += (uint32_t)__popcll(commit_match_m);
   d.advance(consumed);
   return c < 63;

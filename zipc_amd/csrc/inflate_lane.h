@@ -62,10 +62,10 @@ constexpr int RING_MIRROR = 4;     // slots 64..67 repeat slots 0..3: readers ta
 constexpr int QUEUE_ENTRIES = 64;  // deferred copies, one packed word each (queue_pack)
 constexpr int LDS_RING = 0;
 constexpr int LDS_QUEUE = LDS_RING + RING_WORDS + RING_MIRROR;
-constexpr int LDS_WIDE_LIT = LDS_QUEUE + QUEUE_ENTRIES;       // 512 x u32, see wide_lit_entry
+constexpr int LDS_WIDE_LIT = LDS_QUEUE + QUEUE_ENTRIES + 4;   // 512 x u32, see wide_lit_entry (+4: the spare queue slot)
 constexpr int LDS_WIDE_DIST = LDS_WIDE_LIT + 512;            // 128 x u32, see wide_dist_entry
-constexpr int LDS_U32_PER_LANE = LDS_WIDE_DIST + 128;        // 772
-constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 5072
+constexpr int LDS_U32_PER_LANE = LDS_WIDE_DIST + 128;        // 776
+constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 5088
 constexpr uint32_t DEFER_MAX_LEN = 16;
 // A queued copy is one word: its destination relative to the first queued copy's
 // (InflateLane::hole_min), distance and length.

@@ -6,7 +6,7 @@
 namespace zd {
 
 // ---- inflate.hip
-constexpr int INFLATE_LDS_BYTES_PER_LANE = 5072;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
+constexpr int INFLATE_LDS_BYTES_PER_LANE = 5088;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
 __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      uint8_t *__restrict__ dst_arena,
                                      const StreamDesc *__restrict__ descs,
