@@ -80,7 +80,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   const uint32_t room = d.cap_min - d.out_pos;
   const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
   const uint32_t first_match_dst = first_match >= 0 ? d.out_pos + outoff[first_match] : INF;
-  const uint32_t qbase = d.q_count ? d.hole_min : first_match_dst;
+  const uint32_t qbase = d.hole_min < first_match_dst ? d.hole_min : first_match_dst;
   int c = -1;
   for (int t = 0; t < 64 && c < 0; t++) {
     if (!visited[t]) continue;
@@ -88,7 +88,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     bool late = outoff[t] + sp[t].outlen() > room;
     if (sp[t].is_match()) {
       const uint32_t dstp = d.out_pos + outoff[t];
-      const uint32_t h0 = d.q_count ? d.hole_min : INF, h1 = mrank[t] ? first_match_dst : INF;
+      const uint32_t h0 = d.hole_min, h1 = mrank[t] ? first_match_dst : INF;
       const uint32_t hole = h0 < h1 ? h0 : h1;
       late = late || sp[t].dist > dstp || mrank[t] >= qfree || dstp - qbase > QUEUE_REL_MAX ||
              dstp - sp[t].dist + sp[t].length > hole;
@@ -118,7 +118,7 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
     d.out_pos += incl[last];
     if (c == 63) consumed = end[last];
   }
-  if (d.q_count == 0 && n_match) d.hole_min = first_match_dst;
+  if (n_match && first_match_dst < d.hole_min) d.hole_min = first_match_dst;
   d.q_count += n_match;
   d.advance(consumed);
   sim_stats[3] += consumed;
@@ -179,6 +179,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
       deferred_store(c, dst);
     }
     d.q_count = 0;
+    d.hole_min = 0xFFFFFFFFu;
     if (d.phase == PH_REQ_MATCH) {
       lane_copy_match(dst, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
       lane_after_match(d);

@@ -229,42 +229,45 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   // (scalar work is the scarce resource of this kernel: one scalar instruction
   // issues per clock and CU, against four vector ones -- so what follows prefers
   // vector arithmetic and selects to mask algebra and branches)
-  const uint32_t fm_off = (uint32_t)__builtin_amdgcn_readlane((int)outoff, (__ffsll((long long)match0_m) - 1) & 63);
-  const uint32_t first_match_dst = match0_m ? d.out_pos + fm_off : INF;
+  const uint32_t fm_lane = (uint32_t)(__ffsll((long long)match0_m) - 1);  // 0xFFFFFFFF: the window has no match
+  const uint32_t fm_dst = d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, (int)(fm_lane & 63u));
+  const uint32_t first_match_dst = match0_m ? fm_dst : INF;
   // symbols that would overflow, reach before the start, overfill the queue or
   // read an unfilled hole end the turn in front of them; the holes are the
-  // queued copies and, behind the turn's first match, that match.  over(a, b) > 0
-  // exactly when a > b; the conditions are OR-ed as numbers and tested once.
+  // queued copies (from hole_min on) and, behind the turn's first match, that
+  // match.  over(a, b) > 0 exactly when a > b; the conditions are OR-ed as numbers
+  // and tested once.
   const uint32_t room = d.cap_min - d.out_pos;
   const uint32_t qfree = (uint32_t)QUEUE_ENTRIES - d.q_count;
   const uint32_t dstp = d.out_pos + outoff;
   const uint32_t src_end = dstp - sp.dist + sp.length;
-  const uint32_t h0 = d.q_count ? d.hole_min : INF;
-  const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;
-  const uint32_t qbase = d.q_count ? d.hole_min : first_match_dst;  // what queued destinations are relative to
+  const uint32_t h0 = d.hole_min;
+  const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;  // also what queued destinations are relative to
   const uint32_t hole = mrank == 0 ? h0 : h1;  // the turn's first match only sees the queued copies
-  const uint32_t bad_match = over(sp.dist, dstp) | over(mrank + 1u, qfree) | over(dstp - qbase, QUEUE_REL_MAX) |
+  const uint32_t bad_match = over(sp.dist, dstp) | over(mrank + 1u, qfree) | over(dstp - h1, QUEUE_REL_MAX) |
                              over(src_end, hole);
   const uint32_t bad = over(outoff + outlen, room) | (lane_in(match0_m) ? bad_match : 0u);
   const mask_t late_m = commit0_m & wave_mask(bad != 0u);
   // the path ends in a stop, or it runs into the sink (bit 63: the sink's own hop
   // need not be covered by LEVELS)
   const mask_t cut_m = (visited_m & ~ok_m) | late_m | (1ull << 63);
-  const int c = __ffsll((long long)cut_m) - 1;
+  const uint32_t c = (uint32_t)(__ffsll((long long)cut_m) - 1);  // a lane on the path, or the sink
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
   if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
   // every lane writes a queue word: the ones without a committed match into the spare slot
-  L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - qbase, sp.dist, sp.length);
-  const int last = (63 - __clzll((long long)commit_m)) & 63;
-  const uint32_t n_out = (uint32_t)__builtin_amdgcn_readlane((int)incl, last);
-  const uint32_t end_last = (uint32_t)__builtin_amdgcn_readlane((int)end, last);
-  d.out_pos += commit_m ? n_out : 0u;
-  const uint32_t consumed = (c == 63 && commit_m) ? end_last : (uint32_t)c;  // the last symbol may leave the window
-  d.hole_min = (d.q_count == 0 && commit_match_m) ? first_match_dst : d.hole_min;
+  L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - h1, sp.dist, sp.length);
+  // bytes produced: what precedes the cut lane.  Bits used: up to the cut lane, or
+  // past it when the last symbol runs over the sink.
+  d.out_pos += (uint32_t)__builtin_amdgcn_readlane((int)outoff, (int)c);
+  const uint32_t end_c = lane_in(commit_m) ? end : 0u;
+  const uint32_t end_last = (uint32_t)__builtin_amdgcn_readlane((int)end_c, (63 - __clzll((long long)commit_m)) & 63);
+  const uint32_t consumed = c > end_last ? c : end_last;
+  const uint32_t fm_kept = fm_lane < c ? fm_dst : INF;  // the first match, if it was committed
+  d.hole_min = d.hole_min < fm_kept ? d.hole_min : fm_kept;
   d.q_count += (uint32_t)__popcll(commit_match_m);
   d.advance(consumed);
-  return c < 63;
+  return c < 63u;
 }
 
 // Wide turns until one stops, the round's turns are used up or the staged input
@@ -382,6 +385,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       if ((uint32_t)lane < d.q_count) deferred_load(c0, dst, d.hole_min, L.queue(lane));
       if (c0.len) deferred_store(c0, dst);
       d.q_count = 0;
+      d.hole_min = 0xFFFFFFFFu;
     }
     if (d.phase == PH_REQ_MATCH) {
       if (writer) lane_copy_match(dst, d.out_pos, d.req_dist, d.req_len, d.hard_cap);

@@ -133,7 +133,7 @@ struct InflateLane {
   int32_t lit_max_sym, dist_max_sym;
   uint32_t blk_out_start;  // first output byte of the current block
   uint32_t req_src, req_len, req_dist;
-  uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position
+  uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position (0xFFFFFFFF: none)
   int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max;  // dynamic header in progress
   int32_t hdr_fixed;   // PH_TABLES: 1 = the fixed codes
   uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
@@ -493,10 +493,11 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
   d.advance((uint32_t)c.used);
   // Buf.recopy zd.ml:615 -- queued, or handed to the wave
   const uint32_t src_pos = d.out_pos - dist;
-  const bool hazard = d.q_count != 0 && src_pos + length > d.hole_min;
-  const bool in_reach = d.q_count == 0 || d.out_pos - d.hole_min <= QUEUE_REL_MAX;
+  const bool hazard = src_pos + length > d.hole_min;
+  const uint32_t qbase = d.hole_min < d.out_pos ? d.hole_min : d.out_pos;  // hole_min once this one is queued
+  const bool in_reach = d.out_pos - qbase <= QUEUE_REL_MAX;
   if (length <= DEFER_MAX_LEN && dist >= length && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
-    if (d.q_count == 0) d.hole_min = d.out_pos;
+    d.hole_min = qbase;
     if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
     d.q_count++;
     d.out_pos += length;
@@ -676,7 +677,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.blk_out_start = 0;
   d.req_src = d.req_len = d.req_dist = 0;
   d.q_count = 0;
-  d.hole_min = 0;
+  d.hole_min = 0xFFFFFFFFu;
   d.hdr_num = d.hdr_hlit = d.hdr_hdist = d.hdr_cl_max = 0;
   d.hdr_fixed = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
