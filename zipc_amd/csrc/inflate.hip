@@ -180,14 +180,14 @@ __device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds
   d.phase = PH_SYMBOLS;
 }
 
-// One wide turn.  Returns true when the path stopped inside the window: the
-// symbol at the new position is then for lane_one_symbol.
+// One wide turn.  Returns the lane the path was cut at: below 63 it stopped inside
+// the window and the symbol at the new position is for lane_one_symbol.
 //
 // LEVELS: the path has at most 63 / (shortest code of the block) symbols, so
 // 2^LEVELS - 1 hops of doubling are enough (InflateLane::levels).
 // PLENTY: the input does not end within the turn's reach, no lane can run out of bits.
 template <int LEVELS, bool PLENTY>
-__device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
+__device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
   typedef unsigned long long mask_t;  // one bit per lane; the predicates of the turn are kept as masks
   // the symbol that would start at my offset
   const uint32_t p = d.boff + (uint32_t)lane;
@@ -199,7 +199,9 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const mask_t match_m = wave_mask((int32_t)sp.e >= 0x40000000) & wave_mask(sp.dist >= sp.length);
   const uint32_t tot = sp.b1 + (is_lit ? 0u : sp.t2);
   const uint32_t outlen = is_lit ? 1u : sp.length;
-  mask_t ok_m = (lit_m | match_m) & ~(1ull << 63);  // lane 63 is the sink: the next turn starts there
+  // Lane 63 is the path's sink (the next turn starts there): its J[0] below is itself
+  // whatever it decodes, and it never commits because the cut is at 63 at the latest.
+  mask_t ok_m = lit_m | match_m;
   if (!PLENTY) ok_m &= wave_mask((int)tot <= (int)d.bits_left() - lane);
   const uint32_t lane4 = (uint32_t)lane * 4u;
   const uint32_t end = (uint32_t)lane + tot;
@@ -229,9 +231,9 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   // (scalar work is the scarce resource of this kernel: one scalar instruction
   // issues per clock and CU, against four vector ones -- so what follows prefers
   // vector arithmetic and selects to mask algebra and branches)
-  const uint32_t fm_lane = (uint32_t)(__ffsll((long long)match0_m) - 1);  // 0xFFFFFFFF: the window has no match
-  const uint32_t fm_dst = d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, (int)(fm_lane & 63u));
-  const uint32_t first_match_dst = match0_m ? fm_dst : INF;
+  // the turn's first match (lane 63 when there is none: the sink commits nothing)
+  const uint32_t fm_lane = (uint32_t)__builtin_ctzll(match0_m | (1ull << 63));
+  const uint32_t first_match_dst = d.out_pos + (uint32_t)__builtin_amdgcn_readlane((int)outoff, (int)fm_lane);
   // symbols that would overflow, reach before the start, overfill the queue or
   // read an unfilled hole end the turn in front of them; the holes are the
   // queued copies (from hole_min on) and, behind the turn's first match, that
@@ -251,7 +253,7 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   // the path ends in a stop, or it runs into the sink (bit 63: the sink's own hop
   // need not be covered by LEVELS)
   const mask_t cut_m = (visited_m & ~ok_m) | late_m | (1ull << 63);
-  const uint32_t c = (uint32_t)(__ffsll((long long)cut_m) - 1);  // a lane on the path, or the sink
+  const uint32_t c = (uint32_t)__builtin_ctzll(cut_m);  // a lane on the path, or the sink
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
   if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
@@ -263,11 +265,11 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
   const uint32_t end_c = lane_in(commit_m) ? end : 0u;
   const uint32_t end_last = (uint32_t)__builtin_amdgcn_readlane((int)end_c, (63 - __clzll((long long)commit_m)) & 63);
   const uint32_t consumed = c > end_last ? c : end_last;
-  const uint32_t fm_kept = fm_lane < c ? fm_dst : INF;  // the first match, if it was committed
+  const uint32_t fm_kept = fm_lane < c ? first_match_dst : INF;  // the first match, if it was committed
   d.hole_min = d.hole_min < fm_kept ? d.hole_min : fm_kept;
   d.q_count += (uint32_t)__popcll(commit_match_m);
   d.advance(consumed);
-  return c < 63u;
+  return c;
 }
 
 // Wide turns until one stops, the round's turns are used up or the staged input
@@ -276,16 +278,23 @@ __device__ __forceinline__ bool wide_turn(InflateLane &d, const LaneLds &L, uint
 template <int LEVELS>
 __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane,
                                            int &turn) {
+  // turns with input to spare (PLENTY) while the staged words reach, then the careful form
   const uint32_t total = d.total_words();
   const uint32_t plenty_below = total > 8u ? total - 8u : 0u;  // 8 words > 31 + 63 + 48 bits + the peek
-  bool stopped = false;
-  while (turn < ROUND_TURNS && d.input_ready(TURN_WORDS)) {
+  const uint32_t staged_below = d.ring_wr >= (uint32_t)TURN_WORDS ? d.ring_wr - (uint32_t)TURN_WORDS + 1u : 0u;
+  const uint32_t fast_below = plenty_below < staged_below ? plenty_below : staged_below;
+  for (;;) {
+    if (turn >= ROUND_TURNS) return false;
+    if (d.in_word >= fast_below) break;
     turn++;
-    stopped = d.in_word < plenty_below ? wide_turn<LEVELS, true>(d, L, dst, lane)
-                                       : wide_turn<LEVELS, false>(d, L, dst, lane);
-    if (stopped) break;
+    if (wide_turn<LEVELS, true>(d, L, dst, lane) < 63u) return true;
   }
-  return stopped;
+  for (;;) {
+    if (turn >= ROUND_TURNS) return false;
+    if (!d.input_ready(TURN_WORDS)) return false;
+    turn++;
+    if (wide_turn<LEVELS, false>(d, L, dst, lane) < 63u) return true;
+  }
 }
 
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
