@@ -155,6 +155,14 @@ constexpr int NEAR = 8;
 constexpr int PLAIN_TURNS = 4;  // peel turns before the neighbour short-cut is worth its LDS reads
 static_assert(SWEEP_PERIOD % CHAIN_ROUND == 0, "sweeps fall on round boundaries");
 
+// The threads of the chain kernel exchange data through LDS only, so its barriers
+// wait for the LDS counter alone: __syncthreads() would also wait (vmcnt) for the
+// next round's source words, which are requested a round ahead, and for the
+// round's stores of the links.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
                                                                  DeflateScratch S) {
@@ -173,7 +181,22 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_ROUND + NEAR + t] = 0xFFFF; }
   if (t < 2) peel_more[t] = 0;
 
+  // the 4 source bytes of a round's positions are requested one round ahead (the
+  // barriers below do not wait for them)
+  uint32_t word_next[CHAIN_PPT];
+#pragma unroll
+  for (int i = 0; i < CHAIN_PPT; i++) {
+    const uint32_t p = t + CHAIN_THREADS * (uint32_t)i;
+    word_next[i] = load_u32_le(s + (p <= max_pos ? p : max_pos));  // unconditional: the wait counts stay exact
+  }
   for (uint32_t B = 0; B <= max_pos; B += CHAIN_ROUND) {
+    uint32_t word[CHAIN_PPT];
+#pragma unroll
+    for (int i = 0; i < CHAIN_PPT; i++) {
+      word[i] = word_next[i];
+      const uint64_t pn = (uint64_t)B + CHAIN_ROUND + t + CHAIN_THREADS * (uint32_t)i;
+      word_next[i] = load_u32_le(s + (pn <= max_pos ? pn : (uint64_t)max_pos));
+    }
     if ((B % SWEEP_PERIOD) == 0) {
       const uint16_t mark = (uint16_t)(B + SWEEP_MARK);
       for (uint32_t i = t; i < 32768; i += CHAIN_THREADS) {
@@ -184,7 +207,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
         }
         if (!keep) head[i] = mark;
       }
-      __syncthreads();
+      lds_barrier();
     }
     // local index of my i-th position: t + 1024 * i (coalesced loads and stores)
     uint32_t h[CHAIN_PPT], e_old[CHAIN_PPT];
@@ -194,11 +217,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
       const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
       const uint32_t p = B + li;
       active[i] = p <= max_pos;
-      h[i] = active[i] ? hash4(load_u32_le(s + p)) : 0xFFFFu;
+      h[i] = active[i] ? hash4(word[i]) : 0xFFFFu;
       hs[NEAR + li] = (uint16_t)h[i];
       e_old[i] = active[i] ? head[h[i]] : 0;
     }
-    __syncthreads();
+    lds_barrier();
 
     // The peel starts with every position both reading and writing (exact on its
     // own).  Only if it is still running after PLAIN_TURNS turns -- runs, short
@@ -239,7 +262,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
 #pragma unroll
       for (int i = 0; i < CHAIN_PPT; i++)
         if (pending[i]) head[h[i]] = (uint16_t)(B + t + CHAIN_THREADS * (uint32_t)i);
-      __syncthreads();
+      lds_barrier();
       any_pending = false;
 #pragma unroll
       for (int i = 0; i < CHAIN_PPT; i++) {
@@ -256,7 +279,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
       // read behind the barrier that also keeps this turn's read-backs ahead of the
       // next turn's stores, cleared for the turn after next.
       if (__builtin_amdgcn_ballot_w64(any_pending) && (t & 63u) == 0) peel_more[turn & 1] = 1;
-      __syncthreads();
+      lds_barrier();
       const uint32_t more = peel_more[turn & 1];
       if (t == 0) peel_more[(turn + 1) & 1] = 0;
       if (!more) break;
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
         prev[p] = (uint16_t)d;
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
