@@ -33,6 +33,8 @@
 namespace zd {
 
 constexpr uint32_t POS_PAD = 256;            // scratch slack per stream, in positions
+constexpr uint32_t PARSE_PAD = 200;          // table entries behind the last position the parse may load (3 tiles of 64 + 3)
+static_assert(PARSE_PAD <= POS_PAD, "inside the stream's scratch");
 constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 - 258 source bytes
 
 // streams with an out-of-range length are rejected by every kernel and take no scratch
@@ -338,6 +340,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
     act[i] = p[i] <= len - 4;
     if (!act[i]) p[i] = 0;
   }
+  if ((uint64_t)chunk * MATCH_TILE + MATCH_TILE > (uint64_t)len - 4 && threadIdx.x < PARSE_PAD)
+    S.match[base + (len - 3) + threadIdx.x] = 0;  // what the parse may read behind the last position
   lz_match_positions<MATCH_NP>(src_arena + sd.src_off, len, p, act, S.prev + base, K, Kq, out);
 #pragma unroll
   for (int i = 0; i < MATCH_NP; i++)
@@ -433,6 +437,8 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
   const uint64_t wbeg = (uint64_t)t0 + (tid / 64u) * per_wave;
   const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
+  // the parse reads up to PARSE_PAD entries behind the last position without a range test
+  if ((uint64_t)t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
   if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
     uint32_t pbeg[MATCHW_NP];
 #pragma unroll
@@ -476,18 +482,32 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
 
   uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
   uint32_t B = 0;
-  uint64_t m_cur = 0;
-  uint32_t lit_cur = 0;  // my position's source byte
-  if (has_match && (uint32_t)lane <= max_pos) m_cur = match[lane];
-  if ((uint32_t)lane < len) lit_cur = s[lane];
+  // Table entries and source bytes of three tiles are kept in registers: the current
+  // one, the next one (the lazy chains look into it) and the one after, which is
+  // requested while the current tile is worked on -- two tiles ahead of its first use.
+  // The loads are unconditional (clamped index, value selected afterwards) so that
+  // the wait counters stay exact and nothing waits for the newest requests.
+  // (lz_match zeroes the PARSE_PAD table entries behind the last position, so
+  // the table is read without a range test; source bytes past the end are never used)
+  auto load_match = [&](uint32_t tile) -> uint64_t {
+    return has_match ? match[(uint64_t)tile + (uint32_t)lane] : 0ull;  // uniform condition
+  };
+  auto load_lit = [&](uint32_t tile) -> uint32_t {
+    const uint64_t i = (uint64_t)tile + (uint32_t)lane;
+    return s[i < len ? i : (uint64_t)(len - 1)];  // len >= 1 inside the loop
+  };
+  uint64_t m_cur = 0, m_nxt = 0;
+  uint32_t lit_cur = 0, lit_nxt = 0;
+  if (len) {
+    m_cur = load_match(0);
+    lit_cur = load_lit(0);
+    m_nxt = load_match(PARSE_TILE);
+    lit_nxt = load_lit(PARSE_TILE);
+  }
   while (B < len) {
-    // next tile's table entries and source bytes are requested before this tile is
-    // worked on: nothing below waits for memory
     uint32_t Bn = B + PARSE_TILE;
-    uint64_t m_nxt = 0;
-    uint32_t lit_nxt = 0;
-    if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
-    if (Bn + (uint32_t)lane < len) lit_nxt = s[Bn + lane];
+    const uint64_t m_nx2 = load_match(Bn + PARSE_TILE);
+    const uint32_t lit_nx2 = load_lit(Bn + PARSE_TILE);
 
     const uint32_t p = B + (uint32_t)lane;
     const bool valid = p < len;
@@ -500,40 +520,44 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
       uint32_t n_lits = 0, j = p + 1;
       const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
       const uint32_t nxt_lo = (uint32_t)m_nxt, nxt_hi = (uint32_t)(m_nxt >> 32);
-      while (__builtin_amdgcn_ballot_w64(chaining)) {
-        // every chaining lane looks at the same distance ahead: lane + 1 + n_lits
-        const uint32_t off = j - B;  // >= 1
+      // one step of a lane's lazy chain with the entry mj of position j
+      auto chain_step = [&](uint32_t mj_lo, uint32_t mj_hi, bool use_hi) {
+        if (j > max_pos) { chaining = false; return; }
+        const uint32_t pl = pend & 0x1FF;
+        const uint32_t rem = len - j;
+        const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
+        uint32_t nb = 0;
+        if (pl < maxlen) {
+          const uint32_t c = use_hi ? mj_hi : mj_lo;
+          if ((c & 0x1FF) > pl) nb = c;
+        }
+        if (nb == 0) chaining = false;
+        else { n_lits++; pend = nb; j++; }
+      };
+      // chains within the staged tiles (all but pathological ones): entries by shuffle
+      for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining); ahead++) {
+        // every chaining lane looks at the same distance ahead: lane + ahead (< 128)
+        const uint32_t off = (uint32_t)lane + ahead;
         const uint32_t addr = (off & 63u) * 4u;
         const bool in_cur = off < 64u;
         // best-of-K of position j; best-of-K/4 only if a pending match is that long
         // (all lanes take part in every shuffle: a lane is also somebody's source)
         const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
-        uint32_t mj_lo = in_cur ? a_lo : b_lo;
+        const uint32_t mj_lo = in_cur ? a_lo : b_lo;
         uint32_t mj_hi = 0;
         const bool want_hi = chaining && (pend & 0x1FF) >= (uint32_t)good_match;
         if (__builtin_amdgcn_ballot_w64(want_hi)) {
           const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
           mj_hi = in_cur ? a_hi : b_hi;
         }
-        if (chaining) {
-          if (j > max_pos) chaining = false;
-          else {
-            if (off >= 128u) {  // beyond the staged tiles: rare
-              const uint64_t mj = match[j];
-              mj_lo = (uint32_t)mj;
-              mj_hi = (uint32_t)(mj >> 32);
-            }
-            const uint32_t pl = pend & 0x1FF;
-            const uint32_t rem = len - j;
-            const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
-            uint32_t nb = 0;
-            if (pl < maxlen) {
-              const uint32_t c = want_hi ? mj_hi : mj_lo;
-              if ((c & 0x1FF) > pl) nb = c;
-            }
-            if (nb == 0) chaining = false;
-            else { n_lits++; pend = nb; j++; }
-          }
+        if (chaining) chain_step(mj_lo, mj_hi, want_hi);
+      }
+      // a chain of 64 strictly growing matches and more: straight from the table
+      // (kept out of the loop above: its load would make that loop wait for memory)
+      if (__builtin_amdgcn_ballot_w64(chaining)) {
+        while (chaining) {
+          const uint64_t mj = j <= max_pos ? match[j] : 0ull;
+          chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match);
         }
       }
       if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
@@ -607,15 +631,18 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     // tiles the parse jumps over entirely are skipped
     const uint32_t Be = entry & ~63u;
     if (Be > Bn) {
-      Bn = Be;
-      m_nxt = 0;
-      lit_nxt = 0;
-      if (has_match && Bn + (uint32_t)lane <= max_pos) m_nxt = match[Bn + lane];
-      if (Bn + (uint32_t)lane < len) lit_nxt = s[Bn + lane];
+      B = Be;
+      m_cur = load_match(Be);
+      lit_cur = load_lit(Be);
+      m_nxt = load_match(Be + PARSE_TILE);
+      lit_nxt = load_lit(Be + PARSE_TILE);
+    } else {
+      B = Bn;
+      m_cur = m_nxt;
+      lit_cur = lit_nxt;
+      m_nxt = m_nx2;
+      lit_nxt = lit_nx2;
     }
-    B = Bn;
-    m_cur = m_nxt;
-    lit_cur = lit_nxt;
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
