@@ -995,22 +995,35 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     for (int i = lane; i < 288; i += 64) lit_freq[i] = 0;
     if (lane < 32) dist_freq[lane] = 0;
     wave_sync();
-    // 4 tiles of symbols per turn: the loads are issued together
-    for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 256) {
-      uint32_t sref[4];
+    // 4 tiles of symbols per turn, the next turn's requested before this one's are
+    // counted.  The loads are unconditional (clamped index, validity tested at use) so
+    // that the wait counters stay exact and nothing waits for the newest requests.
+    {
+      const uint32_t last_sym = bd.n_syms ? bd.n_syms - 1u : 0u;
+      auto load4 = [&](uint32_t k0, uint32_t *v) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
-        sref[u] = k < bd.n_syms ? syms[bd.sym_start + k] : 0xFFFFFFFFu;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        if (sref[u] == 0xFFFFFFFFu) continue;
-        if ((sref[u] >> 9) == 0) atomicAdd(&lit_freq[sref[u]], 1u);
-        else {
-          atomicAdd(&lit_freq[length_to_sym((int)(sref[u] & 0x1FF))], 1u);
-          atomicAdd(&dist_freq[dist_to_sym((int)(sref[u] >> 9))], 1u);
+        for (int u = 0; u < 4; u++) {
+          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+          v[u] = syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
         }
+      };
+      uint32_t cur[4], nxt[4];
+      load4(0, cur);
+      for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 256) {
+        load4(k0 + 256u, nxt);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
+          if (k < bd.n_syms) {
+            if ((cur[u] >> 9) == 0) atomicAdd(&lit_freq[cur[u]], 1u);
+            else {
+              atomicAdd(&lit_freq[length_to_sym((int)(cur[u] & 0x1FF))], 1u);
+              atomicAdd(&dist_freq[dist_to_sym((int)(cur[u] >> 9))], 1u);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) cur[u] = nxt[u];
       }
     }
     wave_sync();
@@ -1066,12 +1079,13 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
     const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
     // symbols of the next tiles are requested before the current ones are packed
+    // item idx of the block: 0 type bits, 1..n_hdr the dynamic header, then the symbols,
+    // then EOB.  Symbol loads are unconditional (clamped); what an item is gets decided
+    // when it is used, a turn after its load was issued.
+    const uint32_t last_sym = bd.n_syms ? bd.n_syms - 1u : 0u;
     auto fetch = [&](uint32_t idx) -> uint32_t {
-      if (idx > n_hdr && idx < n_items) {
-        const uint32_t k = idx - 1 - n_hdr;
-        return k < bd.n_syms ? syms[bd.sym_start + k] : (uint32_t)LITLEN_EOB;
-      }
-      return 0u;
+      const uint32_t k = idx > n_hdr ? idx - 1u - n_hdr : 0u;
+      return syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
     };
     uint32_t sref_cur[PACK_TILES], sref_next[PACK_TILES];
 #pragma unroll
@@ -1080,8 +1094,9 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       uint64_t value[PACK_TILES];
       int nbits[PACK_TILES];
 #pragma unroll
+      for (int u = 0; u < PACK_TILES; u++) sref_next[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
+#pragma unroll
       for (int u = 0; u < PACK_TILES; u++) {
-        sref_next[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
         const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
         value[u] = 0;
         nbits[u] = 0;
@@ -1094,7 +1109,8 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
             dyn_header_item(c, (int)idx - 1, v, nbits[u]);
             value[u] = v;
           } else {
-            symbol_bits(sref_cur[u], hl, hd, value[u], nbits[u]);
+            const uint32_t sref = idx - 1u - n_hdr < bd.n_syms ? sref_cur[u] : (uint32_t)LITLEN_EOB;
+            symbol_bits(sref, hl, hd, value[u], nbits[u]);
           }
         }
       }
