@@ -171,6 +171,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   __shared__ uint16_t head[32768];
   __shared__ uint16_t hs[CHAIN_ROUND + 2 * NEAR];
   __shared__ uint32_t peel_more[2];
+  __shared__ uint32_t head_spare;
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x;
   const uint32_t t = threadIdx.x;
@@ -231,19 +232,25 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
     // within 8 to its left takes that one as predecessor and stops reading, and
     // one with an equal hash within 8 to its right stops writing (it is never the
     // predecessor of a position that still reads, nor the group's last).
+    // Branch-light on purpose: the workgroup's 16 waves share the CU's one scalar issue
+    // per clock, so a turn is select-and-arithmetic on per-lane integers, stores of
+    // lanes that have nothing to store go to a spare LDS slot, and only the neighbour
+    // pass and the vote branch.
     uint32_t near_pred[CHAIN_PPT];
-    bool reader[CHAIN_PPT], writer[CHAIN_PPT], pending[CHAIN_PPT], notmax[CHAIN_PPT];
-    int pred_local[CHAIN_PPT];
-    bool any_pending = false;
+    uint32_t reader[CHAIN_PPT], writer[CHAIN_PPT], pending[CHAIN_PPT];  // 0 / 1
+    int notmax[CHAIN_PPT];      // > 0: a later member of my group landed
+    int pred_local[CHAIN_PPT];  // nearest earlier member seen so far, -1: none
+    uint32_t h2[CHAIN_PPT];     // byte offset of my head entry (entry 0 for positions past the end)
 #pragma unroll
     for (int i = 0; i < CHAIN_PPT; i++) {
       near_pred[i] = 0;
-      reader[i] = active[i];
-      writer[i] = active[i];
-      pending[i] = active[i];
-      notmax[i] = false;
+      reader[i] = writer[i] = pending[i] = active[i] ? 1u : 0u;
+      notmax[i] = 0;
       pred_local[i] = -1;
+      h2[i] = active[i] ? h[i] * 2u : 0u;
     }
+    uint8_t *const head_bytes = (uint8_t *)head;
+    const uint32_t spare = (uint32_t)((uint8_t *)&head_spare - head_bytes);  // where idle lanes store
     for (int turn = 0;; turn++) {
       if (turn == PLAIN_TURNS) {
 #pragma unroll
@@ -257,30 +264,33 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
 #pragma unroll
             for (int k = 1; k <= NEAR; k++) has_succ |= hs[NEAR + li + k] == h[i];
           }
-          reader[i] = active[i] && near_pred[i] == 0;
-          if (has_succ) { writer[i] = false; pending[i] = false; }
+          reader[i] = (active[i] && near_pred[i] == 0) ? 1u : 0u;
+          if (has_succ) { writer[i] = 0; pending[i] = 0; }
         }
       }
 #pragma unroll
       for (int i = 0; i < CHAIN_PPT; i++)
-        if (pending[i]) head[h[i]] = (uint16_t)(B + t + CHAIN_THREADS * (uint32_t)i);
+        *(uint16_t *)(head_bytes + (pending[i] ? h2[i] : spare)) = (uint16_t)(B + t + CHAIN_THREADS * (uint32_t)i);
       lds_barrier();
-      any_pending = false;
+      uint32_t any_pending = 0;
 #pragma unroll
       for (int i = 0; i < CHAIN_PPT; i++) {
-        if (reader[i] || writer[i]) {
-          const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
-          const uint32_t r_local = ((uint32_t)head[h[i]] - B) & 0xFFFFu;
-          if (r_local == li) pending[i] = false;
-          else if (r_local < li) { if (reader[i] && (int)r_local > pred_local[i]) pred_local[i] = (int)r_local; }
-          else notmax[i] = true;
-        }
+        // who landed in my bucket, relative to me: 0 me, < 0 an earlier member, > 0 a later one.
+        // (Lanes that neither read nor write any more -- neighbour pass -- and positions past
+        // the end compute values nobody uses.)
+        const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
+        const uint32_t r_local = ((uint32_t)*(const uint16_t *)(head_bytes + h2[i]) - B) & 0xFFFFu;
+        const int rel = (int)r_local - (int)li;
+        pending[i] = rel != 0 ? pending[i] : 0u;
+        const int cand = rel < 0 ? (int)r_local : -1;
+        pred_local[i] = cand > pred_local[i] ? cand : pred_local[i];
+        notmax[i] = rel > notmax[i] ? rel : notmax[i];
         any_pending |= pending[i];
       }
       // does anybody still peel?  One flag per turn parity: set by the waves that do,
       // read behind the barrier that also keeps this turn's read-backs ahead of the
       // next turn's stores, cleared for the turn after next.
-      if (__builtin_amdgcn_ballot_w64(any_pending) && (t & 63u) == 0) peel_more[turn & 1] = 1;
+      if (__builtin_amdgcn_ballot_w64(any_pending != 0) && (t & 63u) == 0) peel_more[turn & 1] = 1;
       lds_barrier();
       const uint32_t more = peel_more[turn & 1];
       if (t == 0) peel_more[(turn + 1) & 1] = 0;
@@ -290,7 +300,8 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
     for (int i = 0; i < CHAIN_PPT; i++) {
       const uint32_t li = t + CHAIN_THREADS * (uint32_t)i;
       const uint32_t p = B + li;
-      if (writer[i] && !notmax[i]) head[h[i]] = (uint16_t)p;
+      // the largest member of each group leaves its position in head[h]
+      *(uint16_t *)(head_bytes + ((writer[i] && notmax[i] <= 0) ? h2[i] : spare)) = (uint16_t)p;
       if (active[i]) {
         uint32_t d;
         if (near_pred[i]) d = near_pred[i];
