@@ -1006,6 +1006,9 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     for (int i = lane; i < 288; i += 64) lit_freq[i] = 0;
     if (lane < 32) dist_freq[lane] = 0;
     wave_sync();
+    // length -> litlen symbol as a table (in the heap's LDS, idle until the codes are built)
+    for (int len = lane; len <= MAX_MATCH_LEN; len += 64) heap[len] = len >= MIN_MATCH_LEN - 1 ? (uint32_t)length_to_sym(len) : 0u;
+    wave_sync();
     // 4 tiles of symbols per turn, the next turn's requested before this one's are
     // counted.  The loads are unconditional (clamped index, validity tested at use) so
     // that the wait counters stay exact and nothing waits for the newest requests.
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
           if (k < bd.n_syms) {
             if ((cur[u] >> 9) == 0) atomicAdd(&lit_freq[cur[u]], 1u);
             else {
-              atomicAdd(&lit_freq[length_to_sym((int)(cur[u] & 0x1FF))], 1u);
+              atomicAdd(&lit_freq[heap[cur[u] & 0x1FF]], 1u);
               atomicAdd(&dist_freq[dist_to_sym((int)(cur[u] >> 9))], 1u);
             }
           }
@@ -1089,6 +1092,25 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     const uint32_t *hd = kind == 1 ? fix_dist : dyn_dist;
     const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
     const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
+    // What a match length turns into -- code and extra bits merged, like the
+    // reference's single write_bits (zd.ml:893-899) -- depends on the length and the
+    // block's code only: one table entry per length, (bits << 5) | count, and per
+    // distance symbol its base and extra-bit count; both in the heap's LDS, idle again.
+    uint32_t *len_item = heap, *dist_info = heap + 272;
+    for (int len = MIN_MATCH_LEN - 1 + lane; len <= MAX_MATCH_LEN; len += 64) {
+      const int lsym = length_to_sym(len);
+      const uint32_t si = hl[lsym];
+      const uint32_t count = si & 0x1F;
+      uint32_t vbase, vextra;
+      length_sym_value(lsym, vbase, vextra);
+      len_item[len] = (((si >> 5) | (((uint32_t)len - vbase) << count)) << 5) | (count + vextra);
+    }
+    if (lane <= DIST_SYM_MAX) {
+      uint32_t vbase, vextra;
+      dist_sym_value(lane, vbase, vextra);
+      dist_info[lane] = (vbase << 5) | vextra;
+    }
+    wave_sync();
     // symbols of the next tiles are requested before the current ones are packed
     // item idx of the block: 0 type bits, 1..n_hdr the dynamic header, then the symbols,
     // then EOB.  Symbol loads are unconditional (clamped); what an item is gets decided
@@ -1121,7 +1143,20 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
             value[u] = v;
           } else {
             const uint32_t sref = idx - 1u - n_hdr < bd.n_syms ? sref_cur[u] : (uint32_t)LITLEN_EOB;
-            symbol_bits(sref, hl, hd, value[u], nbits[u]);
+            // write_block_symbols zd.ml:879-910 (symbol_bits), by table
+            const uint32_t dist = sref >> 9, len = sref & 0x1FF;
+            if (dist == 0) {
+              const uint32_t si = hl[len];
+              value[u] = si >> 5;
+              nbits[u] = (int)(si & 0x1F);
+            } else {
+              const uint32_t li = len_item[len];
+              const int dsym = dist_to_sym((int)dist);
+              const uint32_t si = hd[dsym], di = dist_info[dsym];
+              const uint32_t n = li & 0x1F, count = si & 0x1F;
+              value[u] = (uint64_t)(li >> 5) | (((uint64_t)(si >> 5) | ((uint64_t)(dist - (di >> 5)) << count)) << n);
+              nbits[u] = (int)(n + count + (di & 0x1F));
+            }
           }
         }
       }
