@@ -12,6 +12,7 @@ def lib():
     deps = [os.path.join(HERE, s) for s in SRCS]
     csrc = os.path.join(HERE, "..", "..", "zipc_amd", "csrc")
     deps += [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith(".h")]
+    deps += [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall",
                                "-Wno-unknown-pragmas", "-o", LIB] + [os.path.join(HERE, s) for s in SRCS])

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <vector>
 #include "../../zipc_amd/csrc/deflate_lane.h"
+#include "serial_walk.h"
 
 using namespace zd;
 
