@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <thread>
 #include <vector>
 #include "ctx.h"
 
@@ -62,6 +63,22 @@ void zipc_hip_ctx::end(const char *name, hipEvent_t start) {
   pending.push_back(p);
 }
 
+hipError_t zipc_hip_ctx::ensure_pinned(Buf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return hipSuccess;
+  if (b.p) {
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return e;
+    (void)hipHostFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes < 4096 ? 4096 : bytes;
+  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+  if (e != hipSuccess) { b.p = nullptr; return e; }
+  b.cap = want;
+  return hipSuccess;
+}
+
 hipError_t zipc_hip_ctx::ensure(Buf &b, size_t bytes) {
   if (bytes <= b.cap && b.p) return hipSuccess;
   if (b.p) {
@@ -102,6 +119,18 @@ static void free_buf(zipc_hip_ctx::Buf &b) {
 }
 
 // ---- context API -------------------------------------------------------------
+
+// host-side loop over the streams of a batch on a few threads (memcpy bound)
+template <class F>
+static void parallel_for(size_t n, F f) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t nt = n < 256 ? 1 : (hw >= 8 ? 8 : (hw ? hw : 1));
+  if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  std::vector<std::thread> th;
+  for (size_t t = 0; t < nt; t++)
+    th.emplace_back([&, t] { for (size_t i = t; i < n; i += nt) f(i); });
+  for (auto &x : th) x.join();
+}
 
 extern "C" {
 
@@ -163,6 +192,8 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch);
+  if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
+  if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -444,10 +475,13 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dof + 64));
   HIP_TRY(ctx, ctx->ensure(ctx->io_desc, n * sizeof(StreamDesc)));
   HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
-  for (size_t i = 0; i < n; i++)
-    if (src_len[i])
-      HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->io_src.p + descs[i].src_off, src[i], src_len[i],
-                                  hipMemcpyHostToDevice, ctx->stream));
+  // the streams are gathered into one pinned buffer (host threads) and cross the bus
+  // as ONE copy: thousands of small pageable copies cost far more than the kernels
+  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
+  parallel_for(n, [&](size_t i) {
+    if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
+  });
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_src.p, ctx->pin_src.p, so, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice,
                               ctx->stream));
   int st;
@@ -461,14 +495,21 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
   HIP_TRY(ctx, hipMemcpyAsync(results, ctx->io_res.p, n * sizeof(StreamResult), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  uint64_t used = 0;  // the part of the destination arena that holds output
   for (size_t i = 0; i < n; i++) {
     if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
     if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; continue; }
-    if (results[i].out_len)
-      HIP_TRY(ctx, hipMemcpyAsync(dst[i], (const uint8_t *)ctx->io_dst.p + descs[i].dst_off, results[i].out_len,
-                                  hipMemcpyDeviceToHost, ctx->stream));
+    if (results[i].out_len) used = descs[i].dst_off + results[i].out_len;
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (used) {
+    HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, used + 64));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_dst.p, ctx->io_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    parallel_for(n, [&](size_t i) {
+      if (results[i].status == ST_OK && results[i].out_len)
+        memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
+    });
+  }
   return ZIPC_HIP_OK;
 }
 

@@ -28,6 +28,7 @@ struct zipc_hip_ctx {
     size_t cap = 0;
   };
   Buf io_src, io_dst, io_desc, io_res, io_small;  // staging of the host forms
+  Buf pin_src, pin_dst;                           // pinned host memory of the many-stream host forms
   Buf crc_partials, adler_sums;                   // checksum kernels
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)
 
@@ -36,6 +37,7 @@ struct zipc_hip_ctx {
   void begin(const char *name, hipEvent_t &start);
   void end(const char *name, hipEvent_t start);
   hipError_t ensure(Buf &b, size_t bytes);
+  hipError_t ensure_pinned(Buf &b, size_t bytes);
   hipError_t collect_times();
 };
 
