@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <thread>
 #include <vector>
 #include "ctx.h"
@@ -120,17 +121,55 @@ static void free_buf(zipc_hip_ctx::Buf &b) {
 
 // ---- context API -------------------------------------------------------------
 
-// host-side loop over the streams of a batch on a few threads (memcpy bound)
+// host-side loop over streams [lo, hi) of a batch on a few threads (memcpy bound).
+// ZIPC_HIP_HOST_THREADS overrides the count (default: 8 or the core count, if lower).
+static size_t host_threads() {
+  static const size_t nt = [] {
+    const char *e = getenv("ZIPC_HIP_HOST_THREADS");
+    long v = e ? atol(e) : 0;
+    if (v < 1) {
+      const unsigned hw = std::thread::hardware_concurrency();
+      v = hw >= 8 ? 8 : (hw ? hw : 1);
+    }
+    return (size_t)(v > 64 ? 64 : v);
+  }();
+  return nt;
+}
+// ZIPC_HIP_HOST_CHUNKS: groups a batch's arena is cut into so that the host memcpys of
+// one group overlap the bus copy of its neighbour (1 = no overlap)
+static size_t host_chunks() {
+  static const size_t k = [] {
+    const char *e = getenv("ZIPC_HIP_HOST_CHUNKS");
+    long v = e ? atol(e) : 0;
+    if (v < 1) v = 4;  // profiles/r01_host_forms_sweep.txt: 1 -> 4 saves ~20%, 4 vs 8 within ~5%
+    return (size_t)(v > 64 ? 64 : v);
+  }();
+  return k;
+}
 template <class F>
-static void parallel_for(size_t n, F f) {
-  const unsigned hw = std::thread::hardware_concurrency();
-  const size_t nt = n < 256 ? 1 : (hw >= 8 ? 8 : (hw ? hw : 1));
-  if (nt == 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+static void parallel_for(size_t lo, size_t hi, F f) {
+  const size_t n = hi - lo;
+  const size_t nt = n < 64 ? 1 : host_threads();
+  if (nt == 1) { for (size_t i = lo; i < hi; i++) f(i); return; }
   std::vector<std::thread> th;
   for (size_t t = 0; t < nt; t++)
-    th.emplace_back([&, t] { for (size_t i = t; i < n; i += nt) f(i); });
+    th.emplace_back([&, t] { for (size_t i = lo + t; i < hi; i += nt) f(i); });
   for (auto &x : th) x.join();
 }
+// events of one call, destroyed on every exit path
+struct EventSet {
+  std::vector<hipEvent_t> ev;
+  ~EventSet() { for (auto e : ev) (void)hipEventDestroy(e); }
+  hipError_t make(size_t k) {
+    for (size_t i = 0; i < k; i++) {
+      hipEvent_t e;
+      hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      if (r != hipSuccess) return r;
+      ev.push_back(e);
+    }
+    return hipSuccess;
+  }
+};
 
 extern "C" {
 
@@ -456,6 +495,19 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // ZIPC_HIP_HOST_TIMING=1: wall time of each stage of this call on stderr (the
+  // stream is synchronised at every mark, so it perturbs what it measures a little)
+  static const bool timing = getenv("ZIPC_HIP_HOST_TIMING") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  double t_ms[6] = {0, 0, 0, 0, 0, 0};  // [0] setup [2] gather+H2D [3] kernels [5] D2H+scatter
+  auto mark = [&](int k) -> hipError_t {
+    if (!timing) return hipSuccess;
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    auto now = std::chrono::steady_clock::now();
+    t_ms[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
+    t_last = now;
+    return e;
+  };
   std::vector<StreamDesc> descs(n);
   uint64_t so = 0, dof = 0;
   size_t max_src = 0, max_cap = 0, total_src = 0;
@@ -478,12 +530,29 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   // the streams are gathered into one pinned buffer (host threads) and cross the bus
   // as ONE copy: thousands of small pageable copies cost far more than the kernels
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
-  parallel_for(n, [&](size_t i) {
-    if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
-  });
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_src.p, ctx->pin_src.p, so, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, mark(0));  // descriptors + buffer (re)allocation
+  // group g = streams [cut[g], cut[g+1]): about equal shares of the source arena
+  const size_t K = n < 1024 ? 1 : host_chunks();
+  std::vector<size_t> cut(K + 1, n);
+  cut[0] = 0;
+  for (size_t g = 1, i = 0; g < K; g++) {
+    while (i < n && descs[i].src_off < so / K * g) i++;
+    cut[g] = i;
+  }
+  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
+  for (size_t g = 0; g < K; g++) {
+    if (cut[g] == cut[g + 1]) continue;
+    parallel_for(cut[g], cut[g + 1], [&](size_t i) {
+      if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
+    });
+    const uint64_t a = src_end(cut[g]), b = src_end(cut[g + 1]);
+    // the copy of this group runs while the host gathers the next one
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->io_src.p + a, (const uint8_t *)ctx->pin_src.p + a, b - a,
+                                hipMemcpyHostToDevice, ctx->stream));
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice,
                               ctx->stream));
+  HIP_TRY(ctx, mark(2));  // H2D
   int st;
   if (is_inflate)
     st = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
@@ -495,6 +564,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
   HIP_TRY(ctx, hipMemcpyAsync(results, ctx->io_res.p, n * sizeof(StreamResult), hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, mark(3));  // kernels + results
   uint64_t used = 0;  // the part of the destination arena that holds output
   for (size_t i = 0; i < n; i++) {
     if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
@@ -503,13 +573,36 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   }
   if (used) {
     HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, used + 64));
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->pin_dst.p, ctx->io_dst.p, used, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    parallel_for(n, [&](size_t i) {
-      if (results[i].status == ST_OK && results[i].out_len)
-        memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
-    });
+    // every group's bytes are requested up front; group g is scattered to the caller's
+    // buffers as soon as its copy has landed, while the later ones are still in flight
+    EventSet done;
+    HIP_TRY(ctx, done.make(K));
+    for (size_t g = 0; g < K; g++) {
+      uint64_t a = ~0ull, b = 0;
+      for (size_t i = cut[g]; i < cut[g + 1]; i++)
+        if (results[i].status == ST_OK && results[i].out_len) {
+          if (a == ~0ull) a = descs[i].dst_off;
+          b = descs[i].dst_off + results[i].out_len;
+        }
+      if (b)
+        HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + a, (const uint8_t *)ctx->io_dst.p + a, b - a,
+                                    hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipEventRecord(done.ev[g], ctx->stream));
+    }
+    for (size_t g = 0; g < K; g++) {
+      HIP_TRY(ctx, hipEventSynchronize(done.ev[g]));
+      parallel_for(cut[g], cut[g + 1], [&](size_t i) {
+        if (results[i].status == ST_OK && results[i].out_len)
+          memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
+      });
+    }
+    HIP_TRY(ctx, mark(5));  // D2H + scatter (overlapped)
   }
+  if (timing)
+    fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_used=%llu ms: setup %.2f gather+h2d %.2f "
+                    "kernels %.2f d2h+scatter %.2f (threads %zu chunks %zu)\n",
+            is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)used, t_ms[0],
+            t_ms[2], t_ms[3], t_ms[5], host_threads(), K);
   return ZIPC_HIP_OK;
 }
 
