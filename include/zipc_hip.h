@@ -149,7 +149,13 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
  * be NULL (no ?decompressed_size for any stream); a stream whose output does not
  * fit reports ZIPC_HIP_ERR_DST_TOO_SMALL (or the reference's size message when a
  * limit is given) in its own result.  The call itself fails only for bad
- * arguments or HIP errors. */
+ * arguments or HIP errors.
+ * Staging: the streams are gathered into a pinned buffer the context keeps (sized
+ * to the batch; the first call of a size pays for pinning it) on a few host
+ * threads, and cross the bus in a few large copies overlapped with those memcpys.
+ * Environment, read once per process: ZIPC_HIP_HOST_THREADS (default 8 or the core
+ * count), ZIPC_HIP_HOST_CHUNKS (default 4), ZIPC_HIP_HOST_TIMING=1 (per-stage wall
+ * time of every call on stderr; adds stream synchronisations). */
 struct zipc_hip_stream_result_s;
 int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           int level, int crc_op, void *const *dst, const size_t *dst_cap,
