@@ -53,7 +53,8 @@ def measured_traffic(kernel):
         return None, None
     try:
         d = json.load(open(files[-1]))
-        return d["kernels"][kernel]["bytes"], os.path.basename(files[-1])
+        k = d["kernels"][kernel]
+        return k, os.path.basename(files[-1])
     except Exception:
         return None, None
 
@@ -219,13 +220,22 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic["bytes"] if traffic else None,
                 "traffic_source": traffic_src, "algorithmic_bytes": alg, "launch_ms": dom_ms,
             },
             "deflate_gib_s": N / GIB * psteps / t_def,
             "inflate_gib_s": N / GIB * psteps / t_inf,
             "kernels_ms_per_step": per_step,
         }
+        if traffic:
+            # what "traffic" is: raw FETCH_SIZE + WRITE_SIZE. Calibrated on this kernel's stored-block
+            # path (profiles/r01_inflate_traffic.txt): WRITE_SIZE exact, FETCH_SIZE tallies every
+            # request at 64 B and reads 0.504x a wide streamed read, so raw <= true fetch <= 2 x raw;
+            # Infinity-Cache hits are included, so HBM-side bytes can be lower.
+            line["roofline"]["traffic_fetch_bounds"] = [traffic["fetch_bytes"], 2 * traffic["fetch_bytes"]]
+            line["roofline"]["traffic_write"] = traffic["write_bytes"]
+            line["roofline"]["traffic_is"] = "raw FETCH_SIZE+WRITE_SIZE per launch (L2->fabric, lower bound on reads)"
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, args.bits, args.level, L)
         print(json.dumps(line))
