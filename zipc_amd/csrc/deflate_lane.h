@@ -178,11 +178,13 @@ ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p,
 // results as lz_match_position.
 struct MatchRun {
   uint32_t p, q, best_len, best, snap, maxlen, steps;
+  uint32_t dn;  // prev[q], read ahead: whether the chain goes on is known before the next step
   bool alive, snapped;
   uint64_t pw;
 };
 template <bool WORDS>
-ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend) {
+ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend,
+                           const uint16_t *prev) {
   r.alive = p < pend;
   r.p = r.alive ? p : (pend ? pend - 1u : 0u);  // a finished run parks on a valid position
   r.q = r.p;
@@ -192,21 +194,28 @@ ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t
   r.pw = 0;
   if (WORDS) r.pw = load_u64_words(s, r.p);
   else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
+  r.dn = prev[r.p];
 }
 // One iteration of a run: a chain step of its current position.  Returns true when
 // the position is finished (its result has been written to out[p]); the caller
-// starts the run's next position.
+// starts the run's next position.  The step that compares a candidate also reads
+// that candidate's link, so a position ends in the step of its LAST candidate
+// (max(1, chain length) steps per position, not chain length + 1).
+// (A form with the predicates as integers and selects instead of ifs -- what paid in
+// the inflate kernel -- was measured here and lost: 8.85 ms against 7.27 on C2.  The
+// branches skip work that selects execute, and this loop is nearer its vector bound
+// than its scalar one.)
 template <bool WORDS>
 ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
                           uint64_t *out) {
   if (!r.alive) return false;
-  const uint32_t d = prev[r.q];
-  const uint32_t qn = r.q - d;
-  const bool walk = d != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
+  const uint32_t qn = r.q - r.dn;
+  const bool walk = r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
   const uint32_t qc = walk ? qn : r.p;
   uint64_t x = 0;
   if (WORDS) x = load_u64_words(s, qc) ^ r.pw;
   else if (r.maxlen >= 8) x = load_u64_le(s + qc) ^ r.pw;
+  const uint32_t d2 = prev[qc];
   uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
   if (walk && (x == 0 || r.maxlen < 8)) l = common_prefix(s, qc, r.p, r.maxlen);
   r.q = qc;
@@ -216,7 +225,11 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
     r.best = ((r.p - qc) << 9) | l;
   }
   if (walk && r.steps == Kq) { r.snap = r.best; r.snapped = true; }
-  if (!walk || l == r.maxlen) {  // zd.ml:1194: nothing later can be longer
+  r.dn = d2;
+  // would the next step walk?  (l < maxlen implies best_len < maxlen; zd.ml:1194:
+  // after l == maxlen nothing later can be longer)
+  const bool more = walk && l != r.maxlen && d2 != 0 && r.steps != K && r.p - (qc - d2) <= (uint32_t)MAX_MATCH_DIST;
+  if (!more) {
     if (!r.snapped) r.snap = r.best;
     if (Kq == 0) r.snap = 0;
     out[r.p] = (uint64_t)r.best | ((uint64_t)r.snap << 32);
@@ -224,14 +237,14 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
   }
   return false;
 }
-// Runs with a fixed schedule: run i takes pbeg[i], pbeg[i] + stride, ...  (The
-// window kernel hands positions out as lanes finish instead, deflate.hip.)
+// Runs with a fixed schedule: run i takes pbeg[i], pbeg[i] + stride, ...  (Handing
+// positions out as lanes finish was measured and lost on C2)
 template <int NP, bool WORDS>
 ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, uint32_t pend, uint32_t stride,
                          const uint16_t *prev, int K, int Kq, uint64_t *out) {
   MatchRun r[NP];
 #pragma unroll
-  for (int i = 0; i < NP; i++) match_run_start<WORDS>(r[i], s, len, pbeg[i], pend);
+  for (int i = 0; i < NP; i++) match_run_start<WORDS>(r[i], s, len, pbeg[i], pend, prev);
   // On the GPU the loop is left by the whole wave at once (the exit test is
   // wave-uniform): that keeps it ONE loop whose iterations mix positions, instead
   // of a loop per position that the lanes would have to leave together.
@@ -240,7 +253,7 @@ ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, u
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       if (match_run_step<WORDS>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out))
-        match_run_start<WORDS>(r[i], s, len, r[i].p + stride, pend);
+        match_run_start<WORDS>(r[i], s, len, r[i].p + stride, pend, prev);
       alive |= r[i].alive;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
