@@ -218,6 +218,8 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
   uint32_t x = gf2_xpow8n(CRC_PIECE_BYTES);
   for (int k = 0; k < 8; k++) { ctx->crc_consts.xpiece[k] = x; x = gf2_mul(x, x); }
   ctx->crc_consts.xseg = gf2_xpow8n(CRC_SEG_BYTES);
+  x = 0x00800000u;  // x^8
+  for (int k = 0; k < 48; k++) { ctx->crc_consts.xbyte[k] = x; x = gf2_mul(x, x); }
   *out = ctx;
   return ZIPC_HIP_OK;
 }
@@ -301,9 +303,14 @@ static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const St
   ZD_LAUNCH(ctx, "crc32_segments", crc32_segments_kernel, dim3((unsigned)(n_ranges * segs)), dim3(256), 0,
             base, mode, d_descs, (const StreamResult *)d_results, single_off, single_len,
             (uint32_t)segs, ctx->crc_consts, partials);
-  ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
-            d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts,
-            (const uint32_t *)partials, d_single_out);
+  if (mode != RANGE_SINGLE && segs <= 16)  // a batch of short streams: one per thread
+    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_streams_kernel, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0,
+              mode, d_descs, d_results, (uint32_t)n_ranges, (uint32_t)segs, ctx->crc_consts,
+              (const uint32_t *)partials);
+  else
+    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
+              d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts,
+              (const uint32_t *)partials, d_single_out);
   HIP_TRY(ctx, hipGetLastError());
   return ZIPC_HIP_OK;
 }

@@ -20,6 +20,7 @@ enum : int { RANGE_INFLATE_OUT = 0, RANGE_DEFLATE_SRC = 1, RANGE_SINGLE = 2 };
 struct CrcConsts {
   uint32_t xpiece[8];
   uint32_t xseg;
+  uint32_t xbyte[48];  // x^(8 * 2^k) mod P: x^(8n) is one multiply per set bit of n
 };
 __global__ void crc32_segments_kernel(const uint8_t *__restrict__ base, int mode,
                                       const StreamDesc *__restrict__ descs,
@@ -32,6 +33,10 @@ __global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ des
                                     uint32_t segs_per_range, CrcConsts K,
                                     const uint32_t *__restrict__ partials,
                                     uint32_t *__restrict__ single_out);
+__global__ void crc32_finish_streams_kernel(int mode, const StreamDesc *__restrict__ descs,
+                                            StreamResult *__restrict__ results, uint32_t n_ranges,
+                                            uint32_t segs_per_range, CrcConsts K,
+                                            const uint32_t *__restrict__ partials);
 __global__ void adler_chunks_kernel(const uint8_t *__restrict__ p, uint64_t n, uint64_t n_chunks,
                                     uint2 *__restrict__ sums);
 constexpr uint32_t ADLER_AMB_CAP = 8192;  // ambiguous-chunk records (16 bytes each)
