@@ -220,6 +220,16 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
   ctx->crc_consts.xseg = gf2_xpow8n(CRC_SEG_BYTES);
   x = 0x00800000u;  // x^8
   for (int k = 0; k < 48; k++) { ctx->crc_consts.xbyte[k] = x; x = gf2_mul(x, x); }
+  {
+    std::vector<uint32_t> nib((size_t)CRC_NIB_CONSTS * GF2_NIB_WORDS);
+    for (int k = 0; k < 8; k++) gf2_nib_table(ctx->crc_consts.xpiece[k], nib.data() + (size_t)k * GF2_NIB_WORDS);
+    gf2_nib_table(ctx->crc_consts.xseg, nib.data() + (size_t)CRC_NIB_XSEG * GF2_NIB_WORDS);
+    if (ctx->ensure(ctx->crc_nib, nib.size() * sizeof(uint32_t)) != hipSuccess ||
+        hipMemcpy(ctx->crc_nib.p, nib.data(), nib.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+      zipc_hip_destroy(ctx);
+      return ZIPC_HIP_ERR_HIP;
+    }
+  }
   *out = ctx;
   return ZIPC_HIP_OK;
 }
@@ -231,7 +241,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   for (auto &p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
-  free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->adler_sums);
+  free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
@@ -302,14 +312,14 @@ static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const St
   uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
   ZD_LAUNCH(ctx, "crc32_segments", crc32_segments_kernel, dim3((unsigned)(n_ranges * segs)), dim3(256), 0,
             base, mode, d_descs, (const StreamResult *)d_results, single_off, single_len,
-            (uint32_t)segs, ctx->crc_consts, partials);
+            (uint32_t)segs, (const uint32_t *)ctx->crc_nib.p, partials);
   if (mode != RANGE_SINGLE && segs <= 16)  // a batch of short streams: one per thread
     ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_streams_kernel, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0,
               mode, d_descs, d_results, (uint32_t)n_ranges, (uint32_t)segs, ctx->crc_consts,
               (const uint32_t *)partials);
   else
     ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
-              d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts,
+              d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts, (const uint32_t *)ctx->crc_nib.p,
               (const uint32_t *)partials, d_single_out);
   HIP_TRY(ctx, hipGetLastError());
   return ZIPC_HIP_OK;

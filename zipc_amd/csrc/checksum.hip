@@ -63,8 +63,10 @@ __device__ __forceinline__ void build_crc_tables(uint32_t (*T)[256], int t) {
 __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
     const uint8_t *__restrict__ base, int mode, const StreamDesc *__restrict__ descs,
     const StreamResult *__restrict__ results, uint64_t single_off, uint64_t single_len,
-    uint32_t segs_per_range, CrcConsts K, uint32_t *__restrict__ partials) {
+    uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials) {
   __shared__ uint32_t T[4][256];
+  __shared__ __attribute__((aligned(16))) uint32_t N[8 * GF2_NIB_WORDS];  // xpiece[0..7] as nibble tables (4 KiB)
+  static_assert(8 * GF2_NIB_WORDS == 4 * CRC_THREADS, "one 16-byte load per thread");
   __shared__ __attribute__((aligned(16))) uint8_t stage[CRC_THREADS * CRC_PIECE_STRIDE];
   __shared__ uint32_t wave_part[CRC_THREADS / 64];
   const int t = threadIdx.x;
@@ -83,6 +85,7 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
   const uint8_t *p = base + off;
   constexpr int UNITS = CRC_SEG / 16 / CRC_THREADS;  // 16-byte units per thread
   u32x4 v[UNITS];
+  const u32x4 nib_mine = ((const u32x4 *)nib)[t];  // in flight with the data
   if (len >= 16) {
     // unit u = i * 256 + t: consecutive threads, consecutive 16 bytes; all loads in flight together
 #pragma unroll
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
     const uint32_t u = (uint32_t)i * CRC_THREADS + (uint32_t)t;
     *(u32x4 *)(stage + (u / (CRC_PIECE / 16)) * CRC_PIECE_STRIDE + (u % (CRC_PIECE / 16)) * 16) = v[i];
   }
+  ((u32x4 *)N)[t] = nib_mine;
   __syncthreads();
   // my piece (Crc_32.string_update's word loop, src/zipc_deflate.ml:141-150; leading
   // zero bytes leave c = 0)
@@ -132,18 +136,20 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
     u = c ^ w.w;
     c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
   }
-  // merge the 256 equal-length pieces: tree over lanes, then over waves
+  // merge the 256 equal-length pieces: tree over lanes, then over waves.  The
+  // multipliers are constants: nibble-table products (the bit-serial gf2_mul here was
+  // two thirds of the kernel's instructions)
 #pragma unroll
   for (int k = 0; k < 6; k++) {
-    uint32_t other = __shfl_down(c, 1u << k, 64);
-    if ((t & ((2 << k) - 1)) == 0) c = gf2_mul(c, K.xpiece[k]) ^ other;
+    const uint32_t other = __shfl_down(c, 1u << k, 64);
+    c = gf2_mul_nib(c, N + k * GF2_NIB_WORDS) ^ other;  // only lanes with (t & ((2 << k) - 1)) == 0 are used further
   }
   if ((t & 63) == 0) wave_part[t >> 6] = c;
   __syncthreads();
   if (t == 0) {
-    uint32_t a = gf2_mul(wave_part[0], K.xpiece[6]) ^ wave_part[1];
-    uint32_t b = gf2_mul(wave_part[2], K.xpiece[6]) ^ wave_part[3];
-    partials[(uint64_t)range * segs_per_range + seg] = gf2_mul(a, K.xpiece[7]) ^ b;
+    const uint32_t a = gf2_mul_nib(wave_part[0], N + 6 * GF2_NIB_WORDS) ^ wave_part[1];
+    const uint32_t b = gf2_mul_nib(wave_part[2], N + 6 * GF2_NIB_WORDS) ^ wave_part[3];
+    partials[(uint64_t)range * segs_per_range + seg] = gf2_mul_nib(a, N + 7 * GF2_NIB_WORDS) ^ b;
   }
 }
 
@@ -188,9 +194,10 @@ __global__ __launch_bounds__(256) void crc32_finish_streams_kernel(
 
 __global__ __launch_bounds__(256) void crc32_finish_kernel(
     int mode, const StreamDesc *__restrict__ descs, StreamResult *__restrict__ results,
-    uint64_t single_len, uint32_t segs_per_range, CrcConsts K,
+    uint64_t single_len, uint32_t segs_per_range, CrcConsts K, const uint32_t *__restrict__ nib,
     const uint32_t *__restrict__ partials, uint32_t *__restrict__ single_out) {
   __shared__ uint32_t sh[256];
+  __shared__ uint32_t NS[GF2_NIB_WORDS];  // xseg as a nibble table
   const int t = threadIdx.x;
   const uint32_t range = blockIdx.x;
   uint64_t off, len;
@@ -208,11 +215,13 @@ __global__ __launch_bounds__(256) void crc32_finish_kernel(
     // right-aligned grid of 256 runs of R partials each
     const uint64_t R = (nseg + 255) / 256;
     const uint64_t padp = 256 * R - nseg;
+    if (t < GF2_NIB_WORDS) NS[t] = nib[CRC_NIB_XSEG * GF2_NIB_WORDS + t];
+    __syncthreads();
     uint32_t c = 0;
     for (uint64_t j = 0; j < R; j++) {
       const int64_t idx = (int64_t)((uint64_t)t * R + j) - (int64_t)padp;
       const uint32_t v = idx >= 0 ? P[idx] : 0u;
-      c = gf2_mul(c, K.xseg) ^ v;
+      c = gf2_mul_nib(c, NS) ^ v;
     }
     sh[t] = c;
     __syncthreads();

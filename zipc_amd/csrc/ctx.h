@@ -30,6 +30,7 @@ struct zipc_hip_ctx {
   Buf io_src, io_dst, io_desc, io_res, io_small;  // staging of the host forms
   Buf pin_src, pin_dst;                           // pinned host memory of the many-stream host forms
   Buf crc_partials, adler_sums;                   // checksum kernels
+  Buf crc_nib;                                    // nibble tables of the CRC merge constants (kernels.h)
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)
 
   int name_index(const char *name);

@@ -22,15 +22,19 @@ struct CrcConsts {
   uint32_t xseg;
   uint32_t xbyte[48];  // x^(8 * 2^k) mod P: x^(8n) is one multiply per set bit of n
 };
+// nibble tables (zd_common.h gf2_mul_nib) of the constant multipliers, in device memory
+// owned by the context: xpiece[0..7], then xseg
+constexpr int CRC_NIB_CONSTS = 9;
+constexpr int CRC_NIB_XSEG = 8;
 __global__ void crc32_segments_kernel(const uint8_t *__restrict__ base, int mode,
                                       const StreamDesc *__restrict__ descs,
                                       const StreamResult *__restrict__ results,
                                       uint64_t single_off, uint64_t single_len,
-                                      uint32_t segs_per_range, CrcConsts K,
+                                      uint32_t segs_per_range, const uint32_t *__restrict__ nib,
                                       uint32_t *__restrict__ partials);
 __global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ descs,
                                     StreamResult *__restrict__ results, uint64_t single_len,
-                                    uint32_t segs_per_range, CrcConsts K,
+                                    uint32_t segs_per_range, CrcConsts K, const uint32_t *__restrict__ nib,
                                     const uint32_t *__restrict__ partials,
                                     uint32_t *__restrict__ single_out);
 __global__ void crc32_finish_streams_kernel(int mode, const StreamDesc *__restrict__ descs,
