@@ -1,0 +1,139 @@
+"""zipc_hip_deflate_many / zipc_hip_inflate_many (include/zipc_hip.h) on batches big and
+ragged enough that the staging runs its chunked form (>= 1024 streams: the arena is cut
+into groups whose host memcpys overlap the bus copies, api.hip many_streams).  Every
+stream's bytes, length, checksum and status against the oracle; guard bytes behind every
+destination.  The archive-level tests (test_gpu_zipc.py) only reach these entry points
+with a handful of members."""
+import ctypes as C
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+GUARD = 16
+ERR_DST_TOO_SMALL = 16
+
+
+def _ragged_inputs(n, seed):
+    rnd = random.Random(seed)
+    big_at = {rnd.randrange(n): rnd.randrange(100_000, 300_000) for _ in range(6)}  # uneven chunks
+    out = []
+    for i in range(n):
+        if i in big_at:
+            ln = big_at[i]
+        elif i % 50 == 7:
+            ln = 0
+        else:
+            ln = rnd.randrange(1, 2000)
+        kind = rnd.randrange(4)
+        if kind == 0:
+            d = util.rand_bytes(ln, seed * 100003 + i)
+        elif kind == 1:
+            d = util.rand_bytes(ln, seed * 100003 + i, 3)
+        elif kind == 2:
+            k = rnd.randrange(1, 40)
+            d = (util.rand_bytes(k, i) * (ln // k + 1))[:ln]
+        else:
+            d = util.text(ln, i)
+        assert len(d) == ln
+        out.append(bytes(d))
+    return out
+
+
+class _Bufs:
+    """n caller-owned destination buffers with guard bytes behind their capacity."""
+
+    def __init__(self, caps):
+        self.caps = list(caps)
+        self.arr = [np.full(c + GUARD, 0xA5, np.uint8) for c in self.caps]
+        n = len(self.caps)
+        self.ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in self.arr])
+        self.cap = (C.c_size_t * n)(*self.caps)
+
+    def bytes(self, i, ln):
+        return self.arr[i][:ln].tobytes()
+
+    def guards_intact(self):
+        return all(bool((a[c:] == 0xA5).all()) for a, c in zip(self.arr, self.caps))
+
+
+def _srcs(datas):
+    keep = [np.frombuffer(d, np.uint8) if d else np.zeros(1, np.uint8) for d in datas]
+    n = len(datas)
+    return keep, (C.c_void_p * n)(*[a.ctypes.data for a in keep]), (C.c_size_t * n)(*[len(d) for d in datas])
+
+
+def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
+    from zipc_amd import _lib
+
+    lib = _lib.lib()
+    n = 2500
+    assert n >= 1024  # below that many_streams() does not cut the arena
+    plain = _ragged_inputs(n, 5)
+    level = 2
+
+    # ---- deflate: one stream gets a destination that cannot hold its output
+    small = next(i for i, d in enumerate(plain) if 500 < len(d) < 2000 and i > 1300)
+    caps = [int(lib.zipc_hip_deflate_bound(len(d))) for d in plain]
+    caps[small] = 3
+    dst = _Bufs(caps)
+    keep, sp, sl = _srcs(plain)
+    res = (_lib.StreamResult * n)()
+    assert lib.zipc_hip_deflate_many(gpu_ctx.handle, n, sp, sl, level, 1, dst.ptrs, dst.cap, res) == 0
+    assert dst.guards_intact()
+    comp = []
+    for i, d in enumerate(plain):
+        if i == small:
+            assert (int(res[i].status), int(res[i].out_len)) == (ERR_DST_TOO_SMALL, 0), i
+            assert bool((dst.arr[i] == 0xA5).all())  # nothing is copied for a failed stream
+            comp.append(oracle.deflate(d, level=level)[1])
+            continue
+        st, want, crc = oracle.deflate(d, level=level, crc_op=oracle.CRC_CRC32)
+        assert st == 0
+        assert int(res[i].status) == 0 and int(res[i].out_len) == len(want), (i, len(d))
+        assert dst.bytes(i, len(want)) == want, (i, len(d))
+        assert int(res[i].checksum) == crc == zlib.crc32(d), i
+        comp.append(want)
+
+    # ---- inflate: a corrupted stream, a truncated one, a stream whose limit is one byte short.
+    # The victims are streams that really compressed (Huffman blocks: flipping bytes of a
+    # stored block only changes the data), and the oracle must reject what was made of them.
+    rnd = random.Random(9)
+    huff = [i for i in range(n) if len(comp[i]) > 120 and len(comp[i]) < 0.8 * len(plain[i])]
+    bad = next(i for i in huff if 600 < i < 900)
+    for attempt in range(50):
+        c = bytearray(comp[bad])
+        for k in range(4, min(60, len(c))):
+            c[k] ^= rnd.randrange(1, 256)
+        if oracle.inflate(bytes(c), decompressed_size=len(plain[bad]))[0] != 0:
+            break
+    comp[bad] = bytes(c)
+    trunc = next(i for i in huff if 1500 < i < 1900)
+    comp[trunc] = comp[trunc][: len(comp[trunc]) // 2]
+    short = next(i for i, d in enumerate(plain) if len(d) > 100 and i > 2000)
+    limits = [len(d) for d in plain]
+    limits[short] -= 1
+    expect_fail = {bad, trunc, short}
+    for i in expect_fail:  # the failure paths are really exercised
+        assert oracle.inflate(comp[i], decompressed_size=limits[i])[0] != 0, i
+    out = _Bufs(limits)
+    keep2, cp, cl = _srcs(comp)
+    lim = (C.c_size_t * n)(*limits)
+    ires = (_lib.StreamResult * n)()
+    assert lib.zipc_hip_inflate_many(gpu_ctx.handle, n, cp, cl, lim, 1, out.ptrs, out.cap, ires) == 0
+    assert out.guards_intact()
+    for i, d in enumerate(plain):
+        st, want, crc = oracle.inflate(comp[i], decompressed_size=limits[i], crc_op=oracle.CRC_CRC32)
+        assert int(ires[i].status) == st, (i, st, int(ires[i].status))
+        assert (st != 0) == (i in expect_fail), i
+        if st != 0:
+            assert int(ires[i].out_len) == 0, i
+            continue
+        assert int(ires[i].out_len) == len(want) and out.bytes(i, len(want)) == want == d, i
+        assert int(ires[i].checksum) == crc, i
+    assert int(ires[short].status) == 2  # "Expected decompression size exceeded"
