@@ -375,12 +375,28 @@ constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the globa
 static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
 static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
 
+#ifdef ZD_MATCH_PHASES  // timing-only build (tools/exp_match_phases.py): clock deltas, data paths untouched
+// Slot = workgroup index mod ZD_PH_SLOTS (plain atomics on one address from every workgroup
+// cost more than the kernel), 8 words each, s_memtime (shader clock) ticks unless noted:
+// [0] sum over waves of staging (entry -> staging barrier)   [1] sum over waves of the match loop
+// [2] waves   [3] slowest wave's loop end - staging barrier   [4] workgroups
+// [5] all waves done - entry   [6] the same in s_memrealtime ticks (100 MHz): calibrates [0..5]
+constexpr int ZD_PH_SLOTS = 1024;
+__device__ unsigned long long zd_match_phases[ZD_PH_SLOTS * 8];
+#endif
+
 __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream, int K, int Kq) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
+#ifdef ZD_MATCH_PHASES
+  __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
+  const unsigned long long ph0 = __builtin_readcyclecounter();
+  const unsigned long long pr0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x < 4) ph_acc[threadIdx.x] = 0;
+#endif
   if (S.error[0]) return;
   // XCD-aware order as in lz_match_kernel: the tiles of a stream re-read each
   // other's windows, so they go to one XCD's L2
@@ -439,6 +455,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if (tid < ((src_end - w0) & 15u)) win_src[n_src + tid] = s[w0 + n_src + tid];
   }
   __syncthreads();
+#ifdef ZD_MATCH_PHASES
+  const unsigned long long ph1 = __builtin_readcyclecounter();
+#endif
   const uint8_t *ws = win_src - w0;       // indexed by stream position
   const uint16_t *wp = win_prev - w0;
   // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
@@ -456,6 +475,28 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     for (int i = 0; i < MATCHW_NP; i++) pbeg[i] = (uint32_t)wbeg + (tid & 63u) + 64u * (uint32_t)i;
     lz_match_runs<MATCHW_NP, true>(ws, len, pbeg, (uint32_t)wend, 64u * MATCHW_NP, wp, K, Kq, S.match + base);
   }
+#ifdef ZD_MATCH_PHASES
+  {
+    const unsigned long long ph2 = __builtin_readcyclecounter();
+    if ((tid & 63u) == 0) {
+      atomicAdd(&ph_acc[0], ph1 - ph0);
+      atomicAdd(&ph_acc[1], ph2 - ph1);
+      atomicAdd(&ph_acc[2], 1ull);
+      atomicMax(&ph_acc[3], ph2);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long *slot = zd_match_phases + (size_t)(blockIdx.x % ZD_PH_SLOTS) * 8;
+      atomicAdd(slot + 0, ph_acc[0]);
+      atomicAdd(slot + 1, ph_acc[1]);
+      atomicAdd(slot + 2, ph_acc[2]);
+      atomicAdd(slot + 3, ph_acc[3] - ph1);
+      atomicAdd(slot + 4, 1ull);
+      atomicAdd(slot + 5, (unsigned long long)__builtin_readcyclecounter() - ph0);
+      atomicAdd(slot + 6, (unsigned long long)__builtin_amdgcn_s_memrealtime() - pr0);
+    }
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -1269,3 +1310,21 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
 }
 
 }  // namespace zd
+
+#ifdef ZD_MATCH_PHASES
+extern "C" int zipc_hip_debug_match_phases(unsigned long long *out8, int reset) {
+  static unsigned long long host[zd::ZD_PH_SLOTS * 8];
+  if (out8) {
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(zd::zd_match_phases), sizeof host) != hipSuccess) return 1;
+    for (int k = 0; k < 8; k++) {
+      out8[k] = 0;
+      for (int sl = 0; sl < zd::ZD_PH_SLOTS; sl++) out8[k] += host[sl * 8 + k];
+    }
+  }
+  if (reset) {
+    for (auto &h : host) h = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_phases), host, sizeof host) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
