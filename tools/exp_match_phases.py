@@ -31,16 +31,16 @@ ms = {k: v[1] / v[0] for k, v in ctx.kernel_times().items()}["lz_match"]
 mhz = wg_wall / (wg_wall_rt / 100.0)  # s_memtime ticks per us, calibrated on s_memrealtime (100 MHz)
 us = lambda ticks: ticks / mhz
 res = batch.results_from_device(d_res)
-tile_cu_us = ms * 1e3 * 256 / (wgs / reps)  # one workgroup per CU at a time
+tile_cu_us = ms * 1e3 * 256 / (wgs / reps)  # one workgroup per CU at a time; slot [4] counts tiles
 wg = us(wg_wall / wgs)
 print(json.dumps({
-    "kernel_ms (timing build; the product kernel is 7.27)": round(ms, 3), "workgroups per launch": wgs // reps,
+    "kernel_ms (timing build; the product kernel is 7.27)": round(ms, 3), "tiles per launch": wgs // reps,
     "all streams ok": bool((res["status"] == 0).all()), "s_memtime MHz (calibrated)": round(mhz, 1),
     "per tile, us": {
         "CU time per tile (kernel time x 256 CUs / tiles)": round(tile_cu_us, 2),
-        "inside the workgroup, entry -> all waves done": round(wg, 2),
-        "staging, mean over waves (entry -> barrier)": round(us(stage / waves), 2),
-        "match loop, mean over waves": round(us(loop / waves), 2),
-        "match loop, slowest wave of the workgroup": round(us(loop_wall / wgs), 2),
+        "inside a workgroup (tile start -> all waves done)": round(wg, 2),
+        "staging, mean over waves (tile start -> window ready)": round(us(stage / waves), 2),
+        "next-window load issue + match loop, mean over waves": round(us(loop / waves), 2),
+        "the same, slowest wave of the workgroup": round(us(loop_wall / wgs), 2),
         "not inside any workgroup (launch, drain)": round(tile_cu_us - wg, 2),
     }}))

@@ -385,48 +385,71 @@ constexpr int ZD_PH_SLOTS = 1024;
 __device__ unsigned long long zd_match_phases[ZD_PH_SLOTS * 8];
 #endif
 
+// What one tile stages: source bytes [w0, src_end) and links [w0, link_end) of its stream
+struct MatchTile {
+  uint32_t t0, w0;            // first position of the tile, first staged position
+  uint32_t src_end;           // one past the last staged source byte
+  uint32_t n_src, n_links;    // staged in whole 16-byte units: source bytes, links
+};
+__device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
+  MatchTile g;
+  g.t0 = tile * MATCHW_TILE;
+  g.w0 = g.t0 > MAX_MATCH_DIST ? g.t0 - MAX_MATCH_DIST : 0;
+  const uint64_t want = (uint64_t)g.t0 + MATCHW_TILE + 264;
+  g.src_end = want < len ? (uint32_t)want : len;
+  g.n_src = (g.src_end - g.w0) & ~15u;  // whole 16-byte units; the rest byte by byte
+  const uint32_t link_end = (uint64_t)g.t0 + MATCHW_TILE < len ? g.t0 + MATCHW_TILE : len;
+  g.n_links = (link_end - g.w0 + 7u) & ~7u;  // the scratch is padded past len
+  return g;
+}
+
+// A workgroup takes tiles_per_group consecutive tiles of one stream.  While the waves
+// walk the chains of a tile out of LDS, the next tile's window is already on its way
+// from L2 into registers (LDS leaves one workgroup of 4 waves per SIMD on a CU, so
+// there are registers to spare); it goes to LDS between two barriers when the last
+// wave is done.  Measured per tile on C2 before this (tools/exp_match_phases.py): 4.4 us
+// between workgroups + 4.3 us staging with nothing else resident, of 29.3 us.
 __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
-                                                                         uint32_t tiles_per_stream, int K, int Kq) {
+                                                                         uint32_t tiles_per_stream,
+                                                                         uint32_t tiles_per_group, int K, int Kq) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
-  const unsigned long long ph0 = __builtin_readcyclecounter();
-  const unsigned long long pr0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long ph0 = __builtin_readcyclecounter();
+  unsigned long long pr0 = __builtin_amdgcn_s_memrealtime();
   if (threadIdx.x < 4) ph_acc[threadIdx.x] = 0;
 #endif
   if (S.error[0]) return;
-  // XCD-aware order as in lz_match_kernel: the tiles of a stream re-read each
+  // XCD-aware order as in lz_match_kernel: the groups of a stream re-read each
   // other's windows, so they go to one XCD's L2
   const uint32_t nb = gridDim.x;
   const uint32_t per_xcd = (nb + 7) / 8;
   const uint32_t logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
-  const uint32_t stream = logical / tiles_per_stream;
-  const uint32_t tile = logical % tiles_per_stream;
+  const uint32_t groups_per_stream = (tiles_per_stream + tiles_per_group - 1) / tiles_per_group;
+  const uint32_t stream = logical / groups_per_stream;
+  const uint32_t group = logical % groups_per_stream;
   if (stream >= n_streams) return;  // grid is padded to a multiple of 8
   const StreamDesc sd = descs[stream];
   if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
   const uint32_t len = (uint32_t)sd.src_len;
-  const uint64_t t0_64 = (uint64_t)tile * MATCHW_TILE;
-  if (t0_64 > len - 4) return;
-  const uint32_t t0 = (uint32_t)t0_64;
-  const uint32_t w0 = t0 > MAX_MATCH_DIST ? t0 - MAX_MATCH_DIST : 0;  // first staged position
+  // tiles [tile, tile_end) of the stream; a tile exists when its first position can start a match
+  const uint32_t stream_tiles = (uint32_t)(((uint64_t)len - 4) / MATCHW_TILE) + 1;
+  uint32_t tile = group * tiles_per_group;
+  if (tile >= stream_tiles) return;
+  const uint32_t tile_end = tile + tiles_per_group < stream_tiles ? tile + tiles_per_group : stream_tiles;
   const uint64_t base = S.pos_base[stream];
   const uint8_t *s = src_arena + sd.src_off;
   const uint32_t tid = threadIdx.x;
-  {  // stage source bytes [w0, t0 + tile + 264) and links [w0, t0 + tile): every
-     // thread first issues all its 16-byte loads, then stores them
-    const uint64_t want = (uint64_t)t0 + MATCHW_TILE + 264;
-    const uint32_t src_end = want < len ? (uint32_t)want : len;
-    const uint32_t n_src = (src_end - w0) & ~15u;  // whole 16-byte units; the rest below
-    const uint32_t link_end = (uint64_t)t0 + MATCHW_TILE < len ? t0 + MATCHW_TILE : len;
-    const uint32_t n_links = (link_end - w0 + 7u) & ~7u;  // the scratch is padded past len
+  constexpr int SRC_ROUNDS = (MATCHW_SRC_BYTES / 16 + MATCHW_THREADS - 1) / MATCHW_THREADS;
+  constexpr int LINK_ROUNDS = (MATCHW_LINKS / 8 + MATCHW_THREADS - 1) / MATCHW_THREADS;
+  u32x4 vs[SRC_ROUNDS], vl[LINK_ROUNDS];
+  // every thread issues all its 16-byte loads of a window at once (clamped, never
+  // conditional: a load behind an if is waited for on the spot) ...
+  auto issue = [&](uint32_t w0, uint32_t n_src, uint32_t n_links) {
     const uint16_t *pv = S.prev + base + w0;
-    constexpr int SRC_ROUNDS = (MATCHW_SRC_BYTES / 16 + MATCHW_THREADS - 1) / MATCHW_THREADS;
-    constexpr int LINK_ROUNDS = (MATCHW_LINKS / 8 + MATCHW_THREADS - 1) / MATCHW_THREADS;
-    u32x4 vs[SRC_ROUNDS], vl[LINK_ROUNDS];
     const uint32_t last_src = n_src ? n_src - 16u : 0u;
     if (n_src == 0) {  // a stream shorter than one unit in a batch of long ones
 #pragma unroll
@@ -435,68 +458,89 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 #pragma unroll
     for (int j = 0; j < SRC_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
-      vs[j] = load16_unaligned(s + w0 + (o < n_src ? o : last_src));  // unconditional: all in flight together
+      vs[j] = load16_unaligned(s + w0 + (o < n_src ? o : last_src));
     }
 #pragma unroll
     for (int j = 0; j < LINK_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
       vl[j] = *(const u32x4 *)(pv + (o < n_links ? o : n_links - 8u));
     }
+  };
+  // ... and stores them to the window later
+  auto store = [&](const MatchTile &g) {
 #pragma unroll
     for (int j = 0; j < SRC_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
-      if (o < n_src) *(u32x4 *)(win_src + o) = vs[j];
+      if (o < g.n_src) *(u32x4 *)(win_src + o) = vs[j];
     }
 #pragma unroll
     for (int j = 0; j < LINK_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
-      if (o < n_links) *(u32x4 *)(win_prev + o) = vl[j];
+      if (o < g.n_links) *(u32x4 *)(win_prev + o) = vl[j];
     }
-    if (tid < ((src_end - w0) & 15u)) win_src[n_src + tid] = s[w0 + n_src + tid];
-  }
+    if (tid < ((g.src_end - g.w0) & 15u)) win_src[g.n_src + tid] = s[g.w0 + g.n_src + tid];
+  };
+  MatchTile g = match_tile(tile, len);
+  issue(g.w0, g.n_src, g.n_links);
+  store(g);
   __syncthreads();
+  for (;;) {
 #ifdef ZD_MATCH_PHASES
-  const unsigned long long ph1 = __builtin_readcyclecounter();
+    const unsigned long long ph1 = __builtin_readcyclecounter();
 #endif
-  const uint8_t *ws = win_src - w0;       // indexed by stream position
-  const uint16_t *wp = win_prev - w0;
-  // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
-  // as MATCHW_NP interleaved runs.  (Handing positions out as lanes finish -- a
-  // wave-uniform counter, ballot + mbcnt -- was measured: -2 % on C2, +7 % on the
-  // long chains of C4; the fixed schedule stays.)
-  const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
-  const uint64_t wbeg = (uint64_t)t0 + (tid / 64u) * per_wave;
-  const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
-  // the parse reads up to PARSE_PAD entries behind the last position without a range test
-  if ((uint64_t)t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
-  if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
-    uint32_t pbeg[MATCHW_NP];
+    // the next tile's window; behind the last tile every load is clamped to one unit
+    const bool has_next = tile + 1 < tile_end;
+    const MatchTile gn = match_tile(has_next ? tile + 1 : tile, len);
+    issue(gn.w0, has_next ? gn.n_src : (gn.n_src ? 16u : 0u), has_next ? gn.n_links : 8u);
+    const uint8_t *ws = win_src - g.w0;  // indexed by stream position
+    const uint16_t *wp = win_prev - g.w0;
+    // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
+    // as MATCHW_NP interleaved runs.  (Handing positions out as lanes finish -- a
+    // wave-uniform counter, ballot + mbcnt -- was measured: -2 % on C2, +7 % on the
+    // long chains of C4; the fixed schedule stays.)
+    const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
+    const uint64_t wbeg = (uint64_t)g.t0 + (tid / 64u) * per_wave;
+    const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
+    // the parse reads up to PARSE_PAD entries behind the last position without a range test
+    if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
+    if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
+      uint32_t pbeg[MATCHW_NP];
 #pragma unroll
-    for (int i = 0; i < MATCHW_NP; i++) pbeg[i] = (uint32_t)wbeg + (tid & 63u) + 64u * (uint32_t)i;
-    lz_match_runs<MATCHW_NP, true>(ws, len, pbeg, (uint32_t)wend, 64u * MATCHW_NP, wp, K, Kq, S.match + base);
-  }
+      for (int i = 0; i < MATCHW_NP; i++) pbeg[i] = (uint32_t)wbeg + (tid & 63u) + 64u * (uint32_t)i;
+      lz_match_runs<MATCHW_NP, true>(ws, len, pbeg, (uint32_t)wend, 64u * MATCHW_NP, wp, K, Kq, S.match + base);
+    }
 #ifdef ZD_MATCH_PHASES
-  {
-    const unsigned long long ph2 = __builtin_readcyclecounter();
-    if ((tid & 63u) == 0) {
-      atomicAdd(&ph_acc[0], ph1 - ph0);
-      atomicAdd(&ph_acc[1], ph2 - ph1);
-      atomicAdd(&ph_acc[2], 1ull);
-      atomicMax(&ph_acc[3], ph2);
+    {
+      const unsigned long long ph2 = __builtin_readcyclecounter();
+      if ((tid & 63u) == 0) {
+        atomicAdd(&ph_acc[0], ph1 - ph0);
+        atomicAdd(&ph_acc[1], ph2 - ph1);
+        atomicAdd(&ph_acc[2], 1ull);
+        atomicMax(&ph_acc[3], ph2);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long *slot = zd_match_phases + (size_t)(blockIdx.x % ZD_PH_SLOTS) * 8;
+        atomicAdd(slot + 0, ph_acc[0]);
+        atomicAdd(slot + 1, ph_acc[1]);
+        atomicAdd(slot + 2, ph_acc[2]);
+        atomicAdd(slot + 3, ph_acc[3] - ph1);
+        atomicAdd(slot + 4, 1ull);  // tiles
+        atomicAdd(slot + 5, (unsigned long long)__builtin_readcyclecounter() - ph0);
+        atomicAdd(slot + 6, (unsigned long long)__builtin_amdgcn_s_memrealtime() - pr0);
+        ph_acc[0] = 0; ph_acc[1] = 0; ph_acc[2] = 0; ph_acc[3] = 0;
+      }
+      ph0 = __builtin_readcyclecounter();
+      pr0 = __builtin_amdgcn_s_memrealtime();
     }
-    __syncthreads();
-    if (tid == 0) {
-      unsigned long long *slot = zd_match_phases + (size_t)(blockIdx.x % ZD_PH_SLOTS) * 8;
-      atomicAdd(slot + 0, ph_acc[0]);
-      atomicAdd(slot + 1, ph_acc[1]);
-      atomicAdd(slot + 2, ph_acc[2]);
-      atomicAdd(slot + 3, ph_acc[3] - ph1);
-      atomicAdd(slot + 4, 1ull);
-      atomicAdd(slot + 5, (unsigned long long)__builtin_readcyclecounter() - ph0);
-      atomicAdd(slot + 6, (unsigned long long)__builtin_amdgcn_s_memrealtime() - pr0);
-    }
-  }
 #endif
+    if (!has_next) break;
+    __syncthreads();  // every wave is done with this tile's window
+    store(gn);
+    __syncthreads();
+    tile++;
+    g = gn;
+  }
 }
 
 // ---------------------------------------------------------------------------------
@@ -1300,8 +1344,13 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   } else {
     const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
     if (n * tps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * tps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, K, K / 4);
+    // consecutive tiles of a stream per workgroup: as many as leave the grid >= 2048
+    // workgroups (8 per CU), so few long streams still spread over the chip
+    size_t tpg = n * tps / 2048;
+    tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
+    const size_t gps = (tps + tpg - 1) / tpg;
+    ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
+              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4);
   }
   ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
