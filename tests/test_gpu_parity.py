@@ -1,6 +1,7 @@
 """Parity of the HIP path against the CPU oracle, through the C ABI
 (include/zipc_hip.h), on a real MI355X.  Bar: bit-exact bytes, identical
 accept/reject status, identical checksums (integer/byte work: no tolerance)."""
+import random
 import zlib
 
 import numpy as np
@@ -288,6 +289,75 @@ def test_deflate_batch_ragged_equals_oracle(gpu_ctx, oracle):
                 assert int(res["out_len"][i]) == len(c0), (names[i], level)
                 assert out[o:o + len(c0)].tobytes() == c0, (names[i], level)
                 assert res["checksum"][i] == k0, (names[i], level, crc_op)
+
+
+def _grouped_tile_streams(n, max_len, seed):
+    """Ragged streams for the window kernel's grouped form: lengths around the multiples of
+    its 16 384-position tile, data of several entropies (numpy-generated: tens of MB)."""
+    from zipc_amd import synth
+
+    rnd = random.Random(seed)
+    specials = [16384 * k + d for k in range(1, max_len // 16384 + 1) for d in (-5, -4, -3, -1, 0, 1, 3, 4, 5)]
+    specials = [x for x in specials if 0 < x <= max_len] + [0, 1, 3, 4, 5, max_len]
+    out = []
+    for i in range(n):
+        ln = specials[i] if i < len(specials) else rnd.randrange(4, max_len + 1)
+        kind = i % 7
+        if kind < 5:
+            d = synth.stream_bytes_np(9, i, ln, (1, 2, 3, 4, 8)[kind]).tobytes()
+        elif kind == 5:  # periodic: long matches, l == maxlen exits, chains at the cap
+            k = rnd.randrange(1, 300)
+            d = (synth.stream_bytes_np(9, i, k, 8).tobytes() * (ln // k + 1))[:ln]
+        else:  # two alternating regimes: chain lengths differ a lot between tiles of one stream
+            a = synth.stream_bytes_np(9, i, ln, 2).tobytes()
+            b = synth.stream_bytes_np(9, i, ln, 8).tobytes()
+            d = b"".join((a if (q // 20000) % 2 else b)[q:q + 20000] for q in range(0, ln, 20000))
+        assert len(d) == ln
+        out.append(d)
+    return out
+
+
+def test_deflate_grouped_tiles_ragged_equals_oracle(gpu_ctx, oracle):
+    """lz_match_window_kernel with several tiles per workgroup (deflate.hip: taken when
+    n_streams x tiles_per_stream / 2048 > 1) on a ragged batch: streams that end inside a
+    group, groups that start behind a stream's end, a group size that does not divide the
+    tile count.  Every stream's bytes against the oracle.  (The full-size tests sample the
+    grouped form on uniform streams only.)"""
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    n, max_len = 700, 150000
+    tps = (max_len + 16383) // 16384
+    tpg = max(1, min(tps, n * tps // 2048))  # the host's rule (launch_deflate)
+    assert tpg > 1 and tps % tpg != 0, (tps, tpg)
+    streams = _grouped_tile_streams(n, max_len, 21)
+    assert max(len(s) for s in streams) == max_len
+    src_off = np.cumsum([0] + [(len(s) + 15) // 16 * 16 for s in streams[:-1]]).astype(np.uint64)
+    caps = [batch.deflate_bound(len(s)) for s in streams]
+    slots = [(c + 255) // 256 * 256 for c in caps]
+    dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+    descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+    arena = np.zeros(int(src_off[-1]) + len(streams[-1]) + 64, np.uint8)
+    for o, s in zip(src_off, streams):
+        arena[int(o):int(o) + len(s)] = np.frombuffer(s, np.uint8)
+    src = torch.from_numpy(arena).to(dev)
+    d_descs = batch.to_device(descs, dev)
+    total = int(sum(len(s) for s in streams))
+    for level in (2, 1):
+        dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        batch.deflate_batch(gpu_ctx, src, dst, d_descs, d_res, n, max_len, total, level, 1)
+        res = batch.results_from_device(d_res)
+        out = dst.cpu().numpy()
+        for i, s in enumerate(streams):
+            st0, c0, k0 = oracle.deflate(s, level=level, crc_op=oracle.CRC_CRC32)
+            assert res["status"][i] == 0, (i, len(s), level)
+            o = int(dst_off[i])
+            assert int(res["out_len"][i]) == len(c0), (i, len(s), level)
+            assert out[o:o + len(c0)].tobytes() == c0, (i, len(s), level)
+            assert res["checksum"][i] == k0, (i, len(s), level)
 
 
 def test_deflate_dst_too_small_is_reported(gpu_ctx):
