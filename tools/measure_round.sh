@@ -1,0 +1,34 @@
+#!/bin/bash
+# The round's measurement set, one command: bench.py (default flags, with cpu_baseline), the
+# rocprofv3 --kernel-trace --stats summary of the same command, the FETCH_SIZE / WRITE_SIZE
+# PMC passes (separate runs), bench.py under torch.distributed.run with one process, the
+# other BASELINE configs and the PCIe-inclusive host forms.  Run on the GPU box:
+#   gpurun -- 'bash tools/measure_round.sh r1j'      -> gpurun_out/r1j/*
+# The PMC passes rewrite profiles/r01_hbm_traffic.json on the box BEFORE the final bench.py
+# run, so that run's roofline.traffic comes from counters of the same build; the file is
+# also copied to the output directory.
+set -u
+TAG=${1:-run}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B="$ROOT/bench.py"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmcF" -o p --output-format csv -- python3 "$B" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmcF.log" 2>&1 || echo "FETCH_SIZE pass failed"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmcW" -o p --output-format csv -- python3 "$B" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmcW.log" 2>&1 || echo "WRITE_SIZE pass failed"
+python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" --hbm-json "$ROOT/profiles/r01_hbm_traffic.json" && cp "$ROOT/profiles/r01_hbm_traffic.json" "$OUT/hbm_traffic.json"
+python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" > "$OUT/pmc_hbm.txt"
+python3 "$B" > "$OUT/bench.json" 2> "$OUT/bench.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python3 "$B" --no-cpu-baseline > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || echo "kernel-trace pass failed"
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 "$B" --gpus 1 --no-cpu-baseline > "$OUT/torchrun.json" 2> "$OUT/torchrun.err" || echo "torchrun failed"
+cd "$ROOT"
+python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
+python3 tools/bench_host_forms.py > "$OUT/host_forms.json" 2> /dev/null
+echo "== bench"; python3 -c "
+import json,sys
+d=json.load(open('$OUT/bench.json'))
+print({k:d[k] for k in ('value','ms_per_step','deflate_gib_s','inflate_gib_s')}); print(d['roofline']); print(d['cpu_baseline']); print({k:round(v,3) for k,v in d['kernels_ms_per_step'].items()})"
+echo "== rocprofv3 kernel stats (same command)"; head -12 "$OUT/trace/"*kernel_stats.csv | cut -d, -f1-6
+echo "== torchrun"; cut -c1-200 "$OUT/torchrun.json"
+echo "== configs"; cut -c1-260 "$OUT/configs.jsonl"
+echo "== host forms"; cat "$OUT/host_forms.json"
