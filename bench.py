@@ -59,6 +59,32 @@ def measured_traffic(kernel):
         return None, None
 
 
+SHADER_CLOCK_HZ = 2.38e9  # s_memtime against s_memrealtime under load, profiles/r01_match_phases.txt
+
+
+def issue_bound(kernel, launch_ms):
+    """What the instruction-issue ports allow for `kernel`, from the committed SQ counter pass
+    (profiles/*sq_counters.json, tools/exp_sq_counters.sh): a SIMD issues one wave64 vector
+    instruction per 4 clocks (1024 SIMDs), a CU one scalar instruction per clock for all its
+    waves (256 CUs).  None of the path's kernels is bound by HBM or MFMA; this is the bound
+    that is close."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"][kernel]
+        vec = k["SQ_INSTS_VALU"] * 4 / (1024 * SHADER_CLOCK_HZ) * 1e3
+        sca = (k["SQ_INSTS_SALU"] + k["SQ_INSTS_BRANCH"] + k.get("SQ_INSTS_SMEM", 0)) / (256 * SHADER_CLOCK_HZ) * 1e3
+        bound = max(vec, sca)
+        return {"vector_ms": vec, "scalar_ms": sca, "launch_ms": launch_ms, "frac": bound / launch_ms if launch_ms else None,
+                "clock_hz": SHADER_CLOCK_HZ, "source": os.path.basename(files[-1]),
+                "is": "max(vector, scalar) issue time / measured launch time; counters from a separate profiled run"}
+    except Exception:
+        return None
+
+
 def cpu_baseline(config_id, bits, level, stream_len, budget_s=15.0):
     """The oracle (C port of the reference algorithm) on this host, 1 thread, on a
     bounded sample of the same workload."""
@@ -236,6 +262,9 @@ def main():
             line["roofline"]["traffic_fetch_bounds"] = [traffic["fetch_bytes"], 2 * traffic["fetch_bytes"]]
             line["roofline"]["traffic_write"] = traffic["write_bytes"]
             line["roofline"]["traffic_is"] = "raw FETCH_SIZE+WRITE_SIZE per launch (L2->fabric, lower bound on reads)"
+        ib = issue_bound(dom, dom_ms)
+        if ib:
+            line["roofline"]["issue_bound"] = ib
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(2, args.bits, args.level, L)
         print(json.dumps(line))

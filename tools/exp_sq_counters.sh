@@ -18,4 +18,5 @@ for ctrs in "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_
 done
 cd "$ROOT"
 python3 tools/pmc_report.py "$OUT/*/*counter_collection.csv" | tee "$OUT/summary.txt"
+python3 tools/pmc_report.py "$OUT/*/*counter_collection.csv" --sq-json "$OUT/sq_counters.json"
 grep -h '"ms"' "$OUT"/p1.log | tail -1 >> "$OUT/summary.txt"
