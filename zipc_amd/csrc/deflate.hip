@@ -1346,7 +1346,9 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
     if (n * tps > 0x7FFFFFFFull) return hipErrorInvalidValue;
     // consecutive tiles of a stream per workgroup: as many as leave the grid >= 2048
     // workgroups (8 per CU), so few long streams still spread over the chip
-    size_t tpg = n * tps / 2048;
+    // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
+    static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
+    size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 2048;
     tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
     const size_t gps = (tps + tpg - 1) / tpg;
     ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
