@@ -172,9 +172,8 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       for (uint32_t wbeg = 0; wbeg + 4 <= len; wbeg += 1024) {
         const uint32_t wend = wbeg + 1024 < len - 3 ? wbeg + 1024 : len - 3;
         for (uint32_t lane = 0; lane < 64; lane++) {
-          const uint32_t pb[2] = {wbeg + lane, wbeg + lane + 64};
-          lz_match_runs<2, true>(padded.data(), len, pb, wend, 128, prev.data(), K, K / 4, match2.data());
-          lz_match_runs<1, false>(src, len, pb, wend, 64, prev.data(), K, K / 4, match3.data());
+          lz_match_runs<2, true>(padded.data(), len, wbeg + lane, 64, wend, prev.data(), K, K / 4, match2.data());
+          lz_match_runs<1, false>(src, len, wbeg + lane, 64, wend, prev.data(), K, K / 4, match3.data());
         }
       }
       for (uint32_t p = 0; p + 4 <= len; p++)

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     const uint8_t *ws = win_src - g.w0;  // indexed by stream position
     const uint16_t *wp = win_prev - g.w0;
     // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
-    // as MATCHW_NP interleaved runs.  (Handing positions out as lanes finish -- a
+    // walked by MATCHW_NP run slots that share the lane's cursor.  (Handing positions out as lanes finish -- a
     // wave-uniform counter, ballot + mbcnt -- was measured: -2 % on C2, +7 % on the
     // long chains of C4; the fixed schedule stays.)
     const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
@@ -504,10 +504,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     // the parse reads up to PARSE_PAD entries behind the last position without a range test
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
-      uint32_t pbeg[MATCHW_NP];
-#pragma unroll
-      for (int i = 0; i < MATCHW_NP; i++) pbeg[i] = (uint32_t)wbeg + (tid & 63u) + 64u * (uint32_t)i;
-      lz_match_runs<MATCHW_NP, true>(ws, len, pbeg, (uint32_t)wend, 64u * MATCHW_NP, wp, K, Kq, S.match + base);
+      lz_match_runs<MATCHW_NP, true>(ws, len, (uint32_t)wbeg + (tid & 63u), 64u, (uint32_t)wend, wp, K, Kq, S.match + base);
     }
 #ifdef ZD_MATCH_PHASES
     {

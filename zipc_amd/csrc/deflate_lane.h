@@ -237,14 +237,23 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
   }
   return false;
 }
-// Runs with a fixed schedule: run i takes pbeg[i], pbeg[i] + stride, ...  (Handing
-// positions out as lanes finish was measured and lost on C2)
+// A lane's positions are first, first + step, first + 2 step, ... < pend.  Its NP run
+// slots draw from ONE cursor over them: a slot that finishes a position takes the
+// lane's next one, whichever slot that is.  (With the positions split into NP fixed
+// runs a lane needed max over its runs of the run's steps and the early slot idled;
+// now it needs about the sum / NP.  No cross-lane traffic -- handing positions out
+// across the wave was measured and lost on C2)  Results are
+// stored per position, so the order in which a lane takes them does not matter.
 template <int NP, bool WORDS>
-ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, uint32_t pend, uint32_t stride,
+ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uint32_t step, uint32_t pend,
                          const uint16_t *prev, int K, int Kq, uint64_t *out) {
   MatchRun r[NP];
+  uint32_t cursor = first;
 #pragma unroll
-  for (int i = 0; i < NP; i++) match_run_start<WORDS>(r[i], s, len, pbeg[i], pend, prev);
+  for (int i = 0; i < NP; i++) {
+    match_run_start<WORDS>(r[i], s, len, cursor, pend, prev);
+    cursor = cursor < pend ? cursor + step : cursor;  // stays put once past the end (no wrap)
+  }
   // On the GPU the loop is left by the whole wave at once (the exit test is
   // wave-uniform): that keeps it ONE loop whose iterations mix positions, instead
   // of a loop per position that the lanes would have to leave together.
@@ -252,8 +261,10 @@ ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, const uint32_t *pbeg, u
     bool alive = false;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      if (match_run_step<WORDS>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out))
-        match_run_start<WORDS>(r[i], s, len, r[i].p + stride, pend, prev);
+      if (match_run_step<WORDS>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out)) {
+        match_run_start<WORDS>(r[i], s, len, cursor, pend, prev);
+        cursor = cursor < pend ? cursor + step : cursor;
+      }
       alive |= r[i].alive;
     }
 #if defined(__HIP_DEVICE_COMPILE__)
