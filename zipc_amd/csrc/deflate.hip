@@ -368,7 +368,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
 // takes divergent addresses, out of LDS a wave's 64 addresses go in a few clocks.
 constexpr uint32_t MATCHW_THREADS = 1024;
 constexpr uint32_t MATCHW_TILE = 16384;
-constexpr int MATCHW_NP = 2;  // runs per lane
+constexpr int MATCHW_NP = 2;  // run slots per lane.  3 and 4 measured on C2 with the shared cursor: +3 % and +7.5 % (and
+                               // +3 % / +8 % on 1 MiB streams of 3-bit symbols): the loop is nearer its vector bound than latency-bound
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
