@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Phase times inside deflate_emit_kernel, from a timing-only build of the library
-(-DZD_EMIT_PHASES: the per-stream results carry s_memtime deltas instead of lengths).
+(-DZD_EMIT_PHASES: the per-stream results carry s_memtime deltas, shader-clock ticks, instead of lengths).
 ZIPC_HIP_LIB must point at that build."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,5 +19,8 @@ res = batch.results_from_device(d_res)
 tot = res["checksum"].astype(np.float64) * 16
 hist = (res["out_len"] & 0xFFFFFFFF).astype(np.float64) * 16
 code = (res["out_len"] >> 32).astype(np.float64) * 16
-print("per stream, s_memtime ticks (100 MHz): total %.0f  histogram %.0f  codes %.0f  pack+rest %.0f"
-      % (tot.mean(), hist.mean(), code.mean(), (tot - hist - code).mean()))
+MHZ = 2381.0  # s_memtime is the shader clock; calibrated against s_memrealtime in tools/exp_match_phases.py
+us = lambda t: t / MHZ
+print("per stream, us (s_memtime at %.0f MHz): total %.1f  histogram %.1f  codes %.1f  pack+rest %.1f   (streams %d)"
+      % (MHZ, us(tot.mean()), us(hist.mean()), us(code.mean()), us((tot - hist - code).mean()), n))
+print("slowest / mean stream: %.2f ; p99 / mean: %.2f" % (tot.max() / tot.mean(), np.percentile(tot, 99) / tot.mean()))
