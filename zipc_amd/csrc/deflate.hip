@@ -583,12 +583,17 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   // the wait counters stay exact and nothing waits for the newest requests.
   // (lz_match zeroes the PARSE_PAD table entries behind the last position, so
   // the table is read without a range test; source bytes past the end are never used)
+  // (addresses are a wave-uniform base, made scalar explicitly, plus a small lane part:
+  // per-lane 64-bit address arithmetic costs vector instructions this kernel is bound by)
   auto load_match = [&](uint32_t tile) -> uint64_t {
-    return has_match ? match[(uint64_t)tile + (uint32_t)lane] : 0ull;  // uniform condition
+    const uint64_t *mt = match + (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);  // the tile's entries
+    return has_match ? mt[lane] : 0ull;  // uniform condition
   };
   auto load_lit = [&](uint32_t tile) -> uint32_t {
-    const uint64_t i = (uint64_t)tile + (uint32_t)lane;
-    return s[i < len ? i : (uint64_t)(len - 1)];  // len >= 1 inside the loop
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    const uint32_t tc = t < len ? t : len - 1;  // len >= 1 inside the loop; len <= 0xFFFFFFF0: no wrap below
+    const uint32_t i = tc + (uint32_t)lane;
+    return s[i < len ? i : len - 1];
   };
   uint64_t m_cur = 0, m_nxt = 0;
   uint32_t lit_cur = 0, lit_nxt = 0;
@@ -683,8 +688,10 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     if (next_entry > len) next_entry = len;
     // symbol indices: exclusive scan of cnt over the visited lanes
     const uint32_t incl = wave_scan_incl(visited ? cnt : 0u);
-    const uint32_t total = __shfl(incl, 63, 64);
-    const uint32_t first = nsym + incl - (visited ? cnt : 0u);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);  // scalar: nsym stays in an SGPR
+    const uint32_t first_rel = incl - (visited ? cnt : 0u);  // within the tile's symbols (< 64 * 513)
+    const uint32_t first = nsym + first_rel;
+    uint32_t *tsyms = syms + nsym;  // scalar base of the tile's symbols
     // symbols (lz_emit_position): a literal position writes its byte, a match
     // position its deferral literals -- the bytes of the next positions, taken
     // from their lanes -- then its match
@@ -694,22 +701,24 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
       while (__builtin_amdgcn_ballot_w64(lit_run && k < lits)) {  // rarely more than one turn
         const uint32_t at = (uint32_t)lane + k;
         const uint32_t a = lane_value((at & 63u) * 4u, lit_cur), b2 = lane_value((at & 63u) * 4u, lit_nxt);
-        if (lit_run && k < lits) syms[first + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
+        if (lit_run && k < lits) tsyms[first_rel + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
         k++;
       }
-      if (visited) syms[first + (br ? lits : 0u)] = br ? br : lit_cur;
+      if (visited) tsyms[first_rel + (br ? lits : 0u)] = br ? br : lit_cur;
     }
     // block cut: the first visited node that ends past blk_start + 65534
-    const uint64_t limit = (uint64_t)blk_start + MAX_BLOCK_SRC_LEN;
-    const unsigned long long cb = __ballot(visited && (uint64_t)p + adv > limit);
+    // (a visited position is at or behind blk_start, so the test runs on 32-bit
+    // distances from it; lanes that are not visited are masked out)
+    const uint32_t rel = p - blk_start;
+    const unsigned long long cb = __ballot(visited && rel + adv > (uint32_t)MAX_BLOCK_SRC_LEN);
     if (cb) {
       const int c = __ffsll((long long)cb) - 1;
       uint32_t cutpos, symidx;
       if (br == 0) { cutpos = p; symidx = first; }
-      else if ((uint64_t)p + lits > limit) { const uint32_t i = (uint32_t)(limit - p); cutpos = p + i; symidx = first + i; }
+      else if (rel + lits > (uint32_t)MAX_BLOCK_SRC_LEN) { const uint32_t i = (uint32_t)MAX_BLOCK_SRC_LEN - rel; cutpos = p + i; symidx = first + i; }
       else { cutpos = p + lits; symidx = first + lits; }
-      cutpos = __shfl(cutpos, c, 64);
-      symidx = __shfl(symidx, c, 64);
+      cutpos = (uint32_t)__builtin_amdgcn_readlane((int)cutpos, c);  // scalar: the block bookkeeping stays in SGPRs
+      symidx = (uint32_t)__builtin_amdgcn_readlane((int)symidx, c);
       if (lane == 0) {
         BlockDesc b;
         b.src_start = blk_start; b.src_len = cutpos - blk_start;
