@@ -189,14 +189,21 @@ typedef struct zipc_hip_stream_result_s {
 /* All pointers are DEVICE pointers (descs and results too).  Work is enqueued
  * on the context stream and NOT synchronised: call zipc_hip_synchronize (or
  * synchronise the stream) before reading results. */
-/* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). */
+/* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream
+ * whose output is longer than that reports ZIPC_HIP_ERR_INVALID_ARG in its result when a
+ * CRC-32 is asked for (its checksum would cover only a part). A descriptor with src_len or
+ * dst_cap above 0xFFFFFFF0 reports ZIPC_HIP_ERR_INVALID_ARG in its own result. */
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs,
                            zipc_hip_stream_result *d_results, size_t n_streams,
                            size_t max_dst_cap, int crc_op);
 
-/* max_src_len: upper bound of src_len over the batch (sizes the scratch);
- * total_src_len: sum of src_len over the batch. */
+/* max_src_len: upper bound of src_len over the batch (sizes the kernels' grids);
+ * total_src_len: sum of src_len over the batch (sizes the scratch). Both are checked on the
+ * device against the descriptors: if a stream is longer than max_src_len or the sum exceeds
+ * total_src_len, EVERY stream of the batch reports ZIPC_HIP_ERR_INVALID_ARG and nothing is
+ * compressed. max_src_len above 0xFFFFFFF0 fails the call; a single descriptor with src_len
+ * or dst_cap above 0xFFFFFFF0 reports ZIPC_HIP_ERR_INVALID_ARG in its own result only. */
 int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs,
                            zipc_hip_stream_result *d_results, size_t n_streams,

@@ -360,6 +360,109 @@ def test_deflate_grouped_tiles_ragged_equals_oracle(gpu_ctx, oracle):
             assert res["checksum"][i] == k0, (i, len(s), level)
 
 
+def test_batch_declared_sizes_are_checked(gpu_ctx, oracle):
+    """What include/zipc_hip.h promises about max_src_len / total_src_len / max_dst_cap and about
+    descriptors beyond the format's range: the library reports ZIPC_HIP_ERR_INVALID_ARG -- it
+    never compresses a stream in part or sums a part of it."""
+    import torch
+
+    from zipc_amd import _lib, batch
+
+    INVALID = 18
+    dev = torch.device("cuda", 0)
+    plain = [util.text(5000, 1), util.rand_bytes(3000, 2, 3), util.text(200000, 3), util.rand_bytes(7000, 4)]
+    lens = [len(p) for p in plain]
+    src_off = np.cumsum([0] + [(l + 15) // 16 * 16 for l in lens[:-1]]).astype(np.uint64)
+    caps = [batch.deflate_bound(l) for l in lens]
+    dst_off = np.cumsum([0] + [(c + 255) // 256 * 256 for c in caps[:-1]]).astype(np.uint64)
+    arena = np.zeros(int(src_off[-1]) + lens[-1] + 64, np.uint8)
+    for o, pl in zip(src_off, plain):
+        arena[int(o):int(o) + len(pl)] = np.frombuffer(pl, np.uint8)
+    src = torch.from_numpy(arena).to(dev)
+    dst = torch.zeros(int(dst_off[-1]) + caps[-1] + 256, dtype=torch.uint8, device=dev)
+    n = len(plain)
+
+    def deflate(descs, max_len, total, crc_op=1):
+        d_res = torch.full((n * 16,), 0xEE, dtype=torch.uint8, device=dev)
+        batch.deflate_batch(gpu_ctx, src, dst, batch.to_device(descs, dev), d_res, n, max_len, total, 2, crc_op)
+        return batch.results_from_device(d_res), dst.cpu().numpy()
+
+    honest = batch.make_descs(src_off, lens, dst_off, caps)
+    want = [oracle.deflate(pl, level=2, crc_op=oracle.CRC_CRC32) for pl in plain]
+
+    def exact(res, out, which):
+        for i in which:
+            st0, c0, k0 = want[i]
+            assert res["status"][i] == 0 and int(res["out_len"][i]) == len(c0) and res["checksum"][i] == k0, i
+            assert out[int(dst_off[i]):int(dst_off[i]) + len(c0)].tobytes() == c0, i
+
+    # honest declarations: every stream exact (the control for what follows)
+    res, out = deflate(honest, max(lens), sum(lens))
+    exact(res, out, range(n))
+    # a stream longer than the declared max_src_len: the whole batch is refused
+    for crc_op in (0, 1, 2):
+        res, _ = deflate(honest, 10000, sum(lens), crc_op)
+        assert (res["status"] == INVALID).all() and (res["out_len"] == 0).all(), crc_op
+    # the sum longer than the declared total_src_len: the same
+    res, _ = deflate(honest, max(lens), 50000)
+    assert (res["status"] == INVALID).all() and (res["out_len"] == 0).all()
+    # ... and the next honest call on the same context is exact again (nothing sticks)
+    res, out = deflate(honest, max(lens), sum(lens))
+    exact(res, out, range(n))
+    # one descriptor beyond the format's range (its bytes are never touched): only that stream fails
+    lying = honest.copy()
+    lying["src_len"][1] = 1 << 32
+    res, out = deflate(lying, max(lens), sum(lens) - lens[1])
+    assert res["status"][1] == INVALID and res["out_len"][1] == 0
+    exact(res, out, (0, 2, 3))
+    lying = honest.copy()
+    lying["dst_cap"][3] = 1 << 33
+    res, out = deflate(lying, max(lens), sum(lens))
+    assert res["status"][3] == INVALID and res["out_len"][3] == 0
+    exact(res, out, (0, 1, 2))
+    # max_src_len itself out of range: the call fails, nothing is launched
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    assert _lib.lib().zipc_hip_deflate_batch(gpu_ctx.handle, src.data_ptr(), dst.data_ptr(),
+                                             batch.to_device(honest, dev).data_ptr(), d_res.data_ptr(), n, 1 << 32,
+                                             sum(lens), 2, 1) == INVALID
+
+    # ---- inflate side
+    comp = [w[1] for w in want]
+    c_off = np.cumsum([0] + [(len(c) + 15) // 16 * 16 for c in comp[:-1]]).astype(np.uint64)
+    carena = np.zeros(int(c_off[-1]) + len(comp[-1]) + 64, np.uint8)
+    for o, c in zip(c_off, comp):
+        carena[int(o):int(o) + len(c)] = np.frombuffer(c, np.uint8)
+    csrc = torch.from_numpy(carena).to(dev)
+    o_off = np.cumsum([0] + [(l + 255) // 256 * 256 + 256 for l in lens[:-1]]).astype(np.uint64)
+    odst = torch.zeros(int(o_off[-1]) + lens[-1] + 512, dtype=torch.uint8, device=dev)
+
+    def inflate(descs, max_cap, crc_op=1):
+        d_res = torch.full((n * 16,), 0xEE, dtype=torch.uint8, device=dev)
+        batch.inflate_batch(gpu_ctx, csrc, odst, batch.to_device(descs, dev), d_res, n, max_cap, crc_op)
+        return batch.results_from_device(d_res), odst.cpu().numpy()
+
+    def plain_back(res, out, which):
+        for i in which:
+            assert res["status"][i] == 0 and int(res["out_len"][i]) == lens[i], i
+            assert out[int(o_off[i]):int(o_off[i]) + lens[i]].tobytes() == plain[i], i
+            assert res["checksum"][i] == zlib.crc32(plain[i]), i
+
+    ihonest = batch.make_descs(c_off, [len(c) for c in comp], o_off, lens, limit=lens)
+    res, out = inflate(ihonest, max(lens))
+    plain_back(res, out, range(n))
+    # an output longer than the declared max_dst_cap, CRC-32 asked for: that stream is refused, not half-summed
+    res, out = inflate(ihonest, 40000)
+    assert res["status"][2] == INVALID
+    plain_back(res, out, (0, 1, 3))
+    # descriptors beyond the range
+    for field in ("src_len", "dst_cap"):
+        lying = ihonest.copy()
+        lying[field][0] = 1 << 32
+        res, out = inflate(lying, max(lens))
+        assert res["status"][0] == INVALID and res["out_len"][0] == 0, field
+        plain_back(res, out, (1, 2, 3))
+
+
 def test_deflate_dst_too_small_is_reported(gpu_ctx):
     import ctypes as C
 

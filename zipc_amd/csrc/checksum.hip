@@ -184,10 +184,15 @@ __global__ __launch_bounds__(256) void crc32_finish_streams_kernel(
   uint64_t off, len;
   get_range(mode, range, descs, results, 0, 0, off, len);
   if (mode == RANGE_INFLATE_OUT && results[range].status != ST_OK) return;
-  const uint32_t nseg = (uint32_t)((len + CRC_SEG - 1) / CRC_SEG);
+  const uint64_t nseg = (len + CRC_SEG - 1) / CRC_SEG;
+  if (nseg > segs_per_range) {  // longer than the caller declared (max_src_len / max_dst_cap): only part of it was summed
+    results[range].status = ST_INVALID_ARG;
+    results[range].checksum = 0;
+    return;
+  }
   const uint32_t *P = partials + (uint64_t)range * segs_per_range;
   uint32_t raw = 0;
-  for (uint32_t j = 0; j < nseg; j++) raw = gf2_mul(raw, K.xseg) ^ P[j];
+  for (uint32_t j = 0; j < (uint32_t)nseg; j++) raw = gf2_mul(raw, K.xseg) ^ P[j];
   const uint32_t state = crc_state_advance(0xFFFFFFFFu, raw, xpow8n_tab(K, len));
   results[range].checksum = state ^ 0xFFFFFFFFu;
 }
@@ -204,6 +209,10 @@ __global__ __launch_bounds__(256) void crc32_finish_kernel(
   get_range(mode, range, descs, results, 0, single_len, off, len);
   if (mode == RANGE_INFLATE_OUT && results[range].status != ST_OK) return;
   const uint64_t nseg = (len + CRC_SEG - 1) / CRC_SEG;
+  if (nseg > segs_per_range) {  // see crc32_finish_streams_kernel (uniform per workgroup)
+    if (t == 0 && mode != RANGE_SINGLE) { results[range].status = ST_INVALID_ARG; results[range].checksum = 0; }
+    return;
+  }
   const uint32_t *P = partials + (uint64_t)range * segs_per_range;
   uint32_t raw = 0;
   if (nseg <= 1) {

@@ -51,7 +51,8 @@ struct DeflateScratch {
   uint64_t *pos_base;   // [n] first position slot of stream i
   uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
   uint32_t *n_blocks;   // [n]
-  uint32_t *error;      // [1] != 0: scratch too small for the batch (bad total_src_len)
+  uint32_t *error;      // [1] != 0: the batch does not fit what the caller declared (total_src_len too small,
+                        //     or a stream longer than max_src_len: the grids are sized from it)
   uint16_t *prev;       // [P] chain links
   uint64_t *match;      // [P] lz_match_position: best-of-K | best-of-K/4 << 32
   uint32_t *syms;       // [P]
@@ -103,15 +104,27 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
 // ---------------------------------------------------------------------------------
 // Exclusive scan of the per-stream scratch needs (single workgroup).
 __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc *__restrict__ descs,
-                                                               uint32_t n, DeflateScratch S) {
+                                                               uint32_t n, DeflateScratch S, uint64_t max_src_len) {
   __shared__ uint64_t part_p[1024], part_b[1024];
+  __shared__ uint32_t too_long;
   const uint32_t t = threadIdx.x;
+  if (t == 0) too_long = 0;
+  __syncthreads();
   const uint32_t per = (n + 1023) / 1024;
   const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
   uint64_t sp = 0, sb = 0;
-  for (uint32_t i = lo; i < hi; i++) { sp += padded_positions(descs[i].src_len); sb += max_blocks_of(descs[i].src_len); }
+  bool over = false;
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint64_t l = descs[i].src_len;
+    sp += padded_positions(l);
+    sb += max_blocks_of(l);
+    // a stream beyond the format's range is rejected on its own (above); one beyond what the
+    // caller declared would be matched and checksummed only in part: the whole batch is refused
+    over |= l <= 0xFFFFFFF0ull && l > max_src_len;
+  }
   part_p[t] = sp;
   part_b[t] = sb;
+  if (over) too_long = 1;
   __syncthreads();
   if (t == 0) {
     uint64_t ap = 0, ab = 0;
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
       part_p[i] = ap; part_b[i] = ab;
       ap += vp; ab += vb;
     }
-    S.error[0] = (ap > S.cap_positions || ab > S.cap_blocks) ? 1u : 0u;
+    S.error[0] = (ap > S.cap_positions || ab > S.cap_blocks || too_long) ? 1u : 0u;
   }
   __syncthreads();
   sp = part_p[t];
@@ -1341,7 +1354,8 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   DeflateScratch S = carve(ctx->deflate_scratch.p, n, total_src_len, level);
   int good_match, K;
   level_params(level, good_match, K);
-  ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S);
+  ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S,
+            (uint64_t)max_src_len);
   ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
   if (max_src_len <= MATCHW_SMALL) {  // short streams: a whole-CU window per tile would sit mostly idle
     const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
