@@ -150,12 +150,14 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
  * fit reports ZIPC_HIP_ERR_DST_TOO_SMALL (or the reference's size message when a
  * limit is given) in its own result.  The call itself fails only for bad
  * arguments or HIP errors.
- * Staging: the streams are gathered into a pinned buffer the context keeps (sized
- * to the batch; the first call of a size pays for pinning it) on a few host
- * threads, and cross the bus in a few large copies overlapped with those memcpys.
- * Environment, read once per process: ZIPC_HIP_HOST_THREADS (default 8 or the core
- * count), ZIPC_HIP_HOST_CHUNKS (default 4), ZIPC_HIP_HOST_TIMING=1 (per-stage wall
- * time of every call on stderr; adds stream synchronisations). */
+ * Staging: the call runs as a pipeline of a few sub-batches.  Each is gathered into
+ * pinned memory the context keeps (sized to the batch; the first call of a size pays
+ * for pinning it) on a few host threads, copied H2D, run, copied D2H and scattered to
+ * the caller's buffers, on streams of its own -- so bus copies and kernels of one
+ * sub-batch run under the host memcpys of the others.  Environment, read once per
+ * process: ZIPC_HIP_HOST_THREADS (default 8 or the core count), ZIPC_HIP_HOST_CHUNKS
+ * (sub-batches, default 3; fewer when a sub-batch would hold under 1024 streams),
+ * ZIPC_HIP_HOST_TIMING=1 (wall time of the call's host phases on stderr). */
 struct zipc_hip_stream_result_s;
 int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           int level, int crc_op, void *const *dst, const size_t *dst_cap,

@@ -1,6 +1,7 @@
 """zipc_hip_deflate_many / zipc_hip_inflate_many (include/zipc_hip.h) on batches big and
-ragged enough that the staging runs its chunked form (>= 1024 streams: the arena is cut
-into groups whose host memcpys overlap the bus copies, api.hip many_streams).  Every
+ragged enough that the call runs as a pipeline of several sub-batches (api.hip many_streams:
+3 of them from 3072 streams on, each through gather, H2D, kernels, D2H and scatter on its
+own streams and events).  Every
 stream's bytes, length, checksum and status against the oracle; guard bytes behind every
 destination.  The archive-level tests (test_gpu_zipc.py) only reach these entry points
 with a handful of members."""
@@ -72,13 +73,13 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
     from zipc_amd import _lib
 
     lib = _lib.lib()
-    n = 2500
-    assert n >= 1024  # below that many_streams() does not cut the arena
+    n = 4500
+    assert n // 3 >= 1024  # many_streams() keeps its default of 3 sub-batches only if each holds >= 1024 streams
     plain = _ragged_inputs(n, 5)
     level = 2
 
     # ---- deflate: one stream gets a destination that cannot hold its output
-    small = next(i for i, d in enumerate(plain) if 500 < len(d) < 2000 and i > 1300)
+    small = next(i for i, d in enumerate(plain) if 500 < len(d) < 2000 and i > 2300)
     caps = [int(lib.zipc_hip_deflate_bound(len(d))) for d in plain]
     caps[small] = 3
     dst = _Bufs(caps)
@@ -105,7 +106,7 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
     # stored block only changes the data), and the oracle must reject what was made of them.
     rnd = random.Random(9)
     huff = [i for i in range(n) if len(comp[i]) > 120 and len(comp[i]) < 0.8 * len(plain[i])]
-    bad = next(i for i in huff if 600 < i < 900)
+    bad = next(i for i in huff if 600 < i < 900)       # in the first sub-batch (of about 1500 streams each)
     for attempt in range(50):
         c = bytearray(comp[bad])
         for k in range(4, min(60, len(c))):
@@ -113,9 +114,9 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
         if oracle.inflate(bytes(c), decompressed_size=len(plain[bad]))[0] != 0:
             break
     comp[bad] = bytes(c)
-    trunc = next(i for i in huff if 1500 < i < 1900)
+    trunc = next(i for i in huff if 1700 < i < 2100)   # in the second
     comp[trunc] = comp[trunc][: len(comp[trunc]) // 2]
-    short = next(i for i, d in enumerate(plain) if len(d) > 100 and i > 2000)
+    short = next(i for i, d in enumerate(plain) if len(d) > 100 and i > 4400)  # in the last
     limits = [len(d) for d in plain]
     limits[short] -= 1
     expect_fail = {bad, trunc, short}

@@ -135,13 +135,14 @@ static size_t host_threads() {
   }();
   return nt;
 }
-// ZIPC_HIP_HOST_CHUNKS: groups a batch's arena is cut into so that the host memcpys of
-// one group overlap the bus copy of its neighbour (1 = no overlap)
+// ZIPC_HIP_HOST_CHUNKS: sub-batches a many-stream call is cut into; each goes through
+// gather, H2D, kernels, D2H and scatter on its own, so those overlap (1 = one after the other)
 static size_t host_chunks() {
   static const size_t k = [] {
     const char *e = getenv("ZIPC_HIP_HOST_CHUNKS");
     long v = e ? atol(e) : 0;
-    if (v < 1) v = 4;  // profiles/r01_host_forms_sweep.txt: 1 -> 4 saves ~20%, 4 vs 8 within ~5%
+    if (v < 1) v = 3;  // profiles/r01_host_forms_sweep.txt: medians of 11 calls, 2 / 3 / 4 sub-batches:
+                       // deflate 49 / 41.5 / 55 ms, inflate 45 / 38 / 36 ms (4 has the best single calls, unstable medians)
     return (size_t)(v > 64 ? 64 : v);
   }();
   return k;
@@ -245,6 +246,9 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->deflate_scratch);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
+  if (ctx->pin_res.p) (void)hipHostFree(ctx->pin_res.p);
+  if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+  if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -512,22 +516,15 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // ZIPC_HIP_HOST_TIMING=1: wall time of each stage of this call on stderr (the
-  // stream is synchronised at every mark, so it perturbs what it measures a little)
+  // ZIPC_HIP_HOST_TIMING=1: wall time of the call's three host phases on stderr
   static const bool timing = getenv("ZIPC_HIP_HOST_TIMING") != nullptr;
-  auto t_last = std::chrono::steady_clock::now();
-  double t_ms[6] = {0, 0, 0, 0, 0, 0};  // [0] setup [2] gather+H2D [3] kernels [5] D2H+scatter
-  auto mark = [&](int k) -> hipError_t {
-    if (!timing) return hipSuccess;
-    hipError_t e = hipStreamSynchronize(ctx->stream);
-    auto now = std::chrono::steady_clock::now();
-    t_ms[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
-    t_last = now;
-    return e;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto since = [&](std::chrono::steady_clock::time_point t) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
   };
   std::vector<StreamDesc> descs(n);
   uint64_t so = 0, dof = 0;
-  size_t max_src = 0, max_cap = 0, total_src = 0;
+  size_t max_src = 0, max_cap = 0;
   for (size_t i = 0; i < n; i++) {
     if ((!src[i] && src_len[i]) || (!dst[i] && dst_cap[i])) return ZIPC_HIP_ERR_INVALID_ARG;
     StreamDesc &d = descs[i];
@@ -538,88 +535,124 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     dof += (dst_cap[i] + 255) / 256 * 256 + 256;
     max_src = src_len[i] > max_src ? src_len[i] : max_src;
     max_cap = dst_cap[i] > max_cap ? dst_cap[i] : max_cap;
-    total_src += src_len[i];
   }
-  HIP_TRY(ctx, ctx->ensure(ctx->io_src, so + 64));
-  HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dof + 64));
-  HIP_TRY(ctx, ctx->ensure(ctx->io_desc, n * sizeof(StreamDesc)));
-  HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
-  // the streams are gathered into one pinned buffer (host threads) and cross the bus
-  // as ONE copy: thousands of small pageable copies cost far more than the kernels
-  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
-  HIP_TRY(ctx, mark(0));  // descriptors + buffer (re)allocation
-  // group g = streams [cut[g], cut[g+1]): about equal shares of the source arena
-  const size_t K = n < 1024 ? 1 : host_chunks();
+  if (!is_inflate && max_src > 0xFFFFFFF0ull) return ZIPC_HIP_ERR_INVALID_ARG;  // (inflate reports it per stream)
+  // The batch is cut into K sub-batches of about equal source bytes, and sub-batch g
+  // goes through  gather (host threads, into pinned memory) -> H2D (copy_in) -> kernels
+  // (the context's stream) -> D2H (copy_out) -> scatter (host threads)  on its own, so
+  // the bus copies and kernels of one sub-batch run under the host memcpys of the
+  // others; PCIe is full duplex and the kernels do not touch it.  Thousands of small
+  // pageable copies -- the first version of this function -- cost far more than the
+  // kernels.  K: ZIPC_HIP_HOST_CHUNKS, fewer when sub-batches would get too small to
+  // fill the chip.
+  size_t K = host_chunks();
+  while (K > 1 && n / K < 1024) K--;
   std::vector<size_t> cut(K + 1, n);
   cut[0] = 0;
   for (size_t g = 1, i = 0; g < K; g++) {
     while (i < n && descs[i].src_off < so / K * g) i++;
     cut[g] = i;
   }
-  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
+  size_t n_max = 0, total_max = 0;
   for (size_t g = 0; g < K; g++) {
-    if (cut[g] == cut[g + 1]) continue;
-    parallel_for(cut[g], cut[g + 1], [&](size_t i) {
+    size_t t = 0;
+    for (size_t i = cut[g]; i < cut[g + 1]; i++) t += src_len[i];
+    n_max = cut[g + 1] - cut[g] > n_max ? cut[g + 1] - cut[g] : n_max;
+    total_max = t > total_max ? t : total_max;
+  }
+  // everything is allocated before the first sub-batch is under way (growing a buffer
+  // synchronises the stream)
+  HIP_TRY(ctx, ctx->ensure(ctx->io_src, so + 64));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dof + 64));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_desc, n * sizeof(StreamDesc)));
+  HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
+  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
+  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, dof + 64));
+  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_res, n * sizeof(StreamResult)));
+  if (!is_inflate) {
+    const int st = zipc_hip_reserve(ctx, n_max, max_src, total_max);
+    if (st) return st;
+  }
+  if (crc_op == ZIPC_HIP_CRC_CRC32) {
+    const size_t longest = is_inflate ? max_cap : max_src;
+    size_t segs = (longest + CRC_SEG_BYTES - 1) / CRC_SEG_BYTES;
+    HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_max * (segs ? segs : 1) * sizeof(uint32_t)));
+  }
+  if (!ctx->copy_in) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+  if (!ctx->copy_out) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+  EventSet ev_in, ev_k, ev_out;
+  HIP_TRY(ctx, ev_in.make(K));
+  HIP_TRY(ctx, ev_k.make(K));
+  HIP_TRY(ctx, ev_out.make(K));
+  // earlier work of this context (the previous call's kernels read io_src / io_desc) first
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  const double ms_setup = since(t_begin);
+  const auto t_feed = std::chrono::steady_clock::now();
+  static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
+  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
+  auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
+  int failed = 0;
+  for (size_t g = 0; g < K && !failed; g++) {
+    const size_t lo = cut[g], hi = cut[g + 1];
+    if (lo == hi) continue;
+    parallel_for(lo, hi, [&](size_t i) {
       if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
     });
-    const uint64_t a = src_end(cut[g]), b = src_end(cut[g + 1]);
-    // the copy of this group runs while the host gathers the next one
+    const uint64_t a = src_end(lo), b = src_end(hi);
     HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->io_src.p + a, (const uint8_t *)ctx->pin_src.p + a, b - a,
-                                hipMemcpyHostToDevice, ctx->stream));
+                                hipMemcpyHostToDevice, ctx->copy_in));
+    HIP_TRY(ctx, hipEventRecord(ev_in.ev[g], ctx->copy_in));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
+    zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
+    zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
+    size_t total_g = 0;
+    for (size_t i = lo; i < hi; i++) total_g += src_len[i];
+    if (is_inflate)
+      failed = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op);
+    else
+      failed = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
+    if (failed) break;
+    HIP_TRY(ctx, hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev_k.ev[g], ctx->stream));
+    // the whole destination slots of the sub-batch: what is used of them is only known on the
+    // host, and waiting for that would stall the feeding of the next sub-batch
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
+    const uint64_t c = dst_end(lo), e = dst_end(hi);
+    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
+                                hipMemcpyDeviceToHost, ctx->copy_out));
+    HIP_TRY(ctx, hipEventRecord(ev_out.ev[g], ctx->copy_out));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice,
-                              ctx->stream));
-  HIP_TRY(ctx, mark(2));  // H2D
-  int st;
-  if (is_inflate)
-    st = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
-                                (zipc_hip_stream_result *)ctx->io_res.p, n, max_cap, crc_op);
-  else
-    st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, (zipc_hip_stream_desc *)ctx->io_desc.p,
-                                (zipc_hip_stream_result *)ctx->io_res.p, n, max_src, total_src, level, crc_op);
-  if (st) return st;
-  static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
-  HIP_TRY(ctx, hipMemcpyAsync(results, ctx->io_res.p, n * sizeof(StreamResult), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  HIP_TRY(ctx, mark(3));  // kernels + results
-  uint64_t used = 0;  // the part of the destination arena that holds output
-  for (size_t i = 0; i < n; i++) {
-    if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
-    if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; continue; }
-    if (results[i].out_len) used = descs[i].dst_off + results[i].out_len;
+  if (failed) {  // a batch call refused its arguments or a HIP call failed: nothing is handed out
+    (void)hipStreamSynchronize(ctx->copy_in);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_out);
+    return failed;
   }
-  if (used) {
-    HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, used + 64));
-    // every group's bytes are requested up front; group g is scattered to the caller's
-    // buffers as soon as its copy has landed, while the later ones are still in flight
-    EventSet done;
-    HIP_TRY(ctx, done.make(K));
-    for (size_t g = 0; g < K; g++) {
-      uint64_t a = ~0ull, b = 0;
-      for (size_t i = cut[g]; i < cut[g + 1]; i++)
-        if (results[i].status == ST_OK && results[i].out_len) {
-          if (a == ~0ull) a = descs[i].dst_off;
-          b = descs[i].dst_off + results[i].out_len;
-        }
-      if (b)
-        HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + a, (const uint8_t *)ctx->io_dst.p + a, b - a,
-                                    hipMemcpyDeviceToHost, ctx->stream));
-      HIP_TRY(ctx, hipEventRecord(done.ev[g], ctx->stream));
+  const double ms_feed = since(t_feed);
+  const auto t_drain = std::chrono::steady_clock::now();
+  for (size_t g = 0; g < K; g++) {
+    const size_t lo = cut[g], hi = cut[g + 1];
+    if (lo == hi) continue;
+    HIP_TRY(ctx, hipEventSynchronize(ev_out.ev[g]));  // behind ev_k[g]: the results have landed too
+    const StreamResult *pr = (const StreamResult *)ctx->pin_res.p;
+    for (size_t i = lo; i < hi; i++) {
+      results[i].status = pr[i].status; results[i].checksum = pr[i].checksum; results[i].out_len = pr[i].out_len;
+      if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
+      if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; }
     }
-    for (size_t g = 0; g < K; g++) {
-      HIP_TRY(ctx, hipEventSynchronize(done.ev[g]));
-      parallel_for(cut[g], cut[g + 1], [&](size_t i) {
-        if (results[i].status == ST_OK && results[i].out_len)
-          memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
-      });
-    }
-    HIP_TRY(ctx, mark(5));  // D2H + scatter (overlapped)
+    parallel_for(lo, hi, [&](size_t i) {
+      if (results[i].status == ST_OK && results[i].out_len)
+        memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
+    });
   }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
   if (timing)
-    fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_used=%llu ms: setup %.2f gather+h2d %.2f "
-                    "kernels %.2f d2h+scatter %.2f (threads %zu chunks %zu)\n",
-            is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)used, t_ms[0],
-            t_ms[2], t_ms[3], t_ms[5], host_threads(), K);
+    fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_arena=%llu ms: setup %.2f feed (gather + enqueue) %.2f "
+                    "drain (wait + scatter) %.2f (threads %zu sub-batches %zu)\n",
+            is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)dof, ms_setup, ms_feed,
+            since(t_drain), host_threads(), K);
   return ZIPC_HIP_OK;
 }
 
