@@ -1,7 +1,7 @@
 // deflate.hip -- batch deflate pipeline for gfx950 (CDNA4, wave64).
 //
 // The reference encoder (src/zipc_deflate.ml:742-1277) is one sequential loop per
-// stream.  It is restated as five kernels over a batch of independent streams
+// stream.  It is restated as a handful of kernels over a batch of independent streams
 // (deflate_lane.h explains why each split preserves the output bit for bit):
 //
 //   deflate_offsets_kernel   per-stream bases into the scratch arrays (one scan)
@@ -10,9 +10,15 @@
 //                            zd.ml:1145-1152).  One 1024-thread workgroup per
 //                            stream, the 32 Ki-entry head table as u16 in LDS
 //                            (64 KiB), 1024 positions inserted per round.
-//   lz_match_kernel          one lane per position: best match over the first K and
-//                            the first K/4 chain candidates (find_backref,
-//                            zd.ml:1176-1201) -> 8 bytes per position.
+//   lz_match_window_kernel   best match of every position over the first K and the first
+//                            K/4 chain candidates (find_backref, zd.ml:1176-1201) -> 8
+//                            bytes per position.  A 1024-thread workgroup takes several
+//                            consecutive 16 Ki-position tiles of one stream; a tile's 32 KiB
+//                            window + tile of source and links sits in LDS (144 KiB), the
+//                            next tile's is loaded into registers meanwhile.  A lane walks
+//                            its 16 positions of a tile with 2 run slots on one cursor.
+//   lz_match_kernel          the same for streams of up to 8 KiB, out of global memory,
+//                            4 positions per lane (a whole-CU window would sit idle).
 //   lz_parse_kernel          one wave per stream: the "macro step" of every position
 //                            (deflate_lane.h), then which positions the lazy parse
 //                            visits (Lz77.compress zd.ml:1203-1244), found per
@@ -21,8 +27,8 @@
 //                            cut (zd.ml:1118-1123).
 //   deflate_emit_kernel      one wave per stream, blocks in order: histogram (LDS
 //                            atomics), Huffman codes + stored/fixed/dynamic choice
-//                            (write_block zd.ml:1094-1104, lane 0), then all 64 lanes
-//                            pack bits: wave prefix-scan of the per-symbol bit
+//                            (write_block zd.ml:1094-1104) by the whole wave, then all 64
+//                            lanes pack bits: wave prefix-scan of the per-symbol bit
 //                            lengths, scatter-OR into an LDS staging row, coalesced
 //                            flush of the completed bytes.
 //   deflate_stored_kernel    level `None (write_all_non_compressed zd.ml:1106-1116).
