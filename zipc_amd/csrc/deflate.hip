@@ -423,12 +423,14 @@ __device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
   return g;
 }
 
-// A workgroup takes tiles_per_group consecutive tiles of one stream.  While the waves
-// walk the chains of a tile out of LDS, the next tile's window is already on its way
-// from L2 into registers (LDS leaves one workgroup of 4 waves per SIMD on a CU, so
-// there are registers to spare); it goes to LDS between two barriers when the last
-// wave is done.  Measured per tile on C2 before this (tools/exp_match_phases.py): 4.4 us
-// between workgroups + 4.3 us staging with nothing else resident, of 29.3 us.
+// A workgroup takes tiles_per_group consecutive tiles of one stream: between workgroups
+// a CU sat idle for 4.4 us of a 29.3 us tile on C2 (tools/exp_match_phases.py).  A wave
+// requests its share of the next tile's window into registers as soon as it has walked
+// its own positions -- the faster waves' loads are then in flight while the workgroup
+// waits for its slowest wave -- and the window goes to LDS between two barriers.
+// (Requesting it BEFORE the walk, to hide the whole latency, was the first version and
+// measured slower: the loop ran 3 us longer per tile with the loads in flight, more than
+// the 2.7 us they hid; 6.10-6.20 against 5.80 ms on C2.)
 __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
@@ -466,8 +468,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   constexpr int SRC_ROUNDS = (MATCHW_SRC_BYTES / 16 + MATCHW_THREADS - 1) / MATCHW_THREADS;
   constexpr int LINK_ROUNDS = (MATCHW_LINKS / 8 + MATCHW_THREADS - 1) / MATCHW_THREADS;
   u32x4 vs[SRC_ROUNDS], vl[LINK_ROUNDS];
-  // every thread issues all its 16-byte loads of a window at once (clamped, never
-  // conditional: a load behind an if is waited for on the spot) ...
+  // every thread issues all its 16-byte loads of a window at once (clamped indices) ...
   auto issue = [&](uint32_t w0, uint32_t n_src, uint32_t n_links) {
     const uint16_t *pv = S.prev + base + w0;
     const uint32_t last_src = n_src ? n_src - 16u : 0u;
@@ -508,10 +509,8 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
 #endif
-    // the next tile's window; behind the last tile every load is clamped to one unit
-    const bool has_next = tile + 1 < tile_end;
+    const bool has_next = tile + 1 < tile_end;  // uniform over the workgroup
     const MatchTile gn = match_tile(has_next ? tile + 1 : tile, len);
-    issue(gn.w0, has_next ? gn.n_src : (gn.n_src ? 16u : 0u), has_next ? gn.n_links : 8u);
     const uint8_t *ws = win_src - g.w0;  // indexed by stream position
     const uint16_t *wp = win_prev - g.w0;
     // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
@@ -552,6 +551,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     }
 #endif
     if (!has_next) break;
+    issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     store(gn);
     __syncthreads();
