@@ -429,8 +429,10 @@ __device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
 // its own positions -- the faster waves' loads are then in flight while the workgroup
 // waits for its slowest wave -- and the window goes to LDS between two barriers.
 // (Requesting it BEFORE the walk, to hide the whole latency, was the first version and
-// measured slower: the loop ran 3 us longer per tile with the loads in flight, more than
-// the 2.7 us they hid; 6.10-6.20 against 5.80 ms on C2.)
+// measured slower, 6.02-6.05 against 5.62-5.65 ms on C2 with the same unconditional loads:
+// the walk phase of a tile ran 15.5 instead of 13.5 us.  About 1 us of that is the issue
+// work itself; the rest was not explained.  That first version also had a branch around
+// the source loads, whose join made every wave wait for them -- see issue() below.)
 __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
@@ -472,14 +474,15 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   auto issue = [&](uint32_t w0, uint32_t n_src, uint32_t n_links) {
     const uint16_t *pv = S.prev + base + w0;
     const uint32_t last_src = n_src ? n_src - 16u : 0u;
-    if (n_src == 0) {  // a stream shorter than one unit in a batch of long ones
-#pragma unroll
-      for (int j = 0; j < SRC_ROUNDS; j++) vs[j] = u32x4{0, 0, 0, 0};
-    } else
+    // A stream shorter than one unit (in a batch of long ones) has no source to load here; its
+    // lanes read scratch instead and the values are never stored.  NOT a branch around the
+    // loads: at the join the compiler waits for every load issued so far (vmcnt(0)), which
+    // put one full memory latency between the source and the link loads of every tile.
+    const uint8_t *sp = n_src ? s + w0 : (const uint8_t *)pv;
 #pragma unroll
     for (int j = 0; j < SRC_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
-      vs[j] = load16_unaligned(s + w0 + (o < n_src ? o : last_src));
+      vs[j] = load16_unaligned(sp + (o < n_src ? o : last_src));
     }
 #pragma unroll
     for (int j = 0; j < LINK_ROUNDS; j++) {
