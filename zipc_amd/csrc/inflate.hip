@@ -180,6 +180,19 @@ __device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds
   d.phase = PH_SYMBOLS;
 }
 
+// A match that could not be queued (overlapping, long, or reading a hole) copied by the
+// whole wave.  Buf.recopy's bytewise overlapped copy (zd.ml:63-75) produces the periodic
+// extension of the last dist bytes, so output byte i is src[i mod dist]: no byte depends
+// on another new one and all of them move at once.  (Copied by the writer lane alone, a
+// byte at a time through memory when dist < 8, a 258-byte match took 28 us: a 1 MiB run
+// of one byte inflated in 114 ms.)
+__device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t len, int lane) {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the source bytes were stored by other lanes of this wave
+  uint8_t *o = dst + pos;
+  const uint8_t *s = o - dist;
+  for (uint32_t i = (uint32_t)lane; i < len; i += 64u) o[i] = s[dist >= len ? i : i % dist];
+}
+
 // One wide turn.  Returns the lane the path was cut at: below 63 it stopped inside
 // the window and the symbol at the new position is for lane_one_symbol.
 //
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       d.hole_min = 0xFFFFFFFFu;
     }
     if (d.phase == PH_REQ_MATCH) {
-      if (writer) lane_copy_match(dst, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
+      wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
       lane_after_match(d);
     } else if (d.phase == PH_REQ_COPY) {
       wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
