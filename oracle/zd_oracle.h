@@ -14,8 +14,10 @@
  *   - its size-limit test (test/test.ml:45-55),
  *   - its embedded zip-docs.zip fixture (test/test.ml:131-3294; sizes + CRCs),
  *   - Python zlib as an independent inflate / CRC-32 / Adler-32 implementation.
- * The reference's tests never assert compressed BYTES, so deflate byte parity is
- * "parity unpinned" beyond these: it is defined by the source semantics this
+ * The reference's tests never assert compressed BYTES, and the zip-docs.zip fixture
+ * was not made by zipc's encoder (made-by Info-ZIP 3.0; zlib level 6 reproduces the
+ * 11 132 compressed bytes of rfc1951.txt exactly, no level of this restatement does:
+ * tests/test_oracle_pins.py), so deflate byte parity is "parity unpinned" beyond these: it is defined by the source semantics this
  * file restates (incl. quirks Q1-Q7 of SURVEY.md Appendix A).
  */
 #ifndef ZD_ORACLE_H

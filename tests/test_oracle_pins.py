@@ -93,6 +93,23 @@ def test_zip_docs_fixture(oracle):  # test/test.ml:57-118
         assert zlib.decompress(c, -15) == d
 
 
+def test_zip_docs_fixture_was_not_made_by_the_reference_encoder(oracle):
+    """Why the fixture pins inflate and the checksums but NOT the deflate bytes (DESIGN.md row (c),
+    oracle/zd_oracle.h): its members were compressed by Info-ZIP / zlib.  zlib level 6 reproduces the
+    stored bytes of rfc1951.txt exactly; no level of the restated reference encoder does.  If this
+    ever fails the other way round, the fixture has become a pin for deflate and the docs must say so."""
+    members = dict((m["path"], (m, raw)) for m, raw in util.zip_docs_members())
+    m, raw = members["zip-docs/rfc1951.txt"]
+    plain = zlib.decompress(raw, -15)
+    assert len(raw) == 11132 and len(plain) == 36944
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    assert co.compress(plain) + co.flush() == raw
+    for _, (mm, rr) in members.items():
+        d = zlib.decompress(rr, -15)
+        for level in (oracle.LEVEL_NONE, oracle.LEVEL_FAST, oracle.LEVEL_DEFAULT, oracle.LEVEL_BEST):
+            assert oracle.deflate(d, level=level)[1] != rr, (mm["path"], level)
+
+
 def test_inflate_zlib_made_streams(oracle):
     n = 0
     for s in util.zlib_streams():
