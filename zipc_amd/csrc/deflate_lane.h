@@ -217,7 +217,18 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
   else if (r.maxlen >= 8) x = load_u64_le(s + qc) ^ r.pw;
   const uint32_t d2 = prev[qc];
   uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-  if (walk && (x == 0 || r.maxlen < 8)) l = common_prefix(s, qc, r.p, r.maxlen);
+  if (walk && (x == 0 || r.maxlen < 8)) {
+    // The first 8 bytes agree: the long compare -- unless the candidate cannot beat best_len
+    // anyway, which takes agreement in the 8 bytes that END at best_len as well.  On text a
+    // quarter of the candidates get here (8.5 per position on the reference's own documents)
+    // and 91 % of them fail this check; their exact length (8 .. best_len) is not needed.
+    bool compare = true;
+    if (WORDS && x == 0 && r.best_len >= 8u) {
+      const uint32_t toff = r.best_len - 7u;  // best_len < maxlen: these bytes lie inside both strings
+      compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
+    }
+    if (compare) l = common_prefix(s, qc, r.p, r.maxlen);
+  }
   r.q = qc;
   r.steps += walk ? 1u : 0u;
   if (walk && l > r.best_len) {
