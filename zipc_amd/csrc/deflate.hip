@@ -437,7 +437,8 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
-                                                                         uint32_t tiles_per_group, int K, int Kq) {
+                                                                         uint32_t tiles_per_group, int K, int Kq,
+                                                                         uint32_t pool_iters) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
 #ifdef ZD_MATCH_PHASES
@@ -508,6 +509,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   issue(g.w0, g.n_src, g.n_links);
   store(g);
   __syncthreads();
+  // a wave whose last tile took it more than pool_iters iterations (long chains) hands the next
+  // tile's positions out across its lanes (lz_match_runs_pool); 0: always
+  bool pool = pool_iters == 0;
   for (;;) {
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
@@ -526,7 +530,10 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     // the parse reads up to PARSE_PAD entries behind the last position without a range test
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
-      lz_match_runs<MATCHW_NP, true>(ws, len, (uint32_t)wbeg + (tid & 63u), 64u, (uint32_t)wend, wp, K, Kq, S.match + base);
+      uint32_t iters;
+      if (pool) iters = lz_match_runs_pool<MATCHW_NP>(ws, len, (uint32_t)wbeg, (uint32_t)wend, tid & 63u, wp, K, Kq, S.match + base);
+      else iters = lz_match_runs<MATCHW_NP, true>(ws, len, (uint32_t)wbeg + (tid & 63u), 64u, (uint32_t)wend, wp, K, Kq, S.match + base);
+      pool = iters > pool_iters;  // wave-uniform
     }
 #ifdef ZD_MATCH_PHASES
     {
@@ -1378,11 +1385,16 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
     // workgroups (8 per CU), so few long streams still spread over the chip
     // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
     static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
+    // iterations of a tile's walk above which a wave hands positions out across its lanes on its next
+    // tile (ZIPC_HIP_MATCH_POOL_ITERS; 0 = always, a huge value = never).  A tile is 16 positions per
+    // lane on 2 run slots: the benchmark's symbols take 13-24 iterations, 3-bit symbols about 70, text 300+.
+    static const long pool_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_POOL_ITERS"); return e ? atol(e) : 128L; }();
     size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 2048;
     tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
     const size_t gps = (tps + tpg - 1) / tpg;
     ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4);
+              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4,
+              (uint32_t)(pool_env < 0 ? 0 : pool_env));
   }
   ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,

@@ -255,10 +255,13 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
 // now it needs about the sum / NP.  No cross-lane traffic -- handing positions out
 // across the wave was measured and lost on C2)  Results are
 // stored per position, so the order in which a lane takes them does not matter.
+// Returns the number of iterations of its loop (what the window kernel's waves go by to
+// pick their schedule for the next tile).
 template <int NP, bool WORDS>
-ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uint32_t step, uint32_t pend,
-                         const uint16_t *prev, int K, int Kq, uint64_t *out) {
+ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uint32_t step, uint32_t pend,
+                             const uint16_t *prev, int K, int Kq, uint64_t *out) {
   MatchRun r[NP];
+  uint32_t iters = 0;
   uint32_t cursor = first;
 #pragma unroll
   for (int i = 0; i < NP; i++) {
@@ -270,6 +273,7 @@ ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uint32_
   // of a loop per position that the lanes would have to leave together.
   for (;;) {
     bool alive = false;
+    iters++;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       if (match_run_step<WORDS>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out)) {
@@ -284,7 +288,48 @@ ZD_HD void lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uint32_
     if (!alive) break;
 #endif
   }
+  return iters;
 }
+
+#if defined(__HIPCC__)  // device code of the HIP build only (the host models walk one lane at a time)
+// The same for a whole wave, with ONE pool of positions [wbeg, wend): a run slot that finishes
+// a position takes the wave's next unassigned one, whichever lane it belongs to (rank among
+// the slots finishing in the same iteration: ballot + mbcnt).  With fixed positions per lane a
+// wave needs max over lanes of a lane's total steps; on text those totals differ a lot (about
+// 550 +- 160 steps for a lane's 16 positions of a tile) and a wave ran at ~60 % lane use.  The
+// handout costs a dozen instructions per iteration, which shows when a position takes 1-8 steps
+// (measured earlier: +7 % on 1 MiB streams of 3-bit symbols) and not when it takes 34: the
+// window kernel's waves switch to this form when a tile took them many iterations.  Results are
+// stored per position, so who walks which position does not matter.
+template <int NP>
+__device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t wbeg, uint32_t wend,
+                                                        uint32_t lane, const uint16_t *prev, int K, int Kq,
+                                                        uint64_t *out) {
+  MatchRun r[NP];
+  uint32_t iters = 0;
+#pragma unroll
+  for (int i = 0; i < NP; i++) match_run_start<true>(r[i], s, len, wbeg + lane + 64u * (uint32_t)i, wend, prev);
+  uint32_t next = wbeg + 64u * (uint32_t)NP;  // wave-uniform: the first position nobody has been given
+  for (;;) {
+    bool alive = false;
+    iters++;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const bool fin = match_run_step<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out);
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
+      if (fm) {  // wave-uniform
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+        if (fin) match_run_start<true>(r[i], s, len, next < wend ? next + rank : wend, wend, prev);
+        const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
+        next = wend - next > taken ? next + taken : wend;  // saturates at wend
+      }
+      alive |= r[i].alive;
+    }
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+  }
+  return iters;
+}
+#endif
 
 // ---------------------------------------------------------------------------
 // The lazy parse (Lz77.compress zd.ml:1203-1244) in three parallel-friendly
