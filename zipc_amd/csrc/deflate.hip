@@ -437,10 +437,10 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
-                                                                         uint32_t tiles_per_group, int K, int Kq,
-                                                                         uint32_t pool_iters) {
+                                                                         uint32_t tiles_per_group, int K, int Kq) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
+  __shared__ uint32_t pool_next;  // the tile's first position no wave has been given yet
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
   unsigned long long ph0 = __builtin_readcyclecounter();
@@ -508,10 +508,8 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   MatchTile g = match_tile(tile, len);
   issue(g.w0, g.n_src, g.n_links);
   store(g);
+  if (tid == 0) pool_next = g.t0;
   __syncthreads();
-  // a wave whose last tile took it more than pool_iters iterations (long chains) hands the next
-  // tile's positions out across its lanes (lz_match_runs_pool); 0: always
-  bool pool = pool_iters == 0;
   for (;;) {
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
@@ -520,20 +518,17 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     const MatchTile gn = match_tile(has_next ? tile + 1 : tile, len);
     const uint8_t *ws = win_src - g.w0;  // indexed by stream position
     const uint16_t *wp = win_prev - g.w0;
-    // a wave takes 1 Ki consecutive positions, lane l every 64th of them from l on,
-    // walked by MATCHW_NP run slots that share the lane's cursor.  (Handing positions out as lanes finish -- a
-    // wave-uniform counter, ballot + mbcnt -- was measured: -2 % on C2, +7 % on the
-    // long chains of C4; the fixed schedule stays.)
-    const uint32_t per_wave = MATCHW_TILE / (MATCHW_THREADS / 64);
-    const uint64_t wbeg = (uint64_t)g.t0 + (tid / 64u) * per_wave;
-    const uint64_t wend = wbeg + per_wave < (uint64_t)len - 3 ? wbeg + per_wave : (uint64_t)len - 3;
+    // The tile's positions are ONE pool for the workgroup's 16 waves (lz_match_runs_pool): a wave
+    // fetches chunks of 256 from pool_next and hands them to its run slots as they finish.  The
+    // first schedule gave every wave a fixed 1 Ki positions and every lane every 64th of them: a
+    // tile then took as long as its slowest wave (a fifth of a tile on the benchmark's symbols by
+    // the phase timers, more on text) and a wave as long as its slowest lane.  Same box, the pool
+    // against that: 5.46 vs 5.83-5.87 ms on C2, 171.8 vs 174.7 ms on C4, 153 vs 241 ms on real text.
     // the parse reads up to PARSE_PAD entries behind the last position without a range test
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
-    if (wbeg < wend) {  // wave-uniform: lz_match_runs is entered by whole waves
-      uint32_t iters;
-      if (pool) iters = lz_match_runs_pool<MATCHW_NP>(ws, len, (uint32_t)wbeg, (uint32_t)wend, tid & 63u, wp, K, Kq, S.match + base);
-      else iters = lz_match_runs<MATCHW_NP, true>(ws, len, (uint32_t)wbeg + (tid & 63u), 64u, (uint32_t)wend, wp, K, Kq, S.match + base);
-      pool = iters > pool_iters;  // wave-uniform
+    {
+      const uint64_t tend64 = (uint64_t)g.t0 + MATCHW_TILE < (uint64_t)len - 3 ? (uint64_t)g.t0 + MATCHW_TILE : (uint64_t)len - 3;
+      lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
     }
 #ifdef ZD_MATCH_PHASES
     {
@@ -564,6 +559,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     store(gn);
+    if (tid == 0) pool_next = gn.t0;
     __syncthreads();
     tile++;
     g = gn;
@@ -1385,16 +1381,11 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
     // workgroups (8 per CU), so few long streams still spread over the chip
     // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
     static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
-    // iterations of a tile's walk above which a wave hands positions out across its lanes on its next
-    // tile (ZIPC_HIP_MATCH_POOL_ITERS; 0 = always, a huge value = never).  A tile is 16 positions per
-    // lane on 2 run slots: the benchmark's symbols take 13-24 iterations, 3-bit symbols about 70, text 300+.
-    static const long pool_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_POOL_ITERS"); return e ? atol(e) : 128L; }();
     size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 2048;
     tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
     const size_t gps = (tps + tpg - 1) / tpg;
     ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4,
-              (uint32_t)(pool_env < 0 ? 0 : pool_env));
+              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4);
   }
   ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
   ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,

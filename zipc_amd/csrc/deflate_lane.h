@@ -292,24 +292,37 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 }
 
 #if defined(__HIPCC__)  // device code of the HIP build only (the host models walk one lane at a time)
-// The same for a whole wave, with ONE pool of positions [wbeg, wend): a run slot that finishes
-// a position takes the wave's next unassigned one, whichever lane it belongs to (rank among
-// the slots finishing in the same iteration: ballot + mbcnt).  With fixed positions per lane a
-// wave needs max over lanes of a lane's total steps; on text those totals differ a lot (about
-// 550 +- 160 steps for a lane's 16 positions of a tile) and a wave ran at ~60 % lane use.  The
-// handout costs a dozen instructions per iteration, which shows when a position takes 1-8 steps
-// (measured earlier: +7 % on 1 MiB streams of 3-bit symbols) and not when it takes 34: the
-// window kernel's waves switch to this form when a tile took them many iterations.  Results are
-// stored per position, so who walks which position does not matter.
+// The window kernel's schedule: ONE pool of a tile's positions [*, pend) for the whole workgroup,
+// behind a counter in LDS.  A wave fetches chunks of POOL_CHUNK positions from it, and inside its
+// chunk a run slot that finishes a position takes the next unassigned one, whichever lane it
+// belongs to (rank among the slots finishing in the same iteration: ballot + mbcnt).  With
+// fixed positions per lane (lz_match_runs above) a wave needs the max over its lanes of a lane's
+// total steps and a tile the slowest of its 16 waves; the pool needs about the mean.  The handout
+// costs a dozen instructions per iteration; a wave-level pool (each wave its own 1 Ki positions)
+// paid for that only on long chains (-15 % on text, +8 % on 3-bit symbols), the tile-wide one pays
+// everywhere: -6.5 % on the benchmark's symbols, -2 % on 3-bit symbols, -36 % on text.  Results
+// are stored per position, so who walks which position does not matter.  Returns the wave's
+// iteration count.
+constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any one handout
 template <int NP>
-__device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t wbeg, uint32_t wend,
-                                                        uint32_t lane, const uint16_t *prev, int K, int Kq,
-                                                        uint64_t *out) {
+__device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
+                                                        uint32_t pend, uint32_t lane, const uint16_t *prev, int K,
+                                                        int Kq, uint64_t *out) {
+  static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
+  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (>= pend: the pool is empty)
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    return c < pend ? c : pend;
+  };
+  uint32_t next = fetch();  // my chunk is [next, cend)
+  uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
+  bool empty = next >= pend;
 #pragma unroll
-  for (int i = 0; i < NP; i++) match_run_start<true>(r[i], s, len, wbeg + lane + 64u * (uint32_t)i, wend, prev);
-  uint32_t next = wbeg + 64u * (uint32_t)NP;  // wave-uniform: the first position nobody has been given
+  for (int i = 0; i < NP; i++) match_run_start<true>(r[i], s, len, next + lane + 64u * (uint32_t)i, cend, prev);
+  next = cend - next > 64u * NP ? next + 64u * NP : cend;
   for (;;) {
     bool alive = false;
     iters++;
@@ -319,9 +332,20 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-        if (fin) match_run_start<true>(r[i], s, len, next < wend ? next + rank : wend, wend, prev);
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
-        next = wend - next > taken ? next + taken : wend;  // saturates at wend
+        const uint32_t rem = cend - next;
+        uint32_t np = next + rank, lim = cend;
+        if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
+          const uint32_t c = fetch();
+          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
+          empty = c >= pend;
+          if (rank >= rem) { np = c + (rank - rem); lim = ce; }
+          next = ce - c > taken - rem ? c + (taken - rem) : ce;
+          cend = ce;
+        } else {
+          next = rem > taken ? next + taken : cend;
+        }
+        if (fin) match_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev);
       }
       alive |= r[i].alive;
     }
