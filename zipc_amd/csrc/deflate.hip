@@ -388,7 +388,8 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
 constexpr uint32_t MATCHW_THREADS = 1024;
 constexpr uint32_t MATCHW_TILE = 16384;
 constexpr int MATCHW_NP = 2;  // run slots per lane.  3 and 4 measured on C2 with the shared cursor: +3 % and +7.5 % (and
-                               // +3 % / +8 % on 1 MiB streams of 3-bit symbols): the loop is nearer its vector bound than latency-bound
+                               // +3 % / +8 % on 1 MiB streams of 3-bit symbols); 3 again under the tile-wide pool: +9 % on C2,
+                               // +6 % on real text: the loop is nearer its vector bound than latency-bound
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
@@ -432,7 +433,10 @@ __device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
 // measured slower, 6.02-6.05 against 5.62-5.65 ms on C2 with the same unconditional loads:
 // the walk phase of a tile ran 15.5 instead of 13.5 us.  About 1 us of that is the issue
 // work itself; the rest was not explained.  That first version also had a branch around
-// the source loads, whose join made every wave wait for them -- see issue() below.)
+// the source loads, whose join made every wave wait for them -- see issue() below.  Measured
+// once more under the tile-wide pool, where no slow wave is left to hide the loads behind:
+// before the walk is still slower, 5.82-5.85 against 5.35-5.45 ms on C2, 154.5 against 149.9 ms
+// on real text.)
 __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const uint8_t *__restrict__ src_arena,
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
