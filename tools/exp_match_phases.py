@@ -34,7 +34,7 @@ res = batch.results_from_device(d_res)
 tile_cu_us = ms * 1e3 * 256 / (wgs / reps)  # one workgroup per CU at a time; slot [4] counts tiles
 wg = us(wg_wall / wgs)
 print(json.dumps({
-    "kernel_ms (timing build; the product kernel is 7.27)": round(ms, 3), "tiles per launch": wgs // reps,
+    "kernel_ms (timing build; compare with the product kernel's time from tools/exp_inflate.py to see the perturbation)": round(ms, 3), "tiles per launch": wgs // reps,
     "all streams ok": bool((res["status"] == 0).all()), "s_memtime MHz (calibrated)": round(mhz, 1),
     "per tile, us": {
         "CU time per tile (kernel time x 256 CUs / tiles)": round(tile_cu_us, 2),
