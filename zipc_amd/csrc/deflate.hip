@@ -444,7 +444,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          uint32_t tiles_per_group, int K, int Kq) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
-  __shared__ uint32_t pool_next;  // the tile's first position no wave has been given yet
+  __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
   unsigned long long ph0 = __builtin_readcyclecounter();
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   MatchTile g = match_tile(tile, len);
   issue(g.w0, g.n_src, g.n_links);
   store(g);
-  if (tid == 0) pool_next = g.t0;
+  if (tid == 0) pool_next = 0;
   __syncthreads();
   for (;;) {
 #ifdef ZD_MATCH_PHASES
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     {
       const uint64_t tend64 = (uint64_t)g.t0 + MATCHW_TILE < (uint64_t)len - 3 ? (uint64_t)g.t0 + MATCHW_TILE : (uint64_t)len - 3;
-      lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
+      lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
     }
 #ifdef ZD_MATCH_PHASES
     {
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     store(gn);
-    if (tid == 0) pool_next = gn.t0;
+    if (tid == 0) pool_next = 0;
     __syncthreads();
     tile++;
     g = gn;

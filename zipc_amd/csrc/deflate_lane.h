@@ -307,16 +307,18 @@ constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any on
                                       // C2 5.58 / 5.44-5.48 / 5.83 ms, real text 145.5 / 150.1 / 167.5 ms
 template <int NP>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
-                                                        uint32_t pend, uint32_t lane, const uint16_t *prev, int K,
-                                                        int Kq, uint64_t *out) {
+                                                        uint32_t pbeg, uint32_t pend, uint32_t lane,
+                                                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
-  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (>= pend: the pool is empty)
+  // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
+  // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
+  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
     uint32_t c = 0;
     if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-    return c < pend ? c : pend;
+    return c < pend - pbeg ? pbeg + c : pend;
   };
   uint32_t next = fetch();  // my chunk is [next, cend)
   uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
