@@ -323,8 +323,13 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
   uint32_t next = fetch();  // my chunk is [next, cend)
   uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
   bool empty = next >= pend;
+  // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
+  // may end within a chunk of 2^32 and a sum must not wrap into a position that looks valid)
 #pragma unroll
-  for (int i = 0; i < NP; i++) match_run_start<true>(r[i], s, len, next + lane + 64u * (uint32_t)i, cend, prev);
+  for (int i = 0; i < NP; i++) {
+    const uint32_t off = lane + 64u * (uint32_t)i;
+    match_run_start<true>(r[i], s, len, off < cend - next ? next + off : cend, cend, prev);
+  }
   next = cend - next > 64u * NP ? next + 64u * NP : cend;
   for (;;) {
     bool alive = false;
@@ -337,12 +342,12 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;
-        uint32_t np = next + rank, lim = cend;
+        uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
           const uint32_t c = fetch();
           const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
           empty = c >= pend;
-          if (rank >= rem) { np = c + (rank - rem); lim = ce; }
+          if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
           next = ce - c > taken - rem ? c + (taken - rem) : ce;
           cend = ce;
         } else {
