@@ -35,6 +35,10 @@ extern "C" {
 
 #define ZIPC_HIP_ABI_VERSION 1
 
+/* Longest single stream, and largest destination capacity, in bytes: 4 GiB - 64 KiB (positions are
+ * 32-bit inside the kernels).  The reference's own limit is OCaml's string length. */
+#define ZIPC_HIP_MAX_STREAM_LEN 0xFFFF0000ull
+
 /* ---- status codes --------------------------------------------------------
  * 1..6 are the reference's Failure messages (zipc_deflate.ml:233,29,728-730,104) */
 enum {
@@ -194,7 +198,7 @@ typedef struct zipc_hip_stream_result_s {
 /* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream
  * whose output is longer than that reports ZIPC_HIP_ERR_INVALID_ARG in its result when a
  * CRC-32 is asked for (its checksum would cover only a part). A descriptor with src_len or
- * dst_cap above 0xFFFFFFF0 reports ZIPC_HIP_ERR_INVALID_ARG in its own result. */
+ * dst_cap above ZIPC_HIP_MAX_STREAM_LEN reports ZIPC_HIP_ERR_INVALID_ARG in its own result. */
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs,
                            zipc_hip_stream_result *d_results, size_t n_streams,
@@ -204,8 +208,8 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
  * total_src_len: sum of src_len over the batch (sizes the scratch). Both are checked on the
  * device against the descriptors: if a stream is longer than max_src_len or the sum exceeds
  * total_src_len, EVERY stream of the batch reports ZIPC_HIP_ERR_INVALID_ARG and nothing is
- * compressed. max_src_len above 0xFFFFFFF0 fails the call; a single descriptor with src_len
- * or dst_cap above 0xFFFFFFF0 reports ZIPC_HIP_ERR_INVALID_ARG in its own result only. */
+ * compressed. max_src_len above ZIPC_HIP_MAX_STREAM_LEN fails the call; a single descriptor
+ * with src_len or dst_cap above it reports ZIPC_HIP_ERR_INVALID_ARG in its own result only. */
 int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs,
                            zipc_hip_stream_result *d_results, size_t n_streams,

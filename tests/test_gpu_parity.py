@@ -410,11 +410,12 @@ def test_batch_declared_sizes_are_checked(gpu_ctx, oracle):
     res, out = deflate(honest, max(lens), sum(lens))
     exact(res, out, range(n))
     # one descriptor beyond the format's range (its bytes are never touched): only that stream fails
-    lying = honest.copy()
-    lying["src_len"][1] = 1 << 32
-    res, out = deflate(lying, max(lens), sum(lens) - lens[1])
-    assert res["status"][1] == INVALID and res["out_len"][1] == 0
-    exact(res, out, (0, 2, 3))
+    for too_long in (1 << 32, 0xFFFF0001):  # ZIPC_HIP_MAX_STREAM_LEN is 0xFFFF0000 (4 GiB - 64 KiB)
+        lying = honest.copy()
+        lying["src_len"][1] = too_long
+        res, out = deflate(lying, max(lens), sum(lens) - lens[1])
+        assert res["status"][1] == INVALID and res["out_len"][1] == 0, too_long
+        exact(res, out, (0, 2, 3))
     lying = honest.copy()
     lying["dst_cap"][3] = 1 << 33
     res, out = deflate(lying, max(lens), sum(lens))
@@ -455,9 +456,9 @@ def test_batch_declared_sizes_are_checked(gpu_ctx, oracle):
     assert res["status"][2] == INVALID
     plain_back(res, out, (0, 1, 3))
     # descriptors beyond the range
-    for field in ("src_len", "dst_cap"):
+    for field, too_long in (("src_len", 1 << 32), ("dst_cap", 1 << 32), ("src_len", 0xFFFF0001), ("dst_cap", 0xFFFF0001)):
         lying = ihonest.copy()
-        lying[field][0] = 1 << 32
+        lying[field][0] = too_long
         res, out = inflate(lying, max(lens))
         assert res["status"][0] == INVALID and res["out_len"][0] == 0, field
         plain_back(res, out, (1, 2, 3))

@@ -354,7 +354,7 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
   if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n_streams > 0x7FFFFFFFull)
     return ZIPC_HIP_ERR_INVALID_ARG;
-  if (max_src_len > 0xFFFFFFF0ull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (max_src_len > MAX_STREAM_LEN) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, ctx->ensure(ctx->deflate_scratch,
@@ -536,7 +536,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     max_src = src_len[i] > max_src ? src_len[i] : max_src;
     max_cap = dst_cap[i] > max_cap ? dst_cap[i] : max_cap;
   }
-  if (!is_inflate && max_src > 0xFFFFFFF0ull) return ZIPC_HIP_ERR_INVALID_ARG;  // (inflate reports it per stream)
+  if (!is_inflate && max_src > MAX_STREAM_LEN) return ZIPC_HIP_ERR_INVALID_ARG;  // (inflate reports it per stream)
   // The batch is cut into K sub-batches of about equal source bytes, and sub-batch g
   // goes through  gather (host threads, into pinned memory) -> H2D (copy_in) -> kernels
   // (the context's stream) -> D2H (copy_out) -> scatter (host threads)  on its own, so

@@ -45,11 +45,11 @@ constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 
 
 // streams with an out-of-range length are rejected by every kernel and take no scratch
 __host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
-  if (src_len > 0xFFFFFFF0ull) src_len = 0;
+  if (src_len > MAX_STREAM_LEN) src_len = 0;
   return ((src_len + 255) & ~255ull) + POS_PAD;
 }
 __host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
-  if (src_len > 0xFFFFFFF0ull) src_len = 0;
+  if (src_len > MAX_STREAM_LEN) src_len = 0;
   return src_len / MIN_BLOCK_SRC + 2;
 }
 
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
     sb += max_blocks_of(l);
     // a stream beyond the format's range is rejected on its own (above); one beyond what the
     // caller declared would be matched and checksummed only in part: the whole batch is refused
-    over |= l <= 0xFFFFFFF0ull && l > max_src_len;
+    over |= l <= MAX_STREAM_LEN && l > max_src_len;
   }
   part_p[t] = sp;
   part_b[t] = sb;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   const uint32_t stream = blockIdx.x;
   const uint32_t t = threadIdx.x;
   const StreamDesc sd = descs[stream];
-  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
   const uint8_t *s = src_arena + sd.src_off;
   uint16_t *prev = S.prev + S.pos_base[stream];
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
   const uint32_t chunk = logical % chunks_per_stream;
   if (stream >= n_streams) return;  // grid is padded to a multiple of 8
   const StreamDesc sd = descs[stream];
-  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
   const uint32_t p0 = chunk * MATCH_TILE + threadIdx.x;
   if (chunk * MATCH_TILE > len - 4) return;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint32_t group = logical % groups_per_stream;
   if (stream >= n_streams) return;  // grid is padded to a multiple of 8
   const StreamDesc sd = descs[stream];
-  if (sd.src_len < 4 || sd.src_len > 0xFFFFFFF0ull) return;
+  if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
   // tiles [tile, tile_end) of the stream; a tile exists when its first position can start a match
   const uint32_t stream_tiles = (uint32_t)(((uint64_t)len - 4) / MATCHW_TILE) + 1;
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
-  if (sd.src_len > 0xFFFFFFF0ull) {
+  if (sd.src_len > MAX_STREAM_LEN) {
     if (lane == 0) S.n_blocks[stream] = 0;
     return;
   }
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   };
   auto load_lit = [&](uint32_t tile) -> uint32_t {
     const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    const uint32_t tc = t < len ? t : len - 1;  // len >= 1 inside the loop; len <= 0xFFFFFFF0: no wrap below
+    const uint32_t tc = t < len ? t : len - 1;  // len >= 1 inside the loop; len <= MAX_STREAM_LEN: no wrap below
     const uint32_t i = tc + (uint32_t)lane;
     return s[i < len ? i : len - 1];
   };
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
-  if (S.error[0] || sd.src_len > 0xFFFFFFF0ull || sd.dst_cap > 0xFFFFFFF0ull) {
+  if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
     if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
     return;
   }
@@ -1319,7 +1319,7 @@ __global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__res
   const StreamDesc sd = descs[stream];
   StreamResult r;
   r.status = ST_OK; r.checksum = 0; r.out_len = 0;
-  if (sd.src_len > 0xFFFFFFF0ull || sd.dst_cap > 0xFFFFFFF0ull) {
+  if (sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
     r.status = ST_INVALID_ARG;
     if (lane == 0) results[stream] = r;
     return;

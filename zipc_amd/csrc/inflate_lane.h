@@ -682,7 +682,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.hdr_fixed = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
   d.levels = 6;
-  if (s.src_len > 0xFFFFFFF0ull || s.dst_cap > 0xFFFFFFF0ull) {
+  if (s.src_len > MAX_STREAM_LEN || s.dst_cap > MAX_STREAM_LEN) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;
     d.fail(ST_INVALID_ARG);
     return;

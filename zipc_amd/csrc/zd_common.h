@@ -39,6 +39,11 @@ constexpr int LITLEN_EOB = 256;        // zd.ml:240
 constexpr int LITLEN_FIRST_LEN = 257;  // zd.ml:241
 constexpr int DIST_SYM_MAX = 29;       // zd.ml:271
 constexpr int CODELEN_SYM_MAX = 18;    // zd.ml:310
+// Longest stream (and largest destination capacity) the kernels take: positions are 32-bit and are
+// advanced in tile-sized steps (64 .. 16 Ki positions and a chunk of overshoot), so the limit keeps
+// 64 KiB of headroom below 2^32.  Longer streams report ST_INVALID_ARG.  (include/zipc_hip.h:
+// ZIPC_HIP_MAX_STREAM_LEN.)
+constexpr uint64_t MAX_STREAM_LEN = 0xFFFF0000ull;
 constexpr int MAX_BLOCK_SRC_LEN = 65534;  // zd.ml:747-750
 constexpr int MIN_MATCH_LEN = 4;       // zd.ml:1141
 constexpr int MAX_MATCH_LEN = 258;     // zd.ml:1142
