@@ -15,7 +15,7 @@ def lib():
     deps += [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-Wall",
-                               "-Wno-unknown-pragmas", "-o", LIB] + [os.path.join(HERE, s) for s in SRCS])
+                               "-Wno-unknown-pragmas", "-I", HERE, "-o", LIB] + [os.path.join(HERE, s) for s in SRCS])
     L = C.CDLL(LIB)
     L.sim_inflate.restype = C.c_int
     L.sim_inflate.argtypes = [C.c_char_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int, C.c_uint64, C.c_int,

@@ -7,6 +7,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../zipc_amd/csrc/inflate_lane.h"
+#include "../../zipc_amd/csrc/inflate_span.h"
 
 using namespace zd;
 
@@ -125,13 +126,51 @@ static bool wide_turn_model(InflateLane &d, const LaneLds &L, uint8_t *dst) {
   return c < 63;
 }
 
+// inflate.hip's span step on the emulated wave (wave_emu.h): every lane runs span_decode on its
+// own copy of the (wave-uniform) state; the copies must agree afterwards.
+struct SpanCall {
+  InflateLane d[64];
+  int ret[64];
+  const LaneLds *L;
+  const uint8_t *src;
+  uint8_t *dst;
+};
+static void span_lane(int lane, void *arg) {
+  SpanCall &c = *(SpanCall *)arg;
+  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, lane);
+}
+extern "C" { uint64_t sim_span_stats[8]; }  // spans run, symbols' bits committed, output bytes committed, per return code
+static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending) {
+  static wv::Emu emu;
+  static SpanCall c;
+  emu.descending = descending;
+  for (int i = 0; i < 64; i++) c.d[i] = d;
+  c.L = &L; c.src = src; c.dst = dst;
+  emu.run(span_lane, &c);
+  for (int i = 1; i < 64; i++) {
+    if (c.ret[i] != c.ret[0] || memcmp(&c.d[i], &c.d[0], sizeof(InflateLane)) != 0) {
+      fprintf(stderr, "span_model: lane %d disagrees with lane 0\n", i);
+      abort();
+    }
+  }
+  if (c.ret[0] != SPAN_NONE) {
+    sim_span_stats[0]++;
+    sim_span_stats[1] += (uint64_t)(c.d[0].in_word - d.in_word) * 32u + c.d[0].boff - d.boff;
+    sim_span_stats[2] += c.d[0].out_pos - d.out_pos;
+    sim_span_stats[3 + c.ret[0]]++;
+  }
+  d = c.d[0];
+  return c.ret[0];
+}
+
 extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, uint64_t dst_cap,
                            int has_limit, uint64_t limit, int crc_op, uint64_t *out_len,
                            uint32_t *checksum, int budget) {
   static uint16_t w[LDS_U16_PER_LANE];
   static uint32_t r[LDS_U32_PER_LANE];
+  static __attribute__((aligned(16))) uint8_t x[SPAN_LDS_BYTES];
   LaneLds L;
-  L.w = w; L.r = r;
+  L.w = w; L.r = r; L.x = x;
   StreamDesc s;
   memset(&s, 0, sizeof s);
   s.src_off = 0; s.src_len = src_len; s.dst_off = 0; s.dst_cap = dst_cap;
@@ -142,6 +181,9 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   lane_init(d, s);
   const bool crc_adler = crc_op == CRC_ADLER32;
   const bool wide = getenv("SIM_INFLATE_WIDE") != nullptr;
+  const char *span_env = getenv("SIM_INFLATE_SPAN");  // "a": lanes resumed in ascending order, "d": descending
+  const bool span = span_env != nullptr;
+  const bool span_desc = span && span_env[0] == 'd';
   refill(d, L, src);
   for (;;) {
     // decode phase: the kernel's round
@@ -158,6 +200,15 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
           d.levels = levels_for(shortest);
         }
       } else if (d.phase == PH_SYMBOLS) {
+        if (span && !d.span_off) {  // as inflate.hip
+          if (d.q_count) break;
+          const int sr = span_model(d, L, src, dst, span_desc);
+          if (sr != SPAN_NONE) {
+            d.span_off = sr == SPAN_OFF;
+            break;
+          }
+          d.span_off = 1;
+        }
         bool stopped = true;
         if (wide) {
           if (!d.input_ready(TURN_WORDS)) break;

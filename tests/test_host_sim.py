@@ -169,3 +169,66 @@ def test_inflate_models_header_fuzz(sim, oracle, monkeypatch):
             assert st == st0
             if st0 == 0:
                 assert d == d0 and a == c0
+
+
+def test_inflate_span_model(sim, oracle, monkeypatch):
+    """inflate_span.h (regions per lane, self-synchronising walks, LDS output tiles) -- the very
+    code the kernel runs, on the emulated wave (host_sim/wave_emu.h), lanes resumed in ascending
+    and in descending order: same bytes, checksums and statuses as the oracle on every input
+    shape, under size limits that fall inside a span, and on damaged streams."""
+    monkeypatch.setenv("SIM_INFLATE_WIDE", "1")
+    stats = (C.c_uint64 * 8).in_dll(sim, "sim_span_stats")
+    r = random.Random(2024)
+    long_random = []
+    while len(long_random) < 24:
+        try:
+            long_random.append(util.random_dynamic_stream(r, 0, max_symbols=9000))
+        except (KeyError, IndexError, ValueError):
+            pass
+    for order in ("a", "d"):
+        monkeypatch.setenv("SIM_INFLATE_SPAN", order)
+        for i in range(8):
+            stats[i] = 0
+        for name, data in util.deflate_cases().items():
+            for lvl in (0, 1, 2, 3) if order == "a" else (2,):
+                st0, c, a0 = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+                st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
+                assert (st, d, a) == (0, data, a0), (name, lvl, order)
+        assert stats[0] > 20 and stats[2] > 900000, list(stats)  # spans ran and produced most of the bytes
+        # limits inside the data: the reference's "Expected decompression size exceeded", same prefix rules
+        for name in ("nib64k", "text150k", "mixed", "zip-docs/rfc1951.txt"):
+            data = util.deflate_cases()[name]
+            c = oracle.deflate(data, level=2)[1]
+            for lim in (len(data) - 1, len(data) // 2, 5000, len(data) - 300):
+                st0, d0, _ = oracle.inflate(c, decompressed_size=lim)
+                st, d, _ = sim_inflate(sim, c, lim, limit=lim)
+                assert (st, d) == (st0, d0), (name, lim, order)
+        for s in util.zlib_streams():
+            st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
+            st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=24)
+            assert (st, d, a) == (st0, d0, a0), s["name"]
+        # random complete codes (long codes, odd alphabets), thousands of symbols; then damaged
+        seen = {}
+        for k, s in enumerate(long_random):
+            st0, d0, a0 = oracle.inflate(s, decompressed_size=1 << 21, crc_op=2)
+            st, d, a = sim_inflate(sim, s, 1 << 21, limit=1 << 21, crc_op=2, budget=24)
+            assert st0 == 0 and (st, d, a) == (st0, d0, a0), k
+            for v in util.corrupt_variants(s, k, 6 if order == "a" else 2):
+                st0, d0, a0 = oracle.inflate(v, decompressed_size=1 << 21, crc_op=2)
+                st, d, a = sim_inflate(sim, v, 1 << 21, limit=1 << 21, crc_op=2, budget=24)
+                assert st == st0 and (st != 0 or (d == d0 and a == a0)), k
+                seen[st] = seen.get(st, 0) + 1
+        for i, s in enumerate(util.zlib_streams()):
+            if len(s["raw"]) < 2000:
+                continue
+            cap = s["plain_len"] * 2 + 1000
+            for v in util.corrupt_variants(s["raw"], i, 12 if order == "a" else 4):
+                if len(v) > 300 and r.random() < 0.5:  # damage past the header too
+                    b = bytearray(v)
+                    b[r.randrange(200, len(b))] ^= 1 << r.randrange(8)
+                    v = bytes(b)
+                st0, d0, a0 = oracle.inflate(v, decompressed_size=cap, crc_op=oracle.CRC_ADLER32)
+                st, d, a = sim_inflate(sim, v, cap, limit=cap, crc_op=2)
+                assert st == st0 and (st != 0 or (d == d0 and a == a0)), s["name"]
+                seen[st] = seen.get(st, 0) + 1
+        assert seen.get(0, 0) > 5 and seen.get(1, 0) > 20, seen

@@ -148,10 +148,10 @@ def _canonical(lengths):
     return codes
 
 
-def random_dynamic_stream(r, damage):
+def random_dynamic_stream(r, damage, max_symbols=120):
     """one final dynamic block with a random complete litlen / dist / codelen code,
-    a few literals and matches; damage > 0 perturbs that many code lengths (the
-    stream then is usually, not always, rejected)"""
+    a few literals and matches (up to max_symbols of them); damage > 0 perturbs that
+    many code lengths (the stream then is usually, not always, rejected)"""
     n_lit = r.choice([1, 2, 5, 20, 60, 200])
     used = set(r.sample(range(256), n_lit)) | {256} | set(r.sample(range(257, 286), r.choice([0, 1, 3, 10])))
     used = sorted(used)
@@ -214,7 +214,7 @@ def random_dynamic_stream(r, damage):
     lext = [0] * 8 + [1] * 4 + [2] * 4 + [3] * 4 + [4] * 4 + [5] * 4 + [0]
     dbase = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
     dext = [0, 0, 0, 0] + [i // 2 for i in range(2, 28)]
-    for _ in range(r.randrange(1, 120)):
+    for _ in range(r.randrange(1, max_symbols)):
         if lens_ and lits and produced > 0 and r.random() < 0.3:
             ok_d = [d for d in range(30) if dl[d] and dbase[d] <= produced]
             if ok_d:

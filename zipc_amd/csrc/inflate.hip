@@ -34,6 +34,7 @@
 // readfirstlane so that the control flow around the turns is scalar branches,
 // not exec-mask arithmetic.  LDS: 5088 B per stream (tables + ring + queue).
 #include "inflate_lane.h"
+#include "inflate_span.h"
 #include "kernels.h"
 #include "wave_ops.h"
 
@@ -57,6 +58,7 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
   ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
+  ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off);
 #undef ZD_U
 }
 
@@ -177,7 +179,7 @@ __device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds
   }
   wave_build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS, lane);
   wave_build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS, lane);
-  d.phase = PH_SYMBOLS;
+  lane_begin_symbols(d);
 }
 
 // A match that could not be queued (overlapping, long, or reading a hole) copied by the
@@ -310,12 +312,12 @@ __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uin
   }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            StreamResult *__restrict__ results,
                                                            uint32_t n_streams, int /*log2S*/, int crc_op) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE + SPAN_LDS_BYTES];
   const int lane = threadIdx.x;
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
@@ -325,7 +327,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   LaneLds L;
   L.r = (uint32_t *)lds_raw;  // the input ring first: its reads encode their offsets
   L.w = (uint16_t *)(lds_raw + LDS_U32_PER_LANE * 4);
-  static_assert(LDS_U32_PER_LANE * 4 % 16 == 0, "u16 regions stay aligned");
+  static_assert(LDS_U32_PER_LANE * 4 % 16 == 0 && LDS_BYTES_PER_LANE % 16 == 0, "u16 and span regions stay aligned");
+  L.x = lds_raw + LDS_BYTES_PER_LANE;
 
   Arenas A;
   A.src = src_arena;
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
 #ifdef ZD_INFLATE_PHASES  // timing-only build: the results carry cycle counts (tools/exp_inflate_phases.py)
   uint64_t ph_hdr = 0, ph_wide = 0, ph_plain = 0, ph_t;
+  uint64_t span_ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint64_t ph_begin = __builtin_readcyclecounter();
 #define ZD_PH(acc) do { const uint64_t now_ = __builtin_readcyclecounter(); acc += now_ - ph_t; ph_t = now_; } while (0)
 #define ZD_PH_START() ph_t = __builtin_readcyclecounter()
@@ -380,6 +384,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
         ZD_PH(ph_hdr);
       } else if (d.phase == PH_SYMBOLS) {
+        if (!d.span_off) {  // the block's symbols by regions, all lanes busy (inflate_span.h)
+          if (d.q_count) break;  // queued copies first: the span reads its match sources from memory
+          ZD_PH_START();
+#ifdef ZD_INFLATE_PHASES
+          const int sr = span_decode(d, L, src, dst, lane, span_ph);
+#else
+          const int sr = span_decode(d, L, src, dst, lane);
+#endif
+          if (sr != SPAN_NONE) {
+            uniformize(d);
+            d.span_off = sr == SPAN_OFF;
+            ZD_PH(ph_plain);  // (timing build: the span's clocks are booked as "plain")
+            break;  // the input ring starts over at the new position
+          }
+          d.span_off = 1;  // too little input left for a span: the wide turns take the rest
+        }
         if (!d.input_ready(TURN_WORDS)) break;
         ZD_PH_START();
         bool stopped;
@@ -436,6 +456,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     r.status = (uint32_t)((__builtin_readcyclecounter() - ph_begin) >> 6);
     r.checksum = (uint32_t)(ph_hdr >> 6);
     r.out_len = (ph_wide >> 6) | ((ph_plain >> 6) << 32);
+    for (int i = 0; i < 8; i++) ((uint64_t *)dst)[i] = span_ph[i];  // over the stream's first output bytes (dst slots are 256-byte aligned)
 #endif
     results[stream] = r;
   }

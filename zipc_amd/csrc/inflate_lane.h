@@ -81,6 +81,7 @@ constexpr int HEADER_WORDS = 6;    // words a block header step may touch: (31 +
 struct LaneLds {
   uint16_t *w;  // u16 regions of this stream's block
   uint32_t *r;  // u32 regions
+  uint8_t *x;   // the span decoder's regions (inflate_span.h), 16-byte aligned
   ZD_HD uint16_t &u16(int off, int i) const { return w[off + i]; }
   ZD_HD uint32_t &slot(int s) const { return r[LDS_RING + s]; }
   ZD_HD uint32_t &queue(int k) const { return r[LDS_QUEUE + k]; }
@@ -138,6 +139,10 @@ struct InflateLane {
   int32_t hdr_fixed;   // PH_TABLES: 1 = the fixed codes
   uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
   int32_t levels;      // doubling levels the block's wide turns need (levels_for)
+  // the span decoder (inflate_span.h)
+  uint32_t blk_in_word, blk_boff;  // where the current block's symbols start
+  uint32_t prev_block_bits;        // bits of the previous compressed block's symbols (0: none yet): sizes the regions
+  int32_t span_off;                // the rest of this block is left to the wide turns
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
 
@@ -520,6 +525,14 @@ ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__r
   return true;
 }
 
+// the block's symbols start at the current position
+ZD_HD void lane_begin_symbols(InflateLane &d) {
+  d.phase = PH_SYMBOLS;
+  d.blk_in_word = d.in_word;
+  d.blk_boff = d.boff;
+  d.span_off = 0;
+}
+
 // Phase PH_TABLES, serial form (the kernel has a wave-parallel one with the same
 // results, inflate.hip): the block's two decoders and their primary tables.
 ZD_HD void lane_finish_tables(InflateLane &d, const LaneLds &L) {
@@ -533,11 +546,13 @@ ZD_HD void lane_finish_tables(InflateLane &d, const LaneLds &L) {
     build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
     build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
   }
-  d.phase = PH_SYMBOLS;
+  lane_begin_symbols(d);
 }
 
 // end of block: inflated_block_crc zd.ml:682-690, then the loop test zd.ml:704
 ZD_HD void lane_end_of_block(InflateLane &d, bool crc_adler) {
+  const uint32_t words = d.in_word - d.blk_in_word;
+  d.prev_block_bits = words >= (1u << 17) ? (1u << 22) : words * 32u + d.boff - d.blk_boff;
   if (crc_adler) d.phase = PH_REQ_ADLER;
   else d.phase = d.final_block ? PH_DONE : PH_HEADER;
 }
@@ -553,17 +568,19 @@ ZD_HD void lane_end_of_block(InflateLane &d, bool crc_adler) {
 // owns every error and edge decision.
 //   litlen: [4:0] code bits (bit 4 clear: the word is its own bit-field offset operand)
 //           [7:5] extra bits  [16:8] literal byte / base length  [22:17] code + extra bits
-//           [30] length symbol  [31] literal
+//           [29] length symbol 268..285 (not for the wide turn)  [30] length symbol 257..267  [31] literal
 //   dist:   [4:0] code bits  [8:5] extra bits  [24:9] base distance  [29:25] code + extra bits
 //           (an invalid code is 0: it decodes to distance 0, which no length is <= to)
 ZD_HD uint32_t wide_lit_entry(uint32_t e16, int lit_max_sym) {
   const uint32_t len = e16 & 15u, sym = e16 >> 4;
   if (len == 0) return 0;
   if (sym < (uint32_t)LITLEN_EOB) return len | (sym << 8) | (len << 17) | (1u << 31);
-  if (sym == (uint32_t)LITLEN_EOB || (int)sym > lit_max_sym || sym > 267u) return 0;
+  if (sym == (uint32_t)LITLEN_EOB || (int)sym > lit_max_sym || sym > (uint32_t)LITLEN_SYM_MAX) return 0;
   uint32_t base, extra;
   length_sym_value((int)sym, base, extra);
-  return len | (extra << 5) | (base << 8) | ((len + extra) << 17) | (1u << 30);
+  // 268..285 (length > DEFER_MAX_LEN): bit 29 instead of bit 30 -- a stop for the wide turn
+  // like the 0 it used to be, a length symbol for the span decoder (inflate_span.h)
+  return len | (extra << 5) | (base << 8) | ((len + extra) << 17) | (sym > 267u ? 1u << 29 : 1u << 30);
 }
 ZD_HD uint32_t wide_dist_entry(uint32_t e16, int dist_max_sym) {
   const uint32_t len = e16 & 15u, sym = e16 >> 4;
@@ -682,6 +699,9 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.hdr_fixed = 0;
   d.adler = 1;  // Adler_32.init zd.ml:173
   d.levels = 6;
+  d.blk_in_word = d.blk_boff = 0;
+  d.prev_block_bits = 0;
+  d.span_off = 0;
   if (s.src_len > MAX_STREAM_LEN || s.dst_cap > MAX_STREAM_LEN) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;
     d.fail(ST_INVALID_ARG);

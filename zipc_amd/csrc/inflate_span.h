@@ -1,0 +1,720 @@
+// inflate_span.h -- the compressed block's symbols, decoded by all 64 lanes at full lane use.
+//
+// inflate.hip's wide turn speculates on 64 BIT OFFSETS and commits the ~8 that are real
+// symbol starts: 13 % useful work, and the kernel is bound by instruction issue.  This file
+// is the other decomposition of read_block_symbols (src/zipc_deflate.ml:593-616): the
+// compressed bits ahead are cut into one REGION per lane (S = K x 256 bits), every lane
+// walks its own region a symbol at a time -- 64 real symbols per wave step -- and the
+// unknown region starts are settled by the fact that Huffman streams self-synchronise
+// (measured on the configs' data: 50-150 bits on average, p99 under 1000):
+//
+//   phase A  lane i walks region i from its first bit (lane 0: the true position),
+//            LENGTHS ONLY: bits and output bytes of each symbol.  At every 256-bit
+//            boundary it crosses it records in LDS where the first symbol at or after the
+//            boundary starts (6 bits) and how many bytes the granule before produced
+//            (10 bits): the INDEX, one u16 per granule.
+//            Then lane i walks on into region i+1, overwriting that region's entries with
+//            its own, until it crosses a boundary at the very bit lane i+1 recorded: from
+//            there on the two walks are the same walk (MERGED).  Lane 0 started on a real
+//            symbol, so the chain lane 0 -> 1 -> ... makes every region's entries those of
+//            the real symbol sequence, as far as every link merged inside its region.
+//            Where a link did not, the span is cut there: a prefix is always exact.  A walk
+//            that meets a symbol it must not decode (end of block, anything invalid) cannot
+//            know whether it is on the real sequence yet: it notes the granule, skips a bit
+//            and walks on; once the chain tells where the walk became real, its first such
+//            note from there on is a real stop, and the span ends in front of that granule.
+//   phase B  the verified granules in stream order, 64 at a time (one per lane, as many as
+//            give at most 4 KiB of output): every lane decodes its granule fully -- the
+//            literals go to their place in an LDS TILE of the output, a match leaves its
+//            {distance, length} in the first 3 bytes of its own hole and a bit in a bitmap.
+//            Then the holes are filled in stream order: sources that lie before the tile
+//            are final in global memory and are all requested first (the random 32 KiB
+//            window reads that missed L2 once per match in the old kernel now overlap),
+//            the others are copied LDS -> LDS in rounds behind a watermark.  The tile
+//            leaves with coalesced 16-byte stores; literals never go to memory one by one.
+//
+// Everything that needs a decision of the reference -- end of block, errors, the last
+// bytes of the input, the size limit -- stops the span IN FRONT of the symbol in question
+// and is left to lane_one_symbol (inflate_lane.h), which owns those decisions.  A span
+// that cannot run (little input left, highly compressible granules) leaves the block to
+// the wide turns.  Written on wave.h's collectives, so tests/host_sim runs this very code.
+#pragma once
+
+#include "inflate_lane.h"
+#include "wave.h"
+
+namespace zd {
+
+constexpr uint32_t SPAN_G = 256;          // granule: bits of input per index entry
+constexpr uint32_t SPAN_K_MAX = 18;       // granules per lane and span at most (36 KiB of input per span)
+constexpr uint32_t SPAN_K_MIN = 4;        // ... and at least: two walks can only merge at a granule boundary
+constexpr uint32_t SPAN_MIN_LANES = 8;    // fewer regions than this: not worth a span
+constexpr uint32_t SPAN_TILE = 4096;      // output bytes assembled in LDS at a time
+constexpr uint32_t SPAN_OD_BIG = 1023;    // index value for "1023 output bytes or more": such a granule is not for a tile
+constexpr uint32_t SPAN_RING = 8;         // input words a lane has waiting in LDS behind the 4 in its registers
+constexpr uint32_t SPAN_TAIL_WORDS = 6;   // input words a span keeps clear of (its reads run ahead of its symbols)
+constexpr uint32_t SPAN_LONG = 32;        // matches longer than this are copied by the whole wave
+constexpr int SPAN_FLY = 8;               // far matches a lane has in flight: decode steps between request and arrival
+
+// LDS of the span, after the stream's tables (LaneLds::x)
+constexpr uint32_t SPAN_IDX_OFF = 0;                                     // u16[64 * K_MAX]
+constexpr uint32_t SPAN_RING_OFF = SPAN_IDX_OFF + 64 * SPAN_K_MAX * 2;    // u32[8 * 64], word-major
+constexpr uint32_t SPAN_TILE_OFF = SPAN_RING_OFF + SPAN_RING * 64 * 4;
+constexpr uint32_t SPAN_BITS_OFF = SPAN_TILE_OFF + SPAN_TILE + 16;        // u32[128 + 2]: a bit per tile byte
+constexpr uint32_t SPAN_LDS_BYTES = SPAN_BITS_OFF + (SPAN_TILE / 32 + 2) * 4;
+static_assert(SPAN_TILE_OFF % 16 == 0 && SPAN_BITS_OFF % 4 == 0, "tile rows leave with 16-byte reads");
+
+enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_OFF = 3 };
+enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERGE = 5 };
+
+// ---- one symbol, from the next 64 bits
+struct SpanSym {
+  uint32_t tot;     // bits
+  uint32_t outlen;  // bytes: 1, or the match length
+  uint32_t val;     // literal byte, or the match distance
+  bool is_lit, stop;
+};
+// The general form: codes longer than the tables' bits, end of block, anything invalid (their
+// table entries are 0) take the canonical walk; what is not a plain literal or match stops.
+ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int lit_max_sym, int dist_max_sym) {
+  SpanSym r;
+  r.stop = false;
+  r.tot = 0; r.outlen = 0; r.val = 0;
+  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  uint32_t b1, lv;
+  if (e != 0) {
+    r.is_lit = (int32_t)e < 0;
+    b1 = (e >> 17) & 63u;
+    lv = ((e >> 8) & 511u) + bit_field(xlo, e, (e >> 5) & 7u);
+  } else {
+    BitCursor c;
+    c.x = ((uint64_t)xhi << 32) | xlo;
+    c.used = 0;
+    c.avail = 64;
+    const int sym = read_symbol(c, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+    r.is_lit = true;
+    if (sym < 0 || sym == LITLEN_EOB || sym > lit_max_sym || sym > LITLEN_SYM_MAX) {
+      r.stop = true;
+      return r;
+    }
+    if (sym < LITLEN_EOB) lv = (uint32_t)sym;
+    else {
+      r.is_lit = false;
+      uint32_t base, extra, v = 0;
+      length_sym_value(sym, base, extra);
+      if (extra) c.take((int)extra, v);
+      lv = base + v;
+    }
+    b1 = (uint32_t)c.used;
+  }
+  if (r.is_lit) {
+    r.tot = b1;
+    r.outlen = 1;
+    r.val = lv;
+    return r;
+  }
+  const uint32_t x2 = funnel32(xhi, xlo, b1);  // b1 <= 20
+  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  uint32_t dist, t2;
+  if (e2 != 0) {
+    dist = ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
+    t2 = e2 >> 25;
+  } else {
+    BitCursor c;
+    c.x = x2;  // 15 + 13 bits at most
+    c.used = 0;
+    c.avail = 32;
+    const int dsym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+    if (dsym < 0 || dsym > dist_max_sym || dsym > DIST_SYM_MAX) {
+      r.stop = true;
+      return r;
+    }
+    uint32_t base, extra, v = 0;
+    dist_sym_value(dsym, base, extra);
+    if (extra) c.take((int)extra, v);
+    dist = base + v;
+    t2 = (uint32_t)c.used;
+  }
+  r.tot = b1 + t2;
+  r.outlen = lv;
+  r.val = dist;
+  return r;
+}
+// The common case without a branch: both lookups always (a literal lane's distance lookup
+// reads a valid, ignored entry, as in the wide turn).  Where an entry is 0 the general form
+// takes over -- behind a wave-uniform test, so that a wave whose 64 symbols are all common ones
+// (nearly always) skips it with one scalar branch.  Every lane calls this (act: the lane's
+// symbol is wanted).  Table entries are the wide turn's (inflate_lane.h) plus length symbols
+// 268..285 (bit 29).
+template <bool FULL>
+ZD_WV SpanSym span_symbol(bool act, uint32_t xlo, uint32_t xhi, const LaneLds &L, int lit_max_sym, int dist_max_sym) {
+  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  const uint32_t b1 = (e >> 17) & 63u;
+  const bool is_lit = (int32_t)e < 0;
+  const uint32_t lv = ((e >> 8) & 511u) + bit_field(xlo, e, (e >> 5) & 7u);
+  const uint32_t x2 = funnel32(xhi, xlo, b1);
+  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  SpanSym r;
+  r.is_lit = is_lit;
+  r.stop = false;
+  r.tot = b1 + (is_lit ? 0u : e2 >> 25);
+  r.outlen = is_lit ? 1u : lv;
+  r.val = 0;
+  if (FULL) r.val = is_lit ? lv : ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
+  const bool rare = act && (e == 0u || (!is_lit && e2 == 0u));
+  if (wv::any(rare)) {
+    if (rare) r = span_symbol_slow(xlo, xhi, L, lit_max_sym, dist_max_sym);
+  }
+  return r;
+}
+
+// ---- a lane's view of its input: the 4 words at its position in registers (a symbol is at most
+// 48 bits), the next 8 waiting in LDS, word-major (word j of lane l at [j][l]: conflict free
+// whatever word each lane is at), refilled 4 words at a time.  A refill requested at one refill
+// point is written at the next, so its latency is a few symbols of the whole wave, not a wait;
+// the peek of a symbol reads no memory at all.
+struct SpanEnv {
+  const uint8_t *src;  // the stream's input from the span's first word on
+  uint32_t *ring;
+  uint32_t max_word;   // words of input that may be loaded 16 bytes at a time
+  int lane;
+};
+struct SpanReader {
+  uint32_t w0, w1, w2, w3;  // input words cw .. cw + 3
+  uint32_t cw;
+  uint32_t wr;  // words below wr are in the registers or the ring
+  wv::Quad pend;
+  uint32_t has_pend;
+};
+// 4 words from word w on; past the loadable input the address is clamped (those words are never decoded)
+ZD_WV wv::Quad span_load(const SpanEnv &E, uint32_t w) {
+  const uint32_t c = w + 4u <= E.max_word ? w : E.max_word - 4u;
+  return wv::load_quad(E.src + (uint64_t)c * 4u);
+}
+ZD_WV void span_ring_put(const SpanEnv &E, uint32_t w, const wv::Quad &q) {
+  uint32_t *r = E.ring + (uint32_t)E.lane;
+  r[((w + 0u) & (SPAN_RING - 1)) * 64u] = q.x;
+  r[((w + 1u) & (SPAN_RING - 1)) * 64u] = q.y;
+  r[((w + 2u) & (SPAN_RING - 1)) * 64u] = q.z;
+  r[((w + 3u) & (SPAN_RING - 1)) * 64u] = q.w;
+}
+ZD_WV void span_reader_start(SpanReader &R, const SpanEnv &E, uint32_t p) {
+  R.cw = p >> 5;
+  const wv::Quad q0 = span_load(E, R.cw), q1 = span_load(E, R.cw + 4u), q2 = span_load(E, R.cw + 8u);
+  R.w0 = q0.x; R.w1 = q0.y; R.w2 = q0.z; R.w3 = q0.w;
+  span_ring_put(E, R.cw + 4u, q1);
+  span_ring_put(E, R.cw + 8u, q2);
+  R.wr = R.cw + 12u;
+  R.has_pend = 0;
+  R.pend = q0;
+}
+ZD_WV void span_reader_refill(SpanReader &R, const SpanEnv &E, bool active) {
+  if (R.has_pend) {
+    span_ring_put(E, R.wr, R.pend);
+    R.wr += 4u;
+    R.has_pend = 0;
+  }
+  if (active && R.wr - R.cw <= 8u) {  // 4 words or fewer wait in the ring
+    R.pend = span_load(E, R.wr);
+    R.has_pend = 1;
+  }
+}
+// a step may cross two word boundaries
+ZD_WV bool span_can_step(const SpanReader &R) { return R.cw + 6u <= R.wr; }
+ZD_WV void span_peek(const SpanReader &R, uint32_t p, uint32_t &xlo, uint32_t &xhi) {
+  xlo = funnel32(R.w1, R.w0, p);
+  xhi = funnel32(R.w2, R.w1, p);
+}
+ZD_WV void span_advance(SpanReader &R, const SpanEnv &E, uint32_t p) {  // the position is now p; every lane calls this
+  const uint32_t *r = E.ring + (uint32_t)E.lane;
+  const uint32_t ncw = p >> 5;
+  const bool s1 = ncw != R.cw;  // (nearly every step some lane crosses a word: no branch around this)
+  const uint32_t nx = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
+  R.w0 = s1 ? R.w1 : R.w0;
+  R.w1 = s1 ? R.w2 : R.w1;
+  R.w2 = s1 ? R.w3 : R.w2;
+  R.w3 = s1 ? nx : R.w3;
+  R.cw += s1 ? 1u : 0u;
+  const bool s2 = ncw != R.cw;  // a symbol of more than 32 bits
+  if (wv::any(s2)) {
+    if (s2) {
+      R.w0 = R.w1; R.w1 = R.w2; R.w2 = R.w3;
+      R.w3 = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
+      R.cw++;
+    }
+  }
+}
+
+#ifdef SPAN_TRACE
+static uint64_t span_trace_steps[8];
+static uint32_t span_lane_steps[64];
+#endif
+// ---- phase A: a lane's walk over a region, recording the index
+struct SpanWalk {
+  uint32_t p;         // bit position of the next symbol (from the span's first word)
+  uint32_t nb;        // the next 256-bit boundary
+  uint32_t k;         // granule of the region the walk is in
+  uint32_t region_e;  // index entry of the region's granule 0
+  uint32_t pd, od;    // the current granule: where its first symbol starts, bytes so far
+  uint32_t stops;     // own region: granules in which the walk met a stop (and skipped a bit)
+  bool run;
+  uint32_t kind, rk, rp;  // how the walk ended: WK_*, granule, bit position
+};
+ZD_WV uint16_t span_entry(uint32_t pd, uint32_t od) {
+  return (uint16_t)(pd | ((od < SPAN_OD_BIG ? od : SPAN_OD_BIG) << 6));
+}
+ZD_WV void span_walk_end(SpanWalk &W, uint32_t kind, uint32_t k, uint32_t p) {
+  W.kind = kind; W.rk = k; W.rp = p; W.run = false;
+}
+// One step of the walk, by every lane (act: this lane walks on).  STITCH: the region is the
+// next lane's.  Straight-line code with the lane's state selected at the end; what is rare for a
+// lane -- a granule boundary, a stop -- sits behind wave-uniform tests.
+template <bool STITCH>
+ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
+                          uint32_t K, int lit_max_sym, int dist_max_sym) {
+  const bool cross = act && W.p >= W.nb;  // into the next granule (a symbol is at most 48 bits: one boundary at a time)
+  if (wv::any(cross)) {
+    if (cross) {
+      idx[W.region_e + W.k] = span_entry(W.pd, W.od);
+      W.k++;
+      const uint32_t npd = W.p - W.nb;
+      if (W.k == K) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, K, W.p);
+      else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, W.p);
+      else {
+        W.pd = npd;
+        W.od = 0;
+        W.nb += SPAN_G;
+      }
+    }
+  }
+  act = act && W.run;
+  uint32_t xlo, xhi;
+  span_peek(R, W.p, xlo, xhi);
+  const SpanSym s = span_symbol<false>(act, xlo, xhi, L, lit_max_sym, dist_max_sym);
+  uint32_t tot = s.tot, outlen = s.outlen;
+  const bool stop = act && s.stop;
+  if (wv::any(stop)) {
+    if (stop) {
+      if (STITCH) {  // this walk is the real sequence: the span ends in front of this granule
+        span_walk_end(W, WK_STOP, W.k, W.nb - SPAN_G + W.pd);
+        act = false;
+      } else {  // real or not is known later: note the granule, go on a bit further
+        W.stops |= 1u << W.k;
+        tot = 1;
+        outlen = 0;
+      }
+    }
+  }
+  W.p += act ? tot : 0u;
+  W.od += act ? outlen : 0u;
+  span_advance(R, E, W.p);
+}
+template <bool STITCH>
+ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx, uint32_t K,
+                          int lit_max_sym, int dist_max_sym) {
+  for (;;) {
+#ifdef SPAN_TRACE
+    if (E.lane == 0) span_trace_steps[STITCH ? 1 : 0] += 4;
+#endif
+#pragma unroll 1
+    for (int u = 0; u < 4; u++) {
+#ifdef SPAN_TRACE
+      if (W.run && !span_can_step(R)) span_trace_steps[4]++;
+      if (W.run) span_trace_steps[5]++;
+      if (W.run && E.lane == 5) span_trace_steps[6]++;
+      if (W.run && !STITCH) span_lane_steps[E.lane]++;
+#endif
+      span_walk_step<STITCH>(W.run && span_can_step(R), W, R, E, L, idx, K, lit_max_sym, dist_max_sym);
+    }
+    span_reader_refill(R, E, W.run);
+    if (!wv::any(W.run)) break;
+  }
+}
+
+// ---- phase B helpers
+// the 3 bytes at tile + q (any alignment; the tile has 16 bytes of slack behind it)
+ZD_WV uint32_t span_rec(const uint8_t *tile, uint32_t q) {
+  const uint32_t *w = (const uint32_t *)(tile + (q & ~3u));
+  return funnel32(w[1], w[0], (q & 3u) * 8u) & 0xFFFFFFu;
+}
+// 4 bytes at s + i (s any alignment; reads the two aligned words around them)
+ZD_WV uint32_t span_rec4(const uint8_t *s, uint32_t i) {
+  const uintptr_t a = (uintptr_t)(s + i);
+  const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
+  return funnel32(w[1], w[0], (uint32_t)(a & 3u) * 8u);
+}
+// A far match's bytes arrive: meta = (tile position + 1) | length << 16 (0: nothing in flight);
+// a = source bytes 0..3, b = source bytes length-4 .. length-1 (length >= 4).
+ZD_WV void span_land(uint8_t *tile, uint32_t meta, uint32_t a, uint32_t b) {
+  const bool pending = meta != 0u;
+  if (wv::any(pending)) {
+    if (pending) {
+      const uint32_t dp = (meta & 0xFFFFu) - 1u, len = meta >> 16;
+      const uint32_t hi = b >> ((8u * (8u - len)) & 31u);  // bytes 4 .. length-1 (length 5..8)
+      tile[dp] = (uint8_t)a;
+      tile[dp + 1u] = (uint8_t)(a >> 8);
+      tile[dp + 2u] = (uint8_t)(a >> 16);
+      if (len > 3u) tile[dp + 3u] = (uint8_t)(a >> 24);
+      if (len > 4u) tile[dp + 4u] = (uint8_t)hi;
+      if (len > 5u) tile[dp + 5u] = (uint8_t)(hi >> 8);
+      if (len > 6u) tile[dp + 6u] = (uint8_t)(hi >> 16);
+      if (len > 7u) tile[dp + 7u] = (uint8_t)(hi >> 24);
+    }
+  }
+}
+ZD_WV uint32_t span_byte_at(const uint8_t *tile, const uint8_t *gbase, int s) {  // tile byte s, or the byte -s before it
+  return s < 0 ? (uint32_t)gbase[s] : (uint32_t)tile[s];
+}
+// A lane's holes are the set bits of the tile's bitmap inside its own output range [from, to), in
+// stream order.
+struct SpanHoles {
+  uint32_t word;  // bits of the current bitmap word not yet taken (inside the range)
+  uint32_t wi;    // its index
+  uint32_t to;
+};
+ZD_WV uint32_t span_holes_mask(uint32_t wi, uint32_t from, uint32_t to) {  // the bits of word wi that lie in [from, to)
+  uint32_t m = 0xFFFFFFFFu;
+  if ((from >> 5) == wi) m &= 0xFFFFFFFFu << (from & 31u);
+  if ((to >> 5) == wi) m &= ~(0xFFFFFFFFu << (to & 31u));
+  return m;
+}
+ZD_WV void span_holes_start(SpanHoles &H, const uint32_t *mbits, uint32_t from, uint32_t to) {
+  H.wi = from >> 5;
+  H.to = to;
+  H.word = from < to ? mbits[H.wi] & span_holes_mask(H.wi, from, to) : 0u;
+}
+// the next hole's position, or 0xFFFFFFFF
+ZD_WV uint32_t span_holes_next(SpanHoles &H, const uint32_t *mbits) {
+  while (H.word == 0u) {
+    if (((H.wi + 1u) << 5) >= H.to) return 0xFFFFFFFFu;
+    H.wi++;
+    H.word = mbits[H.wi] & span_holes_mask(H.wi, 0u, H.to);
+  }
+  const uint32_t b = (uint32_t)__builtin_ctz(H.word);
+  H.word &= H.word - 1u;
+  return (H.wi << 5) + b;
+}
+
+// The span.  d.phase == PH_SYMBOLS, nothing queued; returns SPAN_NONE when it did not run
+// (nothing changed), else the stream position, out_pos and ring_wr are those after the
+// symbols it committed: SPAN_AGAIN (more of the block may follow the same way) or SPAN_OFF
+// (leave the rest of this block to the wide turns).
+#ifdef ZD_INFLATE_PHASES  // timing-only build (tools/exp_inflate_phases.py): clocks per phase of the span
+#define ZD_SPAN_PH(i) do { const uint64_t now_ = __builtin_readcyclecounter(); span_ph[i] += now_ - span_t; span_t = now_; } while (0)
+#else
+#define ZD_SPAN_PH(i) do {} while (0)
+#endif
+ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, int lane
+#ifdef ZD_INFLATE_PHASES
+                      , uint64_t *span_ph
+#endif
+) {
+#ifdef ZD_INFLATE_PHASES
+  uint64_t span_t = __builtin_readcyclecounter();
+#endif
+  // ---- geometry (wave-uniform: the stream's state is the same in every lane)
+  const uint32_t in_word = wv::uni(d.in_word), base = wv::uni(d.boff), src_len = wv::uni(d.src_len);
+  const uint32_t full_words = src_len >> 2;
+  if (full_words < in_word + SPAN_TAIL_WORDS + 2u) return SPAN_NONE;
+  const uint32_t max_word = full_words - in_word;
+  const uint32_t usable = (max_word - SPAN_TAIL_WORDS) * 32u - base;  // bits a span may walk
+  uint32_t est = usable;
+  const uint32_t prev_bits = wv::uni(d.prev_block_bits);
+  if (prev_bits != 0u) {
+    const uint32_t guess = prev_bits + (prev_bits >> 3) + SPAN_G;
+    if (guess < est) est = guess;
+  }
+  uint32_t K = (est + 64u * SPAN_G - 1u) / (64u * SPAN_G);
+  if (K < SPAN_K_MIN) K = SPAN_K_MIN;
+  if (K > SPAN_K_MAX) K = SPAN_K_MAX;
+  const uint32_t S = K * SPAN_G;
+  uint32_t n_lanes = usable / S;
+  if (n_lanes > 64u) n_lanes = 64u;
+  if (n_lanes < SPAN_MIN_LANES) return SPAN_NONE;
+
+  SpanEnv E;
+  E.src = src_stream + (uint64_t)in_word * 4u;
+  E.ring = (uint32_t *)(L.x + SPAN_RING_OFF);
+  E.max_word = max_word;
+  E.lane = lane;
+  uint16_t *idx = (uint16_t *)(L.x + SPAN_IDX_OFF);
+  uint8_t *tile = L.x + SPAN_TILE_OFF;
+  uint32_t *mbits = (uint32_t *)(L.x + SPAN_BITS_OFF);
+  const int lit_max = (int)wv::uni((uint32_t)d.lit_max_sym), dist_max = (int)wv::uni((uint32_t)d.dist_max_sym);
+  const uint32_t cap_min = wv::uni(d.cap_min), out_pos0 = wv::uni(d.out_pos), hard_cap = wv::uni(d.hard_cap);
+  const uint32_t ulane = (uint32_t)lane;
+  wv::fence_global();  // bytes the wide turns stored are read below as match sources
+
+  // ---- phase A: every lane its own region
+  SpanWalk W;
+  SpanReader R;
+  const bool in_span = ulane < n_lanes;
+  W.p = base + (in_span ? ulane : 0u) * S;
+  W.nb = W.p + SPAN_G;
+  W.k = 0;
+  W.region_e = ulane * K;
+  W.pd = 0;
+  W.od = 0;
+  W.stops = 0;
+  W.run = in_span;
+  W.kind = WK_NONE; W.rk = 0; W.rp = 0;
+  span_reader_start(R, E, W.p);
+  span_walk_loop<false>(W, R, E, L, idx, K, lit_max, dist_max);
+  ZD_SPAN_PH(0);
+  const uint32_t m_p = W.rp, m_stops = W.stops;  // (every walk of a region ends at the region's end: WK_END)
+  wv::sync();
+  // ... and on into the next lane's, until the two walks are one
+  {
+    const bool stitch = ulane + 1u < n_lanes;
+    W.kind = WK_NONE; W.rk = 0; W.rp = 0;
+    W.run = false;
+    if (stitch) {
+      W.region_e = (ulane + 1u) * K;
+      const uint32_t r0 = base + (ulane + 1u) * S;
+      W.p = m_p;
+      W.k = 0;
+      W.pd = W.p - r0;
+      W.od = 0;
+      W.nb = r0 + SPAN_G;
+      if ((idx[W.region_e] & 63u) == W.pd) span_walk_end(W, WK_MERGED, 0, W.p);
+      else W.run = true;
+    }
+  }
+  span_walk_loop<true>(W, R, E, L, idx, K, lit_max, dist_max);
+  const uint32_t s_kind = W.kind, s_k = W.rk, s_p = W.rp;
+  wv::sync();
+  ZD_SPAN_PH(1);
+
+  // ---- how far the chain from lane 0 holds
+  uint32_t n_valid, p_end;
+  bool end_stop = false;
+  {
+    // my own walk is the real sequence from granule mk on, if the lane before merged into it
+    const uint32_t pk = wv::shfl(s_kind, ulane - 1u), pmk = wv::shfl(s_k, ulane - 1u);
+    const bool real = lane == 0 || pk == WK_MERGED;
+    const uint32_t mk = lane == 0 ? 0u : pmk;
+    const uint32_t real_stops = real ? (m_stops >> mk) << mk : 0u;
+    const bool link = in_span && real && real_stops == 0u;
+    const uint64_t lm = wv::ballot(link);
+    const uint32_t f = ~lm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~lm);  // first lane whose region does not end on the real sequence
+    if (f >= n_lanes) {
+      n_valid = n_lanes * K;
+      p_end = wv::readlane(m_p, n_lanes - 1u);
+    } else if (wv::readlane(real ? 1u : 0u, f) != 0u) {  // its own walk met a real stop, in granule ks
+      const uint32_t ks = (uint32_t)__builtin_ctz(wv::readlane(real_stops, f));
+      n_valid = f * K + ks;
+      p_end = base + n_valid * SPAN_G + ((uint32_t)idx[n_valid] & 63u);
+      end_stop = true;
+    } else {  // the walk of the lane before went through the whole region, or met a real stop there
+      const uint32_t kind = wv::readlane(s_kind, f - 1u), kk = wv::readlane(s_k, f - 1u);
+      p_end = wv::readlane(s_p, f - 1u);
+      if (kind == WK_NOMERGE) n_valid = (f + 1u) * K;
+      else { n_valid = f * K + kk; end_stop = true; }  // WK_STOP
+    }
+  }
+#ifdef SPAN_TRACE
+  if (lane == 0) fprintf(stderr, "span: usable %u K %u lanes %u n_valid %u p_end-base %u stop %d\n", usable, K, n_lanes, n_valid, p_end - base, (int)end_stop);
+#endif
+
+  // ---- phase B: the verified granules, a tile of output at a time
+  uint32_t out_pos = out_pos0;
+  uint32_t e = 0;
+  bool cut = false;  // the span ends before n_valid: size limit reached, a granule too rich, or a tile refused
+  while (e < n_valid) {
+    const uint32_t ent = e + ulane;
+    const bool have = ent < n_valid;
+    const uint32_t iv = have ? (uint32_t)idx[ent] : 0u;
+    const uint32_t eod = iv >> 6, epd = iv & 63u;
+    const uint32_t incl = wv::scan_incl(eod);
+    const bool fit = have && eod != SPAN_OD_BIG && incl <= SPAN_TILE && incl <= cap_min - out_pos;
+    const uint64_t fm = wv::ballot(fit);
+    const uint32_t n = ~fm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~fm);
+    const uint32_t tile_start_p = base + e * SPAN_G + wv::readlane(epd, 0u);
+    if (n == 0u) {  // the output limit (the symbol that crosses it is lane_one_symbol's), or a granule too rich for a tile
+      p_end = tile_start_p;
+      cut = true;
+      break;
+    }
+    const uint32_t tile_len = wv::readlane(incl, n - 1u);
+    const bool mine = ulane < n;
+    const uint32_t o0 = incl - eod, o_end = incl;
+    uint32_t o = o0;
+    const uint32_t p0 = base + (mine ? ent : e) * SPAN_G + (mine ? epd : 0u);
+    uint32_t p = p0;
+    const uint32_t pe = ent + 1u == n_valid ? p_end : base + (ent + 1u) * SPAN_G;
+    mbits[ulane] = 0;
+    mbits[ulane + 64u] = 0;
+    if (ulane < 2u) mbits[128u + ulane] = 0;
+    span_reader_start(R, E, p);
+    wv::sync();
+    ZD_SPAN_PH(2);
+    bool err = false;
+    const uint8_t *gbase = dst + out_pos;  // the tile's place in the output; gbase[-n] is final for every n >= 1
+    // A match of up to 8 bytes whose source lies wholly before the tile (on the configs' data: most)
+    // is requested from memory the moment it is decoded and lands SPAN_FLY steps later, when the
+    // lane comes by the same slot again: the random window reads of all lanes overlap with the
+    // decoding, and such a match needs neither a record nor a bit in the bitmap.
+    uint32_t f_meta[SPAN_FLY], f_a[SPAN_FLY], f_b[SPAN_FLY];
+#pragma unroll
+    for (int u = 0; u < SPAN_FLY; u++) { f_meta[u] = 0; f_a[u] = 0; f_b[u] = 0; }
+    // (Every step issues its two loads, lanes without such a match from a fixed valid address, and
+    // the loop is left only between groups of SPAN_FLY steps: with a branch around a load the
+    // compiler must assume at the landing that nothing was requested since, and wait for all.)
+    for (;;) {
+      if (!wv::any(mine && !err && p < pe)) break;
+#pragma unroll
+      for (int u = 0; u < SPAN_FLY; u++) {
+        span_land(tile, f_meta[u], f_a[u], f_b[u]);
+        const bool act = mine && !err && p < pe;
+#ifdef SPAN_TRACE
+        if (lane == 0) span_trace_steps[2]++;
+#endif
+        uint32_t xlo, xhi;
+        span_peek(R, p, xlo, xhi);
+        const SpanSym s = span_symbol<true>(act, xlo, xhi, L, lit_max, dist_max);
+        // what the plain decoder must see for itself: a stop, more bytes than phase A counted, a
+        // distance that reaches before the output (zd.ml:614)
+        const bool bad = act && (s.stop || o + s.outlen > o_end || (!s.is_lit && s.val > out_pos + o));
+        const bool good = act && !bad;
+        err = err || bad;
+        const bool is_match = good && !s.is_lit;
+        const bool fly = is_match && s.outlen <= 8u && s.val >= o + s.outlen;
+        if (good && s.is_lit) tile[o] = (uint8_t)s.val;
+        const uint8_t *sp = fly ? gbase + (int)o - (int)s.val : E.src;
+        f_a[u] = load_u32_le(sp);
+        f_b[u] = load_u32_le(sp + (fly && s.outlen >= 4u ? s.outlen - 4u : 0u));
+        f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
+        if (is_match && !fly) {
+          tile[o] = (uint8_t)(s.val - 1u);
+          tile[o + 1u] = (uint8_t)((s.val - 1u) >> 8);
+          tile[o + 2u] = (uint8_t)(s.outlen - 3u);
+          wv::lds_or(mbits + (o >> 5), 1u << (o & 31u));
+        }
+        o += good ? s.outlen : 0u;
+        p += good ? s.tot : 0u;
+        span_advance(R, E, p);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SPAN_FLY; u++) span_land(tile, f_meta[u], f_a[u], f_b[u]);
+    // both phases must have walked the same symbols
+    {
+      const uint32_t next_start = wv::shfl(p0, ulane + 1u);
+      if (mine && !err) {
+        if (o != o_end) err = true;
+        if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = true;
+      }
+    }
+    if (wv::any(err)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
+      p_end = tile_start_p;
+      cut = true;
+      break;
+    }
+    wv::sync();
+    ZD_SPAN_PH(3);
+
+    // The other holes in stream order.  Every lane works through its own front to back; a hole
+    // may be filled once every byte of its source is final, i.e. lies before the first hole of
+    // the whole tile that is still open (the lanes' ranges are in stream order: that is the open
+    // hole of the lowest lane that has one) -- or it is that hole.
+    {
+      SpanHoles H;
+      span_holes_start(H, mbits, mine ? o0 : 0u, mine ? o_end : 0u);
+      uint32_t dp = span_holes_next(H, mbits);
+      uint8_t *stage = (uint8_t *)E.ring + ulane * 32u;  // the input ring is idle: 32 bytes per lane
+      const bool wide_ok = out_pos + 32u <= hard_cap;    // 16-byte loads of far sources may read into the tile's place
+      for (;;) {
+        const bool open = dp != 0xFFFFFFFFu;
+        const uint64_t om = wv::ballot(open);
+        if (om == 0ull) break;
+        uint32_t dist = 1, len = 0;
+        if (open) {
+          const uint32_t rec = span_rec(tile, dp);
+          dist = (rec & 0x7FFFu) + 1u;
+          len = (rec >> 16) + 3u;
+        }
+        const int sp = (int)dp - (int)dist;
+        const uint32_t first = (uint32_t)__builtin_ctzll(om);
+        const uint32_t wm = wv::readlane(dp, first);
+        const uint32_t flen = wv::readlane(len, first);
+        wv::sync();  // records are read before anybody writes bytes over them
+        if (flen > SPAN_LONG) {  // Buf.recopy zd.ml:63-75: byte i is the source's byte i mod dist
+          const uint32_t fdist = wv::readlane(dist, first);
+          const int fsp = (int)wm - (int)fdist;
+          for (uint32_t i = ulane; i < flen; i += 64u)
+            tile[wm + i] = (uint8_t)span_byte_at(tile, gbase, fsp + (int)(i % fdist));
+          wv::sync();
+          if (ulane == first) dp = span_holes_next(H, mbits);
+          continue;
+        }
+        const bool go = open && len <= SPAN_LONG && (ulane == first || sp + (int)len <= (int)wm);
+        // three ways to move the bytes: from memory through the lane's staging bytes (the source
+        // wholly before the tile), words inside the tile (distance >= 4), byte by byte (the rest)
+        const bool far = go && wide_ok && sp + (int)len <= 0;
+        const bool words = far || (go && sp >= 0 && dist >= 4u);
+        if (wv::any(far)) {
+          if (far) {
+            const uint8_t *g = gbase + sp;
+            const wv::Quad q0 = wv::load_quad(g), q1 = wv::load_quad(g + 16);
+            uint32_t *st = (uint32_t *)stage;
+            st[0] = q0.x; st[1] = q0.y; st[2] = q0.z; st[3] = q0.w;
+            st[4] = q1.x; st[5] = q1.y; st[6] = q1.z; st[7] = q1.w;
+          }
+        }
+        const uint8_t *from = far ? stage : tile + (sp >= 0 ? sp : 0);
+        for (uint32_t i = 0;; i += 4u) {
+          const bool g = words && i < len;
+          if (!wv::any(g)) break;
+          if (g) {
+            const uint32_t v = span_rec4(from, i);
+            tile[dp + i] = (uint8_t)v;
+            if (i + 1u < len) tile[dp + i + 1u] = (uint8_t)(v >> 8);
+            if (i + 2u < len) tile[dp + i + 2u] = (uint8_t)(v >> 16);
+            if (i + 3u < len) tile[dp + i + 3u] = (uint8_t)(v >> 24);
+          }
+        }
+        for (uint32_t i = 0;; i++) {
+          const bool g = go && !words && i < len;
+          if (!wv::any(g)) break;
+          if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+        }
+        wv::sync();
+        if (go) dp = span_holes_next(H, mbits);
+      }
+    }
+    ZD_SPAN_PH(5);
+    // the tile leaves
+    for (uint32_t i = ulane * 16u; i < tile_len; i += 1024u) {
+      if (i + 16u <= tile_len) {
+        const uint32_t *t = (const uint32_t *)(tile + i);
+        wv::Quad q;
+        q.x = t[0]; q.y = t[1]; q.z = t[2]; q.w = t[3];
+        wv::store_quad(dst + out_pos + i, q);
+      } else {
+        for (uint32_t j = i; j < tile_len; j++) dst[out_pos + j] = tile[j];
+      }
+    }
+    wv::fence_global();
+    ZD_SPAN_PH(6);
+#ifdef ZD_INFLATE_PHASES
+    span_ph[7] += 1;
+#endif
+    out_pos += tile_len;
+    e += n;
+  }
+
+  // ---- the stream goes on behind the committed symbols
+#ifdef SPAN_TRACE
+  if (lane == 0) { for (int i = 0; i < 64; i++) fprintf(stderr, "%u ", span_lane_steps[i]); fprintf(stderr, "\n"); }
+  if (lane == 0) fprintf(stderr, "steps: A %llu stitch %llu B %llu; lane-steps starved %llu running %llu lane5 %llu\n", (unsigned long long)span_trace_steps[0], (unsigned long long)span_trace_steps[1], (unsigned long long)span_trace_steps[2], (unsigned long long)span_trace_steps[4], (unsigned long long)span_trace_steps[5], (unsigned long long)span_trace_steps[6]);
+#endif
+  const bool progress = p_end != base || out_pos != out_pos0;
+  d.out_pos = out_pos;
+  d.in_word = in_word + (p_end >> 5);
+  d.boff = p_end & 31u;
+  d.ring_wr = d.in_word;  // the wide path's input ring holds nothing of use now
+  // (a real stop is within a granule of the new position: the wide turns go there)
+  return !progress || cut || end_stop ? SPAN_OFF : SPAN_AGAIN;
+}
+
+}  // namespace zd
