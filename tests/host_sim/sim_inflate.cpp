@@ -137,7 +137,8 @@ struct SpanCall {
 };
 static void span_lane(int lane, void *arg) {
   SpanCall &c = *(SpanCall *)arg;
-  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, lane);
+  static uint16_t idx[SPAN_IDX_ENTRIES];  // the kernel's per-stream slot of global scratch
+  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, lane);
 }
 extern "C" { uint64_t sim_span_stats[8]; }  // spans run, symbols' bits committed, output bytes committed, per return code
 static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending) {
@@ -166,11 +167,9 @@ static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint
 extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, uint64_t dst_cap,
                            int has_limit, uint64_t limit, int crc_op, uint64_t *out_len,
                            uint32_t *checksum, int budget) {
-  static uint16_t w[LDS_U16_PER_LANE];
-  static uint32_t r[LDS_U32_PER_LANE];
-  static __attribute__((aligned(16))) uint8_t x[SPAN_LDS_BYTES];
+  static __attribute__((aligned(16))) uint8_t block[LDS_BYTES_PER_LANE];
   LaneLds L;
-  L.w = w; L.r = r; L.x = x;
+  L.at(block);
   StreamDesc s;
   memset(&s, 0, sizeof s);
   s.src_off = 0; s.src_len = src_len; s.dst_off = 0; s.dst_cap = dst_cap;

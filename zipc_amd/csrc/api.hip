@@ -244,6 +244,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch);
+  free_buf(ctx->inflate_scratch);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
   if (ctx->pin_res.p) (void)hipHostFree(ctx->pin_res.p);
@@ -337,9 +338,10 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // one wave per stream
+  HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));
   ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)n_streams), dim3(64), 0,
             (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
-            (StreamResult *)d_results, (uint32_t)n_streams, 0, crc_op);
+            (StreamResult *)d_results, (uint32_t)n_streams, (uint16_t *)ctx->inflate_scratch.p, crc_op);
   HIP_TRY(ctx, hipGetLastError());
   if (crc_op == ZIPC_HIP_CRC_CRC32)
     return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,

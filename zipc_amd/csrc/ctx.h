@@ -33,6 +33,7 @@ struct zipc_hip_ctx {
   Buf crc_partials, adler_sums;                   // checksum kernels
   Buf crc_nib;                                    // nibble tables of the CRC merge constants (kernels.h)
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)
+  Buf inflate_scratch;                            // inflate: the span decoder's index, 2304 bytes per stream
 
   int name_index(const char *name);
   hipEvent_t get_event();

@@ -32,7 +32,7 @@
 //
 // The stream state is wave-uniform; it is pinned to scalar registers with
 // readfirstlane so that the control flow around the turns is scalar branches,
-// not exec-mask arithmetic.  LDS: 5088 B per stream (tables + ring + queue).
+// not exec-mask arithmetic.  LDS: 9944 B per stream (inflate_lane.h has the map): 16 streams per CU.
 #include "inflate_lane.h"
 #include "inflate_span.h"
 #include "kernels.h"
@@ -312,12 +312,12 @@ __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uin
   }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            StreamResult *__restrict__ results,
-                                                           uint32_t n_streams, int /*log2S*/, int crc_op) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE + SPAN_LDS_BYTES];
+                                                           uint32_t n_streams, uint16_t *__restrict__ span_scratch, int crc_op) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const int lane = threadIdx.x;
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
@@ -325,10 +325,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
   const bool writer = lane == 0;
 
   LaneLds L;
-  L.r = (uint32_t *)lds_raw;  // the input ring first: its reads encode their offsets
-  L.w = (uint16_t *)(lds_raw + LDS_U32_PER_LANE * 4);
-  static_assert(LDS_U32_PER_LANE * 4 % 16 == 0 && LDS_BYTES_PER_LANE % 16 == 0, "u16 and span regions stay aligned");
-  L.x = lds_raw + LDS_BYTES_PER_LANE;
+  L.at(lds_raw);  // (the input ring first: its reads encode their offsets)
+  uint16_t *span_idx = span_scratch + (size_t)stream * SPAN_IDX_ENTRIES;
 
   Arenas A;
   A.src = src_arena;
@@ -388,9 +386,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 4))) void
           if (d.q_count) break;  // queued copies first: the span reads its match sources from memory
           ZD_PH_START();
 #ifdef ZD_INFLATE_PHASES
-          const int sr = span_decode(d, L, src, dst, lane, span_ph);
+          const int sr = span_decode(d, L, src, dst, span_idx, lane, span_ph);
 #else
-          const int sr = span_decode(d, L, src, dst, lane);
+          const int sr = span_decode(d, L, src, dst, span_idx, lane);
 #endif
           if (sr != SPAN_NONE) {
             uniformize(d);

@@ -45,9 +45,20 @@ namespace zd {
 constexpr int LIT_TBITS = 9;   // primary litlen lookup bits
 constexpr int DIST_TBITS = 7;  // primary dist lookup bits (also holds the <=7-bit codelen code)
 
-// Per-stream LDS image.  u16 regions first:
-constexpr int LDS_LIT_TBL = 0;                          // 512 x u16: (sym << 4) | len
-constexpr int LDS_DIST_TBL = LDS_LIT_TBL + 512;         // 128 x u16
+// Per-stream LDS image (9944 bytes: 16 streams per CU).  Byte offsets from the block's start:
+//      0  the span decoder's input ring, 8 words x 64 lanes (inflate_span.h); between spans its
+//         first 560 bytes are the wide turn's input ring (64 + 4 words) and deferred-copy queue
+//   2048  wide litlen table, 512 x u32 (wide_lit_entry)
+//   4096  wide dist table, 128 x u32 (wide_dist_entry)
+//   4608  the span decoder's output tile, 4096 + 16 bytes; while a block's header is read and its
+//         tables are built, the tile's last 1280 bytes are the primary u16 lookup tables (and the
+//         code-length scratch): read_symbol's table form is used for the code-length code only
+//   8720  symbols sorted by code and counts per length of both codes (u16): what the canonical walk
+//         (read_symbol_walk) needs
+//   9424  the tile's bitmap, 130 words
+// The u16 regions are addressed as LaneLds::w[off + i] with w = block + 7440:
+constexpr int LDS_LIT_TBL = 0;                          // 512 x u16: (sym << 4) | len   (transient, in the tile)
+constexpr int LDS_DIST_TBL = LDS_LIT_TBL + 512;         // 128 x u16                     (transient, in the tile)
 constexpr int LDS_LIT_SYMS = LDS_DIST_TBL + 128;        // 288 x u16 symbols sorted by code
 constexpr int LDS_DIST_SYMS = LDS_LIT_SYMS + 288;       // 32 x u16
 constexpr int LDS_LIT_COUNTS = LDS_DIST_SYMS + 32;      // 16 x u16
@@ -56,16 +67,22 @@ constexpr int LDS_U16_PER_LANE = LDS_DIST_COUNTS + 16;  // 992
 // While a dynamic header is read the litlen table is not built yet: its region
 // holds the distribution-sort cursors [0,16) and the 316 code lengths [16,336).
 constexpr int LDS_LENGTHS = LDS_LIT_TBL + 16;
-// then the u32 regions:
+// the u32 regions, addressed as LaneLds::r[off + i] with r = block:
 constexpr int RING_WORDS = 64;     // input ring, 32-bit words, slot = word index & 63
 constexpr int RING_MIRROR = 4;     // slots 64..67 repeat slots 0..3: readers take 3 consecutive words
 constexpr int QUEUE_ENTRIES = 64;  // deferred copies, one packed word each (queue_pack)
 constexpr int LDS_RING = 0;
-constexpr int LDS_QUEUE = LDS_RING + RING_WORDS + RING_MIRROR;
-constexpr int LDS_WIDE_LIT = LDS_QUEUE + QUEUE_ENTRIES + 4;   // 512 x u32, see wide_lit_entry (+4: the spare queue slot)
+constexpr int LDS_QUEUE = LDS_RING + RING_WORDS + RING_MIRROR;  // 64 entries + the spare slot (+3)
+constexpr int LDS_WIDE_LIT = 512;                            // 512 x u32, see wide_lit_entry
 constexpr int LDS_WIDE_DIST = LDS_WIDE_LIT + 512;            // 128 x u32, see wide_dist_entry
-constexpr int LDS_U32_PER_LANE = LDS_WIDE_DIST + 128;        // 776
-constexpr int LDS_BYTES_PER_LANE = LDS_U16_PER_LANE * 2 + LDS_U32_PER_LANE * 4;  // 5088
+static_assert(LDS_QUEUE + QUEUE_ENTRIES + 4 <= LDS_WIDE_LIT, "ring and queue fit in front of the tables");
+constexpr int LDS_SPAN_RING_BYTE = 0;
+constexpr int LDS_SPAN_TILE_BYTE = (LDS_WIDE_DIST + 128) * 4;          // 4608
+constexpr int LDS_SPAN_TILE_BYTES = 4096 + 16;
+constexpr int LDS_W_BYTE = LDS_SPAN_TILE_BYTE + LDS_SPAN_TILE_BYTES - (LDS_LIT_SYMS * 2);  // 7440
+constexpr int LDS_SPAN_BITS_BYTE = LDS_W_BYTE + LDS_U16_PER_LANE * 2;  // 9424
+constexpr int LDS_BYTES_PER_LANE = LDS_SPAN_BITS_BYTE + (4096 / 32 + 2) * 4;  // 9944
+static_assert(LDS_SPAN_TILE_BYTE % 16 == 0 && LDS_W_BYTE % 2 == 0 && LDS_SPAN_BITS_BYTE % 4 == 0, "alignment");
 constexpr uint32_t DEFER_MAX_LEN = 16;
 // A queued copy is one word: its destination relative to the first queued copy's
 // (InflateLane::hole_min), distance and length.
@@ -81,7 +98,12 @@ constexpr int HEADER_WORDS = 6;    // words a block header step may touch: (31 +
 struct LaneLds {
   uint16_t *w;  // u16 regions of this stream's block
   uint32_t *r;  // u32 regions
-  uint8_t *x;   // the span decoder's regions (inflate_span.h), 16-byte aligned
+  uint8_t *x;   // the block itself (the span decoder's regions are byte offsets, inflate_span.h), 16-byte aligned
+  ZD_HD void at(uint8_t *block) {
+    x = block;
+    r = (uint32_t *)block;
+    w = (uint16_t *)(block + LDS_W_BYTE);
+  }
   ZD_HD uint16_t &u16(int off, int i) const { return w[off + i]; }
   ZD_HD uint32_t &slot(int s) const { return r[LDS_RING + s]; }
   ZD_HD uint32_t &queue(int k) const { return r[LDS_QUEUE + k]; }
@@ -308,6 +330,26 @@ ZD_HD int read_symbol(BitCursor &c, const LaneLds &L, int tbl_off, int tbits, in
   return -1;
 }
 
+// read_symbol by the canonical walk alone: what decodes the symbols of a block outside the
+// wide tables (the primary u16 tables share their LDS with the span decoder's output tile and
+// are only valid while a block's tables are being built).
+ZD_HD int read_symbol_walk(BitCursor &c, const LaneLds &L, int counts_off, int syms_off) {
+  int base = 0, offs = 0;
+#pragma unroll 1
+  for (int len = 1; len <= 15; len++) {
+    if (c.used + len > c.avail) return -1;
+    offs = 2 * offs + (int)((c.x >> (c.used + len - 1)) & 1);
+    int count = L.u16(counts_off, len);
+    if (offs < count) {
+      c.used += len;
+      return L.u16(syms_off, base + offs);
+    }
+    base += count;
+    offs -= count;
+  }
+  return -1;
+}
+
 // fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349
 ZD_HD void setup_fixed(InflateLane &d, const LaneLds &L) {
 #pragma unroll 1
@@ -472,7 +514,7 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
   uint8_t *dst = A.dst + d.dst_off;
   if (!d.input_ready(3)) return SYM_STOP;
   BitCursor c = cursor_at(d, L);
-  int sym = read_symbol(c, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+  int sym = read_symbol_walk(c, L, LDS_LIT_COUNTS, LDS_LIT_SYMS);
   if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
   if (sym < LITLEN_EOB) {
     if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
@@ -487,7 +529,7 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
   length_sym_value(sym, vbase, vextra);
   if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
   const uint32_t length = vbase + v;
-  int dsym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+  int dsym = read_symbol_walk(c, L, LDS_DIST_COUNTS, LDS_DIST_SYMS);
   if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
   dist_sym_value(dsym, vbase, vextra);
   v = 0;

@@ -56,13 +56,13 @@ constexpr uint32_t SPAN_TAIL_WORDS = 6;   // input words a span keeps clear of (
 constexpr uint32_t SPAN_LONG = 32;        // matches longer than this are copied by the whole wave
 constexpr int SPAN_FLY = 8;               // far matches a lane has in flight: decode steps between request and arrival
 
-// LDS of the span, after the stream's tables (LaneLds::x)
-constexpr uint32_t SPAN_IDX_OFF = 0;                                     // u16[64 * K_MAX]
-constexpr uint32_t SPAN_RING_OFF = SPAN_IDX_OFF + 64 * SPAN_K_MAX * 2;    // u32[8 * 64], word-major
-constexpr uint32_t SPAN_TILE_OFF = SPAN_RING_OFF + SPAN_RING * 64 * 4;
-constexpr uint32_t SPAN_BITS_OFF = SPAN_TILE_OFF + SPAN_TILE + 16;        // u32[128 + 2]: a bit per tile byte
-constexpr uint32_t SPAN_LDS_BYTES = SPAN_BITS_OFF + (SPAN_TILE / 32 + 2) * 4;
-static_assert(SPAN_TILE_OFF % 16 == 0 && SPAN_BITS_OFF % 4 == 0, "tile rows leave with 16-byte reads");
+// LDS of the span: byte offsets in the stream's block (inflate_lane.h has the map); the index
+// lives in global scratch, 64 * SPAN_K_MAX entries per stream (2304 bytes)
+constexpr uint32_t SPAN_RING_OFF = LDS_SPAN_RING_BYTE;   // u32[8 * 64], word-major
+constexpr uint32_t SPAN_TILE_OFF = LDS_SPAN_TILE_BYTE;   // SPAN_TILE + 16 bytes
+constexpr uint32_t SPAN_BITS_OFF = LDS_SPAN_BITS_BYTE;   // u32[128 + 2]: a bit per tile byte
+constexpr uint32_t SPAN_IDX_ENTRIES = 64 * SPAN_K_MAX;
+static_assert(SPAN_TILE + 16 == LDS_SPAN_TILE_BYTES && SPAN_RING * 64 * 4 <= LDS_WIDE_LIT * 4, "inflate_lane.h's map");
 
 enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_OFF = 3 };
 enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERGE = 5 };
@@ -91,7 +91,7 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
     c.x = ((uint64_t)xhi << 32) | xlo;
     c.used = 0;
     c.avail = 64;
-    const int sym = read_symbol(c, L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+    const int sym = read_symbol_walk(c, L, LDS_LIT_COUNTS, LDS_LIT_SYMS);
     r.is_lit = true;
     if (sym < 0 || sym == LITLEN_EOB || sym > lit_max_sym || sym > LITLEN_SYM_MAX) {
       r.stop = true;
@@ -124,7 +124,7 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
     c.x = x2;  // 15 + 13 bits at most
     c.used = 0;
     c.avail = 32;
-    const int dsym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+    const int dsym = read_symbol_walk(c, L, LDS_DIST_COUNTS, LDS_DIST_SYMS);
     if (dsym < 0 || dsym > dist_max_sym || dsym > DIST_SYM_MAX) {
       r.stop = true;
       return r;
@@ -404,7 +404,7 @@ ZD_WV uint32_t span_holes_next(SpanHoles &H, const uint32_t *mbits) {
 #else
 #define ZD_SPAN_PH(i) do {} while (0)
 #endif
-ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, int lane
+ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, int lane
 #ifdef ZD_INFLATE_PHASES
                       , uint64_t *span_ph
 #endif
@@ -437,7 +437,6 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   E.ring = (uint32_t *)(L.x + SPAN_RING_OFF);
   E.max_word = max_word;
   E.lane = lane;
-  uint16_t *idx = (uint16_t *)(L.x + SPAN_IDX_OFF);
   uint8_t *tile = L.x + SPAN_TILE_OFF;
   uint32_t *mbits = (uint32_t *)(L.x + SPAN_BITS_OFF);
   const int lit_max = (int)wv::uni((uint32_t)d.lit_max_sym), dist_max = (int)wv::uni((uint32_t)d.dist_max_sym);
@@ -462,7 +461,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   span_walk_loop<false>(W, R, E, L, idx, K, lit_max, dist_max);
   ZD_SPAN_PH(0);
   const uint32_t m_p = W.rp, m_stops = W.stops;  // (every walk of a region ends at the region's end: WK_END)
-  wv::sync();
+  wv::fence_global();  // the index is in memory: entries written by one lane are read by others below
   // ... and on into the next lane's, until the two walks are one
   {
     const bool stitch = ulane + 1u < n_lanes;
@@ -482,7 +481,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   }
   span_walk_loop<true>(W, R, E, L, idx, K, lit_max, dist_max);
   const uint32_t s_kind = W.kind, s_k = W.rk, s_p = W.rp;
-  wv::sync();
+  wv::fence_global();
   ZD_SPAN_PH(1);
 
   // ---- how far the chain from lane 0 holds

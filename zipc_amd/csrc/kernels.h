@@ -6,12 +6,13 @@
 namespace zd {
 
 // ---- inflate.hip
-constexpr int INFLATE_LDS_BYTES_PER_LANE = 5088;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
+constexpr int INFLATE_LDS_BYTES_PER_LANE = 9944;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
+constexpr size_t INFLATE_SCRATCH_PER_STREAM = 64 * 18 * 2;  // the span decoder's index (inflate_span.h)
 __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      uint8_t *__restrict__ dst_arena,
                                      const StreamDesc *__restrict__ descs,
                                      StreamResult *__restrict__ results, uint32_t n_streams,
-                                     int log2L, int crc_op);
+                                     uint16_t *__restrict__ span_scratch, int crc_op);
 
 // ---- checksum.hip
 constexpr uint32_t CRC_PIECE_BYTES = 128;  // bytes per thread of crc32_segments_kernel
