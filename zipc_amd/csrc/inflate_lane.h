@@ -611,6 +611,10 @@ ZD_HD void lane_end_of_block(InflateLane &d, bool crc_adler) {
 //   litlen: [4:0] code bits (bit 4 clear: the word is its own bit-field offset operand)
 //           [7:5] extra bits  [16:8] literal byte / base length  [22:17] code + extra bits
 //           [29] length symbol 268..285 (not for the wide turn)  [30] length symbol 257..267  [31] literal
+//           a LITERAL's entry also tells the span decoder (inflate_span.h) about the literal that
+//           follows it when both codes lie inside the table's 9 index bits (wide_lit_pair):
+//           [3:0] bits of the one or two literals  [4] two  [30:23] the second literal -- fields the
+//           wide turn does not look at in a literal's entry ([22:17] stays the first literal's bits)
 //   dist:   [4:0] code bits  [8:5] extra bits  [24:9] base distance  [29:25] code + extra bits
 //           (an invalid code is 0: it decodes to distance 0, which no length is <= to)
 ZD_HD uint32_t wide_lit_entry(uint32_t e16, int lit_max_sym) {
@@ -631,15 +635,34 @@ ZD_HD uint32_t wide_dist_entry(uint32_t e16, int dist_max_sym) {
   dist_sym_value((int)sym, base, extra);
   return len | (extra << 5) | (base << 9) | ((len + extra) << 25);
 }
+// A literal's entry at table index i, with the literal after it: the index bits above the first
+// code are the start of the next code, and when the primary table resolves them to a literal
+// whose code ends inside the index, one lookup decodes both.
+ZD_HD uint32_t wide_lit_pair(uint32_t e, int i, const LaneLds &L) {
+  const uint32_t len1 = (e >> 17) & 63u;
+  uint32_t bits = len1, two = 0, lit2 = 0;
+  if (len1 < (uint32_t)LIT_TBITS) {
+    const uint32_t e2 = L.u16(LDS_LIT_TBL, i >> len1);  // the unknown bits above read as 0
+    const uint32_t len2 = e2 & 15u, sym2 = e2 >> 4;
+    if (len2 != 0 && len1 + len2 <= (uint32_t)LIT_TBITS && sym2 < (uint32_t)LITLEN_EOB) {
+      bits = len1 + len2;
+      two = 1;
+      lit2 = sym2;
+    }
+  }
+  return (e & ~0x1Fu) | bits | (two << 4) | (lit2 << 23);
+}
 // lane `lane` of 64 restates its share of both tables; returns the bits of the
 // shortest symbol it saw that a wide turn may commit
 ZD_HD uint32_t build_wide_tables(const InflateLane &d, const LaneLds &L, int lane) {
   uint32_t shortest = 15;
 #pragma unroll 1
   for (int i = lane; i < (1 << LIT_TBITS); i += 64) {
-    const uint32_t e = wide_lit_entry(L.u16(LDS_LIT_TBL, i), d.lit_max_sym);
+    uint32_t e = wide_lit_entry(L.u16(LDS_LIT_TBL, i), d.lit_max_sym);
+    const uint32_t code_bits = e & 15u;
+    if ((int32_t)e < 0) e = wide_lit_pair(e, i, L);
     L.wide_lit(i) = e;
-    if (e != 0 && (e & 15u) < shortest) shortest = e & 15u;
+    if (e != 0 && code_bits < shortest) shortest = code_bits;
   }
 #pragma unroll 1
   for (int i = lane; i < (1 << DIST_TBITS); i += 64) L.wide_dist(i) = wide_dist_entry(L.u16(LDS_DIST_TBL, i), d.dist_max_sym);

@@ -70,8 +70,9 @@ enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERG
 // ---- one symbol, from the next 64 bits
 struct SpanSym {
   uint32_t tot;     // bits
-  uint32_t outlen;  // bytes: 1, or the match length
+  uint32_t outlen;  // bytes: 1 (a literal), 2 (two literals), or the match length
   uint32_t val;     // literal byte, or the match distance
+  uint32_t val2;    // the second literal
   bool is_lit, stop;
 };
 // The general form: codes longer than the tables' bits, end of block, anything invalid (their
@@ -79,7 +80,7 @@ struct SpanSym {
 ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int lit_max_sym, int dist_max_sym) {
   SpanSym r;
   r.stop = false;
-  r.tot = 0; r.outlen = 0; r.val = 0;
+  r.tot = 0; r.outlen = 0; r.val = 0; r.val2 = 0;
   const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
   uint32_t b1, lv;
   if (e != 0) {
@@ -145,22 +146,28 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
 // takes over -- behind a wave-uniform test, so that a wave whose 64 symbols are all common ones
 // (nearly always) skips it with one scalar branch.  Every lane calls this (act: the lane's
 // symbol is wanted).  Table entries are the wide turn's (inflate_lane.h) plus length symbols
-// 268..285 (bit 29).
+// 268..285 (bit 29) and, in a literal's entry, the literal that follows it when one lookup
+// resolves both: a step then takes two symbols.
 template <bool FULL>
 ZD_WV SpanSym span_symbol(bool act, uint32_t xlo, uint32_t xhi, const LaneLds &L, int lit_max_sym, int dist_max_sym) {
   const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
   const uint32_t b1 = (e >> 17) & 63u;
   const bool is_lit = (int32_t)e < 0;
-  const uint32_t lv = ((e >> 8) & 511u) + bit_field(xlo, e, (e >> 5) & 7u);
+  const uint32_t base = (e >> 8) & 511u;
+  const uint32_t lv = base + bit_field(xlo, e, (e >> 5) & 7u);  // (a literal's entry has other things in these fields)
   const uint32_t x2 = funnel32(xhi, xlo, b1);
   const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
   SpanSym r;
   r.is_lit = is_lit;
   r.stop = false;
-  r.tot = b1 + (is_lit ? 0u : e2 >> 25);
-  r.outlen = is_lit ? 1u : lv;
+  r.tot = is_lit ? e & 15u : b1 + (e2 >> 25);
+  r.outlen = is_lit ? 1u + ((e >> 4) & 1u) : lv;
   r.val = 0;
-  if (FULL) r.val = is_lit ? lv : ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
+  r.val2 = 0;
+  if (FULL) {
+    r.val = is_lit ? base : ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
+    r.val2 = (e >> 23) & 255u;
+  }
   const bool rare = act && (e == 0u || (!is_lit && e2 == 0u));
   if (wv::any(rare)) {
     if (rare) r = span_symbol_slow(xlo, xhi, L, lit_max_sym, dist_max_sym);
@@ -578,7 +585,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         err = err || bad;
         const bool is_match = good && !s.is_lit;
         const bool fly = is_match && s.outlen <= 8u && s.val >= o + s.outlen;
-        if (good && s.is_lit) tile[o] = (uint8_t)s.val;
+        if (good && s.is_lit) {
+          tile[o] = (uint8_t)s.val;
+          if (s.outlen == 2u) tile[o + 1u] = (uint8_t)s.val2;
+        }
         const uint8_t *sp = fly ? gbase + (int)o - (int)s.val : E.src;
         f_a[u] = load_u32_le(sp);
         f_b[u] = load_u32_le(sp + (fly && s.outlen >= 4u ? s.outlen - 4u : 0u));
