@@ -369,6 +369,16 @@ ZD_WV void span_land(uint8_t *tile, uint32_t meta, uint32_t a, uint32_t b) {
     }
   }
 }
+// is any bit of [a, b) set?  0 < b - a <= 64
+ZD_WV bool span_bits_any(const uint32_t *mbits, uint32_t a, uint32_t b) {
+  const uint32_t w = a >> 5, n = b - a;
+  const uint32_t m0 = mbits[w], m1 = mbits[w + 1u], m2 = mbits[w + 2u];
+  uint32_t lo = funnel32(m1, m0, a), hi = funnel32(m2, m1, a);
+  if (n < 32u) lo &= (1u << n) - 1u;
+  if (n <= 32u) hi = 0;
+  else if (n < 64u) hi &= (1u << (n - 32u)) - 1u;
+  return (lo | hi) != 0u;
+}
 ZD_WV uint32_t span_byte_at(const uint8_t *tile, const uint8_t *gbase, int s) {  // tile byte s, or the byte -s before it
   return s < 0 ? (uint32_t)gbase[s] : (uint32_t)tile[s];
 }
@@ -560,6 +570,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // is requested from memory the moment it is decoded and lands SPAN_FLY steps later, when the
     // lane comes by the same slot again: the random window reads of all lanes overlap with the
     // decoding, and such a match needs neither a record nor a bit in the bitmap.
+    bool saw_long = false;
     uint32_t f_meta[SPAN_FLY], f_a[SPAN_FLY], f_b[SPAN_FLY];
 #pragma unroll
     for (int u = 0; u < SPAN_FLY; u++) { f_meta[u] = 0; f_a[u] = 0; f_b[u] = 0; }
@@ -585,6 +596,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         err = err || bad;
         const bool is_match = good && !s.is_lit;
         const bool fly = is_match && s.outlen <= 8u && s.val >= o + s.outlen;
+        saw_long = saw_long || (is_match && s.outlen > SPAN_LONG);
         if (good && s.is_lit) {
           tile[o] = (uint8_t)s.val;
           if (s.outlen == 2u) tile[o + 1u] = (uint8_t)s.val2;
@@ -622,16 +634,22 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     wv::sync();
     ZD_SPAN_PH(3);
 
-    // The other holes in stream order.  Every lane works through its own front to back; a hole
-    // may be filled once every byte of its source is final, i.e. lies before the first hole of
-    // the whole tile that is still open (the lanes' ranges are in stream order: that is the open
-    // hole of the lowest lane that has one) -- or it is that hole.
+    // The other holes.  Every lane works through its own front to back; a hole may be filled once
+    // every byte of its source is final.  Sufficient for that, any of:
+    //   * it is the first open hole of the whole tile (the lanes' ranges are in stream order: the
+    //     open hole of the lowest lane that has one);
+    //   * its source ends before that hole;
+    //   * the bitmap, where a hole's bit stays set until it is filled, shows no open hole starting
+    //     in the source or in the 32 bytes before it -- in a tile without holes of more than 32
+    //     bytes (those are filled by the whole wave, in order, and reach further).
+    // The rounds a tile takes are then the depth of its matches' dependences, not their number.
     {
       SpanHoles H;
       span_holes_start(H, mbits, mine ? o0 : 0u, mine ? o_end : 0u);
       uint32_t dp = span_holes_next(H, mbits);
       uint8_t *stage = (uint8_t *)E.ring + ulane * 32u;  // the input ring is idle: 32 bytes per lane
       const bool wide_ok = out_pos + 32u <= hard_cap;    // 16-byte loads of far sources may read into the tile's place
+      const bool tile_has_long = wv::any(saw_long);
       for (;;) {
         const bool open = dp != 0xFFFFFFFFu;
         const uint64_t om = wv::ballot(open);
@@ -652,11 +670,18 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           const int fsp = (int)wm - (int)fdist;
           for (uint32_t i = ulane; i < flen; i += 64u)
             tile[wm + i] = (uint8_t)span_byte_at(tile, gbase, fsp + (int)(i % fdist));
+          if (ulane == first) wv::lds_and(mbits + (dp >> 5), ~(1u << (dp & 31u)));
           wv::sync();
           if (ulane == first) dp = span_holes_next(H, mbits);
           continue;
         }
-        const bool go = open && len <= SPAN_LONG && (ulane == first || sp + (int)len <= (int)wm);
+        bool clear = false;  // nothing open where the source is
+        {
+          const int a = sp - (int)SPAN_LONG > 0 ? sp - (int)SPAN_LONG : 0;
+          const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
+          if (open && !tile_has_long && b > a && b - a <= 64) clear = !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
+        }
+        const bool go = open && len <= SPAN_LONG && (ulane == first || sp + (int)len <= (int)wm || clear);
         // three ways to move the bytes: from memory through the lane's staging bytes (the source
         // wholly before the tile), words inside the tile (distance >= 4), byte by byte (the rest)
         const bool far = go && wide_ok && sp + (int)len <= 0;
@@ -687,6 +712,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           if (!wv::any(g)) break;
           if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
         }
+        if (go) wv::lds_and(mbits + (dp >> 5), ~(1u << (dp & 31u)));
         wv::sync();
         if (go) dp = span_holes_next(H, mbits);
       }
