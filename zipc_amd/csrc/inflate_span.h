@@ -143,9 +143,7 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
 }
 // The common case without a branch: both lookups always (a literal lane's distance lookup
 // reads a valid, ignored entry, as in the wide turn).  Where an entry is 0 the general form
-// takes over -- behind a wave-uniform test, so that a wave whose 64 symbols are all common ones
-// (nearly always) skips it with one scalar branch.  Every lane calls this (act: the lane's
-// symbol is wanted).  Table entries are the wide turn's (inflate_lane.h) plus length symbols
+// takes over for that lane.  Every lane calls this (act: the lane's symbol is wanted).  Table entries are the wide turn's (inflate_lane.h) plus length symbols
 // 268..285 (bit 29) and, in a literal's entry, the literal that follows it when one lookup
 // resolves both: a step then takes two symbols.
 template <bool FULL>
@@ -168,10 +166,8 @@ ZD_WV SpanSym span_symbol(bool act, uint32_t xlo, uint32_t xhi, const LaneLds &L
     r.val = is_lit ? base : ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
     r.val2 = (e >> 23) & 255u;
   }
-  const bool rare = act && (e == 0u || (!is_lit && e2 == 0u));
-  if (wv::any(rare)) {
-    if (rare) r = span_symbol_slow(xlo, xhi, L, lit_max_sym, dist_max_sym);
-  }
+  // (a divergent branch is skipped by the whole wave when no lane takes it: nearly always here)
+  if (act && (e == 0u || (!is_lit && e2 == 0u))) r = span_symbol_slow(xlo, xhi, L, lit_max_sym, dist_max_sym);
   return r;
 }
 
@@ -242,13 +238,10 @@ ZD_WV void span_advance(SpanReader &R, const SpanEnv &E, uint32_t p) {  // the p
   R.w2 = s1 ? R.w3 : R.w2;
   R.w3 = s1 ? nx : R.w3;
   R.cw += s1 ? 1u : 0u;
-  const bool s2 = ncw != R.cw;  // a symbol of more than 32 bits
-  if (wv::any(s2)) {
-    if (s2) {
-      R.w0 = R.w1; R.w1 = R.w2; R.w2 = R.w3;
-      R.w3 = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
-      R.cw++;
-    }
+  if (ncw != R.cw) {  // a symbol of more than 32 bits
+    R.w0 = R.w1; R.w1 = R.w2; R.w2 = R.w3;
+    R.w3 = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
+    R.cw++;
   }
 }
 
@@ -275,23 +268,20 @@ ZD_WV void span_walk_end(SpanWalk &W, uint32_t kind, uint32_t k, uint32_t p) {
 }
 // One step of the walk, by every lane (act: this lane walks on).  STITCH: the region is the
 // next lane's.  Straight-line code with the lane's state selected at the end; what is rare for a
-// lane -- a granule boundary, a stop -- sits behind wave-uniform tests.
+// lane -- a granule boundary, a stop -- is a divergent branch the wave skips when no lane takes it.
 template <bool STITCH>
 ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
                           uint32_t K, int lit_max_sym, int dist_max_sym) {
-  const bool cross = act && W.p >= W.nb;  // into the next granule (a symbol is at most 48 bits: one boundary at a time)
-  if (wv::any(cross)) {
-    if (cross) {
-      idx[W.region_e + W.k] = span_entry(W.pd, W.od);
-      W.k++;
-      const uint32_t npd = W.p - W.nb;
-      if (W.k == K) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, K, W.p);
-      else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, W.p);
-      else {
-        W.pd = npd;
-        W.od = 0;
-        W.nb += SPAN_G;
-      }
+  if (act && W.p >= W.nb) {  // into the next granule (a symbol is at most 48 bits: one boundary at a time)
+    idx[W.region_e + W.k] = span_entry(W.pd, W.od);
+    W.k++;
+    const uint32_t npd = W.p - W.nb;
+    if (W.k == K) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, K, W.p);
+    else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, W.p);
+    else {
+      W.pd = npd;
+      W.od = 0;
+      W.nb += SPAN_G;
     }
   }
   act = act && W.run;
@@ -299,17 +289,14 @@ ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E
   span_peek(R, W.p, xlo, xhi);
   const SpanSym s = span_symbol<false>(act, xlo, xhi, L, lit_max_sym, dist_max_sym);
   uint32_t tot = s.tot, outlen = s.outlen;
-  const bool stop = act && s.stop;
-  if (wv::any(stop)) {
-    if (stop) {
-      if (STITCH) {  // this walk is the real sequence: the span ends in front of this granule
-        span_walk_end(W, WK_STOP, W.k, W.nb - SPAN_G + W.pd);
-        act = false;
-      } else {  // real or not is known later: note the granule, go on a bit further
-        W.stops |= 1u << W.k;
-        tot = 1;
-        outlen = 0;
-      }
+  if (act && s.stop) {
+    if (STITCH) {  // this walk is the real sequence: the span ends in front of this granule
+      span_walk_end(W, WK_STOP, W.k, W.nb - SPAN_G + W.pd);
+      act = false;
+    } else {  // real or not is known later: note the granule, go on a bit further
+      W.stops |= 1u << W.k;
+      tot = 1;
+      outlen = 0;
     }
   }
   W.p += act ? tot : 0u;
@@ -350,23 +337,15 @@ ZD_WV uint32_t span_rec4(const uint8_t *s, uint32_t i) {
   const uint32_t *w = (const uint32_t *)(a & ~(uintptr_t)3);
   return funnel32(w[1], w[0], (uint32_t)(a & 3u) * 8u);
 }
-// A far match's bytes arrive: meta = (tile position + 1) | length << 16 (0: nothing in flight);
-// a = source bytes 0..3, b = source bytes length-4 .. length-1 (length >= 4).
+// A far match's bytes arrive: meta = (tile position + 1) | length << 16 (0: nothing in flight),
+// 4 <= length <= 8; a = source bytes 0..3, b = source bytes length-4 .. length-1.  Two groups of
+// four bytes, overlapping in the middle when length < 8: no test on the length.
 ZD_WV void span_land(uint8_t *tile, uint32_t meta, uint32_t a, uint32_t b) {
-  const bool pending = meta != 0u;
-  if (wv::any(pending)) {
-    if (pending) {
-      const uint32_t dp = (meta & 0xFFFFu) - 1u, len = meta >> 16;
-      const uint32_t hi = b >> ((8u * (8u - len)) & 31u);  // bytes 4 .. length-1 (length 5..8)
-      tile[dp] = (uint8_t)a;
-      tile[dp + 1u] = (uint8_t)(a >> 8);
-      tile[dp + 2u] = (uint8_t)(a >> 16);
-      if (len > 3u) tile[dp + 3u] = (uint8_t)(a >> 24);
-      if (len > 4u) tile[dp + 4u] = (uint8_t)hi;
-      if (len > 5u) tile[dp + 5u] = (uint8_t)(hi >> 8);
-      if (len > 6u) tile[dp + 6u] = (uint8_t)(hi >> 16);
-      if (len > 7u) tile[dp + 7u] = (uint8_t)(hi >> 24);
-    }
+  if (meta != 0u) {
+    uint8_t *t = tile + ((meta & 0xFFFFu) - 1u);
+    uint8_t *u = t + ((meta >> 16) - 4u);
+    t[0] = (uint8_t)a; t[1] = (uint8_t)(a >> 8); t[2] = (uint8_t)(a >> 16); t[3] = (uint8_t)(a >> 24);
+    u[0] = (uint8_t)b; u[1] = (uint8_t)(b >> 8); u[2] = (uint8_t)(b >> 16); u[3] = (uint8_t)(b >> 24);
   }
 }
 // is any bit of [a, b) set?  0 < b - a <= 64
@@ -566,7 +545,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     ZD_SPAN_PH(2);
     bool err = false;
     const uint8_t *gbase = dst + out_pos;  // the tile's place in the output; gbase[-n] is final for every n >= 1
-    // A match of up to 8 bytes whose source lies wholly before the tile (on the configs' data: most)
+    // A match of 4 to 8 bytes whose source lies wholly before the tile (on the configs' data: most)
     // is requested from memory the moment it is decoded and lands SPAN_FLY steps later, when the
     // lane comes by the same slot again: the random window reads of all lanes overlap with the
     // decoding, and such a match needs neither a record nor a bit in the bitmap.
@@ -595,7 +574,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         const bool good = act && !bad;
         err = err || bad;
         const bool is_match = good && !s.is_lit;
-        const bool fly = is_match && s.outlen <= 8u && s.val >= o + s.outlen;
+        const bool fly = is_match && s.outlen - 4u <= 4u && s.val >= o + s.outlen;
         saw_long = saw_long || (is_match && s.outlen > SPAN_LONG);
         if (good && s.is_lit) {
           tile[o] = (uint8_t)s.val;
@@ -603,7 +582,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         }
         const uint8_t *sp = fly ? gbase + (int)o - (int)s.val : E.src;
         f_a[u] = load_u32_le(sp);
-        f_b[u] = load_u32_le(sp + (fly && s.outlen >= 4u ? s.outlen - 4u : 0u));
+        f_b[u] = load_u32_le(sp + (fly ? s.outlen - 4u : 0u));
         f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
         if (is_match && !fly) {
           tile[o] = (uint8_t)(s.val - 1u);
