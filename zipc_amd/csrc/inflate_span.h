@@ -348,49 +348,52 @@ ZD_WV void span_land(uint8_t *tile, uint32_t meta, uint32_t a, uint32_t b) {
     u[0] = (uint8_t)b; u[1] = (uint8_t)(b >> 8); u[2] = (uint8_t)(b >> 16); u[3] = (uint8_t)(b >> 24);
   }
 }
-// is any bit of [a, b) set?  0 < b - a <= 64
+// The tile's bitmap has a bit per output byte: set while the byte belongs to a hole that is not
+// filled yet.  (Literals and the far matches of the decode loop never set theirs.)
+// set (SET) or clear the bits of [q, q + len)
+template <bool SET>
+ZD_WV void span_bits_mark(uint32_t *mbits, uint32_t q, uint32_t len) {
+  uint32_t w = q >> 5, off = q & 31u;
+  while (len != 0u) {
+    const uint32_t n = 32u - off < len ? 32u - off : len;
+    const uint32_t m = (n == 32u ? 0xFFFFFFFFu : (1u << n) - 1u) << off;
+    if (SET) wv::lds_or(mbits + w, m);
+    else wv::lds_and(mbits + w, ~m);
+    len -= n;
+    w++;
+    off = 0;
+  }
+}
+// is any bit of [a, b) set?  a < b
 ZD_WV bool span_bits_any(const uint32_t *mbits, uint32_t a, uint32_t b) {
-  const uint32_t w = a >> 5, n = b - a;
-  const uint32_t m0 = mbits[w], m1 = mbits[w + 1u], m2 = mbits[w + 2u];
-  uint32_t lo = funnel32(m1, m0, a), hi = funnel32(m2, m1, a);
-  if (n < 32u) lo &= (1u << n) - 1u;
-  if (n <= 32u) hi = 0;
-  else if (n < 64u) hi &= (1u << (n - 32u)) - 1u;
-  return (lo | hi) != 0u;
+  uint32_t w = a >> 5;
+  uint32_t m = mbits[w] & (0xFFFFFFFFu << (a & 31u));
+  const uint32_t wl = (b - 1u) >> 5;
+  while (w < wl) {
+    if (m != 0u) return true;
+    w++;
+    m = mbits[w];
+  }
+  const uint32_t keep = (b & 31u) == 0u ? 0xFFFFFFFFu : (1u << (b & 31u)) - 1u;
+  return (m & keep) != 0u;
+}
+// the first set bit in [from, to), or 0xFFFFFFFF: a lane's next open hole (it fills its holes in
+// stream order, so the first unfilled byte at or after its cursor starts one)
+ZD_WV uint32_t span_bits_first(const uint32_t *mbits, uint32_t from, uint32_t to) {
+  if (from >= to) return 0xFFFFFFFFu;
+  uint32_t w = from >> 5;
+  uint32_t m = mbits[w] & (0xFFFFFFFFu << (from & 31u));
+  while (m == 0u) {
+    w++;
+    if ((w << 5) >= to) return 0xFFFFFFFFu;
+    m = mbits[w];
+  }
+  const uint32_t q = (w << 5) + (uint32_t)__builtin_ctz(m);
+  return q < to ? q : 0xFFFFFFFFu;
 }
 ZD_WV uint32_t span_byte_at(const uint8_t *tile, const uint8_t *gbase, int s) {  // tile byte s, or the byte -s before it
   return s < 0 ? (uint32_t)gbase[s] : (uint32_t)tile[s];
 }
-// A lane's holes are the set bits of the tile's bitmap inside its own output range [from, to), in
-// stream order.
-struct SpanHoles {
-  uint32_t word;  // bits of the current bitmap word not yet taken (inside the range)
-  uint32_t wi;    // its index
-  uint32_t to;
-};
-ZD_WV uint32_t span_holes_mask(uint32_t wi, uint32_t from, uint32_t to) {  // the bits of word wi that lie in [from, to)
-  uint32_t m = 0xFFFFFFFFu;
-  if ((from >> 5) == wi) m &= 0xFFFFFFFFu << (from & 31u);
-  if ((to >> 5) == wi) m &= ~(0xFFFFFFFFu << (to & 31u));
-  return m;
-}
-ZD_WV void span_holes_start(SpanHoles &H, const uint32_t *mbits, uint32_t from, uint32_t to) {
-  H.wi = from >> 5;
-  H.to = to;
-  H.word = from < to ? mbits[H.wi] & span_holes_mask(H.wi, from, to) : 0u;
-}
-// the next hole's position, or 0xFFFFFFFF
-ZD_WV uint32_t span_holes_next(SpanHoles &H, const uint32_t *mbits) {
-  while (H.word == 0u) {
-    if (((H.wi + 1u) << 5) >= H.to) return 0xFFFFFFFFu;
-    H.wi++;
-    H.word = mbits[H.wi] & span_holes_mask(H.wi, 0u, H.to);
-  }
-  const uint32_t b = (uint32_t)__builtin_ctz(H.word);
-  H.word &= H.word - 1u;
-  return (H.wi << 5) + b;
-}
-
 // The span.  d.phase == PH_SYMBOLS, nothing queued; returns SPAN_NONE when it did not run
 // (nothing changed), else the stream position, out_pos and ring_wr are those after the
 // symbols it committed: SPAN_AGAIN (more of the block may follow the same way) or SPAN_OFF
@@ -549,7 +552,6 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // is requested from memory the moment it is decoded and lands SPAN_FLY steps later, when the
     // lane comes by the same slot again: the random window reads of all lanes overlap with the
     // decoding, and such a match needs neither a record nor a bit in the bitmap.
-    bool saw_long = false;
     uint32_t f_meta[SPAN_FLY], f_a[SPAN_FLY], f_b[SPAN_FLY];
 #pragma unroll
     for (int u = 0; u < SPAN_FLY; u++) { f_meta[u] = 0; f_a[u] = 0; f_b[u] = 0; }
@@ -575,7 +577,6 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         err = err || bad;
         const bool is_match = good && !s.is_lit;
         const bool fly = is_match && s.outlen - 4u <= 4u && s.val >= o + s.outlen;
-        saw_long = saw_long || (is_match && s.outlen > SPAN_LONG);
         if (good && s.is_lit) {
           tile[o] = (uint8_t)s.val;
           if (s.outlen == 2u) tile[o + 1u] = (uint8_t)s.val2;
@@ -588,7 +589,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           tile[o] = (uint8_t)(s.val - 1u);
           tile[o + 1u] = (uint8_t)((s.val - 1u) >> 8);
           tile[o + 2u] = (uint8_t)(s.outlen - 3u);
-          wv::lds_or(mbits + (o >> 5), 1u << (o & 31u));
+          span_bits_mark<true>(mbits, o, s.outlen);
         }
         o += good ? s.outlen : 0u;
         p += good ? s.tot : 0u;
@@ -613,26 +614,24 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     wv::sync();
     ZD_SPAN_PH(3);
 
-    // The other holes.  Every lane works through its own front to back; a hole may be filled once
-    // every byte of its source is final.  Sufficient for that, any of:
-    //   * it is the first open hole of the whole tile (the lanes' ranges are in stream order: the
-    //     open hole of the lowest lane that has one);
-    //   * its source ends before that hole;
-    //   * the bitmap, where a hole's bit stays set until it is filled, shows no open hole starting
-    //     in the source or in the 32 bytes before it -- in a tile without holes of more than 32
-    //     bytes (those are filled by the whole wave, in order, and reach further).
-    // The rounds a tile takes are then the depth of its matches' dependences, not their number.
+    // The other holes.  Every lane works through its own front to back; a hole is filled as soon as
+    // the bitmap shows that every byte of its source is final (its own bytes count as final: an
+    // overlapping match is copied front to back).  The first open hole of the tile always is, so
+    // every round makes progress; the rounds a tile takes are the depth of its matches'
+    // dependences, not their number.  Holes of up to 32 bytes are copied by their lanes side by
+    // side, longer ones by the whole wave one after the other.
     {
-      SpanHoles H;
-      span_holes_start(H, mbits, mine ? o0 : 0u, mine ? o_end : 0u);
-      uint32_t dp = span_holes_next(H, mbits);
+      uint32_t cursor = mine ? o0 : 0u;
+      const uint32_t range_end = mine ? o_end : 0u;
       uint8_t *stage = (uint8_t *)E.ring + ulane * 32u;  // the input ring is idle: 32 bytes per lane
       const bool wide_ok = out_pos + 32u <= hard_cap;    // 16-byte loads of far sources may read into the tile's place
-      const bool tile_has_long = wv::any(saw_long);
       for (;;) {
+        const uint32_t dp = span_bits_first(mbits, cursor, range_end);
         const bool open = dp != 0xFFFFFFFFu;
-        const uint64_t om = wv::ballot(open);
-        if (om == 0ull) break;
+        if (!wv::any(open)) break;
+#ifdef SPAN_TRACE
+        if (lane == 0) span_trace_steps[3]++;
+#endif
         uint32_t dist = 1, len = 0;
         if (open) {
           const uint32_t rec = span_rec(tile, dp);
@@ -640,44 +639,32 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           len = (rec >> 16) + 3u;
         }
         const int sp = (int)dp - (int)dist;
-        const uint32_t first = (uint32_t)__builtin_ctzll(om);
-        const uint32_t wm = wv::readlane(dp, first);
-        const uint32_t flen = wv::readlane(len, first);
-        wv::sync();  // records are read before anybody writes bytes over them
-        if (flen > SPAN_LONG) {  // Buf.recopy zd.ml:63-75: byte i is the source's byte i mod dist
-          const uint32_t fdist = wv::readlane(dist, first);
-          const int fsp = (int)wm - (int)fdist;
-          for (uint32_t i = ulane; i < flen; i += 64u)
-            tile[wm + i] = (uint8_t)span_byte_at(tile, gbase, fsp + (int)(i % fdist));
-          if (ulane == first) wv::lds_and(mbits + (dp >> 5), ~(1u << (dp & 31u)));
-          wv::sync();
-          if (ulane == first) dp = span_holes_next(H, mbits);
-          continue;
-        }
-        bool clear = false;  // nothing open where the source is
-        {
-          const int a = sp - (int)SPAN_LONG > 0 ? sp - (int)SPAN_LONG : 0;
+        bool ready = false;
+        if (open) {
+          const int a = sp > 0 ? sp : 0;
           const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
-          if (open && !tile_has_long && b > a && b - a <= 64) clear = !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
+          ready = b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
         }
-        const bool go = open && len <= SPAN_LONG && (ulane == first || sp + (int)len <= (int)wm || clear);
+        wv::sync();  // records and bits are read before anybody writes bytes over them
+        const bool go = ready && len <= SPAN_LONG;
         // three ways to move the bytes: from memory through the lane's staging bytes (the source
         // wholly before the tile), words inside the tile (distance >= 4), byte by byte (the rest)
         const bool far = go && wide_ok && sp + (int)len <= 0;
         const bool words = far || (go && sp >= 0 && dist >= 4u);
-        if (wv::any(far)) {
-          if (far) {
-            const uint8_t *g = gbase + sp;
-            const wv::Quad q0 = wv::load_quad(g), q1 = wv::load_quad(g + 16);
-            uint32_t *st = (uint32_t *)stage;
-            st[0] = q0.x; st[1] = q0.y; st[2] = q0.z; st[3] = q0.w;
-            st[4] = q1.x; st[5] = q1.y; st[6] = q1.z; st[7] = q1.w;
-          }
+        if (far) {
+          const uint8_t *g = gbase + sp;
+          const wv::Quad q0 = wv::load_quad(g), q1 = wv::load_quad(g + 16);
+          uint32_t *st = (uint32_t *)stage;
+          st[0] = q0.x; st[1] = q0.y; st[2] = q0.z; st[3] = q0.w;
+          st[4] = q1.x; st[5] = q1.y; st[6] = q1.z; st[7] = q1.w;
         }
         const uint8_t *from = far ? stage : tile + (sp >= 0 ? sp : 0);
         for (uint32_t i = 0;; i += 4u) {
           const bool g = words && i < len;
           if (!wv::any(g)) break;
+#ifdef SPAN_TRACE
+          if (lane == 0) span_trace_steps[7]++;
+#endif
           if (g) {
             const uint32_t v = span_rec4(from, i);
             tile[dp + i] = (uint8_t)v;
@@ -691,9 +678,19 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           if (!wv::any(g)) break;
           if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
         }
-        if (go) wv::lds_and(mbits + (dp >> 5), ~(1u << (dp & 31u)));
+        // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
+        for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
+          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+          const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
+          const int lsp = (int)ldp - (int)ldist;
+          for (uint32_t i = ulane; i < llen; i += 64u)
+            tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)(i % ldist));
+        }
+        if (ready) {
+          span_bits_mark<false>(mbits, dp, len);
+          cursor = dp + len;
+        }
         wv::sync();
-        if (go) dp = span_holes_next(H, mbits);
       }
     }
     ZD_SPAN_PH(5);
@@ -720,6 +717,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   // ---- the stream goes on behind the committed symbols
 #ifdef SPAN_TRACE
   if (lane == 0) { for (int i = 0; i < 64; i++) fprintf(stderr, "%u ", span_lane_steps[i]); fprintf(stderr, "\n"); }
+  if (lane == 0) fprintf(stderr, "hole rounds %llu word-iters %llu tiles-so-far; ", (unsigned long long)span_trace_steps[3], (unsigned long long)span_trace_steps[7]);
   if (lane == 0) fprintf(stderr, "steps: A %llu stitch %llu B %llu; lane-steps starved %llu running %llu lane5 %llu\n", (unsigned long long)span_trace_steps[0], (unsigned long long)span_trace_steps[1], (unsigned long long)span_trace_steps[2], (unsigned long long)span_trace_steps[4], (unsigned long long)span_trace_steps[5], (unsigned long long)span_trace_steps[6]);
 #endif
   const bool progress = p_end != base || out_pos != out_pos0;
