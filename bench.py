@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""Headline benchmark: BASELINE.json's metric on its config C2.
+"""Headline benchmark: BASELINE.json's metric on its config C2 (default), or C4 (--config c4).
 
 A "step" is one pass of the hot path over one batch of synthetic input:
-  deflate (level `Default, fused CRC-32) of 16 384 x 64 KiB streams of i.i.d.
-  4-bit symbols (1 GiB), then inflate (fused CRC-32) of the 16 384 compressed
-  streams, both through the device-resident batch forms of include/zipc_hip.h.
-Inputs are generated on the device and stay in HBM; value = uncompressed GiB
-round-tripped per second (whole job over all ranks).  With N > 1 ranks the
-streams are member-sharded, one process per GPU, no data-path collective
-(weak scaling: every rank runs the full 1 GiB config on its own streams).
+  c2  deflate (level `Default, CRC-32 of the source by a separate pass) of 16 384 x 64 KiB
+      streams of i.i.d. 4-bit symbols (1 GiB), then inflate (CRC-32 of the output likewise) of
+      the 16 384 compressed streams, both through the device-resident batch forms of
+      include/zipc_hip.h.  value = uncompressed GiB round-tripped per second.
+  c4  crc_32_and_deflate of the members of a ZIP archive, 8192 x 1 MiB of i.i.d. 3-bit symbols,
+      member-sharded: rank r takes a contiguous range of the members in the order Zipc writes
+      them (src/zipc.ml:575-581), deflates it into its own arena, and the ranks all-gather one
+      16-byte record per member (size, CRC-32, arena offset; RCCL) from which every rank can lay
+      out the archive.  value = uncompressed GiB deflated per second, all ranks together.
+Inputs are generated on the device and stay in HBM.  With N > 1 ranks the streams are
+member-sharded, one process per GPU, no data-path collective (c2: weak scaling, every rank
+runs the full 1 GiB config on its own streams; c4: strong scaling, the archive is fixed).
 
-Extra objects in the JSON line: "roofline" (dominant kernel: algorithmic bytes /
-HIP-event duration vs the 8 TB/s HBM peak), "cpu_baseline" (the oracle's C port
-timed on this host on a bounded sample, rank 0 / N=1 only), "kernels"
-(per-kernel ms per step from HIP events), "inflate_gib_s" / "deflate_gib_s".
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment makes THIS process the launcher:
+before anything touches torch or the GPU it starts N workers (this script again, one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relays rank 0's JSON
+line and exits non-zero if any worker failed.  Under torch.distributed.run the environment's
+WORLD_SIZE must equal --gpus.
+
+Extra objects in the JSON line: "roofline" (dominant kernel: algorithmic bytes / HIP-event
+duration vs the 8 TB/s HBM peak), "cpu_baseline" (the oracle's C port timed on this host on a
+bounded sample: 1 thread and all host threads; rank 0 / N=1 only), "kernels_ms_per_step",
+"inflate_gib_s" / "deflate_gib_s", "e2e_gib_s" (PCIe-inclusive host forms, untimed leg).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +40,57 @@ if ROOT not in sys.path:
 
 GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+METRIC = "GiB/s deflate+inflate on 1 GiB synthetic; bit-exact vs Zipc_deflate"
+LEVELS = ["none", "fast", "default", "best"]
 
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: WORLD_SIZE or 1")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2")
+    ap.add_argument("--streams", type=int, default=None, help="c2: streams per rank (16384); c4: members of the archive (8192)")
+    ap.add_argument("--stream-len", type=int, default=None, help="c2: 65536; c4: 1048576")
+    ap.add_argument("--bits", type=int, default=None, help="entropy bits per byte (c2: 4, c4: 3)")
+    ap.add_argument("--level", type=int, default=2, help="0 none, 1 fast, 2 default, 3 best")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (host forms, real text)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)  # the cpu_baseline leg's own process
+    return ap.parse_args(argv)
+
+
+# ---- the launcher (no torch, no GPU in this process) ------------------------------------------------
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_workers(n, argv):
+    """Start n workers (this script, one per GPU) and relay rank 0's JSON line.  Returns the exit code."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: workers failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+# ---- pieces of the JSON line -------------------------------------------------------------------------
 
 def algorithmic_bytes(kernel, N, C):
     """HBM bytes one launch of `kernel` must move at minimum, for N uncompressed
@@ -42,19 +105,22 @@ def algorithmic_bytes(kernel, N, C):
     }.get(kernel, 0)
 
 
+def latest_profile(pattern):
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*hbm_traffic.json,
     made by tools/pmc_report.py --hbm-json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command), or None."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic.json")))
-    if not files:
+    f = latest_profile("*hbm_traffic.json")
+    if not f:
         return None, None
     try:
-        d = json.load(open(files[-1]))
-        k = d["kernels"][kernel]
-        return k, os.path.basename(files[-1])
+        return json.load(open(f))["kernels"][kernel], os.path.basename(f)
     except Exception:
         return None, None
 
@@ -68,89 +134,148 @@ def issue_bound(kernel, launch_ms):
     instruction per 4 clocks (1024 SIMDs), a CU one scalar instruction per clock for all its
     waves (256 CUs).  None of the path's kernels is bound by HBM or MFMA; this is the bound
     that is close."""
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json")))
-    if not files:
+    f = latest_profile("*sq_counters.json")
+    if not f:
         return None
     try:
-        k = json.load(open(files[-1]))["kernels"][kernel]
+        k = json.load(open(f))["kernels"][kernel]
         vec = k["SQ_INSTS_VALU"] * 4 / (1024 * SHADER_CLOCK_HZ) * 1e3
         sca = (k["SQ_INSTS_SALU"] + k["SQ_INSTS_BRANCH"] + k.get("SQ_INSTS_SMEM", 0)) / (256 * SHADER_CLOCK_HZ) * 1e3
         bound = max(vec, sca)
         return {"vector_ms": vec, "scalar_ms": sca, "launch_ms": launch_ms, "frac": bound / launch_ms if launch_ms else None,
-                "clock_hz": SHADER_CLOCK_HZ, "source": os.path.basename(files[-1]),
+                "clock_hz": SHADER_CLOCK_HZ, "source": os.path.basename(f),
                 "is": "max(vector, scalar) issue time / measured launch time; counters from a separate profiled run"}
     except Exception:
         return None
 
 
-def cpu_baseline(config_id, bits, level, stream_len, budget_s=15.0):
-    """The oracle (C port of the reference algorithm) on this host, 1 thread, on a
-    bounded sample of the same workload."""
+def _cpu_worker(job):
+    """one host thread of the cpu_baseline leg: streams j0, j0 + stride, ... until the deadline"""
+    config_id, bits, level, stream_len, j0, stride, budget_s, do_inflate = job
     import oracle
     from zipc_amd import synth
 
     t_def = t_inf = 0.0
-    nbytes = 0
-    j = 0
+    n = 0
+    j = j0
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and j < 65536:
+    while time.perf_counter() - t0 < budget_s and n < 65536:
         plain = synth.stream_bytes_np(config_id, j, stream_len, bits).tobytes()
         a = time.perf_counter()
         st, comp, _ = oracle.deflate(plain, level=level, crc_op=oracle.CRC_CRC32)
         b = time.perf_counter()
-        st2, out, _ = oracle.inflate(comp, decompressed_size=stream_len, crc_op=oracle.CRC_CRC32)
-        c = time.perf_counter()
-        assert st == 0 and st2 == 0 and out == plain
         t_def += b - a
-        t_inf += c - b
-        nbytes += stream_len
-        j += 1
-    return {
-        "value": nbytes / GIB / (t_def + t_inf),
+        assert st == 0
+        if do_inflate:
+            st2, out, _ = oracle.inflate(comp, decompressed_size=stream_len, crc_op=oracle.CRC_CRC32)
+            t_inf += time.perf_counter() - b
+            assert st2 == 0 and out == plain
+        n += 1
+        j += stride
+    return n, t_def, t_inf, time.perf_counter() - t0
+
+
+def cpu_baseline(config_id, bits, level, stream_len, do_inflate=True, budget_s=12.0):
+    """The oracle (C port of the reference algorithm) on this host on a bounded sample of the same
+    workload: 1 thread (like the reference), then every host thread, member-sharded."""
+    import multiprocessing as mp
+
+    n, t_def, t_inf, _ = _cpu_worker((config_id, bits, level, stream_len, 0, 1, budget_s, do_inflate))
+    what = "deflate+inflate" if do_inflate else "deflate"
+    line = {
+        "value": n * stream_len / GIB / (t_def + t_inf),
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d streams x %d B of the same workload (deflate+inflate, oracle/zd_oracle.c, gcc -O2)" % (j, stream_len),
-        "deflate_gib_s": nbytes / GIB / t_def,
-        "inflate_gib_s": nbytes / GIB / t_inf,
+        "sample": "%d streams x %d B of the same workload (%s, oracle/zd_oracle.c, gcc -O2)" % (n, stream_len, what),
+        "deflate_gib_s": n * stream_len / GIB / t_def,
     }
+    if do_inflate:
+        line["inflate_gib_s"] = n * stream_len / GIB / t_inf
+    threads = os.cpu_count() or 1
+    try:
+        with mp.get_context("fork").Pool(threads) as pool:
+            res = pool.map(_cpu_worker, [(config_id, bits, level, stream_len, k, threads, budget_s / 2, do_inflate)
+                                         for k in range(threads)])
+        total = sum(r[0] for r in res)
+        wall = max(r[3] for r in res)
+        line["nproc"] = {"value": total * stream_len / GIB / wall, "unit": "GiB/s", "cores": threads,
+                         "sample": "%d streams, member-sharded over %d host threads" % (total, threads)}
+    except Exception as e:  # a host that cannot fork: the 1-thread figure stands alone
+        line["nproc"] = {"value": None, "error": repr(e)}
+    return line
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=16384, help="streams per rank (config C2: 16384)")
-    ap.add_argument("--stream-len", type=int, default=65536)
-    ap.add_argument("--bits", type=int, default=4, help="entropy bits per byte (C2: 4)")
-    ap.add_argument("--level", type=int, default=2, help="0 none, 1 fast, 2 default, 3 best")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    import numpy as np
+def timed_steps(step, barrier, steps, warmup, world, dev):
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def roofline_of(ctx, per_step_fn, psteps, N, C):
+    """per-kernel durations from HIP events on the launch stream (separate, untimed steps)"""
+    ctx.set_profiling(True)
+    ctx.reset_kernel_times()
+    for _ in range(psteps):
+        per_step_fn()
+    times = ctx.kernel_times()
+    ctx.set_profiling(False)
+    kernels = {k: v[1] / v[0] for k, v in times.items()}  # ms per launch
+    per_step = {k: v[1] / psteps for k, v in times.items()}  # ms per step
+    dom = max(per_step, key=per_step.get)
+    dom_ms = kernels[dom]
+    alg = algorithmic_bytes(dom, N, C)
+    achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic, traffic_src = measured_traffic(dom)
+    roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
+            "traffic_source": traffic_src, "algorithmic_bytes": alg, "launch_ms": dom_ms}
+    if traffic:
+        # "traffic" is the raw FETCH_SIZE + WRITE_SIZE.  Calibrated on the inflate kernel's stored-block
+        # path (profiles/r01_inflate_traffic.txt): WRITE_SIZE exact, FETCH_SIZE tallies every request at
+        # 64 B and reads 0.504x a wide streamed read, so raw <= true fetch <= 2 x raw (the guide's gfx950
+        # correction is the upper bound); Infinity-Cache hits are included, so HBM-side bytes can be lower.
+        roof["traffic_fetch_bounds"] = [traffic["fetch_bytes"], 2 * traffic["fetch_bytes"]]
+        roof["traffic_write"] = traffic["write_bytes"]
+        roof["traffic_corrected"] = 2 * traffic["fetch_bytes"] + traffic["write_bytes"]
+        roof["traffic_over_algorithmic"] = [traffic["bytes"] / alg if alg else None,
+                                            roof["traffic_corrected"] / alg if alg else None]
+        roof["traffic_is"] = "raw FETCH_SIZE+WRITE_SIZE per launch (L2->fabric); corrected = 2 x fetch + write"
+    ib = issue_bound(dom, dom_ms)
+    if ib:
+        roof["issue_bound"] = ib
+    return roof, per_step
+
+
+# ---- C2 ----------------------------------------------------------------------------------------------
+
+def run_c2(args, rank, local_rank, world, dev):
+    import torch
+    import torch.distributed as dist
 
     import zipc_amd
     from zipc_amd import batch, synth
 
     ctx = zipc_amd.Context(local_rank)
-    n, L = args.streams, args.stream_len
+    n = args.streams or 16384
+    L = args.stream_len or 65536
+    bits = args.bits or 4
     N = n * L
     # member-sharded: rank r owns streams [r*n, (r+1)*n) of the synthetic archive
-    src = synth.batch_bytes_torch(2, rank * n, n, L, args.bits, dev)
+    src = synth.batch_bytes_torch(2, rank * n, n, L, bits, dev)
     cap = batch.deflate_bound(L)
     descs = batch.uniform_layout(n, L, cap)
     slot = int(descs["dst_off"][1]) if n > 1 else cap
@@ -174,9 +299,9 @@ def main():
     assert (ires["status"] == 0).all() and torch.equal(out[:N], src), "round trip failed"
     assert (ires["checksum"] == res["checksum"]).all()
 
-    def step(sync_each=False):
-        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1, sync=sync_each)
-        batch.inflate_batch(ctx, comp, out, d_idescs, d_ires, n, L, 1, sync=sync_each)
+    def step():
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1, sync=False)
+        batch.inflate_batch(ctx, comp, out, d_idescs, d_ires, n, L, 1, sync=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -185,93 +310,362 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
 
-    # per-kernel durations: HIP events on the launch stream, separate (untimed)
-    # steps so that the event records do not perturb the headline number
-    ctx.set_profiling(True)
-    ctx.reset_kernel_times()
     psteps = max(1, min(args.steps, 3))
-    t_def = t_inf = 0.0
-    for _ in range(psteps):
+    t = {"def": 0.0, "inf": 0.0}
+
+    def profiled():
         a = time.perf_counter()
         batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1)
         b = time.perf_counter()
         batch.inflate_batch(ctx, comp, out, d_idescs, d_ires, n, L, 1)
-        c = time.perf_counter()
-        t_def += b - a
-        t_inf += c - b
-    times = ctx.kernel_times()
-    ctx.set_profiling(False)
-    kernels = {k: v[1] / v[0] for k, v in times.items()}  # ms per launch
-    per_step = {k: v[1] / psteps for k, v in times.items()}  # ms per step
-    dom = max(per_step, key=per_step.get)
-    dom_ms = kernels[dom]
-    alg = algorithmic_bytes(dom, N, C)
-    achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic, traffic_src = measured_traffic(dom)
+        t["def"] += b - a
+        t["inf"] += time.perf_counter() - b
 
-    if rank == 0:
-        line = {
-            "metric": "GiB/s deflate+inflate on 1 GiB synthetic; bit-exact vs Zipc_deflate",
-            "value": world * N / GIB * args.steps / elapsed,
-            "unit": "GiB/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
-            "config": {
-                "workload": "C2: %d independent streams x %d B of i.i.d. %d-bit symbols per GPU, "
-                            "deflate level %s + inflate, CRC-32 fused, device-resident"
-                            % (n, L, args.bits, ["none", "fast", "default", "best"][args.level]),
-                "streams_per_gpu": n, "stream_len": L, "level": args.level,
-                "compressed_ratio": C / N, "parallelism": "member-shard x%d" % world,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic["bytes"] if traffic else None,
-                "traffic_source": traffic_src, "algorithmic_bytes": alg, "launch_ms": dom_ms,
-            },
-            "deflate_gib_s": N / GIB * psteps / t_def,
-            "inflate_gib_s": N / GIB * psteps / t_inf,
-            "kernels_ms_per_step": per_step,
-        }
-        if traffic:
-            # what "traffic" is: raw FETCH_SIZE + WRITE_SIZE. Calibrated on this kernel's stored-block
-            # path (profiles/r01_inflate_traffic.txt): WRITE_SIZE exact, FETCH_SIZE tallies every
-            # request at 64 B and reads 0.504x a wide streamed read, so raw <= true fetch <= 2 x raw;
-            # Infinity-Cache hits are included, so HBM-side bytes can be lower.
-            line["roofline"]["traffic_fetch_bounds"] = [traffic["fetch_bytes"], 2 * traffic["fetch_bytes"]]
-            line["roofline"]["traffic_write"] = traffic["write_bytes"]
-            line["roofline"]["traffic_is"] = "raw FETCH_SIZE+WRITE_SIZE per launch (L2->fabric, lower bound on reads)"
-        ib = issue_bound(dom, dom_ms)
-        if ib:
-            line["roofline"]["issue_bound"] = ib
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(2, args.bits, args.level, L)
+    roof, per_step = roofline_of(ctx, profiled, psteps, N, C)
+    if rank != 0:
+        return None
+    line = {
+        "metric": METRIC,
+        "value": world * N / GIB * args.steps / elapsed,
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "C2: %d independent streams x %d B of i.i.d. %d-bit symbols per GPU, deflate level %s + "
+                        "inflate, CRC-32 of source and output by a separate pass over the bytes, device-resident"
+                        % (n, L, bits, LEVELS[args.level]),
+            "streams_per_gpu": n, "stream_len": L, "level": args.level,
+            "compressed_ratio": C / N, "parallelism": "member-shard x%d" % world,
+        },
+        "roofline": roof,
+        "deflate_gib_s": N / GIB * psteps / t["def"],
+        "inflate_gib_s": N / GIB * psteps / t["inf"],
+        "kernels_ms_per_step": per_step,
+    }
+    if world == 1 and not args.no_extra_legs:
+        line.update(extra_legs(ctx, dev, n, L))
+    return line
+
+
+def extra_legs(ctx, dev, n, L):
+    """Untimed legs beside the headline (each bounded to a second or two of GPU time): the
+    PCIe-inclusive host forms on the same workload, the whole path on real text, and C4's shape."""
+    import numpy as np
+    import torch
+
+    import zipc_amd
+    from zipc_amd import batch, synth
+
+    out = {}
+    try:  # e2e: pageable host buffers in, host buffers out (zipc_hip_{deflate,inflate}_many)
+        import ctypes as C
+
+        from zipc_amd import _lib
+
+        lib = _lib.lib()
+        m = min(n, 4096)
+        plain = [synth.stream_bytes_np(2, j, L, 4) for j in range(m)]
+        cap = lib.zipc_hip_deflate_bound(L)
+        comp = [np.zeros(cap, np.uint8) for _ in range(m)]
+        back = [np.zeros(L, np.uint8) for _ in range(m)]
+        P, S = C.c_void_p * m, C.c_size_t * m
+        srcp, slen = P(*[a.ctypes.data for a in plain]), S(*([L] * m))
+        dstp, dcap = P(*[a.ctypes.data for a in comp]), S(*([cap] * m))
+        res, ires = (_lib.StreamResult * m)(), (_lib.StreamResult * m)()
+        best = [1e9, 1e9]
+        for rep in range(3):  # the first call pins the staging buffers
+            a = time.perf_counter()
+            assert lib.zipc_hip_deflate_many(ctx.handle, m, srcp, slen, 2, 1, dstp, dcap, res) == 0
+            b = time.perf_counter()
+            clen = S(*[int(res[i].out_len) for i in range(m)])
+            backp, bcap = P(*[a_.ctypes.data for a_ in back]), S(*([L] * m))
+            c = time.perf_counter()
+            assert lib.zipc_hip_inflate_many(ctx.handle, m, dstp, clen, bcap, 1, backp, bcap, ires) == 0
+            d = time.perf_counter()
+            best = [min(best[0], b - a), min(best[1], d - c)]
+        assert all(int(ires[i].status) == 0 for i in range(m)) and np.array_equal(back[m - 1], plain[m - 1])
+        out["e2e_gib_s"] = {"deflate": m * L / GIB / best[0], "inflate": m * L / GIB / best[1],
+                            "is": "PCIe-inclusive host forms (zipc_hip_*_many) on %d of the streams, pageable host memory in and out, best of 3" % m}
+    except Exception as e:
+        out["e2e_gib_s"] = {"error": repr(e)}
+    try:  # the reference's own texts (tests/golden/zip-docs.zip), 64 KiB chunks
+        import zipfile
+
+        z = zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "zip-docs.zip"))
+        app = z.read("zip-docs/APPNOTE.TXT")
+        rfc = z.read("zip-docs/rfc1951.txt")
+        pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+        m = min(n, 4096)
+        src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(m)), np.uint8).copy()).to(dev)
+        gd, gi = device_round_trip(ctx, dev, src, m, L, 2)
+        out["text_gib_s"] = {"deflate": gd, "inflate": gi, "is": "%d x 64 KiB chunks of APPNOTE.TXT / rfc1951.txt, device-resident" % m}
+    except Exception as e:
+        out["text_gib_s"] = {"error": repr(e)}
+    try:  # C4 shape on this GPU: 2048 members x 1 MiB of 3-bit symbols
+        m, ML = 2048, 1 << 20
+        src = synth.batch_bytes_torch(4, 0, m, ML, 3, dev)
+        gd, gi = device_round_trip(ctx, dev, src, m, ML, 2)
+        out["c4_deflate_gib_s"] = gd
+        out["c4_inflate_gib_s"] = gi
+    except Exception as e:
+        out["c4_deflate_gib_s"] = {"error": repr(e)}
+    return out
+
+
+def device_round_trip(ctx, dev, src, n, L, level, reps=2):
+    """GiB/s (deflate, inflate) of n streams of L bytes held in `src`, device-resident, checked"""
+    import torch
+
+    from zipc_amd import batch
+
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    slot = int(descs["dst_off"][1]) if n > 1 else cap
+    comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_ires = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
+    res = batch.results_from_device(d_res)
+    assert (res["status"] == 0).all()
+    d_id = batch.to_device(batch.compact_descs(res, descs, L), dev)
+    batch.inflate_batch(ctx, comp, out, d_id, d_ires, n, L, 1)
+    assert torch.equal(out[:n * L], src)
+    td = ti = 0.0
+    for _ in range(reps):
+        a = time.perf_counter()
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
+        b = time.perf_counter()
+        batch.inflate_batch(ctx, comp, out, d_id, d_ires, n, L, 1)
+        td += b - a
+        ti += time.perf_counter() - b
+    return n * L / GIB * reps / td, n * L / GIB * reps / ti
+
+
+# ---- C4 ----------------------------------------------------------------------------------------------
+
+def run_c4(args, rank, local_rank, world, dev):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import zipc_amd
+    from zipc_amd import batch, shard, synth
+
+    ctx = zipc_amd.Context(local_rank)
+    members = args.streams or 8192
+    L = args.stream_len or (1 << 20)
+    bits = args.bits or 3
+    paths = shard.member_paths(members)           # m/%05d.bin: already in the order Zipc writes them
+    parts = shard.partition([L] * members, world)
+    lo, hi = parts[rank]
+    n = hi - lo
+    N = n * L
+    src = synth.batch_bytes_torch(4, lo, n, L, bits, dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    slot = int(descs["dst_off"][1]) if n > 1 else cap
+    comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    batch.reserve(ctx, n, L, N)
+    counts = [b - a for a, b in parts]
+    state = {}
+
+    def step():
+        # crc_32_and_deflate of this rank's members, then the one exchange of the path: the records
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1, sync=False)
+        ctx.synchronize()
+        res = batch.results_from_device(d_res)
+        local = np.zeros(n, dtype=shard.RECORD_DTYPE)
+        local["compressed_size"] = res["out_len"].astype(np.uint32)
+        local["crc32"] = res["checksum"]
+        local["arena_offset"] = descs["dst_off"]
+        state["res"] = res
+        state["records"] = shard.gather_records(local, counts)
+
+    def barrier():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    elapsed = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
+    res, records = state["res"], state["records"]
+    assert (res["status"] == 0).all(), "deflate failed"
+    assert len(records) == members
+    C_all = int(records["compressed_size"].astype(np.uint64).sum())
+    check = c4_check(ctx, dev, rank, world, parts, paths, records, comp, descs, L, bits, args.level)
+
+    roof, per_step = roofline_of(ctx, lambda: batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1),
+                                 1, N, int(res["out_len"].sum()))
+    if rank != 0:
+        return None
+    line = {
+        "metric": METRIC,
+        "value": members * L / GIB * args.steps / elapsed,
+        "unit": "GiB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {
+            "workload": "C4: ZIP archive of %d members x %d B of i.i.d. %d-bit symbols, crc_32_and_deflate level %s, "
+                        "member-sharded over %d GPU(s), records all-gathered (deflate only: value counts source bytes)"
+                        % (members, L, bits, LEVELS[args.level], world),
+            "members": members, "member_len": L, "level": args.level, "compressed_ratio": C_all / (members * L),
+            "parallelism": "member-shard x%d" % world, "members_per_rank": counts,
+        },
+        "roofline": roof,
+        "kernels_ms_per_step": per_step,
+        "archive_check": check,
+    }
+    return line
+
+
+def c4_check(ctx, dev, rank, world, parts, paths, records, comp, descs, L, bits, level, per_rank=4):
+    """Untimed: a sample of every rank's members goes to rank 0, which (a) deflates the same members
+    itself (regenerated from their seeds) and requires the same bytes -- the N-rank archive equals the
+    1-rank archive on the sample -- and (b) lays the sample out as a ZIP with the host layer
+    (zipc_amd/host) from the gathered records and lets zipfile and `unzip -t` read it back."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from zipc_amd import batch, synth
+
+    lo, hi = parts[rank]
+    take = list(range(lo, min(hi, lo + per_rank)))
+    cap = batch.deflate_bound(L)
+    mine = torch.zeros(per_rank * cap, dtype=torch.uint8, device=dev)
+    for k, j in enumerate(take):
+        o = int(descs["dst_off"][j - lo])
+        size = int(records["compressed_size"][j])
+        mine[k * cap:k * cap + size] = comp[o:o + size]
+    if world > 1:
+        gathered = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        dist.gather(mine, gathered, dst=0)
+    else:
+        gathered = [mine]
+    if rank != 0:
+        return None
+    import shutil
+    import tempfile
+    import zipfile
+
+    from zipc_amd import zipc_host
+
+    sample = []
+    for r in range(world):
+        rlo, rhi = parts[r]
+        for k, j in enumerate(range(rlo, min(rhi, rlo + per_rank))):
+            size = int(records["compressed_size"][j])
+            sample.append((j, gathered[r][k * cap:k * cap + size].cpu().numpy().tobytes()))
+    # (a) rank 0 deflates the sampled members itself
+    m = len(sample)
+    src = torch.cat([synth.batch_bytes_torch(4, j, 1, L, bits, dev) for j, _ in sample])
+    d = batch.uniform_layout(m, L, cap)
+    out = torch.zeros(m * int(d["dst_off"][1] if m > 1 else cap) + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(m * 16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(ctx, src, out, batch.to_device(d, dev), d_res, m, L, m * L, level, 1)
+    r0 = batch.results_from_device(d_res)
+    same = True
+    for k, (j, data) in enumerate(sample):
+        o = int(d["dst_off"][k])
+        mine_k = out[o:o + int(r0["out_len"][k])].cpu().numpy().tobytes()
+        same = same and mine_k == data and int(r0["checksum"][k]) == int(records["crc32"][j])
+    # (b) the sample as an archive, laid out by the host layer from the records
+    a = zipc_host.Archive()
+    for j, data in sample:
+        a.add_file_made(paths[j], 8, data, L, int(records["crc32"][j]))  # 8: the ZIP method number of Deflate
+    blob = a.to_binary_string()
+    names_ok = crc_ok = False
+    with zipfile.ZipFile(__import__("io").BytesIO(blob)) as z:
+        names_ok = z.namelist() == [paths[j].decode() for j, _ in sample]
+        crc_ok = z.testzip() is None
+    unzip_ok = None
+    if shutil.which("unzip"):
+        with tempfile.NamedTemporaryFile(suffix=".zip") as f:
+            f.write(blob)
+            f.flush()
+            unzip_ok = subprocess.run(["unzip", "-tq", f.name], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+    ok = same and names_ok and crc_ok and unzip_ok is not False
+    assert ok, "C4 archive check failed: same=%s names=%s crc=%s unzip=%s" % (same, names_ok, crc_ok, unzip_ok)
+    return {"sampled_members": m, "bytes_equal_one_rank": same, "zipfile_ok": names_ok and crc_ok, "unzip_t_ok": unzip_ok}
+
+
+# ---- main --------------------------------------------------------------------------------------------
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and (args.gpus or 1) > 1:
+        return launch_workers(args.gpus, argv)
+    world = int(env_world) if env_world is not None else 1
+    if args.gpus is not None and args.gpus != world:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d\n" % (args.gpus, world))
+        return 2
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.cpu_baseline_only:  # a process of its own: host threads only, nothing of the GPU in it
+        if args.config == "c4":
+            line = cpu_baseline(4, args.bits or 3, args.level, args.stream_len or (1 << 20), do_inflate=False, budget_s=8.0)
+        else:
+            line = cpu_baseline(2, args.bits or 4, args.level, args.stream_len or 65536)
         print(json.dumps(line))
+        return 0
+    sys.stderr.write("[bench] rank %d of %d (local rank %d), config %s\n" % (rank, world, local_rank, args.config))
+    sys.stderr.flush()
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        # the oracle on this host's cores, timed before this process touches the GPU (its worker pool forks)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"] + argv,
+                           stdout=subprocess.PIPE)
+        try:
+            cpu = json.loads(r.stdout.decode().strip().splitlines()[-1])
+        except Exception:
+            cpu = {"error": "cpu baseline leg failed (exit %d)" % r.returncode}
+
+    import torch
+
+    if not torch.cuda.is_available():
+        sys.stderr.write("bench.py: ZIPC_HIP_ERR_NO_DEVICE: no GPU visible to rank %d (there is no CPU path)\n" % rank)
+        return 3
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    line = (run_c4 if args.config == "c4" else run_c2)(args, rank, local_rank, world, dev)
+    if rank == 0:
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

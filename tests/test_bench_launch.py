@@ -1,0 +1,42 @@
+"""bench.py as the launcher of its own ranks (no GPU here): `--gpus N` starts N worker processes
+with the torch.distributed environment, each fails cleanly without a GPU, and the launcher
+reports that with a non-zero exit; a --gpus that contradicts WORLD_SIZE is refused."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=timeout)
+
+
+def test_gpus_n_spawns_n_ranks_and_fails_cleanly_without_a_gpu():
+    for n, config in ((2, "c2"), (3, "c4")):
+        r = run(["--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--config", config])
+        err = r.stderr.decode()
+        ranks = sorted(int(m.group(1)) for m in re.finditer(r"\[bench\] rank (\d+) of %d " % n, err))
+        assert ranks == list(range(n)), err  # the spawned world size equals --gpus
+        assert r.returncode != 0 and "workers failed" in err
+        assert err.count("ZIPC_HIP_ERR_NO_DEVICE") == n  # every rank says why; nothing falls back to the CPU
+        assert r.stdout.decode().strip() == ""  # and no JSON line is made up
+
+
+def test_gpus_must_agree_with_world_size():
+    r = run(["--gpus", "2"], {"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode == 2 and b"WORLD_SIZE=4" in r.stderr
+
+
+def test_cpu_baseline_leg_reports_one_thread_and_all_threads():
+    import bench
+
+    line = bench.cpu_baseline(2, 4, 2, 65536, budget_s=1.0)
+    assert line["cores"] == 1 and line["kind"] == "port" and line["value"] > 0
+    assert line["nproc"]["cores"] == (os.cpu_count() or 1) and line["nproc"]["value"] > line["value"] * 0.5

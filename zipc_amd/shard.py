@@ -15,6 +15,13 @@ import numpy as np
 RECORD_DTYPE = np.dtype([("compressed_size", "<u4"), ("crc32", "<u4"), ("arena_offset", "<u8")])
 
 
+def member_paths(n: int):
+    """C4's member names m/00000.bin ... (bytes).  Zipc writes members in the byte order of their
+    paths, `mimetype` first (src/zipc.ml:568-583): zero-padded numbers are already in that order,
+    so member index = position in the archive."""
+    return [b"m/%05d.bin" % j for j in range(n)]
+
+
 def partition(sizes, world_size: int):
     """Contiguous ranges [lo, hi) per rank, balanced by uncompressed bytes.
 
