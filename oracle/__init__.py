@@ -199,6 +199,16 @@ def deflate_bound(n: int) -> int:
     return lib().zd_deflate_bound(n)
 
 
+def huffman_retries(reset=False):
+    """(code-length code, litlen/dist codes): how often Huffman.lengths_of_freqs' flatten-and-retry
+    branch (zd.ml:470-473) has run in this process -- lets a test prove that its input reaches it"""
+    a = (C.c_int * 2).in_dll(lib(), "zd_huffman_retries")
+    got = (int(a[0]), int(a[1]))
+    if reset:
+        a[0] = a[1] = 0
+    return got
+
+
 def huffman_lengths(freqs, max_code_len):
     n = len(freqs)
     f = (C.c_int64 * n)(*freqs)

@@ -389,6 +389,10 @@ static void heapdown(int64_t *h, int max, int i) {
   }
 }
 
+/* test instrumentation: how often the flatten-and-retry branch (zd.ml:470-473) ran, for codes
+   limited to 7 bits (the code-length code) [0] and to 15 bits (litlen, dist) [1] */
+int zd_huffman_retries[2];
+
 /* Huffman.lengths_of_freqs zd.ml:404-473.  Writes plain lengths into e. */
 static void lengths_of_freqs(int64_t *heap, int *e, const int64_t *freqs, int max_sym,
                              int max_code_len) {
@@ -434,6 +438,7 @@ static void lengths_of_freqs(int64_t *heap, int *e, const int64_t *freqs, int ma
       e[sym] = len;
     }
     if (!overflow) return;
+    zd_huffman_retries[max_code_len > 7]++;
     freq_cap = freq_cap / 2; /* flatten distribution and retry zd.ml:470-473 */
   }
 }

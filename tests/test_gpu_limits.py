@@ -1,0 +1,76 @@
+"""The corners of the encoder the synthetic configs never reach, on the GPU against the oracle:
+Huffman codes that outgrow their length limit (Huffman.lengths_of_freqs' flatten-and-retry branch,
+zd.ml:470-473 -- on the GPU a wave-parallel coder of its own, wave_lengths_of_freqs in deflate.hip),
+matches at the very edge of the 32 KiB window (zd.ml:1143) next to the chain builder's sweep
+boundaries (zd.ml:1187)."""
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _deflate_batch(gpu_ctx, streams, level, crc_op=2):
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    n = len(streams)
+    src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+    caps = [batch.deflate_bound(len(s)) for s in streams]
+    slots = [(c + 255) // 256 * 256 for c in caps]
+    dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+    descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+    src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+    dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(gpu_ctx, src, dst, batch.to_device(descs, dev), d_res, n, max(len(s) for s in streams),
+                        int(sum(len(s) for s in streams)), level, crc_op)
+    res = batch.results_from_device(d_res)
+    out = dst.cpu().numpy()
+    return [(int(res["status"][i]), out[int(dst_off[i]):int(dst_off[i]) + int(res["out_len"][i])].tobytes(),
+             int(res["checksum"][i])) for i in range(n)]
+
+
+def test_huffman_length_limit_retry_reached_and_bytes_equal(gpu_ctx, oracle):
+    cases = util.deflate_cases()
+    want = {"fib_litlen": (False, True), "fib_codelen": (True, False), "fib_both": (True, True), "fib_multi": (True, True)}
+    # more shapes of the same kind: other alphabet sizes and paddings, several seeds
+    extra = {"fib_%d_%d_%d" % (k, pad, seed): util.fib_block(k, pad, seed)
+             for k in (14, 16, 17, 18, 19) for pad in (2, 3, 5) for seed in (2, 3)}
+    streams = {**{n: cases[n] for n in want}, **extra}
+    names = list(streams)
+    fired = [0, 0]
+    for level in (1, 2, 3):
+        got = _deflate_batch(gpu_ctx, [streams[n] for n in names], level)
+        for name, (st, comp, adler) in zip(names, got):
+            oracle.huffman_retries(reset=True)
+            st0, c0, a0 = oracle.deflate(streams[name], level=level, crc_op=oracle.CRC_ADLER32)
+            cl, ll = oracle.huffman_retries()
+            if name in want:  # the input does reach the branch, for the code-length code and / or litlen
+                assert (cl > 0, ll > 0) == want[name], (name, level, cl, ll)
+            fired[0] += cl > 0
+            fired[1] += ll > 0
+            assert st == 0 and comp == c0 and adler == a0, (name, level)
+            assert zlib.decompress(comp, -15) == streams[name]
+    assert fired[0] >= 12 and fired[1] >= 12, fired
+
+
+def test_matches_at_the_edge_of_the_window(gpu_ctx, oracle):
+    from zipc_amd import zipc_deflate as Z
+
+    for seed in (21, 22, 23):
+        data = util.far_match_data(seed)
+        for level, lv in (("fast", 1), ("default", 2), ("best", 3)):
+            st0, c0, _ = oracle.deflate(data, level=lv)
+            assert len(c0) < len(data) + 6 * 3  # some of the planted repeats were found (all-stored would be len + 15)
+            assert Z.deflate(data, level=level).get_ok() == c0, (seed, level)
+            assert Z.inflate(c0, decompressed_size=len(data)).get_ok() == data
+    got = _deflate_batch(gpu_ctx, [util.far_match_data(s) for s in range(30, 40)], 2)
+    for s, (st, comp, adler) in zip(range(30, 40), got):
+        st0, c0, a0 = oracle.deflate(util.far_match_data(s), level=2, crc_op=oracle.CRC_ADLER32)
+        assert st == 0 and comp == c0 and adler == a0, s

@@ -54,6 +54,42 @@ def trip_strings():
     return [(base64.b64decode(t["s_b64"]), t["block"]) for t in kat()["trip"]]
 
 
+def fib_block(k, pad, seed=1):
+    """a block whose Huffman codes outgrow their length limits: k rare byte values with Fibonacci
+    counts, every occurrence followed by `pad` random bytes of the other 256 - k values (no 4 bytes
+    repeat, so everything stays a literal).  With the right (k, pad) the litlen code wants more than
+    15 bits, or the code-length code more than 7, and Huffman.lengths_of_freqs takes its
+    flatten-and-retry branch (zd.ml:470-473) -- oracle.huffman_retries() tells."""
+    r = random.Random(seed)
+    f = [1, 1]
+    while len(f) < k:
+        f.append(f[-1] + f[-2])
+    occ = [i for i, c in enumerate(f[:k]) for _ in range(c)]
+    r.shuffle(occ)
+    out = bytearray()
+    for sym in occ:
+        out.append(sym)
+        out += bytes(r.randrange(k, 256) for _ in range(pad))
+    return bytes(out)
+
+
+def far_match_data(seed=21):
+    """random bytes with short repeats planted at distances 32766 .. 32770 (the window is 32768:
+    zd.ml:1143) whose second copy lies within a few bytes of a multiple of 16384 -- where the chain
+    builder sweeps entries that have left the window (zd.ml:1187)"""
+    r = random.Random(seed)
+    b = bytearray(r.randbytes(150000))
+    k = 0
+    for base in (32768, 49152, 65536, 81920, 98304, 114688, 131072):
+        for delta in (-3, -1, 0, 1, 2, 5):
+            pos = base + delta + 40 * k
+            dist = 32766 + k % 5
+            n = 6 + k % 13
+            b[pos:pos + n] = b[pos - dist:pos - dist + n]
+            k += 1
+    return bytes(b)
+
+
 def deflate_cases(small=False):
     """name -> plaintext: the edge cases the reference tests plus multi-block, run,
     period, incompressible and mixed inputs"""
@@ -79,6 +115,10 @@ def deflate_cases(small=False):
             "len65534": rand_bytes(65534, 7, 4), "len65535": rand_bytes(65535, 8, 4),
             "len65537": rand_bytes(65537, 9, 5),
             "zeros1M": bytes(1 << 20),
+            # Huffman length limits (litlen > 15 bits, code-length code > 7 bits, both, and both in a
+            # multi-block stream where the code-length counts carry over: Q1) and the window's edge
+            "fib_litlen": fib_block(16, 5), "fib_codelen": fib_block(14, 2), "fib_both": fib_block(18, 2),
+            "fib_multi": fib_block(18, 2) * 4 + fib_block(17, 5), "far_match": far_match_data(),
         })
         for m, raw in zip_docs_members():
             c[m["path"]] = zlib.decompress(raw, -15)

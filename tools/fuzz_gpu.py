@@ -9,7 +9,14 @@ import oracle, util, zipc_amd
 from zipc_amd import batch
 
 dev = torch.device("cuda", 0)
-ctx = zipc_amd.Context(0)
+ctx = None  # made on first use (tests/test_gpu_fuzz.py imports this file for run_seed)
+
+
+def _ctx():
+    global ctx
+    if ctx is None:
+        ctx = zipc_amd.Context(0)
+    return ctx
 
 
 def gen_plain(r):
@@ -49,17 +56,16 @@ def run_inflate(streams, cap, crc_op):
     src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
     dst = torch.zeros(n * (cap + 256) + 256, dtype=torch.uint8, device=dev)
     d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-    batch.inflate_batch(ctx, src, dst, batch.to_device(descs, dev), d_res, n, cap, crc_op)
+    batch.inflate_batch(_ctx(), src, dst, batch.to_device(descs, dev), d_res, n, cap, crc_op)
     return batch.results_from_device(d_res), dst.cpu().numpy(), dst_off
 
 
-def main():
-    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+def run_seed(seed, n_plain=120, n_headers=(100, 300), say=print):
+    """one seed's batch: (checks, mismatches)"""
     total = bad = 0
-    for seed in range(seed0, seed0 + n_seeds):
+    if True:
         r = random.Random(seed)
-        plains = [gen_plain(r) for _ in range(120)]
+        plains = [gen_plain(r) for _ in range(n_plain)]
         # deflate on the GPU at a random level per batch, bytes against the oracle
         level = r.randrange(4)
         cap = batch.deflate_bound(max(len(p) for p in plains))
@@ -70,7 +76,7 @@ def main():
         src = torch.from_numpy(np.frombuffer(b"".join(plains) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
         dst = torch.zeros(n * (cap + 256) + 256, dtype=torch.uint8, device=dev)
         d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
-        batch.deflate_batch(ctx, src, dst, batch.to_device(descs, dev), d_res, n, max(len(p) for p in plains),
+        batch.deflate_batch(_ctx(), src, dst, batch.to_device(descs, dev), d_res, n, max(len(p) for p in plains),
                             sum(len(p) for p in plains), level, 2)
         res, out = batch.results_from_device(d_res), dst.cpu().numpy()
         comps = []
@@ -80,13 +86,13 @@ def main():
             total += 1
             if res["status"][i] != 0 or got != c0 or res["checksum"][i] != a0:
                 bad += 1
-                print("DEFLATE MISMATCH seed", seed, "stream", i, "level", level, len(p))
+                say("DEFLATE MISMATCH seed", seed, "stream", i, "level", level, len(p))
             comps.append(c0)
         # inflate: the valid streams, damaged copies, random headers
         streams = list(comps)
         for i, c in enumerate(comps):
             streams += util.corrupt_variants(c, seed * 1000 + i, 2)
-        streams += util.header_fuzz_streams(seed, 100, 300)
+        streams += util.header_fuzz_streams(seed, n_headers[0], n_headers[1])
         capi = max(max(len(p) for p in plains), 1 << 16) + 64
         for crc_op in (r.choice([0, 1]), 2):
             res, out, doff = run_inflate(streams, capi, crc_op)
@@ -99,10 +105,22 @@ def main():
                     ok = res["out_len"][i] == len(d0) and out[o:o + len(d0)].tobytes() == d0 and res["checksum"][i] == c0
                 if not ok:
                     bad += 1
-                    print("INFLATE MISMATCH seed", seed, "stream", i, "crc_op", crc_op, st0, int(res["status"][i]))
+                    say("INFLATE MISMATCH seed", seed, "stream", i, "crc_op", crc_op, st0, int(res["status"][i]))
+    return total, bad
+
+
+def main():
+    seed0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+    n_seeds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    total = bad = 0
+    for seed in range(seed0, seed0 + n_seeds):
+        t, b = run_seed(seed)
+        total += t
+        bad += b
         print("seed", seed, "done; checks so far", total, "mismatches", bad, flush=True)
     print("FUZZ", "FAILED" if bad else "ok", total, "checks")
     sys.exit(1 if bad else 0)
 
 
-main()
+if __name__ == "__main__":
+    main()
