@@ -60,7 +60,22 @@ enum {
 
 /* crc_op (zipc_deflate.ml:210): which checksum is fused into inflate (over the
  * output) / deflate (over the input), updated once per deflate block. */
-enum { ZIPC_HIP_CRC_NOP = 0, ZIPC_HIP_CRC_CRC32 = 1, ZIPC_HIP_CRC_ADLER32 = 2 };
+enum {
+  ZIPC_HIP_CRC_NOP = 0,
+  ZIPC_HIP_CRC_CRC32 = 1,
+  ZIPC_HIP_CRC_ADLER32 = 2,         /* Zipc_deflate.Adler_32 as the reference computes it (below) */
+  ZIPC_HIP_CRC_ADLER32_RFC1950 = 3  /* RFC 1950's Adler-32: what zlib and everybody else computes */
+};
+/* The reference's Adler-32 takes a SIGNED 32-bit remainder after every 5552-byte chunk
+ * (src/zipc_deflate.ml:95,196) and restarts its chunking at every deflate block (:688,1084): on
+ * data whose running sum crosses 2^31 -- bytes above 0x7F in bulk: 6 KB of random bytes do -- its
+ * value differs from RFC 1950's, and depends on how the bytes were cut into calls.  A drop-in has
+ * to reproduce that (ZIPC_HIP_CRC_ADLER32, the default everywhere): zlib_compress then writes
+ * trailers standard zlib REJECTS for such data, and zlib_decompress reports a checksum mismatch on
+ * valid RFC 1950 streams of such data, exactly as the reference does.  Where interoperation with
+ * zlib matters more than equality with the reference, ask for RFC 1950's value instead: crc_op
+ * ZIPC_HIP_CRC_ADLER32_RFC1950 in the inflate / deflate forms, zipc_hip_set_adler_rfc1950() for the
+ * zlib forms and zipc_hip_checksum_device of a context. */
 
 /* type level (zipc_deflate.mli:123-125) */
 enum {
@@ -99,6 +114,9 @@ typedef struct {
   double total_ms;
 } zipc_hip_kernel_time;
 int zipc_hip_set_profiling(zipc_hip_ctx *ctx, int enabled);
+/* enabled != 0: zipc_hip_zlib_compress / _decompress and zipc_hip_checksum_device's Adler-32 of this
+ * context follow RFC 1950 (see ZIPC_HIP_CRC_ADLER32_RFC1950); 0 (the default): the reference's. */
+int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled);
 int zipc_hip_reset_kernel_times(zipc_hip_ctx *ctx);
 int zipc_hip_kernel_times(zipc_hip_ctx *ctx, zipc_hip_kernel_time *out, size_t cap,
                           size_t *n);

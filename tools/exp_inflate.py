@@ -15,7 +15,15 @@ def main():
     crc = int(os.environ.get("CRC_OP", "0"))  # 0 none, 1 CRC-32, 2 Adler-32 (fused per-stream checksums)
     dev = torch.device("cuda", 0)
     ctx = zipc_amd.Context(0)
-    src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
+    if os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
+        import zipfile
+        import numpy as np
+        z = zipfile.ZipFile(os.path.join(ROOT, "tests/golden/zip-docs.zip"))
+        app = z.read("zip-docs/APPNOTE.TXT"); rfc = z.read("zip-docs/rfc1951.txt")
+        pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+        src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(n)), np.uint8).copy()).to(dev)
+    else:
+        src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
     cap = batch.deflate_bound(L)
     descs = batch.uniform_layout(n, L, cap)
     slot = int(descs["dst_off"][1])

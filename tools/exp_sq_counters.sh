@@ -7,7 +7,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/sq
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-export DEFLATE=1 REPS=2 LEVEL=2 N_STREAMS=16384 BITS=4
+export DEFLATE=${DEFLATE:-1} REPS=2 LEVEL=2 N_STREAMS=${N_STREAMS:-16384} BITS=4
 i=0
 for ctrs in "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAVES SQ_WAVE_CYCLES" \
             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_IFETCH SQ_INSTS_BRANCH SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY" \

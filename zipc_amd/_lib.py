@@ -7,6 +7,7 @@ this package.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,7 +26,7 @@ ERR_INVALID_ARG = 18
 ERR_NO_DEVICE = 19
 ERR_NOMEM = 20
 
-CRC_NOP, CRC_CRC32, CRC_ADLER32 = 0, 1, 2
+CRC_NOP, CRC_CRC32, CRC_ADLER32, CRC_ADLER32_RFC1950 = 0, 1, 2, 3
 LEVEL_NONE, LEVEL_FAST, LEVEL_DEFAULT, LEVEL_BEST = 0, 1, 2, 3
 STREAM_HAS_LIMIT = 1
 
@@ -59,6 +60,7 @@ SYMBOLS = [
     ("zipc_hip_last_error", C.c_char_p, [_P]),
     ("zipc_hip_strerror", C.c_char_p, [C.c_int]),
     ("zipc_hip_set_profiling", C.c_int, [_P, C.c_int]),
+    ("zipc_hip_set_adler_rfc1950", C.c_int, [_P, C.c_int]),
     ("zipc_hip_reset_kernel_times", C.c_int, [_P]),
     ("zipc_hip_kernel_times", C.c_int, [_P, C.POINTER(KernelTime), _SZ, _SZP]),
     ("zipc_hip_crc32", C.c_int, [_P, _P, _SZ, _U32P]),
@@ -135,6 +137,11 @@ class Context:
     def synchronize(self):
         self.check(lib().zipc_hip_synchronize(self._h))
 
+    def set_adler_rfc1950(self, on: bool):
+        """the zlib forms and checksum_device of this context compute RFC 1950's Adler-32 (what zlib
+        computes) instead of the reference's signed-remainder value (include/zipc_hip.h)"""
+        self.check(lib().zipc_hip_set_adler_rfc1950(self._h, int(on)))
+
     def set_profiling(self, on: bool):
         self.check(lib().zipc_hip_set_profiling(self._h, int(on)))
 
@@ -160,11 +167,15 @@ class Context:
             pass
 
 
-_default = {}
+_default = threading.local()  # a context serves one thread at a time: every thread gets its own
 
 
 def default_context(device: int = 0) -> Context:
-    ctx = _default.get(device)
+    """the calling thread's context on `device` (made on first use)"""
+    per_thread = getattr(_default, "ctx", None)
+    if per_thread is None:
+        per_thread = _default.ctx = {}
+    ctx = per_thread.get(device)
     if ctx is None:
-        ctx = _default[device] = Context(device)
+        ctx = per_thread[device] = Context(device)
     return ctx

@@ -264,6 +264,12 @@ int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
 
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 
+int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled) {
+  if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
+  ctx->adler_rfc1950 = enabled != 0;
+  return ZIPC_HIP_OK;
+}
+
 int zipc_hip_set_profiling(zipc_hip_ctx *ctx, int enabled) {
   if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, ctx->collect_times());
@@ -334,7 +340,7 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
                            const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
                            size_t n_streams, size_t max_dst_cap, int crc_op) {
   if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
-  if (crc_op < 0 || crc_op > 2 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (crc_op < 0 || crc_op > 3 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // one wave per stream
@@ -354,7 +360,7 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
                            size_t n_streams, size_t max_src_len, size_t total_src_len, int level,
                            int crc_op) {
   if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
-  if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n_streams > 0x7FFFFFFFull)
+  if (crc_op < 0 || crc_op > 3 || level < 0 || level > 3 || n_streams > 0x7FFFFFFFull)
     return ZIPC_HIP_ERR_INVALID_ARG;
   if (max_src_len > MAX_STREAM_LEN) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
@@ -421,6 +427,12 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
               (uint64_t)len, n_chunks, per, R, amb, ADLER_AMB_CAP);
     ZD_LAUNCH(ctx, "adler_scan_runs", adler_scan_runs_kernel, dim3(1), dim3(1024), 0, (const uint32_t *)R.sum,
               R.res_before, R.n_runs, 0u);
+    if (ctx->adler_rfc1950) {  // RFC 1950's arithmetic: the chunk sums combine without the reference's sign cases
+      ZD_LAUNCH(ctx, "adler_rfc_finish", adler_rfc_finish_kernel, dim3(1), dim3(1024), 0, (const uint2 *)sums,
+                (uint64_t)len, n_chunks, d_out + 1);
+      HIP_TRY(ctx, hipGetLastError());
+      return ZIPC_HIP_OK;
+    }
     ZD_LAUNCH(ctx, "adler_replay", adler_replay_kernel, dim3(1), dim3(1024), 0, (const uint2 *)sums, (uint64_t)len,
               n_chunks, per, R, amb, ADLER_AMB_CAP, d_out + 1);
     HIP_TRY(ctx, hipGetLastError());
@@ -515,7 +527,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
                         const size_t *limit, int level, int crc_op, void *const *dst, const size_t *dst_cap,
                         zipc_hip_stream_result *results) {
   if (!ctx || (n && (!src || !src_len || !dst || !dst_cap || !results))) return ZIPC_HIP_ERR_INVALID_ARG;
-  if (crc_op < 0 || crc_op > 2 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (crc_op < 0 || crc_op > 3 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   // ZIPC_HIP_HOST_TIMING=1: wall time of the call's three host phases on stderr
@@ -586,12 +598,32 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   HIP_TRY(ctx, ev_in.make(K));
   HIP_TRY(ctx, ev_k.make(K));
   HIP_TRY(ctx, ev_out.make(K));
-  // earlier work of this context (the previous call's kernels read io_src / io_desc) first
+  // earlier work of this context (the previous call's kernels read io_src / io_desc; a call that
+  // failed half way may have left copies on the two copy streams) first
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));
+  // From here on copies and kernels are in flight on three streams, reading `descs` and the pinned
+  // buffers and recording into the event sets above: every error exit goes through drain(), which
+  // waits for all three before anything is freed or the next call reuses the buffers.
+  auto drain = [&]() {
+    (void)hipStreamSynchronize(ctx->copy_in);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_out);
+  };
+#define PIPE_TRY(expr)                                                                   \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      drain();                                                                           \
+      return ZIPC_HIP_ERR_HIP;                                                           \
+    }                                                                                    \
+  } while (0)
   const double ms_setup = since(t_begin);
   const auto t_feed = std::chrono::steady_clock::now();
   static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
+  PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
   auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
   auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
   int failed = 0;
@@ -602,10 +634,10 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
       if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
     });
     const uint64_t a = src_end(lo), b = src_end(hi);
-    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->io_src.p + a, (const uint8_t *)ctx->pin_src.p + a, b - a,
+    PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + a, (const uint8_t *)ctx->pin_src.p + a, b - a,
                                 hipMemcpyHostToDevice, ctx->copy_in));
-    HIP_TRY(ctx, hipEventRecord(ev_in.ev[g], ctx->copy_in));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
+    PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
+    PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
     zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
     zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
     size_t total_g = 0;
@@ -615,21 +647,19 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     else
       failed = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
     if (failed) break;
-    HIP_TRY(ctx, hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
+    PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
                                 hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipEventRecord(ev_k.ev[g], ctx->stream));
+    PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
     // the whole destination slots of the sub-batch: what is used of them is only known on the
     // host, and waiting for that would stall the feeding of the next sub-batch
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
+    PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
     const uint64_t c = dst_end(lo), e = dst_end(hi);
-    HIP_TRY(ctx, hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
+    PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
                                 hipMemcpyDeviceToHost, ctx->copy_out));
-    HIP_TRY(ctx, hipEventRecord(ev_out.ev[g], ctx->copy_out));
+    PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->copy_out));
   }
   if (failed) {  // a batch call refused its arguments or a HIP call failed: nothing is handed out
-    (void)hipStreamSynchronize(ctx->copy_in);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->copy_out);
+    drain();
     return failed;
   }
   const double ms_feed = since(t_feed);
@@ -637,7 +667,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   for (size_t g = 0; g < K; g++) {
     const size_t lo = cut[g], hi = cut[g + 1];
     if (lo == hi) continue;
-    HIP_TRY(ctx, hipEventSynchronize(ev_out.ev[g]));  // behind ev_k[g]: the results have landed too
+    PIPE_TRY(hipEventSynchronize(ev_out.ev[g]));  // behind ev_k[g]: the results have landed too
     const StreamResult *pr = (const StreamResult *)ctx->pin_res.p;
     for (size_t i = lo; i < hi; i++) {
       results[i].status = pr[i].status; results[i].checksum = pr[i].checksum; results[i].out_len = pr[i].out_len;
@@ -649,7 +679,8 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
         memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
     });
   }
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
+  PIPE_TRY(hipStreamSynchronize(ctx->copy_in));
+#undef PIPE_TRY
   if (timing)
     fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_arena=%llu ms: setup %.2f feed (gather + enqueue) %.2f "
                     "drain (wait + scatter) %.2f (threads %zu sub-batches %zu)\n",
@@ -686,7 +717,8 @@ int zipc_hip_zlib_decompress(zipc_hip_ctx *ctx, const void *src, size_t len, int
                      ((uint32_t)s[len - 2] << 8) | (uint32_t)s[len - 1];
   uint32_t f = 0;
   // the reference hands inflate the range [2, len-2) (src/zipc_deflate.ml:732)
-  int st = zipc_hip_inflate(ctx, s + 2, len - 4, has_limit, limit, ZIPC_HIP_CRC_ADLER32, dst, dst_cap,
+  int st = zipc_hip_inflate(ctx, s + 2, len - 4, has_limit, limit,
+                            ctx->adler_rfc1950 ? ZIPC_HIP_CRC_ADLER32_RFC1950 : ZIPC_HIP_CRC_ADLER32, dst, dst_cap,
                             out_len, &f);
   if (st) return st;
   if (expect) *expect = e;
@@ -710,7 +742,9 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
   o[1] = (uint8_t)flg;
   size_t body = 0;
   uint32_t a = 0;
-  int st = zipc_hip_deflate(ctx, src, len, level, ZIPC_HIP_CRC_ADLER32, o + 2, dst_cap - 6, &body, &a);
+  int st = zipc_hip_deflate(ctx, src, len, level,
+                            ctx->adler_rfc1950 ? ZIPC_HIP_CRC_ADLER32_RFC1950 : ZIPC_HIP_CRC_ADLER32, o + 2, dst_cap - 6,
+                            &body, &a);
   if (st) return st;
   o[2 + body] = (uint8_t)(a >> 24);
   o[3 + body] = (uint8_t)(a >> 16);

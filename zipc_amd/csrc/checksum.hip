@@ -268,6 +268,37 @@ __global__ __launch_bounds__(256) void adler_chunks_kernel(const uint8_t *__rest
   if (lane == 0) sums[chunk] = make_uint2(S1, S2);
 }
 
+// RFC 1950's Adler-32 of the buffer from its chunk sums: with the unsigned remainder the chunk
+// steps are an affine map mod 65521 in (s1, s2), so chunks combine in any grouping: every thread
+// folds a run of chunks starting from (0, 0), then the runs are chained by one thread
+// (s1' = s1 + A1, s2' = s2 + bytes_of_run * s1 + A2 for a run that maps (0, 0) to (A1, A2)).
+__global__ __launch_bounds__(1024) void adler_rfc_finish_kernel(const uint2 *__restrict__ sums, uint64_t n,
+                                                                uint64_t n_chunks, uint32_t *__restrict__ out) {
+  __shared__ uint32_t a1[1024], a2[1024];
+  __shared__ uint64_t nb[1024];
+  const uint32_t t = threadIdx.x;
+  const uint64_t per = (n_chunks + 1023) / 1024;
+  const uint64_t lo = (uint64_t)t * per, hi = lo + per < n_chunks ? lo + per : n_chunks;
+  const uint64_t r = n % ADLER_CHUNK;
+  uint32_t s1 = 0, s2 = 0;
+  uint64_t bytes = 0;
+  for (uint64_t k = lo; k < hi; k++) {
+    const uint32_t len = k == 0 ? (uint32_t)r : ADLER_CHUNK;
+    adler_chunk_step(s1, s2, len, sums[k].x, sums[k].y, true);
+    bytes += len;
+  }
+  a1[t] = s1; a2[t] = s2; nb[t] = bytes;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t c1 = 1, c2 = 0;  // Adler-32 starts at (1, 0)
+    for (int i = 0; i < 1024; i++) {
+      c2 = (c2 + (nb[i] % ADLER_BASE) * c1 + a2[i]) % ADLER_BASE;
+      c1 = (c1 + a1[i]) % ADLER_BASE;
+    }
+    out[0] = (uint32_t)((c2 << 16) | c1);
+  }
+}
+
 // The chunk chain (src/zipc_deflate.ml:196: s1/s2 := SIGNED rem after every chunk)
 // for hundreds of thousands of chunks, without walking them one by one.
 //   s1 never goes negative, so s1 before chunk k is (1 + sum of S1) mod 65521: a scan.

@@ -12,6 +12,7 @@ struct zipc_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool profiling = false;
+  bool adler_rfc1950 = false;  // zipc_hip_set_adler_rfc1950: the zlib forms and checksum_device use RFC 1950's Adler-32
   std::string last_error;
   zd::CrcConsts crc_consts;
 

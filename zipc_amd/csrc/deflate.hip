@@ -1118,7 +1118,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     const BlockDesc bd = blocks[b];
     const bool final = b + 1 == nblk;
     // deflated_block_src_crc zd.ml:1081-1086 (Adler: one update call per block)
-    if (crc_op == CRC_ADLER32) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane);
+    if (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane, crc_op == CRC_ADLER32_RFC);
 
 #ifdef ZD_EMIT_PHASES
     const uint64_t ph0 = __builtin_readcyclecounter();
@@ -1298,7 +1298,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     StreamResult r;
     r.status = status;
     r.out_len = status == ST_OK ? bo.out_pos : 0;
-    r.checksum = (crc_op == CRC_ADLER32 && status == ST_OK) ? adler : 0u;  // CRC-32: checksum pass
+    r.checksum = ((crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) && status == ST_OK) ? adler : 0u;  // CRC-32: checksum pass
 #ifdef ZD_EMIT_PHASES
     r.checksum = (uint32_t)((__builtin_readcyclecounter() - ph_begin) >> 4);
     r.out_len = (ph_hist >> 4) | ((ph_code >> 4) << 32);
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__res
   for (;;) {
     const uint32_t n = len - start < (uint32_t)MAX_BLOCK_SRC_LEN ? len - start : (uint32_t)MAX_BLOCK_SRC_LEN;
     const bool final = start + n == len;
-    if (crc_op == CRC_ADLER32) adler = wave_adler_update(adler, src + start, n, lane);
+    if (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) adler = wave_adler_update(adler, src + start, n, lane, crc_op == CRC_ADLER32_RFC);
     if (lane == 0) {
       uint8_t *q = dst + out;
       q[0] = final ? 1 : 0;
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__res
     start += n;
   }
   r.out_len = out;
-  r.checksum = crc_op == CRC_ADLER32 ? adler : 0u;
+  r.checksum = (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) ? adler : 0u;
   if (lane == 0) results[stream] = r;
 }
 

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const int lane = threadIdx.x;
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
-  const bool crc_adler = crc_op == CRC_ADLER32;
+  const bool crc_adler = crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC;
+  const bool adler_rfc = crc_op == CRC_ADLER32_RFC;
   const bool writer = lane == 0;
 
   LaneLds L;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (d.phase == PH_REQ_ADLER) {
       // the block's bytes were stored by other lanes of this wave: make them visible
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      d.adler = wave_adler_update(d.adler, dst + d.blk_out_start, d.out_pos - d.blk_out_start, lane);
+      d.adler = wave_adler_update(d.adler, dst + d.blk_out_start, d.out_pos - d.blk_out_start, lane, adler_rfc);
       lane_after_adler(d);
     }
     if (d.phase == PH_DONE && d.q_count == 0) break;

@@ -44,6 +44,9 @@ __global__ void crc32_finish_streams_kernel(int mode, const StreamDesc *__restri
                                             const uint32_t *__restrict__ partials);
 __global__ void adler_chunks_kernel(const uint8_t *__restrict__ p, uint64_t n, uint64_t n_chunks,
                                     uint2 *__restrict__ sums);
+// RFC 1950's Adler-32 from the chunk sums (one workgroup)
+__global__ void adler_rfc_finish_kernel(const uint2 *__restrict__ sums, uint64_t n, uint64_t n_chunks,
+                                        uint32_t *__restrict__ out);
 constexpr uint32_t ADLER_AMB_CAP = 8192;  // ambiguous-chunk records (16 bytes each)
 constexpr uint32_t ADLER_MAX_RUNS = 65536;
 // per-run arrays of the Adler chain (device scratch, n_runs entries each)

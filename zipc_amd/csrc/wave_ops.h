@@ -78,14 +78,14 @@ __device__ __forceinline__ void wave_adler_chunk_sums(const uint8_t *c, uint32_t
 // Adler_32.string_update (src/zipc_deflate.ml:175-198) over p[0, n) by all 64
 // lanes: the FIRST chunk is n mod 5552 bytes (possibly empty), then 5552 each;
 // per chunk every lane applies the reference's signed-remainder step.
-__device__ __forceinline__ uint32_t wave_adler_update(uint32_t a, const uint8_t *p, uint32_t n, int lane) {
+__device__ __forceinline__ uint32_t wave_adler_update(uint32_t a, const uint8_t *p, uint32_t n, int lane, bool rfc = false) {
   uint32_t s1, s2;
   adler_unpack(a, s1, s2);
   uint32_t start = 0, block_len = n % ADLER_CHUNK;
   while (start < n) {
     uint32_t S1, S2;
     wave_adler_chunk_sums(p + start, block_len, lane, S1, S2);
-    adler_chunk_step(s1, s2, block_len, S1, S2);
+    adler_chunk_step(s1, s2, block_len, S1, S2, rfc);
     start += block_len;
     block_len = ADLER_CHUNK;
   }

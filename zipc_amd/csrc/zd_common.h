@@ -31,7 +31,7 @@ enum : uint32_t {
   ST_DST_TOO_SMALL = 16,
   ST_INVALID_ARG = 18,
 };
-enum : int { CRC_NOP = 0, CRC_CRC32 = 1, CRC_ADLER32 = 2 };
+enum : int { CRC_NOP = 0, CRC_CRC32 = 1, CRC_ADLER32 = 2, CRC_ADLER32_RFC = 3 };  // 3: RFC 1950's Adler-32, not the reference's (Q6/Q7)
 enum : int { LEVEL_NONE = 0, LEVEL_FAST = 1, LEVEL_DEFAULT = 2, LEVEL_BEST = 3 };
 
 constexpr int LITLEN_SYM_MAX = 285;    // zd.ml:237
@@ -229,9 +229,17 @@ ZD_HD uint32_t crc_state_advance(uint32_t state, uint32_t raw, uint32_t xpow) {
 // summarised by S1 = sum b_i and S2 = sum (n - i) b_i; the running (s1, s2)
 // then advance with the reference's wrapping int32 arithmetic and its SIGNED
 // remainder (Int32.rem, zd.ml:95,196).
-ZD_HD void adler_chunk_step(uint32_t &s1, uint32_t &s2, uint32_t n, uint32_t S1, uint32_t S2) {
+// rfc: RFC 1950's arithmetic instead (unsigned remainder; with s1, s2 < 65521 and n <= 5552 the
+// sums stay below 2^32, which is what zlib's NMAX = 5552 is chosen for) -- the value every other
+// zlib implementation computes, whatever the chunking.
+ZD_HD void adler_chunk_step(uint32_t &s1, uint32_t &s2, uint32_t n, uint32_t S1, uint32_t S2, bool rfc = false) {
   uint32_t t2 = s2 + n * s1 + S2;  // wraps like int32
   uint32_t t1 = s1 + S1;
+  if (rfc) {
+    s1 = t1 % ADLER_BASE;
+    s2 = t2 % ADLER_BASE;
+    return;
+  }
   s1 = (uint32_t)((int32_t)t1 % (int32_t)ADLER_BASE);
   s2 = (uint32_t)((int32_t)t2 % (int32_t)ADLER_BASE);
 }

@@ -6,13 +6,24 @@
 
 namespace zipc_deflate {
 
+// One context PER HOST THREAD (include/zipc_hip.h: a context owns one HIP stream and staging
+// buffers that every call reuses, so it serves one thread at a time).  The reference module is
+// re-entrant and a drop-in caller may well call it from several threads: each gets its own
+// context on first use, destroyed when the thread exits.
+namespace {
+struct ThreadContext {
+  zipc_hip_ctx *ctx = nullptr;
+  int status = 0;
+  ThreadContext() { status = zipc_hip_create(&ctx, 0); }
+  ~ThreadContext() {
+    if (ctx) zipc_hip_destroy(ctx);
+  }
+};
+}  // namespace
 zipc_hip_ctx *context() {
-  static zipc_hip_ctx *ctx = nullptr;
-  static std::once_flag once;
-  static int status = 0;
-  std::call_once(once, [] { status = zipc_hip_create(&ctx, 0); });
-  if (!ctx) throw std::runtime_error(std::string("zipc_hip_create: ") + zipc_hip_strerror(status));
-  return ctx;
+  thread_local ThreadContext tc;
+  if (!tc.ctx) throw std::runtime_error(std::string("zipc_hip_create: ") + zipc_hip_strerror(tc.status));
+  return tc.ctx;
 }
 
 static std::string message(int status) { return zipc_hip_strerror(status); }

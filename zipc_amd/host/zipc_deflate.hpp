@@ -42,8 +42,10 @@ struct Unit {};
 typedef std::uint16_t uint16;  // zipc_deflate.mli:17
 typedef std::uint32_t uint32;  // zipc_deflate.mli:20
 
-// The context all calls of this process go through (device 0, created on first
-// use).  Throws std::runtime_error when the library cannot create one.
+// The context the calling THREAD's calls go through (device 0, created on the thread's first
+// use, destroyed when it exits): a zipc_hip context serves one thread at a time, and like the
+// reference module these functions may be called from several threads at once.  Throws
+// std::runtime_error when the library cannot create one.
 zipc_hip_ctx *context();
 
 // (start, len) of the reference's optional arguments -> the checked range
