@@ -36,7 +36,11 @@ extern "C" {
 #define ZIPC_HIP_ABI_VERSION 1
 
 /* Longest single stream, and largest destination capacity, in bytes: 4 GiB - 64 KiB (positions are
- * 32-bit inside the kernels).  The reference's own limit is OCaml's string length. */
+ * 32-bit inside the kernels).  The reference's own limit is OCaml's string length.
+ * One exception, for inflate: a batch of ONE stream that begins with a chain of stored blocks of
+ * equal length -- what the reference's encoder makes of incompressible data -- may be of any size
+ * (zipc_hip_inflate_batch with max_dst_cap above this limit; checksum none or CRC-32): the chain is
+ * copied with 64-bit offsets and what follows it has to fit the limit as a stream of its own. */
 #define ZIPC_HIP_MAX_STREAM_LEN 0xFFFF0000ull
 
 /* ---- status codes --------------------------------------------------------

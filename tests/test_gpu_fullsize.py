@@ -194,3 +194,80 @@ def test_config5_full_131072_streams(gpu_ctx, oracle):
     res = _full_round_trip(gpu_ctx, oracle, 5, 131072, 65536, 8, 2, samples=(0, 65535, 65536, 65537, 131071))
     # (a stream in a few hundred holds a 4-byte repeat whose match tips a block's cost: not all are 65 543)
     assert (res["out_len"] == 65543).mean() > 0.98 and (np.abs(res["out_len"].astype(np.int64) - 65543) < 64).all()
+
+
+def _stored_stream(src, block=65534):
+    """`src` (uint8 cuda tensor) as ONE deflate stream of stored blocks of `block` bytes (the last one
+    shorter and final): what the reference's encoder makes of incompressible data"""
+    import torch
+
+    n = src.numel()
+    J = n // block
+    rest = n - J * block
+    out = torch.empty(n + 5 * (J + 1), dtype=torch.uint8, device=src.device)
+    body = out[:J * (block + 5)].view(J, block + 5)
+    body[:, 0] = 0
+    body[:, 1] = block & 255
+    body[:, 2] = block >> 8
+    body[:, 3] = (~block) & 255
+    body[:, 4] = ((~block) >> 8) & 255
+    body[:, 5:] = src[:J * block].view(J, block)
+    tail = out[J * (block + 5):]
+    tail[0] = 1
+    tail[1] = rest & 255
+    tail[2] = rest >> 8
+    tail[3] = (~rest) & 255
+    tail[4] = ((~rest) >> 8) & 255
+    tail[5:] = src[J * block:]
+    return out, J
+
+
+def test_config5_single_8gib_stream_of_stored_blocks(gpu_ctx, oracle):
+    """C5's secondary form: the same 8 GiB as ONE stream, 131 076 stored blocks of 65 534 bytes and a
+    short final one -- beyond the 32-bit positions of the batch kernel, so the chain of equal stored
+    blocks is found and copied with 64-bit offsets (inflate.hip, stored_chain_*).  Every byte comes
+    back, the CRC-32 of the output is the source's, the reference's errors are reported where the
+    chain is damaged near its end or the limit is a byte short; the first blocks, cut out as a stream
+    of their own, are what the oracle makes of them."""
+    import torch
+
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    n = 8 << 30
+    src = synth.batch_bytes_torch(5, 0, 1, n, 8, dev)
+    comp, J = _stored_stream(src)
+    assert J == 131076
+    out = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+
+    def run(limit, cap=n):
+        descs = batch.make_descs([0], [comp.numel()], [0], [cap], limit=None if limit is None else [limit])
+        batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(descs, dev), d_res, 1, cap, 1)
+        return batch.results_from_device(d_res)
+
+    res = run(n)
+    assert int(res["status"][0]) == 0 and int(res["out_len"][0]) == n
+    assert torch.equal(out[:n], src)
+    crc, _ = batch.checksum_device(gpu_ctx, src, want_adler32=False)
+    assert int(res["checksum"][0]) == crc
+    assert int(run(None)["status"][0]) == 0                       # no ?decompressed_size
+    assert int(run(n - 1)["status"][0]) == 2                      # "Expected decompression size exceeded"
+    # the oracle on the stream's first three blocks (made final), and the GPU's ordinary path on the same
+    head = bytearray(comp[:3 * 65539].cpu().numpy().tobytes())
+    head[2 * 65539] |= 1
+    st0, d0, c0 = oracle.inflate(bytes(head), crc_op=oracle.CRC_CRC32)
+    assert st0 == 0 and d0 == src[:3 * 65534].cpu().numpy().tobytes()
+    # a damaged NLEN ten blocks before the end: the chain stops there, the rest is the kernel's and is refused
+    at = (J - 10) * 65539 + 3
+    saved = int(comp[at])
+    comp[at] = saved ^ 0x40
+    res = run(n)
+    assert int(res["status"][0]) == 1 and int(res["out_len"][0]) == 0  # "Corrupted data stream"
+    comp[at] = saved
+    # damaged early: what follows is itself beyond the kernel's range: refused as an argument
+    at = 1000 * 65539 + 3
+    saved = int(comp[at])
+    comp[at] = saved ^ 0x40
+    assert int(run(n)["status"][0]) == 18
+    comp[at] = saved

@@ -61,3 +61,26 @@ if "c4" in which:
     codec(4, 8192, 1 << 20, 3, 2, "C4: 8192 members x 1 MiB of 3-bit symbols, level default (1 GPU)")
 if "c5" in which:
     codec(5, 131072, 65536, 8, 2, "C5: 131072 streams x 64 KiB uniform random (stored 65534 + fixed 2), inflate roofline run")
+if "c5single" in which or not sys.argv[1:]:
+    # C5's secondary form: the same 8 GiB as ONE stream of stored blocks (tests/test_gpu_fullsize.py builds it the same way)
+    import numpy as np
+    n, block = 8 << 30, 65534
+    src = synth.batch_bytes_torch(5, 0, 1, n, 8, dev)
+    J = n // block; rest = n - J * block
+    comp = torch.empty(n + 5 * (J + 1), dtype=torch.uint8, device=dev)
+    body = comp[:J * (block + 5)].view(J, block + 5)
+    for col, val in enumerate((0, block & 255, block >> 8, (~block) & 255, ((~block) >> 8) & 255)): body[:, col] = val
+    body[:, 5:] = src[:J * block].view(J, block)
+    tail = comp[J * (block + 5):]
+    for col, val in enumerate((1, rest & 255, rest >> 8, (~rest) & 255, ((~rest) >> 8) & 255)): tail[col] = val
+    tail[5:] = src[J * block:]
+    out = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(batch.make_descs([0], [comp.numel()], [0], [n], limit=[n]), dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    batch.inflate_batch(ctx, comp, out, d_descs, d_res, 1, n, 0)
+    ok = bool(torch.equal(out[:n], src)) and int(batch.results_from_device(d_res)["status"][0]) == 0
+    ti = timed(lambda: batch.inflate_batch(ctx, comp, out, d_descs, d_res, 1, n, 0, sync=False))
+    ctx.set_profiling(True); ctx.reset_kernel_times(); batch.inflate_batch(ctx, comp, out, d_descs, d_res, 1, n, 0)
+    k = {a: round(b[1] / b[0], 3) for a, b in ctx.kernel_times().items()}; ctx.set_profiling(False)
+    print(json.dumps({"config": "C5 as ONE stream: 8 GiB in %d stored blocks of 65534 bytes + a short final one, inflate (no checksum)" % J,
+                      "round_trip_ok": ok, "inflate_gib_s": n / GIB / ti, "inflate_hbm_gb_s": (n + comp.numel()) / ti / 1e9, "kernels_ms": k}))

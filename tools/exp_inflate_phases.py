@@ -8,9 +8,11 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import zipc_amd
 from zipc_amd import batch, synth, _lib
-n = int(os.environ.get("N_STREAMS", "16384")); L = 65536; bits = int(os.environ.get("BITS", "4"))
+n = int(os.environ.get("N_STREAMS", "16384")); L = int(os.environ.get("LEN", "65536")); bits = int(os.environ.get("BITS", "4"))
 dev = torch.device("cuda", 0); ctx = zipc_amd.Context(0)
-if os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
+if os.environ.get("ZEROS"):
+    src = torch.zeros(n * L, dtype=torch.uint8, device=dev)
+elif os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
     import zipfile
     z = zipfile.ZipFile(os.path.join(ROOT, "tests/golden/zip-docs.zip"))
     app = z.read("zip-docs/APPNOTE.TXT"); rfc = z.read("zip-docs/rfc1951.txt")

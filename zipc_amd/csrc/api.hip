@@ -336,6 +336,71 @@ static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const St
   return ZIPC_HIP_OK;
 }
 
+// One stream beyond ZIPC_HIP_MAX_STREAM_LEN: the chain of equal stored blocks it has to start with
+// (inflate.hip) is found and copied with 64-bit offsets, what follows goes through the batch kernel
+// as a stream of its own, and the two results are put together.
+static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
+                               const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results, int crc_op) {
+  if (crc_op == ZIPC_HIP_CRC_ADLER32 || crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950) return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, ctx->ensure(ctx->io_small, 256));
+  StoredChain *d_st = (StoredChain *)ctx->io_small.p;
+  StreamDesc sd;
+  HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
+  ZD_LAUNCH(ctx, "stored_chain_probe", stored_chain_probe_kernel, dim3(1), dim3(1), 0, (const uint8_t *)d_src_arena,
+            (const StreamDesc *)d_descs, d_st);
+  StoredChain st;
+  HIP_TRY(ctx, hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  StreamResult res;
+  res.status = ZIPC_HIP_ERR_INVALID_ARG; res.checksum = 0; res.out_len = 0;
+  uint64_t blocks = 0;
+  bool done = false;
+  if (st.len0 != 0 && st.candidates != 0) {
+    ZD_LAUNCH(ctx, "stored_chain_scan", stored_chain_scan_kernel, dim3((st.candidates + 255) / 256), dim3(256), 0,
+              (const uint8_t *)d_src_arena, (const StreamDesc *)d_descs, d_st);
+    HIP_TRY(ctx, hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    blocks = st.first_bad;
+    if (st.final_at < blocks) { blocks = (uint64_t)st.final_at + 1; done = true; }  // the final block is one of the chain
+    // blocks that would overrun the destination are the remainder's: it reports the reference's error
+    const uint64_t limit = (sd.flags & STREAM_HAS_LIMIT) ? sd.limit : ~0ull;
+    const uint64_t room = limit < sd.dst_cap ? limit : sd.dst_cap;
+    if (blocks * st.len0 > room) { blocks = room / st.len0; done = false; }
+    if (blocks)
+      ZD_LAUNCH(ctx, "stored_chain_copy", stored_chain_copy_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs, st.len0);
+  }
+  const uint64_t used_src = blocks * (5ull + st.len0), made = blocks * (uint64_t)st.len0;
+  if (done) {
+    res.status = ZIPC_HIP_OK;
+    res.out_len = made;
+  } else {
+    StreamDesc rest = sd;
+    rest.src_off += used_src; rest.src_len -= used_src;
+    rest.dst_off += made; rest.dst_cap -= made;
+    if (rest.flags & STREAM_HAS_LIMIT) rest.limit -= made;
+    if (rest.src_len <= MAX_STREAM_LEN) {
+      if (rest.dst_cap > MAX_STREAM_LEN) rest.dst_cap = MAX_STREAM_LEN;  // (the rest is an ordinary stream: it may produce up to that much)
+      HIP_TRY(ctx, ctx->ensure(ctx->io_desc, sizeof(StreamDesc)));
+      HIP_TRY(ctx, ctx->ensure(ctx->io_res, sizeof(StreamResult)));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, &rest, sizeof rest, hipMemcpyHostToDevice, ctx->stream));
+      const int stb = zipc_hip_inflate_batch(ctx, d_src_arena, d_dst_arena, (const zipc_hip_stream_desc *)ctx->io_desc.p,
+                                             (zipc_hip_stream_result *)ctx->io_res.p, 1, (size_t)rest.dst_cap, ZIPC_HIP_CRC_NOP);
+      if (stb) return stb;
+      HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->io_res.p, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (res.status == ZIPC_HIP_OK) res.out_len += made;
+      else res.out_len = 0;
+    }  // else: the chain ends too early for the rest to be one ordinary stream: INVALID_ARG stands
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(d_results, &res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (crc_op == ZIPC_HIP_CRC_CRC32 && res.status == ZIPC_HIP_OK)
+    return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,
+                      (StreamResult *)d_results, 1, 0, 0, (size_t)res.out_len, nullptr);
+  return ZIPC_HIP_OK;
+}
+
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
                            size_t n_streams, size_t max_dst_cap, int crc_op) {
@@ -343,6 +408,8 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   if (crc_op < 0 || crc_op > 3 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (n_streams == 1 && max_dst_cap > MAX_STREAM_LEN)
+    return inflate_huge_stream(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op);
   // one wave per stream
   HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));
   ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)n_streams), dim3(64), 0,

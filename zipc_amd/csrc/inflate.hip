@@ -192,7 +192,19 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the source bytes were stored by other lanes of this wave
   uint8_t *o = dst + pos;
   const uint8_t *s = o - dist;
-  for (uint32_t i = (uint32_t)lane; i < len; i += 64u) o[i] = s[dist >= len ? i : i % dist];
+  // every source byte lies before the match: all of a lane's loads first (one memory latency for
+  // the match, not one per 64 bytes: written as load-store pairs the compiler keeps them in order)
+  uint8_t v[5];  // 258 bytes at most: 5 per lane
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+    v[k] = s[i < len ? (dist >= len ? i : i % dist) : 0u];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) {
+    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+    if (i < len) o[i] = v[k];
+  }
 }
 
 // One wide turn.  Returns the lane the path was cut at: below 63 it stopped inside
@@ -368,6 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     uniformize(d);
 
     // ---- decode
+    int plain_run = 0;
     for (int turn = 0; turn < ROUND_TURNS;) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
         turn++;
@@ -401,10 +414,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if (!d.input_ready(TURN_WORDS)) break;
         ZD_PH_START();
-        bool stopped;
-        if (d.levels == 4) stopped = wide_turns<4>(d, L, dst, lane, turn);
-        else if (d.levels == 5) stopped = wide_turns<5>(d, L, dst, lane, turn);
-        else stopped = wide_turns<6>(d, L, dst, lane, turn);
+        bool stopped = true;
+        // (where the wide turns commit nothing -- runs of long matches: zeros, periods -- they are
+        // skipped for a few symbols after one that stopped at its very first symbol)
+        if (plain_run > 0) { plain_run--; turn++; }
+        else {
+          const uint32_t before = d.out_pos;
+          if (d.levels == 4) stopped = wide_turns<4>(d, L, dst, lane, turn);
+          else if (d.levels == 5) stopped = wide_turns<5>(d, L, dst, lane, turn);
+          else stopped = wide_turns<6>(d, L, dst, lane, turn);
+          if (stopped && d.out_pos == before) plain_run = 6;
+        }
         ZD_PH(ph_wide);
         if (stopped) {
           const int r = lane_one_symbol(d, L, A, writer);
@@ -412,7 +432,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const int ru = uni(r);
           ZD_PH(ph_plain);
           if (ru == SYM_EOB) lane_end_of_block(d, crc_adler);
-          else if (ru == SYM_STOP) break;
+          else if (ru == SYM_STOP) {
+            // a match that cannot be queued (long, or overlapping its own output) and nothing queued
+            // before it: the wave copies it here and now instead of going round through the services
+            if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
+              wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
+              lane_after_match(d);
+              continue;
+            }
+            break;
+          }
         }
       } else {
         break;
@@ -459,6 +488,61 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 #endif
     results[stream] = r;
   }
+}
+
+
+// ---------------------------------------------------------------------------------
+// A stream longer than MAX_STREAM_LEN (positions are 32-bit in the kernel above) whose
+// blocks are STORED ones of one length -- what the reference's encoder makes of incompressible
+// data, BASELINE's "8 GiB pre-compressed high-entropy stream": 131 073 blocks of 65 534 bytes
+// (read_uncompressed_block zd.ml:671-680, the loop zd.ml:692-709).  Walking 131 073 headers one
+// after the other is a chain of dependent loads; instead every block's header is looked for
+// where it has to be if all blocks before it have the first block's length (offset j * (5 + LEN))
+// and all candidates are checked at once: the chain holds as far as every candidate is a stored
+// header (BTYPE 00 on a byte boundary, LEN = ~NLEN) of that length.  The blocks of that prefix
+// are copied with 64-bit offsets, one workgroup each; whatever follows -- a shorter last block,
+// a block of another kind -- is an ordinary stream for the kernel above (api.hip).
+__global__ void stored_chain_probe_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                          StoredChain *__restrict__ st) {
+  const StreamDesc sd = descs[0];
+  const uint8_t *s = src_arena + sd.src_off;
+  StoredChain c;
+  c.len0 = 0; c.first_bad = 0; c.final_at = 0xFFFFFFFFu; c.candidates = 0;
+  if (sd.src_len >= 5 && (s[0] & 6u) == 0u) {
+    const uint32_t len = s[1] | ((uint32_t)s[2] << 8), nlen = s[3] | ((uint32_t)s[4] << 8);
+    if (len == ((~nlen) & 0xFFFFu) && len != 0u) {
+      c.len0 = len;
+      const uint64_t stride = 5ull + len;
+      const uint64_t j = sd.src_len / stride;
+      c.candidates = j > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)j;
+      c.first_bad = c.candidates;
+    }
+  }
+  *st = c;
+}
+__global__ __launch_bounds__(256) void stored_chain_scan_kernel(const uint8_t *__restrict__ src_arena,
+                                                               const StreamDesc *__restrict__ descs,
+                                                               StoredChain *__restrict__ st) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t len0 = st->len0;
+  if (j >= st->candidates) return;
+  const uint64_t stride = 5ull + len0;
+  const uint8_t *h = src_arena + descs[0].src_off + (uint64_t)j * stride;
+  const uint32_t len = h[1] | ((uint32_t)h[2] << 8), nlen = h[3] | ((uint32_t)h[4] << 8);
+  const bool ok = (h[0] & 6u) == 0u && len == len0 && len == ((~nlen) & 0xFFFFu);
+  if (!ok) atomicMin(&st->first_bad, j);
+  else if (h[0] & 1u) atomicMin(&st->final_at, j);
+}
+// block j of the chain: LEN bytes from src + j * (5 + LEN) + 5 to dst + j * LEN
+__global__ __launch_bounds__(256) void stored_chain_copy_kernel(const uint8_t *__restrict__ src_arena,
+                                                               uint8_t *__restrict__ dst_arena,
+                                                               const StreamDesc *__restrict__ descs, uint32_t len0) {
+  const StreamDesc sd = descs[0];
+  const uint8_t *s = src_arena + sd.src_off + (uint64_t)blockIdx.x * (5ull + len0) + 5u;
+  uint8_t *o = dst_arena + sd.dst_off + (uint64_t)blockIdx.x * len0;
+  const uint32_t body = len0 & ~15u;
+  for (uint32_t i = threadIdx.x * 16u; i < body; i += 256u * 16u) store16_unaligned(o + i, load16_unaligned(s + i));
+  if (threadIdx.x < (len0 & 15u)) o[body + threadIdx.x] = s[body + threadIdx.x];
 }
 
 }  // namespace zd

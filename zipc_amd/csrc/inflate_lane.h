@@ -92,6 +92,7 @@ ZD_HD uint32_t queue_pack(uint32_t dst_rel, uint32_t dist, uint32_t len) {  // d
 }
 constexpr int SPEC_WINDOW = 64;    // bit offsets decoded speculatively (= lanes of the wave)
 constexpr int SPEC_SYM_BITS = 48;  // longest symbol: 15 + 5 + 15 + 13 bits
+constexpr int SPAN_SYM_BITS_MAX = SPEC_SYM_BITS;
 constexpr int TURN_WORDS = 5;      // words a wide turn may touch: (31 + 63) / 32 + 3
 constexpr int HEADER_WORDS = 6;    // words a block header step may touch: (31 + 3 + 71) / 32 + 3
 
@@ -514,27 +515,42 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
   uint8_t *dst = A.dst + d.dst_off;
   if (!d.input_ready(3)) return SYM_STOP;
   BitCursor c = cursor_at(d, L);
-  int sym = read_symbol_walk(c, L, LDS_LIT_COUNTS, LDS_LIT_SYMS);
-  if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  if (sym < LITLEN_EOB) {
-    if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
-    if (writer) dst[d.out_pos] = (uint8_t)sym;
-    d.out_pos++;
-    d.advance((uint32_t)c.used);
-    return SYM_OK;
+  uint32_t length, dist;
+  // A match whose two codes the wide tables resolve (the entries hold only symbols of the block's
+  // alphabets, every check on them made when the tables were built) with the input not about to
+  // end: no walk.  Runs of long matches -- zeros, periods -- come through here one by one.
+  const uint32_t xlo = (uint32_t)c.x;
+  const uint32_t we = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  const uint32_t wb1 = (we >> 17) & 63u;
+  const uint32_t wx2 = (uint32_t)(c.x >> wb1);
+  const uint32_t we2 = L.wide_dist((int)(wx2 & ((1u << DIST_TBITS) - 1)));
+  if ((int32_t)we >= 0x20000000 && we2 != 0u && c.avail >= SPAN_SYM_BITS_MAX) {  // a length symbol's entry (a literal's has bit 31)
+    length = ((we >> 8) & 511u) + bit_field(xlo, we, (we >> 5) & 7u);
+    dist = ((we2 >> 9) & 0xFFFFu) + bit_field(wx2, we2, (we2 >> 5) & 15u);
+    c.used = (int)(wb1 + (we2 >> 25));
+  } else {
+    int sym = read_symbol_walk(c, L, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+    if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    if (sym < LITLEN_EOB) {
+      if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
+      if (writer) dst[d.out_pos] = (uint8_t)sym;
+      d.out_pos++;
+      d.advance((uint32_t)c.used);
+      return SYM_OK;
+    }
+    if (sym == LITLEN_EOB) { d.advance((uint32_t)c.used); return SYM_EOB; }
+    if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    uint32_t vbase, vextra, v = 0;
+    length_sym_value(sym, vbase, vextra);
+    if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    length = vbase + v;
+    int dsym = read_symbol_walk(c, L, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+    if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    dist_sym_value(dsym, vbase, vextra);
+    v = 0;
+    if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+    dist = vbase + v;
   }
-  if (sym == LITLEN_EOB) { d.advance((uint32_t)c.used); return SYM_EOB; }
-  if (sym > d.lit_max_sym || sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  uint32_t vbase, vextra, v = 0;
-  length_sym_value(sym, vbase, vextra);
-  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  const uint32_t length = vbase + v;
-  int dsym = read_symbol_walk(c, L, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-  if (dsym < 0 || dsym > d.dist_max_sym || dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  dist_sym_value(dsym, vbase, vextra);
-  v = 0;
-  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  const uint32_t dist = vbase + v;
   if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
   if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
   d.advance((uint32_t)c.used);

@@ -322,6 +322,12 @@ ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const La
     }
     span_reader_refill(R, E, W.run);
     if (!wv::any(W.run)) break;
+    // lane 0 walks the real sequence from the span's first bit: when already its first granule is too
+    // rich for a tile (runs of long matches: zeros, periods) the span will commit nothing: give up now
+    if (!STITCH && wv::any(E.lane == 0 && W.k == 0u && W.od >= SPAN_OD_BIG)) {
+      W.run = false;
+      break;
+    }
   }
 }
 
@@ -459,6 +465,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   span_reader_start(R, E, W.p);
   span_walk_loop<false>(W, R, E, L, idx, K, lit_max, dist_max);
   ZD_SPAN_PH(0);
+  if (wv::any(lane == 0 && W.kind == WK_NONE)) {  // gave up (see the walk loop): nothing committed,
+    d.ring_wr = d.in_word;                         // but the wide path's input ring was this walk's
+    return SPAN_OFF;
+  }
   const uint32_t m_p = W.rp, m_stops = W.stops;  // (every walk of a region ends at the region's end: WK_END)
   wv::fence_global();  // the index is in memory: entries written by one lane are read by others below
   // ... and on into the next lane's, until the two walks are one

@@ -14,6 +14,20 @@ __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      StreamResult *__restrict__ results, uint32_t n_streams,
                                      uint16_t *__restrict__ span_scratch, int crc_op);
 
+// a huge stream of equal stored blocks (inflate.hip, api.hip)
+struct StoredChain {
+  uint32_t len0;        // LEN of the first block (0: the stream does not start with a stored block)
+  uint32_t candidates;  // header positions j * (5 + len0) inside the input
+  uint32_t first_bad;   // first candidate that is not a stored header of that length
+  uint32_t final_at;    // first candidate with BFINAL set (0xFFFFFFFF: none)
+};
+__global__ void stored_chain_probe_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                          StoredChain *__restrict__ st);
+__global__ void stored_chain_scan_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                         StoredChain *__restrict__ st);
+__global__ void stored_chain_copy_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                         const StreamDesc *__restrict__ descs, uint32_t len0);
+
 // ---- checksum.hip
 constexpr uint32_t CRC_PIECE_BYTES = 128;  // bytes per thread of crc32_segments_kernel
 constexpr uint32_t CRC_SEG_BYTES = 32768;   // per workgroup (256 threads)
