@@ -73,7 +73,37 @@ static void scratch_caps(size_t n, size_t total_src_len, uint64_t &P, uint64_t &
   Bk = total_src_len / MIN_BLOCK_SRC + 2 * (uint64_t)n + 16;
 }
 
-size_t deflate_scratch_bytes(size_t n, size_t /*max_src_len*/, size_t total_src_len, int level) {
+// A batch of more than DEFLATE_GROUP_BYTES of source (8 GiB) goes through the pipeline in groups of
+// consecutive streams, each group of at most that much, one after the other through the same
+// scratch: 14 bytes of scratch per source byte of a GROUP (2-byte links, 8-byte match entries,
+// 4-byte symbols), 112 GiB at most however large the batch.  Smaller groups were measured on C4
+// (8192 x 1 MiB): 4 GiB groups deflate 9 % slower and 2 GiB groups 23 % slower than one group --
+// lz_parse and deflate_emit are one wave per stream, and 2048 streams leave 2 waves per SIMD where
+// 8192 leave 8 -- so the scratch is bounded, not halved.  ZIPC_HIP_DEFLATE_GROUP_BYTES overrides
+// the size (tests run with groups of a few streams).
+static size_t deflate_group_bytes() {
+  static const size_t v = [] {
+    const char *e = getenv("ZIPC_HIP_DEFLATE_GROUP_BYTES");
+    const long long x = e ? atoll(e) : 0;
+    return x > 0 ? (size_t)x : (size_t)8 << 30;
+  }();
+  return v;
+}
+// streams per group, and the source bytes a group can hold at most
+static void deflate_grouping(size_t n, size_t max_src_len, size_t total_src_len, size_t &per_group, size_t &group_total) {
+  per_group = n;
+  group_total = total_src_len;
+  if (total_src_len > deflate_group_bytes() && max_src_len > 0 && n > 1) {
+    per_group = deflate_group_bytes() / max_src_len;
+    per_group = per_group < 1 ? 1 : (per_group > n ? n : per_group);
+    const unsigned __int128 bound = (unsigned __int128)per_group * max_src_len;
+    group_total = bound < total_src_len ? (size_t)bound : total_src_len;
+  }
+}
+
+size_t deflate_scratch_bytes(size_t n_all, size_t max_src_len, size_t total_all, int level) {
+  size_t n, total_src_len;
+  deflate_grouping(n_all, max_src_len, total_all, n, total_src_len);
   uint64_t P, Bk;
   scratch_caps(n, total_src_len, P, Bk);
   size_t b = 0;
@@ -1359,6 +1389,10 @@ __global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__res
 }
 
 // ---------------------------------------------------------------------------------
+static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
+                                       const StreamDesc *d_descs, StreamResult *d_results, size_t n,
+                                       size_t max_src_len, size_t total_src_len, int level, int crc_op);
+
 hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
                           const StreamDesc *d_descs, StreamResult *d_results, size_t n,
                           size_t max_src_len, size_t total_src_len, int level, int crc_op) {
@@ -1367,6 +1401,20 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
               d_descs, d_results, crc_op);
     return hipGetLastError();
   }
+  size_t per_group, group_total;
+  deflate_grouping(n, max_src_len, total_src_len, per_group, group_total);
+  for (size_t g0 = 0; g0 < n; g0 += per_group) {  // the descriptors carry arena offsets: a group is a slice of them
+    const size_t ng = n - g0 < per_group ? n - g0 : per_group;
+    const hipError_t e = launch_deflate_group(ctx, d_src, d_dst, d_descs + g0, d_results + g0, ng, max_src_len,
+                                              group_total, level, crc_op);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
+                                       const StreamDesc *d_descs, StreamResult *d_results, size_t n,
+                                       size_t max_src_len, size_t total_src_len, int level, int crc_op) {
   DeflateScratch S = carve(ctx->deflate_scratch.p, n, total_src_len, level);
   int good_match, K;
   level_params(level, good_match, K);
@@ -1381,11 +1429,12 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   } else {
     const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
     if (n * tps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    // consecutive tiles of a stream per workgroup: as many as leave the grid >= 2048
-    // workgroups (8 per CU), so few long streams still spread over the chip
+    // consecutive tiles of a stream per workgroup: as many as leave the grid >= 8192
+    // workgroups (32 per CU: with 2048 a group of 2048 long streams had one workgroup per stream
+    // and a long tail), so few long streams still spread over the chip
     // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
     static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
-    size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 2048;
+    size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
     tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
     const size_t gps = (tps + tpg - 1) / tpg;
     ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
