@@ -62,8 +62,11 @@ enum {
   ZIPC_HIP_ERR_NOMEM = 20
 };
 
-/* crc_op (zipc_deflate.ml:210): which checksum is fused into inflate (over the
- * output) / deflate (over the input), updated once per deflate block. */
+/* crc_op (zipc_deflate.ml:210): which checksum the reference updates once per deflate block inside
+ * inflate (over the output) / deflate (over the input).  Here Adler-32 is computed inside the codec
+ * kernels block by block (its value depends on that chunking, see below); CRC-32, whose value does
+ * not, is a separate pass of the checksum kernels over the same bytes once the codec kernel is done
+ * (one more read of them; the result is the same word for word). */
 enum {
   ZIPC_HIP_CRC_NOP = 0,
   ZIPC_HIP_CRC_CRC32 = 1,
@@ -238,9 +241,9 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
                            size_t max_src_len, size_t total_src_len, int level,
                            int crc_op);
 
-/* CRC-32 and Adler-32 of one device buffer, both in ONE pass over the bytes
- * (Crc_32.string + Adler_32.string).  d_out receives {crc32, adler32}.
- * Either selector may be 0 to skip that checksum. */
+/* CRC-32 and Adler-32 of one device buffer (Crc_32.string + Adler_32.string): one pass over the
+ * bytes for each of the two, by their own kernels (2 x len bytes of traffic when both are asked
+ * for).  d_out receives {crc32, adler32}.  Either selector may be 0 to skip that checksum. */
 int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len,
                              int want_crc32, int want_adler32, uint32_t *d_out);
 
