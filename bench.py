@@ -416,6 +416,7 @@ def extra_legs(ctx, dev, n, L):
         gd, gi = device_round_trip(ctx, dev, src, m, ML, 2)
         out["c4_deflate_gib_s"] = gd
         out["c4_inflate_gib_s"] = gi
+        out["c4_leg_is"] = "%d members x 1 MiB of 3-bit symbols on this GPU, device-resident (bench.py --config c4 runs all 8192: fuller kernels, higher rates)" % m
     except Exception as e:
         out["c4_deflate_gib_s"] = {"error": repr(e)}
     return out

@@ -3,8 +3,8 @@
 # rocprofv3 --kernel-trace --stats summary of the same command, the FETCH_SIZE / WRITE_SIZE
 # PMC passes (separate runs), bench.py under torch.distributed.run with one process, the
 # other BASELINE configs and the PCIe-inclusive host forms.  Run on the GPU box:
-#   gpurun -- 'bash tools/measure_round.sh r1j'      -> gpurun_out/r1j/*
-# The PMC passes rewrite profiles/r01_hbm_traffic.json on the box BEFORE the final bench.py
+#   gpurun -- 'bash tools/measure_round.sh r02'      -> gpurun_out/r02/*  (TAG names the profiles/ files too)
+# The PMC passes write profiles/${TAG}_hbm_traffic.json on the box BEFORE the final bench.py
 # run, so that run's roofline.traffic comes from counters of the same build; the file is
 # also copied to the output directory.
 set -u
@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 B="$ROOT/bench.py"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmcF" -o p --output-format csv -- python3 "$B" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmcF.log" 2>&1 || echo "FETCH_SIZE pass failed"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmcW" -o p --output-format csv -- python3 "$B" --no-cpu-baseline --steps 3 --warmup 1 > "$OUT/pmcW.log" 2>&1 || echo "WRITE_SIZE pass failed"
-python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" --hbm-json "$ROOT/profiles/r01_hbm_traffic.json" && cp "$ROOT/profiles/r01_hbm_traffic.json" "$OUT/hbm_traffic.json"
+python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" --hbm-json "$ROOT/profiles/${TAG}_hbm_traffic.json" && cp "$ROOT/profiles/${TAG}_hbm_traffic.json" "$OUT/hbm_traffic.json"
 python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" > "$OUT/pmc_hbm.txt"
 python3 "$B" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python3 "$B" --no-cpu-baseline > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || echo "kernel-trace pass failed"
@@ -24,10 +24,14 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127
 cd "$ROOT"
 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"
 python3 tools/bench_host_forms.py > "$OUT/host_forms.json" 2> /dev/null
+python3 tools/bench_text.py > "$OUT/real_text.json" 2> /dev/null
+python3 tools/bench_single.py > "$OUT/single_stream.jsonl" 2> /dev/null
+python3 "$B" --config c4 --steps 3 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
+DEFLATE=1 bash tools/exp_sq_counters.sh > "$OUT/sq.log" 2>&1; cp gpurun_out/sq/sq_counters.json "$OUT/sq_counters.json"; cp gpurun_out/sq/summary.txt "$OUT/sq_counters.txt"
 echo "== bench"; python3 -c "
 import json,sys
 d=json.load(open('$OUT/bench.json'))
-print({k:d[k] for k in ('value','ms_per_step','deflate_gib_s','inflate_gib_s')}); print(d['roofline']); print(d['cpu_baseline']); print({k:round(v,3) for k,v in d['kernels_ms_per_step'].items()})"
+print({k:d[k] for k in ('value','ms_per_step','deflate_gib_s','inflate_gib_s')}); print(d['roofline']); print(d['cpu_baseline']); print({k:round(v,3) for k,v in d['kernels_ms_per_step'].items()}); print({k:d.get(k) for k in ('e2e_gib_s','text_gib_s','c4_deflate_gib_s','c4_inflate_gib_s')})"
 echo "== rocprofv3 kernel stats (same command)"; head -12 "$OUT/trace/"*kernel_stats.csv | cut -d, -f1-6
 echo "== torchrun"; cut -c1-200 "$OUT/torchrun.json"
 echo "== configs"; cut -c1-260 "$OUT/configs.jsonl"
