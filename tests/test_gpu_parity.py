@@ -474,3 +474,20 @@ def test_deflate_dst_too_small_is_reported(gpu_ctx):
     ol, ck = C.c_size_t(), C.c_uint32()
     st = _lib.lib().zipc_hip_deflate(gpu_ctx.handle, d, len(d), 2, 0, dst, 100, C.byref(ol), C.byref(ck))
     assert st == _lib.ERR_DST_TOO_SMALL
+
+
+def test_deflate_start_offset_is_the_requested_range(gpu_ctx, oracle):
+    """`?start ?len` on the encode side: the reference's Lz77.compress mixes absolute and relative
+    indices when start > 0 (zipc_deflate.ml:1206,1215,1220: it would encode [start, len) instead of
+    [start, start + len); no caller passes start > 0 to deflate) -- the boundary deliberately
+    compresses exactly the requested range, and this pins it."""
+    from zipc_amd import zipc_deflate as Z
+
+    data = util.text(40000, 5) + util.rand_bytes(30000, 6, 4)
+    for start, n in ((0, len(data)), (100, 5000), (39990, 20000), (69999, 1), (70000, 0), (12345, 57655)):
+        for level, lv in LEVELS.items():
+            want = oracle.deflate(data[start:start + n], level=lv)[1]
+            assert Z.deflate(data, level=level, start=start, len=n).get_ok() == want, (start, n, level)
+        adler, z = Z.zlib_compress(data, level="default", start=start, len=n).get_ok()
+        assert zlib.decompress(z) == data[start:start + n]  # (text and 4-bit bytes: the two Adler-32s agree)
+        assert adler == zlib.adler32(data[start:start + n])
