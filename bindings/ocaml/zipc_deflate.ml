@@ -36,6 +36,14 @@ let c_deflate =
 let ok = 0 and err_dst_too_small = 16
 let crc_nop = 0 and crc_crc32 = 1 and crc_adler32 = 2
 
+(* ONE context for the whole program: a zipc_hip context owns one HIP stream and staging buffers
+   that every call reuses, so it serves one thread at a time.  The reference module is re-entrant;
+   this shim is not domain-safe as written -- a multi-domain program keeps a context per domain
+   (OCaml 5: a Domain.DLS key holding this lazy value), as the C++ host layer and the Python
+   mirror of this repository do per thread.  (Also: ?start on the encode side selects exactly
+   [start, start + len) here; the reference's Lz77.compress does not when start > 0 -- see
+   INTEGRATION.md.  And Adler_32 is the reference's signed-remainder value unless
+   zipc_hip_set_adler_rfc1950 is called on the context.) *)
 let ctx = lazy begin
   let p = allocate ctx_t null in
   let st = c_create p 0 in
