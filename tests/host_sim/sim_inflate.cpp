@@ -190,6 +190,16 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
         if (!lane_header_step(d, L, src)) break;
         if (d.phase == PH_TABLES) lane_finish_tables(d, L);
+        if (d.phase == PH_SYMBOLS && !d.fixed_lazy) {
+          uint32_t shortest = 15;
+          for (int lane = 0; lane < 64; lane++) {
+            const uint32_t m = build_wide_tables(d, L, lane);
+            if (m < shortest) shortest = m;
+          }
+          d.levels = levels_for(shortest);
+        }
+      } else if (d.phase == PH_TABLES) {  // as inflate.hip: a fixed block beyond its table-free symbols
+        lane_finish_tables(d, L);
         if (d.phase == PH_SYMBOLS) {
           uint32_t shortest = 15;
           for (int lane = 0; lane < 64; lane++) {
@@ -198,6 +208,11 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
           }
           d.levels = levels_for(shortest);
         }
+      } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {
+        const int rr = lane_one_symbol_fixed(d, L, A, true);
+        if (rr == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); }
+        else if (rr == SYM_STOP) break;
+        if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
       } else if (d.phase == PH_SYMBOLS) {
         if (span && !d.span_off) {  // as inflate.hip
           if (d.q_count) break;

@@ -58,7 +58,7 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
   ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
-  ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off);
+  ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off); ZD_U(fixed_lazy);
 #undef ZD_U
 }
 
@@ -390,11 +390,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
         if (!uni((uint32_t)ok)) break;  // waits for input
         if (d.phase == PH_TABLES) wave_finish_tables(d, L, lane);
+        if (d.phase == PH_SYMBOLS && !d.fixed_lazy) {
+          const uint32_t shortest = build_wide_tables(d, L, lane);
+          d.levels = levels_for(wave_min(shortest));
+        }
+        ZD_PH(ph_hdr);
+      } else if (d.phase == PH_TABLES) {  // a fixed block that went on beyond its table-free symbols
+        ZD_PH_START();
+        wave_finish_tables(d, L, lane);
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
         }
         ZD_PH(ph_hdr);
+      } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {  // a fixed block's first symbols, straight from the code
+        turn++;
+        ZD_PH_START();
+        const int r = lane_one_symbol_fixed(d, L, A, writer);
+        uniformize(d);
+        const int ru = uni(r);
+        ZD_PH(ph_plain);
+        if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); }
+        else if (ru == SYM_STOP) {
+          if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
+            wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
+            lane_after_match(d);
+          } else break;
+        }
+        if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
       } else if (d.phase == PH_SYMBOLS) {
         if (!d.span_off) {  // the block's symbols by regions, all lanes busy (inflate_span.h)
           if (d.q_count) break;  // queued copies first: the span reads its match sources from memory

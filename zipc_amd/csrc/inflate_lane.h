@@ -166,6 +166,7 @@ struct InflateLane {
   uint32_t blk_in_word, blk_boff;  // where the current block's symbols start
   uint32_t prev_block_bits;        // bits of the previous compressed block's symbols (0: none yet): sizes the regions
   int32_t span_off;                // the rest of this block is left to the wide turns
+  int32_t fixed_lazy;              // > 0: a fixed block whose tables are not built yet; symbols left before they are
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
 
@@ -462,6 +463,9 @@ ZD_HD void lane_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t l
   }
 }
 
+ZD_HD void lane_begin_symbols(InflateLane &d);
+constexpr int FIXED_LAZY_SYMBOLS = 48;  // symbols of a fixed block decoded without tables
+
 // One block header (inflate_loop zd.ml:694-701) up to the point where symbols
 // can be decoded, or a stored block can be copied.  Returns false when the lane
 // must wait for input (nothing consumed).
@@ -496,8 +500,15 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
     return true;
   }
   case 1:
+    // A fixed block's first symbols are decoded from the code's arithmetic (lane_one_symbol_fixed):
+    // the reference's encoder ends every stream of a few KiB or less, and every 64 KiB stream whose
+    // last block holds a couple of bytes, with such a block, and 1152 table entries would be built
+    // for a handful of symbols.  A block that goes on gets its tables then (PH_TABLES).
     d.hdr_fixed = 1;
-    d.phase = PH_TABLES;
+    lane_begin_symbols(d);
+    d.lit_max_sym = LITLEN_SYM_MAX;  // 286 and 287 are unused (zd.ml:342)
+    d.dist_max_sym = DIST_SYM_MAX;   // 30 and 31 are unused (zd.ml:349)
+    d.fixed_lazy = FIXED_LAZY_SYMBOLS;
     return true;
   case 2:
     if (!setup_dynamic_begin(d, L)) { d.fail(ST_CORRUPTED); return true; }
@@ -508,6 +519,30 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
 }
 
 enum : int { SYM_OK = 0, SYM_EOB = 1, SYM_STOP = 2 };
+
+// A decoded match (its bits in c): the reference's checks, then Buf.recopy zd.ml:615 -- queued, or
+// handed to the wave
+ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const BitCursor &c, uint32_t length, uint32_t dist) {
+  if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
+  if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
+  d.advance((uint32_t)c.used);
+  // Buf.recopy zd.ml:615 -- queued, or handed to the wave
+  const uint32_t src_pos = d.out_pos - dist;
+  const bool hazard = src_pos + length > d.hole_min;
+  const uint32_t qbase = d.hole_min < d.out_pos ? d.hole_min : d.out_pos;  // hole_min once this one is queued
+  const bool in_reach = d.out_pos - qbase <= QUEUE_REL_MAX;
+  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+    d.hole_min = qbase;
+    if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
+    d.q_count++;
+    d.out_pos += length;
+    return SYM_OK;
+  }
+  d.req_dist = dist;
+  d.req_len = length;
+  d.phase = PH_REQ_MATCH;
+  return SYM_STOP;
+}
 
 // Exactly one symbol of read_block_symbols (zd.ml:593-616), decoded the plain
 // way.  SYM_STOP: failed, parked on a request, or waiting for input.
@@ -551,25 +586,55 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
     if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
     dist = vbase + v;
   }
-  if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
-  if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
-  d.advance((uint32_t)c.used);
-  // Buf.recopy zd.ml:615 -- queued, or handed to the wave
-  const uint32_t src_pos = d.out_pos - dist;
-  const bool hazard = src_pos + length > d.hole_min;
-  const uint32_t qbase = d.hole_min < d.out_pos ? d.hole_min : d.out_pos;  // hole_min once this one is queued
-  const bool in_reach = d.out_pos - qbase <= QUEUE_REL_MAX;
-  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
-    d.hole_min = qbase;
-    if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
-    d.q_count++;
-    d.out_pos += length;
+  return lane_match_commit(d, L, writer, c, length, dist);
+}
+
+// read_symbol on the FIXED codes (fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349) without
+// tables: 7-bit codes 0000000..0010111 are 256..279, 8-bit 00110000..10111111 are 0..143,
+// 11000000..11000111 are 280..287, 9-bit 110010000..111111111 are 144..255; codes come most
+// significant bit first.  -1: the input ends inside the code.
+ZD_HD int fixed_litlen_symbol(BitCursor &c) {
+  const uint32_t x = (uint32_t)(c.x >> c.used);
+  const int have = c.avail - c.used;
+  if (have < 7) return -1;
+  const uint32_t r7 = bitrev(x & 127u, 7);
+  if (r7 <= 23u) { c.used += 7; return (int)(256u + r7); }
+  if (have < 8) return -1;
+  const uint32_t r8 = bitrev(x & 255u, 8);
+  if (r8 >= 0x30u && r8 <= 0xBFu) { c.used += 8; return (int)(r8 - 0x30u); }
+  if (r8 >= 0xC0u && r8 <= 0xC7u) { c.used += 8; return (int)(280u + r8 - 0xC0u); }
+  if (have < 9) return -1;
+  c.used += 9;
+  return (int)(144u + bitrev(x & 511u, 9) - 0x190u);
+}
+// lane_one_symbol for a fixed block whose tables are not built
+ZD_HD int lane_one_symbol_fixed(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer) {
+  uint8_t *dst = A.dst + d.dst_off;
+  if (!d.input_ready(3)) return SYM_STOP;
+  BitCursor c = cursor_at(d, L);
+  const int sym = fixed_litlen_symbol(c);
+  if (sym < 0) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  if (sym < LITLEN_EOB) {
+    if (d.out_pos >= d.cap_min) { d.overflow((uint64_t)d.out_pos + 1); return SYM_STOP; }
+    if (writer) dst[d.out_pos] = (uint8_t)sym;
+    d.out_pos++;
+    d.advance((uint32_t)c.used);
     return SYM_OK;
   }
-  d.req_dist = dist;
-  d.req_len = length;
-  d.phase = PH_REQ_MATCH;
-  return SYM_STOP;
+  if (sym == LITLEN_EOB) { d.advance((uint32_t)c.used); return SYM_EOB; }
+  if (sym > LITLEN_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  uint32_t vbase, vextra, v = 0;
+  length_sym_value(sym, vbase, vextra);
+  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  const uint32_t length = vbase + v;
+  uint32_t five;
+  if (!c.take(5, five)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  const int dsym = (int)bitrev(five, 5);
+  if (dsym > DIST_SYM_MAX) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  dist_sym_value(dsym, vbase, vextra);
+  v = 0;
+  if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
+  return lane_match_commit(d, L, writer, c, length, vbase + v);
 }
 
 // One header action: false = must wait for input.
@@ -589,6 +654,7 @@ ZD_HD void lane_begin_symbols(InflateLane &d) {
   d.blk_in_word = d.in_word;
   d.blk_boff = d.boff;
   d.span_off = 0;
+  d.fixed_lazy = 0;
 }
 
 // Phase PH_TABLES, serial form (the kernel has a wave-parallel one with the same
@@ -783,6 +849,7 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.blk_in_word = d.blk_boff = 0;
   d.prev_block_bits = 0;
   d.span_off = 0;
+  d.fixed_lazy = 0;
   if (s.src_len > MAX_STREAM_LEN || s.dst_cap > MAX_STREAM_LEN) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;
     d.fail(ST_INVALID_ARG);
