@@ -47,6 +47,10 @@ namespace zd {
 
 constexpr uint32_t SPAN_G = 256;          // granule: bits of input per index entry
 constexpr uint32_t SPAN_K_MAX = 18;       // granules per lane and span at most (36 KiB of input per span)
+constexpr uint32_t SPAN_PROBE_K_MIN = 8;  // spans of regions this long are cut by symbols (see the probe)
+constexpr uint32_t SPAN_PROBE_BITS = 208;
+constexpr int SPAN_PROBE_STEPS = 32;
+constexpr int SPAN_PROBE_SMOOTH = 3;
 constexpr uint32_t SPAN_K_MIN = 4;        // ... and at least: two walks can only merge at a granule boundary
 constexpr uint32_t SPAN_MIN_LANES = 8;    // fewer regions than this: not worth a span
 constexpr uint32_t SPAN_TILE = 4096;      // output bytes assembled in LDS at a time
@@ -255,6 +259,7 @@ struct SpanWalk {
   uint32_t nb;        // the next 256-bit boundary
   uint32_t k;         // granule of the region the walk is in
   uint32_t region_e;  // index entry of the region's granule 0
+  uint32_t kr;        // granules in the region
   uint32_t pd, od;    // the current granule: where its first symbol starts, bytes so far
   uint32_t stops;     // own region: granules in which the walk met a stop (and skipped a bit)
   bool run;
@@ -271,12 +276,12 @@ ZD_WV void span_walk_end(SpanWalk &W, uint32_t kind, uint32_t k, uint32_t p) {
 // lane -- a granule boundary, a stop -- is a divergent branch the wave skips when no lane takes it.
 template <bool STITCH>
 ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
-                          uint32_t K, int lit_max_sym, int dist_max_sym) {
+                          int lit_max_sym, int dist_max_sym) {
   if (act && W.p >= W.nb) {  // into the next granule (a symbol is at most 48 bits: one boundary at a time)
     idx[W.region_e + W.k] = span_entry(W.pd, W.od);
     W.k++;
     const uint32_t npd = W.p - W.nb;
-    if (W.k == K) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, K, W.p);
+    if (W.k == W.kr) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, W.k, W.p);
     else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, W.p);
     else {
       W.pd = npd;
@@ -304,7 +309,7 @@ ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E
   span_advance(R, E, W.p);
 }
 template <bool STITCH>
-ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx, uint32_t K,
+ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
                           int lit_max_sym, int dist_max_sym) {
   for (;;) {
 #ifdef SPAN_TRACE
@@ -318,7 +323,7 @@ ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const La
       if (W.run && E.lane == 5) span_trace_steps[6]++;
       if (W.run && !STITCH) span_lane_steps[E.lane]++;
 #endif
-      span_walk_step<STITCH>(W.run && span_can_step(R), W, R, E, L, idx, K, lit_max_sym, dist_max_sym);
+      span_walk_step<STITCH>(W.run && span_can_step(R), W, R, E, L, idx, lit_max_sym, dist_max_sym);
     }
     span_reader_refill(R, E, W.run);
     if (!wv::any(W.run)) break;
@@ -449,21 +454,77 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   const uint32_t ulane = (uint32_t)lane;
   wv::fence_global();  // bytes the wide turns stored are read below as match sources
 
-  // ---- phase A: every lane its own region
+  // ---- the regions.  Symbols are not spread evenly over the bits (a stream's first kilobytes are
+  // literals, matches come with the history), and phase A lasts as long as its busiest lane: a short
+  // probe at 64 even places counts symbols per bit, and the regions are cut to equal symbols, not
+  // equal bits.  Any cut is a correct one; the probe only decides how well the lanes are loaded.
   SpanWalk W;
   SpanReader R;
   const bool in_span = ulane < n_lanes;
-  W.p = base + (in_span ? ulane : 0u) * S;
+  uint32_t g0 = ulane * K, kr = K;  // the lane's region: first granule, granules
+  if (K >= SPAN_PROBE_K_MIN) {
+    const uint32_t p0 = base + (in_span ? ulane : 0u) * S;
+    const uint32_t pe = p0 + SPAN_PROBE_BITS;  // (the words the reader starts with cover this: no refill)
+    uint32_t p = p0, rho = 0;
+    span_reader_start(R, E, p);
+#pragma unroll 1
+    for (int u = 0; u < SPAN_PROBE_STEPS; u++) {  // the same steps for every lane; what differs is the bits they take
+      const bool act = in_span && p < pe;
+      uint32_t xlo, xhi;
+      span_peek(R, p, xlo, xhi);
+      const SpanSym s = span_symbol<false>(act, xlo, xhi, L, lit_max, dist_max);
+      p += act ? (s.stop ? 1u : s.tot) : 0u;
+      rho += act ? 1u : 0u;
+      span_advance(R, E, p);
+    }
+    rho = in_span ? rho * 4096u / (p - p0) : 0u;  // symbols per 256 bits, in 16ths
+    // the density is a smooth thing, a probe's count a noisy one
+    for (int round = 0; round < SPAN_PROBE_SMOOTH; round++) {
+      const uint32_t a = wv::shfl(rho, ulane == 0u ? 0u : ulane - 1u);
+      const uint32_t b = wv::shfl(rho, ulane + 1u < n_lanes ? ulane + 1u : n_lanes - 1u);
+      rho = (a + 2u * rho + b) >> 2;
+    }
+    // no region more than about twice or less than half the even one
+    const uint32_t avg = wv::readlane(wv::scan_incl(rho), 63u) / n_lanes;
+    const uint32_t lo = (avg + 1u) >> 1, hi = avg * 2u;
+    rho = !in_span ? 0u : rho < lo ? lo : rho > hi ? hi : rho;
+    const uint32_t incl = wv::scan_incl(rho), before = incl - rho, total = wv::readlane(incl, 63u);
+    // my region starts where the symbols before it are ulane / n_lanes of all: in probe j's stretch
+    const uint32_t target = in_span ? ulane * total / n_lanes : total;
+    uint32_t j = 0;
+    for (uint32_t step = 32u; step != 0u; step >>= 1) {
+      const uint32_t cand = j + step, c = wv::shfl(before, cand);
+      if (cand < n_lanes && c <= target) j = cand;
+    }
+    const uint32_t bj = wv::shfl(before, j), rj = wv::shfl(rho, j);
+    const uint32_t x = in_span ? j * K + (target - bj) * K / rj : n_lanes * K;
+    const uint32_t xn = wv::shfl(x, ulane + 1u);
+    const uint32_t len = (ulane + 1u < n_lanes ? xn : n_lanes * K) - x;
+    if (!wv::any(in_span && (len < SPAN_K_MIN || len > 32u))) {  // (32: a region's stops are a mask)
+      g0 = x;
+      kr = len;
+    }
+  }
+#ifdef SPAN_TRACE
+  if (lane == 0) fprintf(stderr, "regions: ");
+  for (int i = 0; i < 64; i++) { const uint32_t v = wv::readlane(kr, (uint32_t)i); if (lane == 0) fprintf(stderr, "%u ", v); }
+  if (lane == 0) fprintf(stderr, "\n");
+#endif
+
+  ZD_SPAN_PH(4);
+  // ---- phase A: every lane its own region
+  W.p = base + (in_span ? g0 : 0u) * SPAN_G;
   W.nb = W.p + SPAN_G;
   W.k = 0;
-  W.region_e = ulane * K;
+  W.region_e = g0;
+  W.kr = kr;
   W.pd = 0;
   W.od = 0;
   W.stops = 0;
   W.run = in_span;
   W.kind = WK_NONE; W.rk = 0; W.rp = 0;
   span_reader_start(R, E, W.p);
-  span_walk_loop<false>(W, R, E, L, idx, K, lit_max, dist_max);
+  span_walk_loop<false>(W, R, E, L, idx, lit_max, dist_max);
   ZD_SPAN_PH(0);
   if (wv::any(lane == 0 && W.kind == WK_NONE)) {  // gave up (see the walk loop): nothing committed,
     d.ring_wr = d.in_word;                         // but the wide path's input ring was this walk's
@@ -474,11 +535,13 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   // ... and on into the next lane's, until the two walks are one
   {
     const bool stitch = ulane + 1u < n_lanes;
+    const uint32_t g0n = wv::shfl(g0, ulane + 1u), krn = wv::shfl(kr, ulane + 1u);
     W.kind = WK_NONE; W.rk = 0; W.rp = 0;
     W.run = false;
     if (stitch) {
-      W.region_e = (ulane + 1u) * K;
-      const uint32_t r0 = base + (ulane + 1u) * S;
+      W.region_e = g0n;
+      W.kr = krn;
+      const uint32_t r0 = base + g0n * SPAN_G;
       W.p = m_p;
       W.k = 0;
       W.pd = W.p - r0;
@@ -488,7 +551,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       else W.run = true;
     }
   }
-  span_walk_loop<true>(W, R, E, L, idx, K, lit_max, dist_max);
+  span_walk_loop<true>(W, R, E, L, idx, lit_max, dist_max);
   const uint32_t s_kind = W.kind, s_k = W.rk, s_p = W.rp;
   wv::fence_global();
   ZD_SPAN_PH(1);
@@ -510,14 +573,14 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       p_end = wv::readlane(m_p, n_lanes - 1u);
     } else if (wv::readlane(real ? 1u : 0u, f) != 0u) {  // its own walk met a real stop, in granule ks
       const uint32_t ks = (uint32_t)__builtin_ctz(wv::readlane(real_stops, f));
-      n_valid = f * K + ks;
+      n_valid = wv::readlane(g0, f) + ks;
       p_end = base + n_valid * SPAN_G + ((uint32_t)idx[n_valid] & 63u);
       end_stop = true;
     } else {  // the walk of the lane before went through the whole region, or met a real stop there
       const uint32_t kind = wv::readlane(s_kind, f - 1u), kk = wv::readlane(s_k, f - 1u);
       p_end = wv::readlane(s_p, f - 1u);
-      if (kind == WK_NOMERGE) n_valid = (f + 1u) * K;
-      else { n_valid = f * K + kk; end_stop = true; }  // WK_STOP
+      if (kind == WK_NOMERGE) n_valid = wv::readlane(g0, f) + wv::readlane(kr, f);
+      else { n_valid = wv::readlane(g0, f) + kk; end_stop = true; }  // WK_STOP
     }
   }
 #ifdef SPAN_TRACE
