@@ -271,43 +271,26 @@ ZD_WV uint16_t span_entry(uint32_t pd, uint32_t od) {
 ZD_WV void span_walk_end(SpanWalk &W, uint32_t kind, uint32_t k, uint32_t p) {
   W.kind = kind; W.rk = k; W.rp = p; W.run = false;
 }
-// One step of the walk, by every lane (act: this lane walks on).  STITCH: the region is the
-// next lane's.  Straight-line code with the lane's state selected at the end; what is rare for a
-// lane -- a granule boundary, a stop -- is a divergent branch the wave skips when no lane takes it.
-template <bool STITCH>
-ZD_WV void span_walk_step(bool act, SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
-                          int lit_max_sym, int dist_max_sym) {
-  if (act && W.p >= W.nb) {  // into the next granule (a symbol is at most 48 bits: one boundary at a time)
-    idx[W.region_e + W.k] = span_entry(W.pd, W.od);
-    W.k++;
-    const uint32_t npd = W.p - W.nb;
-    if (W.k == W.kr) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, W.k, W.p);
-    else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, W.p);
-    else {
-      W.pd = npd;
-      W.od = 0;
-      W.nb += SPAN_G;
-    }
-  }
-  act = act && W.run;
-  uint32_t xlo, xhi;
-  span_peek(R, W.p, xlo, xhi);
-  const SpanSym s = span_symbol<false>(act, xlo, xhi, L, lit_max_sym, dist_max_sym);
-  uint32_t tot = s.tot, outlen = s.outlen;
-  if (act && s.stop) {
-    if (STITCH) {  // this walk is the real sequence: the span ends in front of this granule
-      span_walk_end(W, WK_STOP, W.k, W.nb - SPAN_G + W.pd);
-      act = false;
-    } else {  // real or not is known later: note the granule, go on a bit further
-      W.stops |= 1u << W.k;
-      tot = 1;
-      outlen = 0;
-    }
-  }
-  W.p += act ? tot : 0u;
-  W.od += act ? outlen : 0u;
-  span_advance(R, E, W.p);
+// The lengths of one symbol (or literal pair), no branch: both lookups always, as in span_symbol
+// below.  slow: an entry was 0, the general form must look.
+ZD_WV void span_lengths(uint32_t xlo, uint32_t xhi, const LaneLds &L, uint32_t &tot, uint32_t &outlen, bool &slow) {
+  const uint32_t e = L.wide_lit((int)(xlo & ((1u << LIT_TBITS) - 1)));
+  const uint32_t b1 = (e >> 17) & 63u;
+  const bool is_lit = (int32_t)e < 0;
+  const uint32_t lv = ((e >> 8) & 511u) + bit_field(xlo, e, (e >> 5) & 7u);
+  const uint32_t x2 = funnel32(xhi, xlo, b1);
+  const uint32_t e2 = L.wide_dist((int)(x2 & ((1u << DIST_TBITS) - 1)));
+  tot = is_lit ? e & 15u : b1 + (e2 >> 25);
+  outlen = is_lit ? 1u + ((e >> 4) & 1u) : lv;
+  slow = e == 0u || (!is_lit && e2 == 0u);
 }
+// The walk, four steps at a time, by every lane.  Straight-line steps; what is rare for a lane (an
+// entry of 0: long codes, stops) is a divergent branch the wave skips when no lane takes it.  A
+// granule boundary is looked for once per four steps -- four symbols are at most 192 bits, so it
+// is one boundary at most -- from the positions the steps left behind: some lane crosses one in
+// nearly every step, and handling it there would be paid by all 64.  The up to three steps a walk
+// takes behind the end of its region, or behind the granule it merges in, change nothing that is
+// used: a stop met there is booked on the granule before, which ends the span a granule early.
 template <bool STITCH>
 ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
                           int lit_max_sym, int dist_max_sym) {
@@ -315,7 +298,8 @@ ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const La
 #ifdef SPAN_TRACE
     if (E.lane == 0) span_trace_steps[STITCH ? 1 : 0] += 4;
 #endif
-#pragma unroll 1
+    uint32_t pq[4], oq[4];  // position and the granule's bytes after each step
+#pragma unroll
     for (int u = 0; u < 4; u++) {
 #ifdef SPAN_TRACE
       if (W.run && !span_can_step(R)) span_trace_steps[4]++;
@@ -323,7 +307,44 @@ ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const La
       if (W.run && E.lane == 5) span_trace_steps[6]++;
       if (W.run && !STITCH) span_lane_steps[E.lane]++;
 #endif
-      span_walk_step<STITCH>(W.run && span_can_step(R), W, R, E, L, idx, lit_max_sym, dist_max_sym);
+      const bool ok = W.run && span_can_step(R);
+      uint32_t xlo, xhi, tot, outlen;
+      bool slow;
+      span_peek(R, W.p, xlo, xhi);
+      span_lengths(xlo, xhi, L, tot, outlen, slow);
+      if (ok && slow) {
+        const SpanSym s = span_symbol_slow(xlo, xhi, L, lit_max_sym, dist_max_sym);
+        tot = s.tot;
+        outlen = s.outlen;
+        if (s.stop) {
+          tot = 0;
+          outlen = 0;
+          if (STITCH) {  // this walk is the real sequence: the span ends in front of this granule
+            span_walk_end(W, WK_STOP, W.k, W.nb - SPAN_G + W.pd);
+          } else {  // real or not is known later: note the granule, go on a bit further
+            W.stops |= 1u << W.k;
+            tot = 1;
+          }
+        }
+      }
+      W.p += ok ? tot : 0u;
+      W.od += ok ? outlen : 0u;
+      span_advance(R, E, W.p);
+      pq[u] = W.p;
+      oq[u] = W.od;
+    }
+    if (W.run && W.p >= W.nb) {  // into the next granule, with the first of the four symbols that crossed
+      const uint32_t pc = pq[0] >= W.nb ? pq[0] : pq[1] >= W.nb ? pq[1] : pq[2] >= W.nb ? pq[2] : pq[3];
+      const uint32_t oc = pq[0] >= W.nb ? oq[0] : pq[1] >= W.nb ? oq[1] : pq[2] >= W.nb ? oq[2] : oq[3];
+      idx[W.region_e + W.k] = span_entry(W.pd, oc);  // (the symbol that crosses started in this granule)
+      W.k++;
+      const uint32_t npd = pc - W.nb;
+      if (W.k == W.kr) span_walk_end(W, STITCH ? WK_NOMERGE : WK_END, W.k, pc);
+      else if (STITCH && (idx[W.region_e + W.k] & 63u) == npd) span_walk_end(W, WK_MERGED, W.k, pc);
+      // (a walk that ended here stands, reader and all, in the granule behind: where its stitch goes on)
+      W.pd = npd;
+      W.od -= oc;
+      W.nb += SPAN_G;
     }
     span_reader_refill(R, E, W.run);
     if (!wv::any(W.run)) break;
@@ -541,13 +562,8 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     if (stitch) {
       W.region_e = g0n;
       W.kr = krn;
-      const uint32_t r0 = base + g0n * SPAN_G;
-      W.p = m_p;
-      W.k = 0;
-      W.pd = W.p - r0;
-      W.od = 0;
-      W.nb = r0 + SPAN_G;
-      if ((idx[W.region_e] & 63u) == W.pd) span_walk_end(W, WK_MERGED, 0, W.p);
+      W.k = 0;  // (position, reader, pd, od, nb: as the walk of the own region left them, in this granule)
+      if ((idx[W.region_e] & 63u) == W.pd) span_walk_end(W, WK_MERGED, 0, m_p);
       else W.run = true;
     }
   }
