@@ -396,6 +396,18 @@ ZD_WV void span_bits_mark(uint32_t *mbits, uint32_t q, uint32_t len) {
     off = 0;
   }
 }
+// set the bits of [q, q + len), 3 <= len: the decode loop's form, two words without a loop for
+// what is shorter than 32
+ZD_WV void span_bits_set(uint32_t *mbits, uint32_t q, uint32_t len) {
+  if (len >= 32u) {
+    span_bits_mark<true>(mbits, q, len);
+    return;
+  }
+  const uint32_t off = q & 31u, over = off + len;
+  uint32_t *w = mbits + (q >> 5);
+  wv::lds_or(w, ((1u << len) - 1u) << off);
+  if (over > 32u) wv::lds_or(w + 1, (1u << (over - 32u)) - 1u);
+}
 // is any bit of [a, b) set?  a < b
 ZD_WV bool span_bits_any(const uint32_t *mbits, uint32_t a, uint32_t b) {
   uint32_t w = a >> 5;
@@ -472,6 +484,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   uint32_t *mbits = (uint32_t *)(L.x + SPAN_BITS_OFF);
   const int lit_max = (int)wv::uni((uint32_t)d.lit_max_sym), dist_max = (int)wv::uni((uint32_t)d.dist_max_sym);
   const uint32_t cap_min = wv::uni(d.cap_min), out_pos0 = wv::uni(d.out_pos), hard_cap = wv::uni(d.hard_cap);
+  if (hard_cap < 8u) return SPAN_NONE;  // (phase B reads the output's first 8 bytes when it has nothing better to read)
   const uint32_t ulane = (uint32_t)lane;
   wv::fence_global();  // bytes the wide turns stored are read below as match sources
 
@@ -635,7 +648,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     span_reader_start(R, E, p);
     wv::sync();
     ZD_SPAN_PH(2);
-    bool err = false;
+    uint32_t err = 0;
     const uint8_t *gbase = dst + out_pos;  // the tile's place in the output; gbase[-n] is final for every n >= 1
     // A match of 4 to 8 bytes whose source lies wholly before the tile (on the configs' data: most)
     // is requested from memory the moment it is decoded and lands SPAN_FLY steps later, when the
@@ -644,43 +657,47 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     uint32_t f_meta[SPAN_FLY], f_a[SPAN_FLY], f_b[SPAN_FLY];
 #pragma unroll
     for (int u = 0; u < SPAN_FLY; u++) { f_meta[u] = 0; f_a[u] = 0; f_b[u] = 0; }
-    // (Every step issues its two loads, lanes without such a match from a fixed valid address, and
-    // the loop is left only between groups of SPAN_FLY steps: with a branch around a load the
-    // compiler must assume at the landing that nothing was requested since, and wait for all.)
+    // (Every step issues its two loads, lanes without such a match from the output's first bytes,
+    // and the loop is left only between groups of SPAN_FLY steps: with a branch around a load the
+    // compiler must assume at the landing that nothing was requested since, and wait for all.
+    // A lane's state is numbers, not flags: it decodes while p < stop_p, and stop_p is 0 for a
+    // lane that has no granule in the tile or met something it must not commit.)
+    uint32_t stop_p = mine ? pe : 0u;
     for (;;) {
-      if (!wv::any(mine && !err && p < pe)) break;
+      if (!wv::any(p < stop_p)) break;
 #pragma unroll
       for (int u = 0; u < SPAN_FLY; u++) {
         span_land(tile, f_meta[u], f_a[u], f_b[u]);
-        const bool act = mine && !err && p < pe;
+        const bool act = p < stop_p;
 #ifdef SPAN_TRACE
         if (lane == 0) span_trace_steps[2]++;
 #endif
         uint32_t xlo, xhi;
         span_peek(R, p, xlo, xhi);
         const SpanSym s = span_symbol<true>(act, xlo, xhi, L, lit_max, dist_max);
+        const uint32_t o2 = o + s.outlen;
         // what the plain decoder must see for itself: a stop, more bytes than phase A counted, a
         // distance that reaches before the output (zd.ml:614)
-        const bool bad = act && (s.stop || o + s.outlen > o_end || (!s.is_lit && s.val > out_pos + o));
+        const bool bad = act && (s.stop || o2 > o_end || (!s.is_lit && s.val > out_pos + o));
         const bool good = act && !bad;
-        err = err || bad;
+        stop_p = bad ? 0u : stop_p;
+        err = bad ? 1u : err;
         const bool is_match = good && !s.is_lit;
-        const bool fly = is_match && s.outlen - 4u <= 4u && s.val >= o + s.outlen;
+        const bool fly = is_match && s.outlen - 4u <= 4u && s.val >= o2;
         if (good && s.is_lit) {
           tile[o] = (uint8_t)s.val;
           if (s.outlen == 2u) tile[o + 1u] = (uint8_t)s.val2;
         }
-        const uint8_t *sp = fly ? gbase + (int)o - (int)s.val : E.src;
-        f_a[u] = load_u32_le(sp);
-        f_b[u] = load_u32_le(sp + (fly ? s.outlen - 4u : 0u));
+        const uint32_t goff = fly ? out_pos + o - s.val : 0u;  // (the output has 8 bytes: checked above)
+        f_a[u] = load_u32_le(dst + goff);
+        f_b[u] = load_u32_le(dst + (goff + (fly ? s.outlen - 4u : 0u)));
         f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
         if (is_match && !fly) {
-          tile[o] = (uint8_t)(s.val - 1u);
-          tile[o + 1u] = (uint8_t)((s.val - 1u) >> 8);
+          store_u16_le(tile + o, (uint16_t)(s.val - 1u));
           tile[o + 2u] = (uint8_t)(s.outlen - 3u);
-          span_bits_mark<true>(mbits, o, s.outlen);
+          span_bits_set(mbits, o, s.outlen);
         }
-        o += good ? s.outlen : 0u;
+        o = good ? o2 : o;
         p += good ? s.tot : 0u;
         span_advance(R, E, p);
       }
@@ -690,12 +707,12 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // both phases must have walked the same symbols
     {
       const uint32_t next_start = wv::shfl(p0, ulane + 1u);
-      if (mine && !err) {
-        if (o != o_end) err = true;
-        if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = true;
+      if (mine && err == 0u) {
+        if (o != o_end) err = 1;
+        if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = 1;
       }
     }
-    if (wv::any(err)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
+    if (wv::any(err != 0u)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
       p_end = tile_start_p;
       cut = true;
       break;

@@ -123,6 +123,10 @@ ZD_HD uint32_t load_u32_le(const uint8_t *p) {
   typedef uint32_t __attribute__((aligned(1), may_alias)) u32u;
   return *(const u32u *)p;
 }
+ZD_HD void store_u16_le(uint8_t *p, uint16_t v) {
+  typedef uint16_t __attribute__((aligned(1), may_alias)) u16u;
+  *(u16u *)p = v;
+}
 ZD_HD uint64_t load_u64_le(const uint8_t *p) {
   typedef uint64_t __attribute__((aligned(1), may_alias)) u64u;
   return *(const u64u *)p;
