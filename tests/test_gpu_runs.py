@@ -1,0 +1,88 @@
+"""Runs of one match -- zeros, a short word repeated: 258 bytes per symbol -- which inflate_batch copies
+as one periodic copy (match_run / wave_copy_match in inflate.hip) instead of a symbol at a time.
+Bytes, accept/reject and checksums against the oracle, with the size limit falling inside, at the
+end of, and just behind a run (Buf's "Expected decompression size exceeded", zd.ml:27-29), periods on
+both sides of the run code's own threshold, and streams zlib wrote (other encoders, other codes)."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _period(word: bytes, n: int) -> bytes:
+    return (word * (n // len(word) + 1))[:n]
+
+
+def _inputs():
+    rng = random.Random(11)
+    out = {"zeros_1m": bytes(1 << 20), "zeros_70000": bytes(70000), "ff_5000": b"\xff" * 5000}
+    for p in (1, 2, 3, 5, 15, 16, 17, 31, 63, 64, 65, 100, 257, 258, 259):
+        out["period_%d" % p] = _period(bytes(rng.randrange(256) for _ in range(p)), 40000 + p)
+    # runs between other things: literals, far matches, a second period
+    mix = bytearray()
+    for i in range(40):
+        mix += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+        mix += _period(bytes(rng.randrange(256) for _ in range(rng.randrange(1, 9))), rng.randrange(300, 9000))
+        if i % 7 == 3:
+            mix += mix[len(mix) // 3:len(mix) // 3 + 500]
+    out["mixed"] = bytes(mix)
+    return out
+
+
+def _streams(oracle):
+    for name, data in _inputs().items():
+        for level in (1, 2, 3):
+            st, comp, _ = oracle.deflate(data, level=level, crc_op=0)
+            assert st == 0
+            yield "%s/L%d" % (name, level), data, comp
+        for zl in (1, 6, 9):
+            co = zlib.compressobj(zl, zlib.DEFLATED, -15)
+            yield "%s/zlib%d" % (name, zl), data, co.compress(data) + co.flush()
+
+
+def test_runs_inflate_to_the_same_bytes(gpu_ctx, oracle):
+    import torch
+
+    from zipc_amd import batch
+
+    cases = list(_streams(oracle))
+    srcs = [c for _, _, c in cases]
+    caps = [len(d) for _, d, _ in cases]
+    for crc_op in (1, 2):
+        got = util.gpu_inflate_batch(gpu_ctx, srcs, caps, [True] * len(cases), caps, crc_op)
+        for i, (name, data, comp) in enumerate(cases):
+            st0, d0, c0 = oracle.inflate(comp, decompressed_size=len(data), crc_op=crc_op)
+            assert st0 == 0 and d0 == data, name
+            assert got[i] == (0, data, c0), (name, crc_op, got[i][0])
+
+
+def test_the_size_limit_inside_a_run(gpu_ctx, oracle):
+    cases = [(n, d, c) for n, d, c in _streams(oracle) if n.split("/")[0] in ("zeros_70000", "period_3", "period_63", "mixed")
+             and n.split("/")[1] in ("L2", "zlib6")]
+    srcs, caps, lims, names = [], [], [], []
+    for name, data, comp in cases:
+        n = len(data)
+        for lim in (n, n - 1, n + 1, n - 257, n - 258, n - 259, n // 2, 600, 259, 258, 257, 3, 1, 0):
+            srcs.append(comp); lims.append(lim); caps.append(n + 64); names.append("%s limit %d" % (name, lim))
+    got = util.gpu_inflate_batch(gpu_ctx, srcs, caps, [True] * len(srcs), lims, 2)
+    for i, name in enumerate(names):
+        st0, d0, c0 = oracle.inflate(srcs[i], decompressed_size=lims[i], crc_op=2)
+        assert got[i][0] == st0, (name, got[i][0], st0)
+        if st0 == 0:
+            assert got[i][1] == d0 and got[i][2] == c0, name
+
+
+def test_a_small_destination_under_a_run(gpu_ctx, oracle):
+    # no limit given: the caller's dst_cap is the boundary's DST_TOO_SMALL, wherever in a run it falls
+    data = bytes(20000)
+    st, comp, _ = oracle.deflate(data, level=2, crc_op=0)
+    caps = [20000, 19999, 19743, 19742, 258, 257, 8, 7, 1]
+    got = util.gpu_inflate_batch(gpu_ctx, [comp] * len(caps), caps, [False] * len(caps), [0] * len(caps), 1)
+    assert got[0][0] == 0 and got[0][1] == data
+    for g in got[1:]:
+        assert g[0] != 0

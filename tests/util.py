@@ -307,3 +307,32 @@ def header_fuzz_streams(seed, n_random, n_flips):
         except (KeyError, IndexError, ValueError):
             pass  # a perturbed table the writer itself cannot encode with
     return out
+
+
+def gpu_inflate_batch(ctx, streams, caps, has_limit, limits, crc_op):
+    """One inflate_batch launch over `streams` through the C ABI: [(status, bytes, checksum)].
+    limits[i] is the ?decompressed_size of stream i where has_limit[i]; caps[i] its dst_cap."""
+    import numpy as np
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    n = len(streams)
+    src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+    slots = [(c + 255) // 256 * 256 + 256 for c in caps]
+    dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+    lim = [limits[i] if has_limit[i] else None for i in range(n)]
+    if all(l is None for l in lim):
+        descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+    else:
+        assert all(l is not None for l in lim), "mixed limit / no limit: two launches"
+        descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps, limit=lim)
+    src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+    dst = torch.full((int(sum(slots)) + 256,), 0xA5, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    batch.inflate_batch(ctx, src, dst, batch.to_device(descs, dev), d_res, n, max(caps), crc_op)
+    res = batch.results_from_device(d_res)
+    out = dst.cpu().numpy()
+    return [(int(res["status"][i]), out[int(dst_off[i]):int(dst_off[i]) + int(res["out_len"][i])].tobytes(),
+             int(res["checksum"][i])) for i in range(n)]

@@ -188,23 +188,86 @@ __device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds
 // on another new one and all of them move at once.  (Copied by the writer lane alone, a
 // byte at a time through memory when dist < 8, a 258-byte match took 28 us: a 1 MiB run
 // of one byte inflated in 114 ms.)
-__device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t len, int lane) {
+// `pattern`: 80 bytes of LDS nobody uses while symbols are decoded one by one (the span's tile).
+constexpr uint32_t MATCH_RUN_DIST = 64;  // periods below this: runs of the same match are one copy (match_run)
+__device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t len, int lane,
+                                                uint8_t *pattern) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the source bytes were stored by other lanes of this wave
   uint8_t *o = dst + pos;
   const uint8_t *s = o - dist;
+  const uint32_t l = (uint32_t)lane;
+  if (dist < MATCH_RUN_DIST && dist < len) {
+    // a short period, any length (match_run: up to 65 matches of 258): the period laid out once,
+    // 80 bytes of it, then every lane stores 16-byte pieces of it, each from where its piece
+    // starts in the period
+    pattern[l] = s[l % dist];
+    if (l < 16u) pattern[64u + l] = s[(64u + l) % dist];
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t step = 1024u % dist;
+    uint32_t off = (16u * l) % dist;
+    for (uint32_t i = 16u * l; i < len; i += 1024u) {
+      wv::Quad q;
+      q.x = load_u32_le(pattern + off);
+      q.y = load_u32_le(pattern + off + 4u);
+      q.z = load_u32_le(pattern + off + 8u);
+      q.w = load_u32_le(pattern + off + 12u);
+      if (i + 16u <= len) wv::store_quad(o + i, q);
+      else
+        for (uint32_t j = 0; i + j < len; j++) o[i + j] = pattern[off + j];
+      off += step;
+      if (off >= dist) off -= dist;
+    }
+    __builtin_amdgcn_wave_barrier();  // (the next pattern is not written before this one is read)
+    return;
+  }
   // every source byte lies before the match: all of a lane's loads first (one memory latency for
   // the match, not one per 64 bytes: written as load-store pairs the compiler keeps them in order)
   uint8_t v[5];  // 258 bytes at most: 5 per lane
+  if (dist >= len) {
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
-    v[k] = s[i < len ? (dist >= len ? i : i % dist) : 0u];
+    for (int k = 0; k < 5; k++) {
+      const uint32_t i = l + 64u * (uint32_t)k;
+      v[k] = s[i < len ? i : 0u];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const uint32_t i = l + 64u * (uint32_t)k;
+      v[k] = s[i < len ? i % dist : 0u];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 5; k++) {
-    const uint32_t i = (uint32_t)lane + 64u * (uint32_t)k;
+    const uint32_t i = l + 64u * (uint32_t)k;
     if (i < len) o[i] = v[k];
   }
+}
+
+// The match lane_one_symbol has just handed to the wave (d.req_len bytes from d.req_dist back, its
+// symbol was `bits` long): how often is the next symbol the same match again?  Lane k decodes what
+// starts k symbols of that length from here; as far as they all are that match, the copies are one
+// periodic copy (zeros, a repeated short word: 258 bytes per symbol, a symbol at a time they cost
+// a turn and a memory round trip each).  Moves the position over them and returns the bytes of
+// the whole run; nothing that needs a check of its own is passed over: the symbols are matches
+// of a distance already accepted, inside the input, their bytes within the output's limit.
+__device__ __forceinline__ uint32_t match_run(InflateLane &d, const LaneLds &L, int lane, uint32_t bits) {
+  const uint32_t k = (uint32_t)lane;
+  const uint32_t p = d.boff + k * bits;
+  const uint32_t wi = p >> 5;
+  const bool staged = wi + 3u <= d.ring_wr - d.in_word;   // the three words a decode reads are in the ring
+  const bool inside = (k + 1u) * bits <= d.bits_left();   // ... and the symbol is real input
+  const uint32_t w = d.in_word + (staged ? wi : 0u);
+  const uint32_t w0 = L.slot((int)(w & (RING_WORDS - 1))), w1 = L.slot((int)((w + 1u) & (RING_WORDS - 1))),
+                 w2 = L.slot((int)((w + 2u) & (RING_WORDS - 1)));
+  const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), L);
+  const bool same = staged && inside && (int32_t)sp.e >= 0x20000000 && sp.length == d.req_len && sp.dist == d.req_dist &&
+                    sp.b1 + sp.t2 == bits;
+  const unsigned long long m = wave_mask(same);
+  uint32_t reps = ~m == 0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+  const uint32_t room = (d.cap_min - d.out_pos) / d.req_len;  // (the first one fits: lane_match_commit)
+  if (reps + 1u > room) reps = room - 1u;
+  d.advance(reps * bits);
+  return d.req_len * (1u + reps);
 }
 
 // One wide turn.  Returns the lane the path was cut at: below 63 it stopped inside
@@ -413,7 +476,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); }
         else if (ru == SYM_STOP) {
           if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
-            wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
+            wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
             lane_after_match(d);
           } else break;
         }
@@ -450,6 +513,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         ZD_PH(ph_wide);
         if (stopped) {
+          const uint32_t pos_before = d.in_word * 32u + d.boff;
           const int r = lane_one_symbol(d, L, A, writer);
           uniformize(d);
           const int ru = uni(r);
@@ -459,7 +523,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // a match that cannot be queued (long, or overlapping its own output) and nothing queued
             // before it: the wave copies it here and now instead of going round through the services
             if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
-              wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
+              if (d.req_dist < MATCH_RUN_DIST) d.req_len = match_run(d, L, lane, d.in_word * 32u + d.boff - pos_before);
+              wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
               lane_after_match(d);
               continue;
             }
@@ -481,7 +546,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       d.hole_min = 0xFFFFFFFFu;
     }
     if (d.phase == PH_REQ_MATCH) {
-      wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane);
+      wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
       lane_after_match(d);
     } else if (d.phase == PH_REQ_COPY) {
       wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
