@@ -12,6 +12,9 @@ n = int(os.environ.get("N_STREAMS", "16384")); L = int(os.environ.get("LEN", "65
 dev = torch.device("cuda", 0); ctx = zipc_amd.Context(0)
 if os.environ.get("ZEROS"):
     src = torch.zeros(n * L, dtype=torch.uint8, device=dev)
+elif os.environ.get("DOC"):  # tools/bench_single.py's text: this repo's SURVEY.md over and over
+    doc = open(os.path.join(ROOT, "SURVEY.md"), "rb").read()
+    src = torch.from_numpy(np.frombuffer((doc * (n * L // len(doc) + 1))[:n * L], np.uint8).copy()).to(dev)
 elif os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
     import zipfile
     z = zipfile.ZipFile(os.path.join(ROOT, "tests/golden/zip-docs.zip"))

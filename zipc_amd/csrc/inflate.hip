@@ -32,7 +32,7 @@
 //
 // The stream state is wave-uniform; it is pinned to scalar registers with
 // readfirstlane so that the control flow around the turns is scalar branches,
-// not exec-mask arithmetic.  LDS: 9944 B per stream (inflate_lane.h has the map): 16 streams per CU.
+// not exec-mask arithmetic.  LDS: 10072 B per stream (inflate_lane.h has the map): 16 streams per CU.
 #include "inflate_lane.h"
 #include "inflate_span.h"
 #include "kernels.h"

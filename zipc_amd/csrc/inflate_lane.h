@@ -45,7 +45,7 @@ namespace zd {
 constexpr int LIT_TBITS = 9;   // primary litlen lookup bits
 constexpr int DIST_TBITS = 7;  // primary dist lookup bits (also holds the <=7-bit codelen code)
 
-// Per-stream LDS image (9944 bytes: 16 streams per CU).  Byte offsets from the block's start:
+// Per-stream LDS image (10072 bytes: 16 streams per CU).  Byte offsets from the block's start:
 //      0  the span decoder's input ring, 8 words x 64 lanes (inflate_span.h); between spans its
 //         first 560 bytes are the wide turn's input ring (64 + 4 words) and deferred-copy queue
 //   2048  wide litlen table, 512 x u32 (wide_lit_entry)
@@ -56,6 +56,8 @@ constexpr int DIST_TBITS = 7;  // primary dist lookup bits (also holds the <=7-b
 //   8720  symbols sorted by code and counts per length of both codes (u16): what the canonical walk
 //         (read_symbol_walk) needs
 //   9424  the tile's bitmap, 130 words
+//   9944  limits and bases per code length of both codes, 64 x u16: the canonical decode without a
+//         walk (canon_symbol) for the span decoder's long codes
 // The u16 regions are addressed as LaneLds::w[off + i] with w = block + 7440:
 constexpr int LDS_LIT_TBL = 0;                          // 512 x u16: (sym << 4) | len   (transient, in the tile)
 constexpr int LDS_DIST_TBL = LDS_LIT_TBL + 512;         // 128 x u16                     (transient, in the tile)
@@ -81,7 +83,9 @@ constexpr int LDS_SPAN_TILE_BYTE = (LDS_WIDE_DIST + 128) * 4;          // 4608
 constexpr int LDS_SPAN_TILE_BYTES = 4096 + 16;
 constexpr int LDS_W_BYTE = LDS_SPAN_TILE_BYTE + LDS_SPAN_TILE_BYTES - (LDS_LIT_SYMS * 2);  // 7440
 constexpr int LDS_SPAN_BITS_BYTE = LDS_W_BYTE + LDS_U16_PER_LANE * 2;  // 9424
-constexpr int LDS_BYTES_PER_LANE = LDS_SPAN_BITS_BYTE + (4096 / 32 + 2) * 4;  // 9944
+constexpr int LDS_CANON_BYTE = LDS_SPAN_BITS_BYTE + (4096 / 32 + 2) * 4;  // 9944: u16[64], see canon_symbol
+constexpr int CANON_LIT = 0, CANON_DIST = 32;  // each: 16 limits, 16 bases
+constexpr int LDS_BYTES_PER_LANE = LDS_CANON_BYTE + 64 * 2;  // 10072
 static_assert(LDS_SPAN_TILE_BYTE % 16 == 0 && LDS_W_BYTE % 2 == 0 && LDS_SPAN_BITS_BYTE % 4 == 0, "alignment");
 constexpr uint32_t DEFER_MAX_LEN = 16;
 // A queued copy is one word: its destination relative to the first queued copy's
@@ -110,6 +114,7 @@ struct LaneLds {
   ZD_HD uint32_t &queue(int k) const { return r[LDS_QUEUE + k]; }
   ZD_HD uint32_t &wide_lit(int i) const { return r[LDS_WIDE_LIT + i]; }
   ZD_HD uint32_t &wide_dist(int i) const { return r[LDS_WIDE_DIST + i]; }
+  ZD_HD uint16_t &canon(int i) const { return ((uint16_t *)(x + LDS_CANON_BYTE))[i]; }
   // stage input word `word` (and its mirror)
   ZD_HD void ring_put(uint32_t word, uint32_t v) const {
     const int s = (int)(word & (uint32_t)(RING_WORDS - 1));
@@ -350,6 +355,40 @@ ZD_HD int read_symbol_walk(BitCursor &c, const LaneLds &L, int counts_off, int s
     offs -= count;
   }
   return -1;
+}
+
+// read_symbol without the walk, for input that does not end within the code (x: the next 15 bits
+// at least).  A canonical code read first bit first is a number that grows with the code's length:
+// limit[l] = the first 15-bit number no code of length <= l starts with (build_canon, from the
+// decoder's counts), so the length is found by bisection and the symbol by its rank among the
+// codes of that length.  -1: no code (the reference's "Corrupted data stream").
+ZD_HD int canon_symbol(uint32_t x, const LaneLds &L, int canon_off, int syms_off, uint32_t &len) {
+  const uint32_t c = bitrev(x & 0x7FFFu, 15);
+  uint32_t lo = 1, hi = 16;
+#pragma unroll
+  for (int step = 0; step < 4; step++) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (c < (uint32_t)L.canon(canon_off + (int)mid)) hi = mid;
+    else lo = mid + 1u;
+  }
+  len = lo;
+  if (lo > 15u) return -1;
+  const uint32_t rank = (c - (uint32_t)L.canon(canon_off + (int)lo - 1)) >> (15u - lo);
+  return L.u16(syms_off, (int)((uint32_t)L.canon(canon_off + 16 + (int)lo) + rank));
+}
+// lanes 0..15 (litlen) and 16..31 (distance): limit and base of one length each
+ZD_HD void build_canon(const LaneLds &L, int lane) {
+  if (lane >= 32) return;
+  const int j = lane & 15, counts_off = lane < 16 ? LDS_LIT_COUNTS : LDS_DIST_COUNTS, to = lane < 16 ? CANON_LIT : CANON_DIST;
+  uint32_t lim = 0, base = 0;
+#pragma unroll 1
+  for (int i = 1; i <= j; i++) {
+    const uint32_t n = L.u16(counts_off, i);
+    lim += n << (15 - i);
+    if (i < j) base += n;
+  }
+  L.canon(to + j) = (uint16_t)(lim < 32768u ? lim : 32768u);
+  L.canon(to + 16 + j) = (uint16_t)base;
 }
 
 // fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349
@@ -748,6 +787,7 @@ ZD_HD uint32_t build_wide_tables(const InflateLane &d, const LaneLds &L, int lan
   }
 #pragma unroll 1
   for (int i = lane; i < (1 << DIST_TBITS); i += 64) L.wide_dist(i) = wide_dist_entry(L.u16(LDS_DIST_TBL, i), d.dist_max_sym);
+  build_canon(L, lane);
   return shortest;
 }
 // The offsets 0..62 hold at most 62 / shortest + 1 symbol starts; the wide turn's

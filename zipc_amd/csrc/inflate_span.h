@@ -92,11 +92,8 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
     b1 = (e >> 17) & 63u;
     lv = ((e >> 8) & 511u) + bit_field(xlo, e, (e >> 5) & 7u);
   } else {
-    BitCursor c;
-    c.x = ((uint64_t)xhi << 32) | xlo;
-    c.used = 0;
-    c.avail = 64;
-    const int sym = read_symbol_walk(c, L, LDS_LIT_COUNTS, LDS_LIT_SYMS);
+    uint32_t n1;
+    const int sym = canon_symbol(xlo, L, CANON_LIT, LDS_LIT_SYMS, n1);
     r.is_lit = true;
     if (sym < 0 || sym == LITLEN_EOB || sym > lit_max_sym || sym > LITLEN_SYM_MAX) {
       r.stop = true;
@@ -105,12 +102,12 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
     if (sym < LITLEN_EOB) lv = (uint32_t)sym;
     else {
       r.is_lit = false;
-      uint32_t base, extra, v = 0;
+      uint32_t base, extra;
       length_sym_value(sym, base, extra);
-      if (extra) c.take((int)extra, v);
-      lv = base + v;
+      lv = base + ((xlo >> n1) & ((1u << extra) - 1u));  // 15 + 5 bits at most
+      n1 += extra;
     }
-    b1 = (uint32_t)c.used;
+    b1 = n1;
   }
   if (r.is_lit) {
     r.tot = b1;
@@ -125,20 +122,16 @@ ZD_HD SpanSym span_symbol_slow(uint32_t xlo, uint32_t xhi, const LaneLds &L, int
     dist = ((e2 >> 9) & 0xFFFFu) + bit_field(x2, e2, (e2 >> 5) & 15u);
     t2 = e2 >> 25;
   } else {
-    BitCursor c;
-    c.x = x2;  // 15 + 13 bits at most
-    c.used = 0;
-    c.avail = 32;
-    const int dsym = read_symbol_walk(c, L, LDS_DIST_COUNTS, LDS_DIST_SYMS);
+    uint32_t n2;
+    const int dsym = canon_symbol(x2, L, CANON_DIST, LDS_DIST_SYMS, n2);
     if (dsym < 0 || dsym > dist_max_sym || dsym > DIST_SYM_MAX) {
       r.stop = true;
       return r;
     }
-    uint32_t base, extra, v = 0;
+    uint32_t base, extra;
     dist_sym_value(dsym, base, extra);
-    if (extra) c.take((int)extra, v);
-    dist = base + v;
-    t2 = (uint32_t)c.used;
+    dist = base + ((x2 >> n2) & ((1u << extra) - 1u));  // 15 + 13 bits at most
+    t2 = n2 + extra;
   }
   r.tot = b1 + t2;
   r.outlen = lv;

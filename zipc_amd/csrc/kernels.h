@@ -6,7 +6,7 @@
 namespace zd {
 
 // ---- inflate.hip
-constexpr int INFLATE_LDS_BYTES_PER_LANE = 9944;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
+constexpr int INFLATE_LDS_BYTES_PER_LANE = 10072;  // = LDS_BYTES_PER_LANE (inflate_lane.h)
 constexpr size_t INFLATE_SCRATCH_PER_STREAM = 64 * 18 * 2;  // the span decoder's index (inflate_span.h)
 __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      uint8_t *__restrict__ dst_arena,
