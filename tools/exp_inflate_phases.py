@@ -46,6 +46,6 @@ print("per stream, clocks: total %.0f  headers %.0f (%.1f%%)  wide turns %.0f (%
       % (tot.mean(), hdr.mean(), 100 * hdr.mean() / tot.mean(), wide.mean(), 100 * wide.mean() / tot.mean(), plain.mean(),
          100 * plain.mean() / tot.mean(), (tot - hdr - wide - plain).mean(), 100 * (tot - hdr - wide - plain).mean() / tot.mean()))
 sp = out[:n * L].view(torch.int64).reshape(n, L // 8)[:, :8].cpu().numpy().astype(np.float64)
-names = ["A walk", "A stitch", "chain+tile setup", "B decode", "setup+probe", "B near holes", "B flush"]
+names = ["A walk", "A stitch", "probe+chain+tile setup", "B decode", "B far holes", "B near holes", "B flush"]
 m = sp.mean(axis=0)
 print("span (booked under 'plain steps'), clocks per stream: " + "  ".join("%s %.0f" % (nm, v) for nm, v in zip(names, m[:7])) + "  tiles %.1f" % m[7])

@@ -58,6 +58,7 @@ constexpr uint32_t SPAN_OD_BIG = 1023;    // index value for "1023 output bytes 
 constexpr uint32_t SPAN_RING = 8;         // input words a lane has waiting in LDS behind the 4 in its registers
 constexpr uint32_t SPAN_TAIL_WORDS = 6;   // input words a span keeps clear of (its reads run ahead of its symbols)
 constexpr uint32_t SPAN_LONG = 32;        // matches longer than this are copied by the whole wave
+constexpr uint32_t SPAN_LIST_MAX = 1024;  // holes of a tile that are listed (in the idle input ring): more end the span
 constexpr int SPAN_FLY = 8;               // far matches a lane has in flight: decode steps between request and arrival
 
 // LDS of the span: byte offsets in the stream's block (inflate_lane.h has the map); the index
@@ -401,6 +402,17 @@ ZD_WV void span_bits_set(uint32_t *mbits, uint32_t q, uint32_t len) {
   wv::lds_or(w, ((1u << len) - 1u) << off);
   if (over > 32u) wv::lds_or(w + 1, (1u << (over - 32u)) - 1u);
 }
+// clear the bits of [q, q + len), 3 <= len
+ZD_WV void span_bits_clear(uint32_t *mbits, uint32_t q, uint32_t len) {
+  if (len >= 32u) {
+    span_bits_mark<false>(mbits, q, len);
+    return;
+  }
+  const uint32_t off = q & 31u, over = off + len;
+  uint32_t *w = mbits + (q >> 5);
+  wv::lds_and(w, ~(((1u << len) - 1u) << off));
+  if (over > 32u) wv::lds_and(w + 1, ~((1u << (over - 32u)) - 1u));
+}
 // is any bit of [a, b) set?  a < b
 ZD_WV bool span_bits_any(const uint32_t *mbits, uint32_t a, uint32_t b) {
   uint32_t w = a >> 5;
@@ -538,7 +550,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   if (lane == 0) fprintf(stderr, "\n");
 #endif
 
-  ZD_SPAN_PH(4);
+  ZD_SPAN_PH(2);
   // ---- phase A: every lane its own region
   W.p = base + (in_span ? g0 : 0u) * SPAN_G;
   W.nb = W.p + SPAN_G;
@@ -656,6 +668,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // A lane's state is numbers, not flags: it decodes while p < stop_p, and stop_p is 0 for a
     // lane that has no granule in the tile or met something it must not commit.)
     uint32_t stop_p = mine ? pe : 0u;
+    uint32_t nh = 0;  // holes the lane leaves in the tile
     for (;;) {
       if (!wv::any(p < stop_p)) break;
 #pragma unroll
@@ -685,6 +698,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         f_a[u] = load_u32_le(dst + goff);
         f_b[u] = load_u32_le(dst + (goff + (fly ? s.outlen - 4u : 0u)));
         f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
+        nh += is_match && !fly ? 1u : 0u;
         if (is_match && !fly) {
           store_u16_le(tile + o, (uint16_t)(s.val - 1u));
           tile[o + 2u] = (uint8_t)(s.outlen - 3u);
@@ -705,7 +719,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = 1;
       }
     }
-    if (wv::any(err != 0u)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
+    const uint32_t hincl = wv::scan_incl(mine ? nh : 0u);
+    uint32_t n_open = wv::readlane(hincl, 63u);
+    // leave the tile's symbols to the plain decoder: it finds what is wrong (or: more holes than the list takes)
+    if (wv::any(err != 0u) || n_open > SPAN_LIST_MAX) {
       p_end = tile_start_p;
       cut = true;
       break;
@@ -713,24 +730,80 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     wv::sync();
     ZD_SPAN_PH(3);
 
-    // The other holes.  Every lane works through its own front to back; a hole is filled as soon as
-    // the bitmap shows that every byte of its source is final (its own bytes count as final: an
-    // overlapping match is copied front to back).  The first open hole of the tile always is, so
-    // every round makes progress; the rounds a tile takes are the depth of its matches'
-    // dependences, not their number.  Holes of up to 32 bytes are copied by their lanes side by
-    // side, longer ones by the whole wave one after the other.
+    // The other holes.  They are listed first (tile positions, in stream order: every lane walks its
+    // own, their places in the list from a scan of the counts the decode loop kept), so that the
+    // work that follows is spread evenly over the lanes whatever granule a hole came from.
+    //   Those whose source lies wholly before the tile (and that are not long) depend on nothing in
+    // it: one pass over the list, the bytes a step requested from memory written by the step after.
+    //   The rest in rounds over what is still open, 64 holes at a time: a hole is filled as soon
+    // as the bitmap shows that every byte of its source is final (its own bytes count as final: an
+    // overlapping match is copied front to back), else it is kept for the next round.  The first
+    // open hole of the tile always is, so every round makes progress; the rounds a tile takes
+    // are the depth of its matches' dependences, not their number.  Holes of up to 32 bytes are
+    // copied by their lanes side by side, longer ones by the whole wave one after the other.
+    uint16_t *list = (uint16_t *)E.ring;  // (the input ring is idle: SPAN_LIST_MAX entries)
     {
-      uint32_t cursor = mine ? o0 : 0u;
+      uint32_t cursor = mine ? o0 : 0u, at = hincl - (mine ? nh : 0u);
       const uint32_t range_end = mine ? o_end : 0u;
-      uint8_t *stage = (uint8_t *)E.ring + ulane * 32u;  // the input ring is idle: 32 bytes per lane
-      const bool wide_ok = out_pos + 32u <= hard_cap;    // 16-byte loads of far sources may read into the tile's place
       for (;;) {
         const uint32_t dp = span_bits_first(mbits, cursor, range_end);
         const bool open = dp != 0xFFFFFFFFu;
         if (!wv::any(open)) break;
+        if (open) {
+          list[at++] = (uint16_t)dp;
+          cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
+        }
+      }
+      wv::sync();
+    }
+    if (out_pos + 32u <= hard_cap) {  // (16-byte loads of far sources may read into the tile's place)
+      wv::Quad a0, a1;
+      a0.x = a0.y = a0.z = a0.w = a1.x = a1.y = a1.z = a1.w = 0;
+      uint32_t a_dp = 0, a_len = 0;  // what the step before requested
+      for (uint32_t c0 = 0;; c0 += 64u) {
+        const bool have = c0 + ulane < n_open;
+        const uint32_t dp = have ? (uint32_t)list[c0 + ulane] : 0u;
+        uint32_t dist = 1, len = 0;
+        if (have) {
+          const uint32_t rec = span_rec(tile, dp);
+          dist = (rec & 0x7FFFu) + 1u;
+          len = (rec >> 16) + 3u;
+        }
+        const bool far = have && len <= SPAN_LONG && dp + len <= dist;
+        const uint32_t goff = far ? out_pos + dp - dist : 0u;  // (lanes with nothing to fetch: the output's first bytes)
+        const wv::Quad q0 = wv::load_quad(dst + goff), q1 = wv::load_quad(dst + (goff + 16u));
+        if (a_len != 0u) {
+          uint8_t *t = tile + a_dp;
+          const uint32_t w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+          for (uint32_t i = 0; i < 8u; i++) {
+            if (4u * i + 4u <= a_len) store_u32_le(t + 4u * i, w[i]);
+            else if (4u * i < a_len) {
+              t[4u * i] = (uint8_t)w[i];
+              if (4u * i + 1u < a_len) t[4u * i + 1u] = (uint8_t)(w[i] >> 8);
+              if (4u * i + 2u < a_len) t[4u * i + 2u] = (uint8_t)(w[i] >> 16);
+            }
+          }
+          span_bits_clear(mbits, a_dp, a_len);
+        }
+        if (far) list[c0 + ulane] = 0xFFFFu;  // done
+        a0 = q0; a1 = q1; a_dp = dp; a_len = far ? len : 0u;
+        if (c0 >= n_open) break;  // (one step behind the last holes: what they requested is written)
+      }
+      wv::sync();
+    }
+    ZD_SPAN_PH(4);
+    for (;;) {
+      uint32_t kept = 0;
 #ifdef SPAN_TRACE
-        if (lane == 0) span_trace_steps[3]++;
+      if (lane == 0) span_trace_steps[3]++;
 #endif
+      for (uint32_t c0 = 0; c0 < n_open; c0 += 64u) {
+#ifdef SPAN_TRACE
+        if (lane == 0) span_trace_steps[7]++;
+#endif
+        const uint32_t dp = c0 + ulane < n_open ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
+        const bool open = dp != 0xFFFFu;
         uint32_t dist = 1, len = 0;
         if (open) {
           const uint32_t rec = span_rec(tile, dp);
@@ -744,53 +817,79 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
           ready = b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
         }
-        wv::sync();  // records and bits are read before anybody writes bytes over them
         const bool go = ready && len <= SPAN_LONG;
-        // three ways to move the bytes: from memory through the lane's staging bytes (the source
-        // wholly before the tile), words inside the tile (distance >= 4), byte by byte (the rest)
-        const bool far = go && wide_ok && sp + (int)len <= 0;
-        const bool words = far || (go && sp >= 0 && dist >= 4u);
-        if (far) {
-          const uint8_t *g = gbase + sp;
-          const wv::Quad q0 = wv::load_quad(g), q1 = wv::load_quad(g + 16);
-          uint32_t *st = (uint32_t *)stage;
-          st[0] = q0.x; st[1] = q0.y; st[2] = q0.z; st[3] = q0.w;
-          st[4] = q1.x; st[5] = q1.y; st[6] = q1.z; st[7] = q1.w;
-        }
-        const uint8_t *from = far ? stage : tile + (sp >= 0 ? sp : 0);
-        for (uint32_t i = 0;; i += 4u) {
-          const bool g = words && i < len;
-          if (!wv::any(g)) break;
-#ifdef SPAN_TRACE
-          if (lane == 0) span_trace_steps[7]++;
-#endif
-          if (g) {
-            const uint32_t v = span_rec4(from, i);
-            tile[dp + i] = (uint8_t)v;
-            if (i + 1u < len) tile[dp + i + 1u] = (uint8_t)(v >> 8);
-            if (i + 2u < len) tile[dp + i + 2u] = (uint8_t)(v >> 16);
-            if (i + 3u < len) tile[dp + i + 3u] = (uint8_t)(v >> 24);
+        // a period of 1, 2 or 3 bytes: twelve bytes of it in registers
+        uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
+        const bool pat = go && dist < 4u;
+        if (pat) {
+          const uint32_t b0 = span_byte_at(tile, gbase, sp), b1 = span_byte_at(tile, gbase, sp + (dist > 1u ? 1 : 0)),
+                         b2 = span_byte_at(tile, gbase, sp + (dist > 2u ? 2 : 0));
+          if (dist == 3u) {
+            pw0 = b0 | b1 << 8 | b2 << 16 | b0 << 24;
+            pw1 = b1 | b2 << 8 | b0 << 16 | b1 << 24;
+            pw2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
+          } else {
+            pw0 = pw1 = pw2 = (b0 | b1 << 8) * 0x00010001u;  // (dist 1: b1 is b0)
           }
         }
-        for (uint32_t i = 0;; i++) {
-          const bool g = go && !words && i < len;
-          if (!wv::any(g)) break;
-          if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+        wv::sync();  // records and bits are read before anybody writes bytes over them
+        // three ways to move the bytes: four at a time inside the tile (distance >= 4), the period's
+        // words, byte by byte (what reaches before the tile from close to its start: rare)
+        const bool words = go && !pat && sp >= 0;
+        if (words || pat) {
+          uint8_t *t = tile + dp;
+          const uint8_t *f = tile + (sp >= 0 ? sp : 0);
+#pragma unroll
+          for (uint32_t i = 0; i < 8u; i++) {
+            if (4u * i + 4u <= len) {
+              const uint32_t pv = i % 3u == 0u ? pw0 : i % 3u == 1u ? pw1 : pw2;
+              store_u32_le(t + 4u * i, pat ? pv : load_u32_le(f + 4u * i));
+            }
+          }
+          if ((len & 3u) != 0u) {
+            const uint32_t k = len >> 2, pv = k % 3u == 0u ? pw0 : k % 3u == 1u ? pw1 : pw2;
+            if (!pat && len >= 4u) store_u32_le(t + (len - 4u), load_u32_le(f + (len - 4u)));  // (over bytes just written)
+            else {
+              const uint32_t v = pat ? pv : load_u32_le(f + 4u * k);  // len 3: (the tile has 16 bytes behind it)
+              t[4u * k] = (uint8_t)v;
+              if ((len & 3u) >= 2u) t[4u * k + 1u] = (uint8_t)(v >> 8);
+              if ((len & 3u) == 3u) t[4u * k + 2u] = (uint8_t)(v >> 16);
+            }
+          }
+        }
+        if (wv::any(go && !words && !pat)) {
+          for (uint32_t i = 0;; i++) {
+            const bool g = go && !words && !pat && i < len;
+            if (!wv::any(g)) break;
+            if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+          }
         }
         // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
         for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
           const uint32_t l = (uint32_t)__builtin_ctzll(lm);
           const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
           const int lsp = (int)ldp - (int)ldist;
-          for (uint32_t i = ulane; i < llen; i += 64u)
-            tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)(i % ldist));
+          if (ldist >= llen) {
+            for (uint32_t i = ulane; i < llen; i += 64u) tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)i);
+          } else {
+            const uint32_t step = 64u % ldist;
+            uint32_t r = ulane % ldist;
+            for (uint32_t i = ulane; i < llen; i += 64u) {
+              tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)r);
+              r += step;
+              if (r >= ldist) r -= ldist;
+            }
+          }
         }
-        if (ready) {
-          span_bits_mark<false>(mbits, dp, len);
-          cursor = dp + len;
-        }
+        if (ready) span_bits_clear(mbits, dp, len);
+        // what is still open moves up in the list
+        const uint64_t km = wv::ballot(open && !ready);
+        if (open && !ready) list[kept + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
+        kept += (uint32_t)__builtin_popcountll(km);
         wv::sync();
       }
+      if (kept == 0u) break;
+      n_open = kept;
     }
     ZD_SPAN_PH(5);
     // the tile leaves
