@@ -59,7 +59,7 @@ constexpr uint32_t SPAN_RING = 8;         // input words a lane has waiting in L
 constexpr uint32_t SPAN_TAIL_WORDS = 6;   // input words a span keeps clear of (its reads run ahead of its symbols)
 constexpr uint32_t SPAN_LONG = 32;        // matches longer than this are copied by the whole wave
 constexpr uint32_t SPAN_LIST_MAX = 1024;  // holes of a tile that are listed (in the idle input ring): more end the span
-constexpr int SPAN_FLY = 8;               // far matches a lane has in flight: decode steps between request and arrival
+constexpr int SPAN_FLY = 4;               // far matches a lane has in flight: decode steps between request and arrival
 
 // LDS of the span: byte offsets in the stream's block (inflate_lane.h has the map); the index
 // lives in global scratch, 64 * SPAN_K_MAX entries per stream (2304 bytes)
