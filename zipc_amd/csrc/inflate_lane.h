@@ -447,40 +447,47 @@ ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
 
 // zd.ml:644-667: the code lengths.  Returns 1 when the header is complete, 0 when
 // the lane must wait for input, -1 for "Corrupted data stream".
+// (One lane reads these, symbol after symbol, while 63 wait: the loop keeps what it can in
+// registers -- the bits left in the input, the last length -- and takes a symbol and its extra
+// bits out of one 32-bit peek: a code-length code has at most 7 bits, which the primary table
+// resolves or no code does, and every way to fail is the same "Corrupted data stream".
+// Reading the code-length code's own lengths and building its table by the whole wave was
+// measured too: 20 K clocks less per header, and 27 spilled VGPRs in the symbol loops for the
+// code it adds to the kernel -- 4.30 ms against 4.15 on C2.)
 ZD_HD int setup_dynamic_lengths(InflateLane &d, const LaneLds &L) {
   const int total = d.hdr_hlit + d.hdr_hdist;
   int num = d.hdr_num;
-  uint32_t v;
+  uint32_t left = d.bits_left();  // (clamped far above what a header can take)
+  uint32_t prev = num > 0 ? L.u16(LDS_LENGTHS, num - 1) : 0u;
 #pragma unroll 1
   while (num < total) {
     if (!d.input_ready(3)) { d.hdr_num = num; return 0; }  // <= 14 bits per turn
-    BitCursor c = cursor_at(d, L);
-    int sym = read_symbol(c, L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
-    if (sym < 0 || sym > d.hdr_cl_max) return -1;  // zd.ml:649
-    int repeat;
-    switch (sym) {
-    case 16:
-      if (num == 0) return -1;  // zd.ml:653
-      if (!c.take(2, v)) return -1;
-      repeat = 3 + (int)v;
-      sym = L.u16(LDS_LENGTHS, num - 1);
-      break;
-    case 17:
-      if (!c.take(3, v)) return -1;
-      repeat = 3 + (int)v;
-      sym = 0;
-      break;
-    case 18:
-      if (!c.take(7, v)) return -1;
-      repeat = 11 + (int)v;
-      sym = 0;
-      break;
-    default: repeat = 1; break;
+    const int s = (int)(d.in_word & (uint32_t)(RING_WORDS - 1));
+    const uint32_t x = funnel32(L.slot(s + 1), L.slot(s), d.boff);
+    const uint32_t e = L.u16(LDS_DIST_TBL, (int)(x & ((1u << DIST_TBITS) - 1)));
+    const uint32_t len = e & 15u, sym = e >> 4;
+    if (len == 0u || (int)sym > d.hdr_cl_max) return -1;  // no such code (read_symbol's walk ends the same way); zd.ml:649
+    const uint32_t extra = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+    const uint32_t used = len + extra;
+    if (used > left) return -1;  // the input ends inside the code or its extra bits
+    const uint32_t v = (x >> len) & ((1u << extra) - 1u);
+    uint32_t repeat = 1, fill = sym;
+    if (sym >= 16u) {
+      if (sym == 16u) {
+        if (num == 0) return -1;  // zd.ml:653
+        repeat = 3u + v;
+        fill = prev;
+      } else {
+        repeat = (sym == 17u ? 3u : 11u) + v;
+        fill = 0;
+      }
     }
-    d.advance((uint32_t)c.used);
-    if (repeat > total - num) return -1;  // zd.ml:659 (may span litlen/dist)
+    d.advance(used);
+    left -= used;
+    if (repeat > (uint32_t)(total - num)) return -1;  // zd.ml:659 (may span litlen/dist)
 #pragma unroll 1
-    while (repeat > 0) { repeat--; L.u16(LDS_LENGTHS, num) = (uint16_t)sym; num++; }
+    while (repeat > 0u) { repeat--; L.u16(LDS_LENGTHS, num) = (uint16_t)fill; num++; }
+    prev = fill;
   }
   d.hdr_num = num;
   if (L.u16(LDS_LENGTHS, 256) == 0) return -1;  // zd.ml:662
