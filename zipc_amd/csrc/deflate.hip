@@ -426,6 +426,10 @@ constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the globa
 static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
 static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
 
+#ifdef ZD_MATCH_UTIL  // counting build (experiments): [0] wave steps (iterations x slots) [1] lane steps that walked a candidate
+// [2] long compares [3] their lengths / 8 [4] iterations with a handout [5] positions handed out
+__device__ unsigned long long zd_match_util[8];
+#endif
 #ifdef ZD_MATCH_PHASES  // timing-only build (tools/exp_match_phases.py): clock deltas, data paths untouched
 // Slot = workgroup index mod ZD_PH_SLOTS (plain atomics on one address from every workgroup
 // cost more than the kernel), 8 words each, s_memtime (shader clock) ticks unless noted:
@@ -1461,6 +1465,18 @@ extern "C" int zipc_hip_debug_match_phases(unsigned long long *out8, int reset) 
   if (reset) {
     for (auto &h : host) h = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_phases), host, sizeof host) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
+
+#ifdef ZD_MATCH_UTIL
+extern "C" int zipc_hip_debug_match_util(unsigned long long *out8, int reset) {
+  static unsigned long long host[8];
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(zd::zd_match_util), sizeof host) != hipSuccess) return 1;
+  if (reset) {
+    for (auto &h : host) h = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_util), host, sizeof host) != hipSuccess) return 1;
   }
   return 0;
 }

@@ -181,6 +181,9 @@ struct MatchRun {
   uint32_t dn;  // prev[q], read ahead: whether the chain goes on is known before the next step
   bool alive, snapped;
   uint64_t pw;
+#ifdef ZD_MATCH_UTIL
+  uint32_t u_walk, u_cmp, u_cmp8;
+#endif
 };
 template <bool WORDS>
 ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend,
@@ -228,7 +231,13 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
       compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
     }
     if (compare) l = common_prefix(s, qc, r.p, r.maxlen);
+#ifdef ZD_MATCH_UTIL
+    if (compare) { r.u_cmp++; r.u_cmp8 += l >> 3; }
+#endif
   }
+#ifdef ZD_MATCH_UTIL
+  r.u_walk += walk ? 1u : 0u;
+#endif
   r.q = qc;
   r.steps += walk ? 1u : 0u;
   if (walk && l > r.best_len) {
@@ -312,6 +321,10 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
+#ifdef ZD_MATCH_UTIL
+  for (int i = 0; i < NP; i++) { r[i].u_walk = 0; r[i].u_cmp = 0; r[i].u_cmp8 = 0; }
+  uint32_t u_hand = 0, u_fin = 0;
+#endif
   // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
   // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
   auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
@@ -339,6 +352,9 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
       const bool fin = match_run_step<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out);
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
+#ifdef ZD_MATCH_UTIL
+        u_hand++; u_fin += (uint32_t)__builtin_popcountll(fm);
+#endif
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;
@@ -359,6 +375,21 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
     }
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
   }
+#ifdef ZD_MATCH_UTIL
+  {
+    extern __device__ unsigned long long zd_match_util[8];
+    uint32_t w = 0, c = 0, c8 = 0;
+    for (int i = 0; i < NP; i++) { w += r[i].u_walk; c += r[i].u_cmp; c8 += r[i].u_cmp8; }
+    atomicAdd(&zd_match_util[1], (unsigned long long)w);
+    atomicAdd(&zd_match_util[2], (unsigned long long)c);
+    atomicAdd(&zd_match_util[3], (unsigned long long)c8);
+    if (lane == 0) {
+      atomicAdd(&zd_match_util[0], (unsigned long long)iters * NP);
+      atomicAdd(&zd_match_util[4], (unsigned long long)u_hand);
+      atomicAdd(&zd_match_util[5], (unsigned long long)u_fin);
+    }
+  }
+#endif
   return iters;
 }
 #endif

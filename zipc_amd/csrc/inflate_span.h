@@ -475,8 +475,11 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   uint32_t K = (est + 64u * SPAN_G - 1u) / (64u * SPAN_G);
   if (K < SPAN_K_MIN) K = SPAN_K_MIN;
   if (K > SPAN_K_MAX) K = SPAN_K_MAX;
-  const uint32_t S = K * SPAN_G;
-  uint32_t n_lanes = usable / S;
+  // the span: TG granules -- all the input allows, 64 regions of K at most -- over as many lanes as get
+  // SPAN_K_MIN each; cut evenly, lane i starts at granule i * TG / n_lanes
+  uint32_t TG = usable / SPAN_G;
+  if (TG > 64u * K) TG = 64u * K;
+  uint32_t n_lanes = TG / SPAN_K_MIN;
   if (n_lanes > 64u) n_lanes = 64u;
   if (n_lanes < SPAN_MIN_LANES) return SPAN_NONE;
 
@@ -500,9 +503,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   SpanWalk W;
   SpanReader R;
   const bool in_span = ulane < n_lanes;
-  uint32_t g0 = ulane * K, kr = K;  // the lane's region: first granule, granules
+  const uint32_t u0 = in_span ? ulane * TG / n_lanes : TG, u1 = in_span ? (ulane + 1u) * TG / n_lanes : TG;
+  uint32_t g0 = u0, kr = u1 - u0;  // the lane's region: first granule, granules
   if (K >= SPAN_PROBE_K_MIN) {
-    const uint32_t p0 = base + (in_span ? ulane : 0u) * S;
+    const uint32_t p0 = base + (in_span ? u0 : 0u) * SPAN_G;
     const uint32_t pe = p0 + SPAN_PROBE_BITS;  // (the words the reader starts with cover this: no refill)
     uint32_t p = p0, rho = 0;
     span_reader_start(R, E, p);
@@ -535,10 +539,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       const uint32_t cand = j + step, c = wv::shfl(before, cand);
       if (cand < n_lanes && c <= target) j = cand;
     }
-    const uint32_t bj = wv::shfl(before, j), rj = wv::shfl(rho, j);
-    const uint32_t x = in_span ? j * K + (target - bj) * K / rj : n_lanes * K;
+    const uint32_t bj = wv::shfl(before, j), rj = wv::shfl(rho, j), uj = wv::shfl(u0, j), kj = wv::shfl(u1 - u0, j);
+    const uint32_t x = in_span ? uj + (target - bj) * kj / rj : TG;
     const uint32_t xn = wv::shfl(x, ulane + 1u);
-    const uint32_t len = (ulane + 1u < n_lanes ? xn : n_lanes * K) - x;
+    const uint32_t len = (ulane + 1u < n_lanes ? xn : TG) - x;
     if (!wv::any(in_span && (len < SPAN_K_MIN || len > 32u))) {  // (32: a region's stops are a mask)
       g0 = x;
       kr = len;
@@ -603,7 +607,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     const uint64_t lm = wv::ballot(link);
     const uint32_t f = ~lm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~lm);  // first lane whose region does not end on the real sequence
     if (f >= n_lanes) {
-      n_valid = n_lanes * K;
+      n_valid = TG;
       p_end = wv::readlane(m_p, n_lanes - 1u);
     } else if (wv::readlane(real ? 1u : 0u, f) != 0u) {  // its own walk met a real stop, in granule ks
       const uint32_t ks = (uint32_t)__builtin_ctz(wv::readlane(real_stops, f));
@@ -618,7 +622,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     }
   }
 #ifdef SPAN_TRACE
-  if (lane == 0) fprintf(stderr, "span: usable %u K %u lanes %u n_valid %u p_end-base %u stop %d\n", usable, K, n_lanes, n_valid, p_end - base, (int)end_stop);
+  if (lane == 0) fprintf(stderr, "span: usable %u K %u TG %u lanes %u n_valid %u p_end-base %u stop %d\n", usable, K, TG, n_lanes, n_valid, p_end - base, (int)end_stop);
 #endif
 
   // ---- phase B: the verified granules, a tile of output at a time
