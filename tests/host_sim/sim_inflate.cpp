@@ -187,7 +187,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   for (;;) {
     // decode phase: the kernel's round
     for (int turn = 0; turn < budget; turn++) {
-      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS || d.phase == PH_HDR_CODELEN) {
         if (!lane_header_step(d, L, src)) break;
         if (d.phase == PH_TABLES) lane_finish_tables(d, L);
         if (d.phase == PH_SYMBOLS && !d.fixed_lazy) {

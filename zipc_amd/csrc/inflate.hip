@@ -57,7 +57,7 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(out_pos); ZD_U(cap_min); ZD_U(limit); ZD_U(hard_cap); ZD_U(status);
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
-  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
+  ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_hclen); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
   ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off); ZD_U(fixed_lazy);
 #undef ZD_U
 }
@@ -159,8 +159,25 @@ __device__ __forceinline__ void wave_build_table(const LaneLds &L, int tbl_off, 
   }
 }
 
-__device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds &L, int lane) {
-  if (d.hdr_fixed) {  // fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349
+// The decoders and primary tables of a block's header, by the wave, ONE instance of the code for all
+// three of a dynamic header's codes (inlined per use it cost the symbol loops their registers):
+// phase PH_HDR_CODELEN -- the code-length code (read_codelen_code zd.ml:624-636: its up to 19 three-bit
+// lengths are read by 19 lanes at once; it lives in the dist regions while the header is read) --
+// and phase PH_TABLES -- the litlen and the distance code, from the lengths or the fixed ones
+// (zd.ml:334-349).  One lane doing the code-length code's part was most of a dynamic header's time.
+__device__ __forceinline__ void wave_tables(InflateLane &d, const LaneLds &L, int lane) {
+  const bool cl = d.phase == PH_HDR_CODELEN;
+  if (cl) {
+    const uint32_t need = 3u * (uint32_t)d.hdr_hclen;
+    if (need > d.bits_left()) { d.fail(ST_CORRUPTED); return; }
+    if (lane < 19) L.u16(LDS_LENGTHS, lane) = 0;
+    if (lane < d.hdr_hclen) {
+      const uint32_t p = d.boff + 3u * (uint32_t)lane, w = d.in_word + (p >> 5);
+      const uint32_t w0 = L.slot((int)(w & (RING_WORDS - 1))), w1 = L.slot((int)((w + 1u) & (RING_WORDS - 1)));
+      L.u16(LDS_LENGTHS, k_codelen_order[lane]) = (uint16_t)(funnel32(w1, w0, p & 31u) & 7u);
+    }
+    d.advance(need);
+  } else if (d.hdr_fixed) {
     if (lane < 16) {
       L.u16(LDS_LIT_COUNTS, lane) = lane == 7 ? 24 : lane == 8 ? 152 : lane == 9 ? 112 : 0;
       L.u16(LDS_DIST_COUNTS, lane) = lane == 5 ? 32 : 0;
@@ -170,16 +187,39 @@ __device__ __forceinline__ void wave_finish_tables(InflateLane &d, const LaneLds
     if (lane < 32) L.u16(LDS_DIST_SYMS, lane) = (uint16_t)lane;
     d.lit_max_sym = LITLEN_SYM_MAX;  // 286 and 287 are unused
     d.dist_max_sym = DIST_SYM_MAX;   // 30 and 31 are unused
-  } else {
-    if (!wave_init_decoder(L, LDS_LIT_COUNTS, LDS_LIT_SYMS, LDS_LIT_TBL, 0, d.hdr_hlit, d.lit_max_sym, lane) ||
-        !wave_init_decoder(L, LDS_DIST_COUNTS, LDS_DIST_SYMS, LDS_DIST_TBL, d.hdr_hlit, d.hdr_hdist, d.dist_max_sym, lane)) {
-      d.fail(ST_CORRUPTED);
-      return;
+  }
+  // jobs: 0 the code-length code, 1 litlen, 2 distance; all decoders first (the lengths lie in the
+  // litlen table's place), then the tables
+  const int first = cl ? 0 : 1, last = cl ? 0 : 2;
+  if (cl || !d.hdr_fixed) {
+#pragma unroll 1
+    for (int job = first; job <= last; job++) {
+      const bool lit = job == 1;
+      int32_t max_sym;
+      if (!wave_init_decoder(L, lit ? LDS_LIT_COUNTS : LDS_DIST_COUNTS, lit ? LDS_LIT_SYMS : LDS_DIST_SYMS,
+                             lit ? LDS_LIT_TBL : LDS_DIST_TBL, job == 2 ? d.hdr_hlit : 0,
+                             job == 0 ? 19 : lit ? d.hdr_hlit : d.hdr_hdist, max_sym, lane) ||
+          (job == 0 && max_sym == -1)) {  // zd.ml:635
+        d.fail(ST_CORRUPTED);
+        return;
+      }
+      if (job == 0) d.hdr_cl_max = max_sym;
+      else if (lit) d.lit_max_sym = max_sym;
+      else d.dist_max_sym = max_sym;
     }
   }
-  wave_build_table(L, LDS_LIT_TBL, LIT_TBITS, LDS_LIT_COUNTS, LDS_LIT_SYMS, lane);
-  wave_build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS, lane);
-  lane_begin_symbols(d);
+#pragma unroll 1
+  for (int job = first; job <= last; job++) {
+    const bool lit = job == 1;
+    wave_build_table(L, lit ? LDS_LIT_TBL : LDS_DIST_TBL, lit ? LIT_TBITS : DIST_TBITS, lit ? LDS_LIT_COUNTS : LDS_DIST_COUNTS,
+                     lit ? LDS_LIT_SYMS : LDS_DIST_SYMS, lane);
+  }
+  if (cl) {
+    d.hdr_num = 0;
+    d.phase = PH_HDR_LENGTHS;
+  } else {
+    lane_begin_symbols(d);
+  }
 }
 
 // A match that could not be queued (overlapping, long, or reading a hole) copied by the
@@ -452,15 +492,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (writer) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
         if (!uni((uint32_t)ok)) break;  // waits for input
-        if (d.phase == PH_TABLES) wave_finish_tables(d, L, lane);
-        if (d.phase == PH_SYMBOLS && !d.fixed_lazy) {
-          const uint32_t shortest = build_wide_tables(d, L, lane);
-          d.levels = levels_for(wave_min(shortest));
-        }
         ZD_PH(ph_hdr);
-      } else if (d.phase == PH_TABLES) {  // a fixed block that went on beyond its table-free symbols
+      } else if (d.phase == PH_TABLES || d.phase == PH_HDR_CODELEN) {  // (PH_TABLES: a dynamic header's lengths are read, or a fixed block went on beyond its table-free symbols)
         ZD_PH_START();
-        wave_finish_tables(d, L, lane);
+        wave_tables(d, L, lane);
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));

@@ -131,7 +131,8 @@ enum : int {
   PH_REQ_MATCH = 4,    // a match that cannot be deferred: waiting for the lockstep copy
   PH_REQ_ADLER = 5,    // block finished: waiting for the cooperative Adler-32 update
   PH_DONE = 6,
-  PH_TABLES = 7        // code lengths known (hdr_fixed, or the lengths scratch): decode tables to be built
+  PH_TABLES = 7,       // code lengths known (hdr_fixed, or the lengths scratch): decode tables to be built
+  PH_HDR_CODELEN = 8   // a dynamic header's counts are read: the code-length code's lengths and tables next
 };
 
 // Arena base pointers stay kernel arguments (so every access is a global_*
@@ -163,7 +164,7 @@ struct InflateLane {
   uint32_t blk_out_start;  // first output byte of the current block
   uint32_t req_src, req_len, req_dist;
   uint32_t q_count, hole_min;  // deferred copies: count, lowest unfilled output position (0xFFFFFFFF: none)
-  int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max;  // dynamic header in progress
+  int32_t hdr_num, hdr_hlit, hdr_hdist, hdr_cl_max, hdr_hclen;  // dynamic header in progress
   int32_t hdr_fixed;   // PH_TABLES: 1 = the fixed codes
   uint32_t adler;      // running Adler_32 value (zd.ml:542) when crc_op = Adler
   int32_t levels;      // doubling levels the block's wide turns need (levels_for)
@@ -417,7 +418,7 @@ ZD_HD void setup_fixed(InflateLane &d, const LaneLds &L) {
 
 // read_dynamic_codes zd.ml:638-643 + read_codelen_code zd.ml:624-636: the fixed
 // part of a dynamic header (at most 71 bits: the caller made HEADER_WORDS ready).
-ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
+ZD_HD bool setup_dynamic_counts(InflateLane &d, const LaneLds &L) {
   uint32_t v;
   if (!d.read_bits(L, 5, v)) return false;
   const int hlit = 257 + (int)v;
@@ -425,11 +426,19 @@ ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
   const int hdist = 1 + (int)v;
   if (hlit > 286 || hdist > 30) return false;  // zd.ml:641
   if (!d.read_bits(L, 4, v)) return false;
-  const int hclen = 4 + (int)v;
+  d.hdr_hlit = hlit;
+  d.hdr_hdist = hdist;
+  d.hdr_hclen = 4 + (int)v;
+  return true;
+}
+// read_codelen_code zd.ml:624-636, one lane's form (the kernel has a wave-parallel one with the
+// same results, wave_tables in inflate.hip)
+ZD_HD bool setup_codelen_code(InflateLane &d, const LaneLds &L) {
+  uint32_t v;
 #pragma unroll 1
   for (int i = 0; i < 19; i++) L.u16(LDS_LENGTHS, i) = 0;
 #pragma unroll 1
-  for (int i = 0; i < hclen; i++) {
+  for (int i = 0; i < d.hdr_hclen; i++) {
     if (!d.read_bits(L, 3, v)) return false;
     L.u16(LDS_LENGTHS, k_codelen_order[i]) = (uint16_t)v;
   }
@@ -439,8 +448,6 @@ ZD_HD bool setup_dynamic_begin(InflateLane &d, const LaneLds &L) {
   if (cl_max_sym == -1) return false;  // zd.ml:635
   build_table(L, LDS_DIST_TBL, DIST_TBITS, LDS_DIST_COUNTS, LDS_DIST_SYMS);
   d.hdr_num = 0;
-  d.hdr_hlit = hlit;
-  d.hdr_hdist = hdist;
   d.hdr_cl_max = cl_max_sym;
   return true;
 }
@@ -557,8 +564,8 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
     d.fixed_lazy = FIXED_LAZY_SYMBOLS;
     return true;
   case 2:
-    if (!setup_dynamic_begin(d, L)) { d.fail(ST_CORRUPTED); return true; }
-    d.phase = PH_HDR_LENGTHS;
+    if (!setup_dynamic_counts(d, L)) { d.fail(ST_CORRUPTED); return true; }
+    d.phase = PH_HDR_CODELEN;
     return true;
   default: d.fail(ST_CORRUPTED); return true;  // zd.ml:701
   }
@@ -686,6 +693,11 @@ ZD_HD int lane_one_symbol_fixed(InflateLane &d, const LaneLds &L, const Arenas &
 // One header action: false = must wait for input.
 ZD_HD bool lane_header_step(InflateLane &d, const LaneLds &L, const uint8_t *__restrict__ sa) {
   if (d.phase == PH_HEADER) return lane_block_header(d, L, sa);
+  if (d.phase == PH_HDR_CODELEN) {  // (the host model's way; its bits were made ready with the header's: HEADER_WORDS)
+    if (!setup_codelen_code(d, L)) d.fail(ST_CORRUPTED);
+    else d.phase = PH_HDR_LENGTHS;
+    return true;
+  }
   const int r = setup_dynamic_lengths(d, L);
   if (r == 0) return false;
   if (r < 0) { d.fail(ST_CORRUPTED); return true; }
