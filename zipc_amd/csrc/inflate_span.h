@@ -3,16 +3,20 @@
 // inflate.hip's wide turn speculates on 64 BIT OFFSETS and commits the ~8 that are real
 // symbol starts: 13 % useful work, and the kernel is bound by instruction issue.  This file
 // is the other decomposition of read_block_symbols (src/zipc_deflate.ml:593-616): the
-// compressed bits ahead are cut into one REGION per lane (S = K x 256 bits), every lane
-// walks its own region a symbol at a time -- 64 real symbols per wave step -- and the
+// compressed bits ahead are cut into one REGION per lane (4 .. 32 granules of 256 bits), every
+// lane walks its own region a symbol at a time -- 64 real symbols per wave step -- and the
 // unknown region starts are settled by the fact that Huffman streams self-synchronise
 // (measured on the configs' data: 50-150 bits on average, p99 under 1000):
 //
+//   regions  all the granules the input allows (64 x 18 at most) over the 64 lanes, cut to equal
+//            numbers of SYMBOLS from a 32-step probe at 64 even places (symbols are not spread
+//            evenly over the bits; any cut is a correct one).
 //   phase A  lane i walks region i from its first bit (lane 0: the true position),
-//            LENGTHS ONLY: bits and output bytes of each symbol.  At every 256-bit
-//            boundary it crosses it records in LDS where the first symbol at or after the
-//            boundary starts (6 bits) and how many bytes the granule before produced
-//            (10 bits): the INDEX, one u16 per granule.
+//            LENGTHS ONLY: bits and output bytes of each symbol, four straight-line steps and
+//            then one look for a granule boundary.  At every 256-bit boundary it crosses it
+//            records where the first symbol at or after the boundary starts (6 bits) and how
+//            many bytes the granule before produced (10 bits): the INDEX, one u16 per granule
+//            (global scratch).
 //            Then lane i walks on into region i+1, overwriting that region's entries with
 //            its own, until it crosses a boundary at the very bit lane i+1 recorded: from
 //            there on the two walks are the same walk (MERGED).  Lane 0 started on a real
@@ -25,13 +29,17 @@
 //            note from there on is a real stop, and the span ends in front of that granule.
 //   phase B  the verified granules in stream order, 64 at a time (one per lane, as many as
 //            give at most 4 KiB of output): every lane decodes its granule fully -- the
-//            literals go to their place in an LDS TILE of the output, a match leaves its
-//            {distance, length} in the first 3 bytes of its own hole and a bit in a bitmap.
-//            Then the holes are filled in stream order: sources that lie before the tile
-//            are final in global memory and are all requested first (the random 32 KiB
-//            window reads that missed L2 once per match in the old kernel now overlap),
-//            the others are copied LDS -> LDS in rounds behind a watermark.  The tile
-//            leaves with coalesced 16-byte stores; literals never go to memory one by one.
+//            literals go to their place in an LDS TILE of the output, a short match whose
+//            source lies before the tile is requested from memory at once and lands four
+//            steps later, any other match leaves its {distance, length} in the first 3 bytes
+//            of its own hole and its bytes in a bitmap of unfilled bytes.
+//   holes    listed (tile positions, stream order) and from there on work for any lane, 64 at
+//            a time: sources wholly before the tile in one pipelined pass, the others in
+//            rounds -- filled when the bitmap shows every source byte final, else kept.  The
+//            tile leaves with coalesced 16-byte stores; literals never go to memory one by one.
+//
+// Codes longer than the tables' index bits -- rare per symbol, not per 64 symbols -- are found by
+// bisection over per-length limits (canon_symbol, inflate_lane.h), not by the bit-by-bit walk.
 //
 // Everything that needs a decision of the reference -- end of block, errors, the last
 // bytes of the input, the size limit -- stops the span IN FRONT of the symbol in question
