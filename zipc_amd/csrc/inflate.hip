@@ -4,6 +4,11 @@
 // deflate stream is a serial chain -- the bit position of symbol k+1 depends on
 // symbol k -- so the wave shortens the chain instead of running many of them:
 //
+//   span        a compressed block's symbols: a region of the bits ahead per lane, region
+//               starts settled by letting the walks self-synchronise, output assembled in
+//               LDS tiles (inflate_span.h).  Nearly all of a stream's time; what follows is
+//               what a span cannot take: headers, the end of every block, the last bytes of
+//               the input, runs of long matches, stored blocks.
 //   wide turn   lane s decodes the whole symbol (literal, or length + distance
 //               with their extra bits) that WOULD start s bits after the
 //               stream's position: 64 speculative decodes, each three words of
