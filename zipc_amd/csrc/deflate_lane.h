@@ -37,8 +37,9 @@ ZD_HD void level_params(int level, int &good_match, int &max_chain) {
 
 // Common prefix of s[q..] and s[p..], capped at maxlen (match_bwd/match_fwd,
 // zd.ml:1154-1174, without the early-out order: the result is the same length).
-ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t maxlen) {
-  uint32_t i = 0;
+// (from: bytes already known to agree, a multiple of 8 not above maxlen)
+ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t maxlen, uint32_t from = 0) {
+  uint32_t i = from;
   while (i + 8 <= maxlen) {
     uint64_t x = load_u64_le(s + q + i) ^ load_u64_le(s + p + i);
     if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
@@ -230,7 +231,7 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
       const uint32_t toff = r.best_len - 7u;  // best_len < maxlen: these bytes lie inside both strings
       compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
     }
-    if (compare) l = common_prefix(s, qc, r.p, r.maxlen);
+    if (compare) l = common_prefix(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);  // (maxlen >= 8 here means x == 0: the first 8 agree)
 #ifdef ZD_MATCH_UTIL
     if (compare) { r.u_cmp++; r.u_cmp8 += l >> 3; }
 #endif
