@@ -271,3 +271,51 @@ def test_config5_single_8gib_stream_of_stored_blocks(gpu_ctx, oracle):
     comp[at] = saved ^ 0x40
     assert int(run(n)["status"][0]) == 18
     comp[at] = saved
+
+
+def test_real_text_at_16384_streams(gpu_ctx, oracle):
+    """The reference's own documents (tests/golden/zip-docs.zip: APPNOTE.TXT, rfc1951.txt) as 16 384
+    chunks of 64 KiB: long hash chains, long matches, long Huffman codes, many dynamic blocks per
+    stream -- what the synthetic configs do not have.  Round trip of every byte, per-stream
+    checksums, and every distinct chunk's compressed bytes against the oracle at `Fast and `Default."""
+    import zipfile
+    import zlib
+
+    import torch
+
+    import util
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    import io
+
+    z = zipfile.ZipFile(io.BytesIO(util.zip_docs()))
+    app, rfc = z.read("zip-docs/APPNOTE.TXT"), z.read("zip-docs/rfc1951.txt")
+    L, n = 65536, 16384
+    pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L], (app[2 * L:] + rfc)[:L], rfc[1000:31000] + bytes(L - 30000)]
+    assert all(len(p) == L for p in pieces)
+    host = np.frombuffer(b"".join(pieces[i % len(pieces)] for i in range(n)), np.uint8).copy()
+    src = torch.from_numpy(host).to(dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    slot = int(descs["dst_off"][1])
+    comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    for level in (1, 2):
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        batch.deflate_batch(gpu_ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
+        res = batch.results_from_device(d_res)
+        assert (res["status"] == 0).all()
+        for j in list(range(len(pieces))) + [n - 1]:
+            st, c0, crc0 = oracle.deflate(pieces[j % len(pieces)], level=level, crc_op=oracle.CRC_CRC32)
+            o = int(descs["dst_off"][j])
+            assert comp[o:o + int(res["out_len"][j])].cpu().numpy().tobytes() == c0, (level, j)
+            assert int(res["checksum"][j]) == crc0 == zlib.crc32(pieces[j % len(pieces)])
+        d_ires = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        out.fill_(0xA5)
+        batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(batch.compact_descs(res, descs, L), dev), d_ires, n, L, 1)
+        ires = batch.results_from_device(d_ires)
+        assert (ires["status"] == 0).all() and (ires["out_len"] == L).all()
+        assert torch.equal(out[:n * L], src)
+        assert (ires["checksum"] == res["checksum"]).all()
