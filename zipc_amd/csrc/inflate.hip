@@ -501,11 +501,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       } else if (d.phase == PH_TABLES || d.phase == PH_HDR_CODELEN) {  // (PH_TABLES: a dynamic header's lengths are read, or a fixed block went on beyond its table-free symbols)
         ZD_PH_START();
         wave_tables(d, L, lane);
+#ifdef ZD_HDR_SPLIT  // (experiment: the tables booked as "wide turns", the wide tables as "services+rest")
+        ZD_PH(ph_wide);
+#endif
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
         }
+#ifndef ZD_HDR_SPLIT
         ZD_PH(ph_hdr);
+#endif
       } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {  // a fixed block's first symbols, straight from the code
         turn++;
         ZD_PH_START();
