@@ -86,3 +86,18 @@ def test_a_small_destination_under_a_run(gpu_ctx, oracle):
     assert got[0][0] == 0 and got[0][1] == data
     for g in got[1:]:
         assert g[0] != 0
+
+
+def test_more_holes_than_a_tile_lists(gpu_ctx, oracle):
+    # a span's tile lists at most 1024 holes (SPAN_LIST_MAX): 1365 three-byte matches fit in 4 KiB
+    cases = []
+    for length, dist, n in ((3, 3, 30000), (3, 1, 30000), (4, 3, 20000), (3, 4, 5000), (5, 2, 12000)):
+        comp, plain = util.fixed_block_of_short_matches(n, length, dist)
+        assert zlib.decompress(comp, -15) == plain
+        st0, d0, c0 = oracle.inflate(comp, decompressed_size=len(plain), crc_op=2)
+        assert st0 == 0 and d0 == plain
+        cases.append((comp, plain, c0))
+    got = util.gpu_inflate_batch(gpu_ctx, [c for c, _, _ in cases], [len(p) for _, p, _ in cases], [True] * len(cases),
+                                 [len(p) for _, p, _ in cases], 2)
+    for i, (comp, plain, c0) in enumerate(cases):
+        assert got[i] == (0, plain, c0), i

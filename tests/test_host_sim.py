@@ -207,6 +207,12 @@ def test_inflate_span_model(sim, oracle, monkeypatch):
             st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
             st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=24)
             assert (st, d, a) == (st0, d0, a0), s["name"]
+        # more holes than a tile lists (SPAN_LIST_MAX): thousands of 3-byte matches in a row, hand-made
+        for length, dist, n in ((3, 3, 6000), (3, 1, 6000), (4, 3, 5000), (3, 4, 3000)):
+            c, data = util.fixed_block_of_short_matches(n, length, dist)
+            st0, d0, a0 = oracle.inflate(c, decompressed_size=len(data), crc_op=2)
+            st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
+            assert (st0, d0) == (0, data) and (st, d, a) == (0, data, a0), (length, dist, order)
         # random complete codes (long codes, odd alphabets), thousands of symbols; then damaged
         seen = {}
         for k, s in enumerate(long_random):

@@ -336,3 +336,43 @@ def gpu_inflate_batch(ctx, streams, caps, has_limit, limits, crc_op):
     out = dst.cpu().numpy()
     return [(int(res["status"][i]), out[int(dst_off[i]):int(dst_off[i]) + int(res["out_len"][i])].tobytes(),
              int(res["checksum"][i])) for i in range(n)]
+
+
+class BitWriter:
+    """deflate's bit order: fields least significant bit first, Huffman codes most significant bit first"""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def field(self, v, nbits):
+        self.acc |= v << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def code(self, v, nbits):
+        self.field(int(format(v, "0%db" % nbits)[::-1], 2), nbits)
+
+    def bytes(self):
+        return bytes(self.out) + (bytes([self.acc]) if self.n else b"")
+
+
+def fixed_block_of_short_matches(n_matches, length, dist, lead=b"abcdefgh"):
+    """one fixed-Huffman block: some literals, then n_matches times (length, dist), all legal but
+    nothing an encoder would write: thousands of 3-byte matches in a row"""
+    assert 3 <= length <= 10 and 1 <= dist <= 4
+    w = BitWriter()
+    w.field(1, 1); w.field(1, 2)              # BFINAL, BTYPE = fixed
+    for c in lead:
+        w.code(0x30 + c, 8)                   # literals 0..143
+    for _ in range(n_matches):
+        w.code(length - 2, 7)                 # length symbols 257..264 (3..10): 7-bit codes 1..8
+        w.code(dist - 1, 5)                   # distances 1..4: codes 0..3, no extra bits
+    w.code(0, 7)                              # end of block
+    plain = bytearray(lead)
+    for _ in range(n_matches):
+        for _ in range(length):
+            plain.append(plain[-dist])
+    return w.bytes(), bytes(plain)
