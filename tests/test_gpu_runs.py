@@ -91,8 +91,9 @@ def test_a_small_destination_under_a_run(gpu_ctx, oracle):
 def test_more_holes_than_a_tile_lists(gpu_ctx, oracle):
     # a span's tile lists at most 1024 holes (SPAN_LIST_MAX): 1365 three-byte matches fit in 4 KiB
     cases = []
-    for length, dist, n in ((3, 3, 30000), (3, 1, 30000), (4, 3, 20000), (3, 4, 5000), (5, 2, 12000)):
-        comp, plain = util.fixed_block_of_short_matches(n, length, dist)
+    for length, dist, n, seed in ((3, 3, 30000, None), (3, 1, 30000, None), (4, 3, 20000, None), (3, 4, 5000, None), (5, 2, 12000, None),
+                                  (3, 4, 30000, 1), (4, 4, 30000, 2), (4, 2, 20000, 3), (10, 4, 20000, 4)):
+        comp, plain = util.fixed_block_of_short_matches(n, length, dist, seed=seed)
         assert zlib.decompress(comp, -15) == plain
         st0, d0, c0 = oracle.inflate(comp, decompressed_size=len(plain), crc_op=2)
         assert st0 == 0 and d0 == plain

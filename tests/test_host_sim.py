@@ -208,8 +208,8 @@ def test_inflate_span_model(sim, oracle, monkeypatch):
             st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=24)
             assert (st, d, a) == (st0, d0, a0), s["name"]
         # more holes than a tile lists (SPAN_LIST_MAX): thousands of 3-byte matches in a row, hand-made
-        for length, dist, n in ((3, 3, 6000), (3, 1, 6000), (4, 3, 5000), (3, 4, 3000)):
-            c, data = util.fixed_block_of_short_matches(n, length, dist)
+        for length, dist, n, seed in ((3, 3, 6000, None), (3, 1, 3000, None), (3, 4, 8000, 1), (4, 4, 8000, 2), (4, 2, 5000, 3)):
+            c, data = util.fixed_block_of_short_matches(n, length, dist, seed=seed)
             st0, d0, a0 = oracle.inflate(c, decompressed_size=len(data), crc_op=2)
             st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
             assert (st0, d0) == (0, data) and (st, d, a) == (0, data, a0), (length, dist, order)

@@ -359,20 +359,23 @@ class BitWriter:
         return bytes(self.out) + (bytes([self.acc]) if self.n else b"")
 
 
-def fixed_block_of_short_matches(n_matches, length, dist, lead=b"abcdefgh"):
+def fixed_block_of_short_matches(n_matches, length, dist, lead=b"abcdefgh", seed=None):
     """one fixed-Huffman block: some literals, then n_matches times (length, dist), all legal but
-    nothing an encoder would write: thousands of 3-byte matches in a row"""
+    nothing an encoder would write: thousands of 3-byte matches in a row.  With a seed the lengths
+    (3 .. length) and distances (1 .. dist) vary from match to match -- a stream of one repeated
+    symbol has a period, and walks that start inside it never fall into step."""
     assert 3 <= length <= 10 and 1 <= dist <= 4
+    r = random.Random(seed) if seed is not None else None
     w = BitWriter()
     w.field(1, 1); w.field(1, 2)              # BFINAL, BTYPE = fixed
     for c in lead:
         w.code(0x30 + c, 8)                   # literals 0..143
-    for _ in range(n_matches):
-        w.code(length - 2, 7)                 # length symbols 257..264 (3..10): 7-bit codes 1..8
-        w.code(dist - 1, 5)                   # distances 1..4: codes 0..3, no extra bits
-    w.code(0, 7)                              # end of block
     plain = bytearray(lead)
     for _ in range(n_matches):
-        for _ in range(length):
-            plain.append(plain[-dist])
+        ln, d = (r.randrange(3, length + 1), r.randrange(1, dist + 1)) if r else (length, dist)
+        w.code(ln - 2, 7)                     # length symbols 257..264 (3..10): 7-bit codes 1..8
+        w.code(d - 1, 5)                      # distances 1..4: codes 0..3, no extra bits
+        for _ in range(ln):
+            plain.append(plain[-d])
+    w.code(0, 7)                              # end of block
     return w.bytes(), bytes(plain)

@@ -735,6 +735,9 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     uint32_t n_open = wv::readlane(hincl, 63u);
     // leave the tile's symbols to the plain decoder: it finds what is wrong (or: more holes than the list takes)
     if (wv::any(err != 0u) || n_open > SPAN_LIST_MAX) {
+#ifdef SPAN_TRACE
+      if (lane == 0) fprintf(stderr, "tile refused: holes %u\n", n_open);
+#endif
       p_end = tile_start_p;
       cut = true;
       break;
