@@ -21,8 +21,13 @@ def _period(word: bytes, n: int) -> bytes:
 def _inputs():
     rng = random.Random(11)
     out = {"zeros_1m": bytes(1 << 20), "zeros_70000": bytes(70000), "ff_5000": b"\xff" * 5000}
-    for p in (1, 2, 3, 5, 15, 16, 17, 31, 63, 64, 65, 100, 257, 258, 259):
+    for p in (1, 2, 3, 5, 15, 16, 17, 31, 63, 64, 65, 79, 80, 81, 100, 257, 258, 259, 300, 1000, 4097):
         out["period_%d" % p] = _period(bytes(rng.randrange(256) for _ in range(p)), 40000 + p)
+    for p in (5000, 32767, 32768, 32769):  # (the last one: no match reaches back that far)
+        out["period_%d" % p] = _period(bytes(rng.randrange(256) for _ in range(p)), 110000)
+    # records that repeat with one byte changing: runs of one match broken by literals
+    rec = bytes(rng.randrange(256) for _ in range(300))
+    out["records"] = b"".join(rec[:150] + bytes([i & 255]) + rec[151:] for i in range(200))
     # runs between other things: literals, far matches, a second period
     mix = bytearray()
     for i in range(40):

@@ -234,7 +234,7 @@ __device__ __forceinline__ void wave_tables(InflateLane &d, const LaneLds &L, in
 // byte at a time through memory when dist < 8, a 258-byte match took 28 us: a 1 MiB run
 // of one byte inflated in 114 ms.)
 // `pattern`: 80 bytes of LDS nobody uses while symbols are decoded one by one (the span's tile).
-constexpr uint32_t MATCH_RUN_DIST = 64;  // periods below this: runs of the same match are one copy (match_run)
+constexpr uint32_t MATCH_RUN_DIST = 64;  // periods below this are laid out in LDS once, longer ones copied from where they are
 __device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint32_t dist, uint32_t len, int lane,
                                                 uint8_t *pattern) {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // the source bytes were stored by other lanes of this wave
@@ -265,33 +265,44 @@ __device__ __forceinline__ void wave_copy_match(uint8_t *dst, uint32_t pos, uint
     __builtin_amdgcn_wave_barrier();  // (the next pattern is not written before this one is read)
     return;
   }
-  // every source byte lies before the match: all of a lane's loads first (one memory latency for
-  // the match, not one per 64 bytes: written as load-store pairs the compiler keeps them in order)
-  uint8_t v[5];  // 258 bytes at most: 5 per lane
-  if (dist >= len) {
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const uint32_t i = l + 64u * (uint32_t)k;
-      v[k] = s[i < len ? i : 0u];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < 5; k++) {
-      const uint32_t i = l + 64u * (uint32_t)k;
-      v[k] = s[i < len ? i % dist : 0u];
-    }
+  // A longer period, or no repetition at all (dist >= len): every byte is one of the `dist` bytes before
+  // the match, byte i the (i mod dist)-th.  The copy goes repetition by repetition in 16-byte pieces
+  // that start at multiples of 16 inside the period -- the last piece of a period moved back to end
+  // with it, over bytes its neighbour writes too, with the same values -- so no piece wraps, every
+  // load reads bytes that were there before the match, and nothing is read or written outside
+  // [pos - dist, pos + len).
+  const uint32_t P = dist < len ? dist : len;  // bytes of one repetition
+  if (P < 16u) {                               // (dist >= 64 here: a short match, once)
+    if (l < len) o[l] = s[l];
+    return;
   }
+  const uint32_t cpp = (P + 15u) >> 4;  // pieces per repetition
+  uint32_t r = l / cpp, c = l - r * cpp;
+  const uint32_t dr = 64u / cpp, dc = 64u - dr * cpp;
+  for (;;) {
+    const uint32_t j = c * 16u + 16u <= P ? c * 16u : P - 16u;
+    const uint32_t i = r * dist + j;
+    if (wave_mask(i < len) == 0ull) break;  // (i grows with the lane: lane 0 is the last to leave)
+    if (i < len) {
+      const wv::Quad q = wv::load_quad(s + j);
+      if (i + 16u <= len) wv::store_quad(o + i, q);
+      else {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-  for (int k = 0; k < 5; k++) {
-    const uint32_t i = l + 64u * (uint32_t)k;
-    if (i < len) o[i] = v[k];
+        for (uint32_t k = 0; k < 16u; k++)
+          if (i + k < len) o[i + k] = (uint8_t)(w[k >> 2] >> (8u * (k & 3u)));
+      }
+    }
+    c += dc;
+    r += dr;
+    if (c >= cpp) { c -= cpp; r++; }
   }
 }
 
 // The match lane_one_symbol has just handed to the wave (d.req_len bytes from d.req_dist back, its
 // symbol was `bits` long): how often is the next symbol the same match again?  Lane k decodes what
 // starts k symbols of that length from here; as far as they all are that match, the copies are one
-// periodic copy (zeros, a repeated short word: 258 bytes per symbol, a symbol at a time they cost
+// periodic copy (zeros, a repeated word or record: 258 bytes per symbol, a symbol at a time they cost
 // a turn and a memory round trip each).  Moves the position over them and returns the bytes of
 // the whole run; nothing that needs a check of its own is passed over: the symbols are matches
 // of a distance already accepted, inside the input, their bytes within the output's limit.
@@ -568,7 +579,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
             // a match that cannot be queued (long, or overlapping its own output) and nothing queued
             // before it: the wave copies it here and now instead of going round through the services
             if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
-              if (d.req_dist < MATCH_RUN_DIST) d.req_len = match_run(d, L, lane, d.in_word * 32u + d.boff - pos_before);
+              d.req_len = match_run(d, L, lane, d.in_word * 32u + d.boff - pos_before);
               wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
               lane_after_match(d);
               continue;
