@@ -939,7 +939,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   d.boff = p_end & 31u;
   d.ring_wr = d.in_word;  // the wide path's input ring holds nothing of use now
   // (a real stop is within a granule of the new position: the wide turns go there)
-  return !progress || cut || end_stop ? SPAN_OFF : SPAN_AGAIN;
+  // (a chain that held for less than a quarter of the span: walks that do not fall into step -- a bit
+  // stream with a period does that -- make every further span of the block as poor: leave it)
+  const bool poor = n_valid * 4u < TG && !end_stop;
+  return !progress || cut || end_stop || poor ? SPAN_OFF : SPAN_AGAIN;
 }
 
 }  // namespace zd
