@@ -211,7 +211,12 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
       } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {
         const int rr = lane_one_symbol_fixed(d, L, A, true);
         if (rr == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); }
-        else if (rr == SYM_STOP) break;
+        else if (rr == SYM_STOP) {
+          if (d.phase == PH_REQ_MATCH && d.q_count == 0) {  // as inflate.hip: copied on the spot
+            lane_copy_match(dst, d.out_pos, d.req_dist, d.req_len, d.hard_cap);
+            lane_after_match(d);
+          } else break;
+        }
         if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
       } else if (d.phase == PH_SYMBOLS) {
         if (span && !d.span_off) {  // as inflate.hip

@@ -342,7 +342,9 @@ __device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, 
   const WideSym sp = wide_decode(funnel32(w1, w0, p), funnel32(w2, w1, p), L);
   const bool is_lit = (int32_t)sp.e < 0;
   const mask_t lit_m = wave_mask(is_lit);
-  const mask_t match_m = wave_mask((int32_t)sp.e >= 0x40000000) & wave_mask(sp.dist >= sp.length);
+  // (a match from very close by mostly copies the match before it: queued, each would cost the queue's
+  // round trip through memory; left to lane_one_symbol they go to the wave at once, runs of them as one copy)
+  const mask_t match_m = wave_mask((int32_t)sp.e >= 0x40000000) & wave_mask(sp.dist >= sp.length && sp.dist >= DEFER_MIN_DIST);
   const uint32_t tot = sp.b1 + (is_lit ? 0u : sp.t2);
   const uint32_t outlen = is_lit ? 1u : sp.length;
   // Lane 63 is the path's sink (the next turn starts there): its J[0] below is itself

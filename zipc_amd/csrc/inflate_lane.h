@@ -88,6 +88,7 @@ constexpr int CANON_LIT = 0, CANON_DIST = 32;  // each: 16 limits, 16 bases
 constexpr int LDS_BYTES_PER_LANE = LDS_CANON_BYTE + 64 * 2;  // 10072
 static_assert(LDS_SPAN_TILE_BYTE % 16 == 0 && LDS_W_BYTE % 2 == 0 && LDS_SPAN_BITS_BYTE % 4 == 0, "alignment");
 constexpr uint32_t DEFER_MAX_LEN = 16;
+constexpr uint32_t DEFER_MIN_DIST = 16;  // nearer matches are not queued (they mostly depend on the copy just before them)
 // A queued copy is one word: its destination relative to the first queued copy's
 // (InflateLane::hole_min), distance and length.
 constexpr uint32_t QUEUE_REL_MAX = 8191;
@@ -584,7 +585,7 @@ ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const
   const bool hazard = src_pos + length > d.hole_min;
   const uint32_t qbase = d.hole_min < d.out_pos ? d.hole_min : d.out_pos;  // hole_min once this one is queued
   const bool in_reach = d.out_pos - qbase <= QUEUE_REL_MAX;
-  if (length <= DEFER_MAX_LEN && dist >= length && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+  if (length <= DEFER_MAX_LEN && dist >= length && dist >= DEFER_MIN_DIST && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
     d.hole_min = qbase;
     if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
     d.q_count++;
@@ -827,7 +828,7 @@ struct WideSym {
   // the predicates the turn forms out of these (as wave masks in the kernel)
   ZD_HD bool is_lit() const { return (int32_t)e < 0; }
   ZD_HD bool is_len() const { return (int32_t)e >= 0x40000000; }
-  ZD_HD bool is_match() const { return is_len() && dist >= length; }  // may be deferred
+  ZD_HD bool is_match() const { return is_len() && dist >= length && dist >= DEFER_MIN_DIST; }  // may be deferred
   ZD_HD uint32_t tot() const { return b1 + (is_lit() ? 0u : t2); }
   ZD_HD uint32_t outlen() const { return is_lit() ? 1u : length; }
 };

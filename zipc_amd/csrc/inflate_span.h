@@ -451,6 +451,22 @@ ZD_WV uint32_t span_bits_first(const uint32_t *mbits, uint32_t from, uint32_t to
 ZD_WV uint32_t span_byte_at(const uint8_t *tile, const uint8_t *gbase, int s) {  // tile byte s, or the byte -s before it
   return s < 0 ? (uint32_t)gbase[s] : (uint32_t)tile[s];
 }
+// one hole by the whole wave (dp, dist, len the same in every lane): Buf.recopy zd.ml:63-75, byte i is
+// the source's byte i mod dist
+ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, uint32_t dist, uint32_t len, uint32_t ulane) {
+  const int sp = (int)dp - (int)dist;
+  if (dist >= len) {
+    for (uint32_t i = ulane; i < len; i += 64u) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+  } else {
+    const uint32_t step = 64u % dist;
+    uint32_t r = ulane % dist;
+    for (uint32_t i = ulane; i < len; i += 64u) {
+      tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)r);
+      r += step;
+      if (r >= dist) r -= dist;
+    }
+  }
+}
 // The span.  d.phase == PH_SYMBOLS, nothing queued; returns SPAN_NONE when it did not run
 // (nothing changed), else the stream position, out_pos and ring_wr are those after the
 // symbols it committed: SPAN_AGAIN (more of the block may follow the same way) or SPAN_OFF
@@ -489,6 +505,9 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   if (TG > 64u * K) TG = 64u * K;
   uint32_t n_lanes = TG / SPAN_K_MIN;
   if (n_lanes > 64u) n_lanes = 64u;
+#ifdef SPAN_TRACE
+  if (lane == 0) fprintf(stderr, "span geometry: usable %u K %u TG %u lanes %u\n", usable, K, TG, n_lanes);
+#endif
   if (n_lanes < SPAN_MIN_LANES) return SPAN_NONE;
 
   SpanEnv E;
@@ -731,13 +750,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = 1;
       }
     }
-    const uint32_t hincl = wv::scan_incl(mine ? nh : 0u);
-    uint32_t n_open = wv::readlane(hincl, 63u);
-    // leave the tile's symbols to the plain decoder: it finds what is wrong (or: more holes than the list takes)
-    if (wv::any(err != 0u) || n_open > SPAN_LIST_MAX) {
-#ifdef SPAN_TRACE
-      if (lane == 0) fprintf(stderr, "tile refused: holes %u\n", n_open);
-#endif
+    if (wv::any(err != 0u)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
       p_end = tile_start_p;
       cut = true;
       break;
@@ -757,15 +770,23 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // are the depth of its matches' dependences, not their number.  Holes of up to 32 bytes are
     // copied by their lanes side by side, longer ones by the whole wave one after the other.
     uint16_t *list = (uint16_t *)E.ring;  // (the input ring is idle: SPAN_LIST_MAX entries)
+    // (A tile of 3-byte matches has up to 1365 holes: the list takes the first SPAN_LIST_MAX in
+    // stream order, and when those are filled the rest -- nothing before a hole depends on it.)
+    uint32_t my_open = mine ? nh : 0u;
+    for (;;) {
+    const uint32_t hincl = wv::scan_incl(my_open), h_total = wv::readlane(hincl, 63u);
+    if (h_total == 0u) break;
+    uint32_t n_open = h_total < SPAN_LIST_MAX ? h_total : SPAN_LIST_MAX;
     {
-      uint32_t cursor = mine ? o0 : 0u, at = hincl - (mine ? nh : 0u);
+      uint32_t cursor = mine ? o0 : 0u, at = hincl - my_open;
       const uint32_t range_end = mine ? o_end : 0u;
       for (;;) {
         const uint32_t dp = span_bits_first(mbits, cursor, range_end);
         const bool open = dp != 0xFFFFFFFFu;
         if (!wv::any(open)) break;
         if (open) {
-          list[at++] = (uint16_t)dp;
+          if (at < SPAN_LIST_MAX) list[at] = (uint16_t)dp;
+          at++;
           cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
         }
       }
@@ -883,18 +904,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
           const uint32_t l = (uint32_t)__builtin_ctzll(lm);
           const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
-          const int lsp = (int)ldp - (int)ldist;
-          if (ldist >= llen) {
-            for (uint32_t i = ulane; i < llen; i += 64u) tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)i);
-          } else {
-            const uint32_t step = 64u % ldist;
-            uint32_t r = ulane % ldist;
-            for (uint32_t i = ulane; i < llen; i += 64u) {
-              tile[ldp + i] = (uint8_t)span_byte_at(tile, gbase, lsp + (int)r);
-              r += step;
-              if (r >= ldist) r -= ldist;
-            }
-          }
+          span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
         }
         if (ready) span_bits_clear(mbits, dp, len);
         // what is still open moves up in the list
@@ -904,7 +914,53 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         wv::sync();
       }
       if (kept == 0u) break;
+      // A round that filled less than an eighth of what was open: the holes form a chain (each
+      // copying from the one before: hand-made streams, short periods cut into short matches), and
+      // rounds would take as many passes as it has links.  In stream order every hole's source is
+      // final when its turn comes: the rest one after the other, each by the whole wave.
+      // (Holes that follow each other at one distance -- a period cut into short matches -- are one
+      // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
+      if (kept * 8u > n_open * 7u && kept >= 16u) {
+        for (uint32_t h = 0; h < kept;) {
+          const bool have = h + ulane < kept;
+          const uint32_t dp = have ? (uint32_t)list[h + ulane] : 0u;
+          uint32_t dist = 0, len = 0;
+          if (have) {
+            const uint32_t rec = span_rec(tile, dp);
+            dist = (rec & 0x7FFFu) + 1u;
+            len = (rec >> 16) + 3u;
+          }
+          const uint32_t pdp = wv::shfl(dp, ulane - 1u), plen = wv::shfl(len, ulane - 1u), pdist = wv::shfl(dist, ulane - 1u);
+          const bool joins = ulane == 0u || (have && dp == pdp + plen && dist == pdist);
+          const uint64_t jm = wv::ballot(joins);
+          const uint32_t run = ~jm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~jm);  // >= 1: lane 0 has a hole
+          const uint32_t total = wv::readlane(wv::scan_incl(len), run - 1u);
+          const uint32_t dp0 = wv::readlane(dp, 0u), dist0 = wv::readlane(dist, 0u);
+          wv::sync();  // (the records are read before any lane writes over them)
+          span_fill_by_wave(tile, gbase, dp0, dist0, total, ulane);
+          if (ulane == 0u) span_bits_mark<false>(mbits, dp0, total);
+          wv::sync();
+          h += run;
+        }
+        break;
+      }
       n_open = kept;
+    }
+    if (h_total <= SPAN_LIST_MAX) break;
+    {  // what is still open of my own holes
+      uint32_t cursor = mine ? o0 : 0u, cnt = 0;
+      const uint32_t range_end = mine ? o_end : 0u;
+      for (;;) {
+        const uint32_t dp = span_bits_first(mbits, cursor, range_end);
+        const bool open = dp != 0xFFFFFFFFu;
+        if (!wv::any(open)) break;
+        if (open) {
+          cnt++;
+          cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
+        }
+      }
+      my_open = cnt;
+    }
     }
     ZD_SPAN_PH(5);
     // the tile leaves
