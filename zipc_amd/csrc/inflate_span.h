@@ -700,6 +700,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // lane that has no granule in the tile or met something it must not commit.)
     uint32_t stop_p = mine ? pe : 0u;
     uint32_t nh = 0;  // holes the lane leaves in the tile
+    uint32_t has_far = 0;
     for (;;) {
       if (!wv::any(p < stop_p)) break;
 #pragma unroll
@@ -734,6 +735,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           store_u16_le(tile + o, (uint16_t)(s.val - 1u));
           tile[o + 2u] = (uint8_t)(s.outlen - 3u);
           span_bits_set(mbits, o, s.outlen);
+          if (s.val >= o2 && s.outlen <= SPAN_LONG) has_far = 1;  // (a hole the pass over far sources is for)
         }
         o = good ? o2 : o;
         p += good ? s.tot : 0u;
@@ -792,7 +794,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       }
       wv::sync();
     }
-    if (out_pos + 32u <= hard_cap) {  // (16-byte loads of far sources may read into the tile's place)
+    if (out_pos + 32u <= hard_cap && wv::any(has_far != 0u)) {  // (16-byte loads of far sources may read into the tile's place)
       wv::Quad a0, a1;
       a0.x = a0.y = a0.z = a0.w = a1.x = a1.y = a1.z = a1.w = 0;
       uint32_t a_dp = 0, a_len = 0;  // what the step before requested
