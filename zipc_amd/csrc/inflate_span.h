@@ -916,13 +916,13 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         wv::sync();
       }
       if (kept == 0u) break;
-      // A round that filled less than an eighth of what was open: the holes form a chain (each
+      // A round that filled one or two of many open holes: they form a chain (each
       // copying from the one before: hand-made streams, short periods cut into short matches), and
       // rounds would take as many passes as it has links.  In stream order every hole's source is
       // final when its turn comes: the rest one after the other, each by the whole wave.
       // (Holes that follow each other at one distance -- a period cut into short matches -- are one
       // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
-      if (kept * 8u > n_open * 7u && kept >= 16u) {
+      if (n_open - kept <= 2u && kept >= 64u) {
         for (uint32_t h = 0; h < kept;) {
           const bool have = h + ulane < kept;
           const uint32_t dp = have ? (uint32_t)list[h + ulane] : 0u;
