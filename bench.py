@@ -414,14 +414,14 @@ def extra_legs(ctx, dev, n, L):
         app = z.read("zip-docs/APPNOTE.TXT")
         rfc = z.read("zip-docs/rfc1951.txt")
         pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
-        m = min(n, 4096)
+        m = min(n, 16384)
         src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(m)), np.uint8).copy()).to(dev)
         gd, gi = device_round_trip(ctx, dev, src, m, L, 2)
         out["text_gib_s"] = {"deflate": gd, "inflate": gi, "is": "%d x 64 KiB chunks of APPNOTE.TXT / rfc1951.txt, device-resident" % m}
     except Exception as e:
         out["text_gib_s"] = {"error": repr(e)}
-    try:  # C4 shape on this GPU: 2048 members x 1 MiB of 3-bit symbols
-        m, ML = 2048, 1 << 20
+    try:  # C4 shape on this GPU: 4096 members x 1 MiB of 3-bit symbols (a wave per member: half of them leaves the GPU half empty)
+        m, ML = 4096, 1 << 20
         src = synth.batch_bytes_torch(4, 0, m, ML, 3, dev)
         gd, gi = device_round_trip(ctx, dev, src, m, ML, 2)
         out["c4_deflate_gib_s"] = gd
