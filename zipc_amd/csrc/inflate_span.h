@@ -75,7 +75,7 @@ constexpr uint32_t SPAN_RING_OFF = LDS_SPAN_RING_BYTE;   // u32[8 * 64], word-ma
 constexpr uint32_t SPAN_TILE_OFF = LDS_SPAN_TILE_BYTE;   // SPAN_TILE + 16 bytes
 constexpr uint32_t SPAN_BITS_OFF = LDS_SPAN_BITS_BYTE;   // u32[128 + 2]: a bit per tile byte
 constexpr uint32_t SPAN_IDX_ENTRIES = 64 * SPAN_K_MAX;
-static_assert(SPAN_TILE + 16 == LDS_SPAN_TILE_BYTES && SPAN_RING * 64 * 4 <= LDS_WIDE_LIT * 4, "inflate_lane.h's map");
+static_assert(SPAN_TILE + 16 == LDS_SPAN_TILE_BYTES && SPAN_RING * 64 * 4 <= LDS_WIDE_LIT * 4 && SPAN_IDX_ENTRIES * 2 <= SPAN_TILE, "inflate_lane.h's map");
 
 enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_OFF = 3 };
 enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERGE = 5 };
@@ -516,6 +516,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   E.max_word = max_word;
   E.lane = lane;
   uint8_t *tile = L.x + SPAN_TILE_OFF;
+  uint16_t *lidx = (uint16_t *)tile;  // phase A's index: in the tile's place (SPAN_IDX_ENTRIES u16) while no tile is being made
   uint32_t *mbits = (uint32_t *)(L.x + SPAN_BITS_OFF);
   const int lit_max = (int)wv::uni((uint32_t)d.lit_max_sym), dist_max = (int)wv::uni((uint32_t)d.dist_max_sym);
   const uint32_t cap_min = wv::uni(d.cap_min), out_pos0 = wv::uni(d.out_pos), hard_cap = wv::uni(d.hard_cap);
@@ -594,14 +595,14 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   W.run = in_span;
   W.kind = WK_NONE; W.rk = 0; W.rp = 0;
   span_reader_start(R, E, W.p);
-  span_walk_loop<false>(W, R, E, L, idx, lit_max, dist_max);
+  span_walk_loop<false>(W, R, E, L, lidx, lit_max, dist_max);
   ZD_SPAN_PH(0);
   if (wv::any(lane == 0 && W.kind == WK_NONE)) {  // gave up (see the walk loop): nothing committed,
     d.ring_wr = d.in_word;                         // but the wide path's input ring was this walk's
     return SPAN_OFF;
   }
   const uint32_t m_p = W.rp, m_stops = W.stops;  // (every walk of a region ends at the region's end: WK_END)
-  wv::fence_global();  // the index is in memory: entries written by one lane are read by others below
+  wv::sync();  // entries written by one lane are read by others below
   // ... and on into the next lane's, until the two walks are one
   {
     const bool stitch = ulane + 1u < n_lanes;
@@ -612,13 +613,13 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       W.region_e = g0n;
       W.kr = krn;
       W.k = 0;  // (position, reader, pd, od, nb: as the walk of the own region left them, in this granule)
-      if ((idx[W.region_e] & 63u) == W.pd) span_walk_end(W, WK_MERGED, 0, m_p);
+      if ((lidx[W.region_e] & 63u) == W.pd) span_walk_end(W, WK_MERGED, 0, m_p);
       else W.run = true;
     }
   }
-  span_walk_loop<true>(W, R, E, L, idx, lit_max, dist_max);
+  span_walk_loop<true>(W, R, E, L, lidx, lit_max, dist_max);
   const uint32_t s_kind = W.kind, s_k = W.rk, s_p = W.rp;
-  wv::fence_global();
+  wv::sync();
   ZD_SPAN_PH(1);
 
   // ---- how far the chain from lane 0 holds
@@ -639,7 +640,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     } else if (wv::readlane(real ? 1u : 0u, f) != 0u) {  // its own walk met a real stop, in granule ks
       const uint32_t ks = (uint32_t)__builtin_ctz(wv::readlane(real_stops, f));
       n_valid = wv::readlane(g0, f) + ks;
-      p_end = base + n_valid * SPAN_G + ((uint32_t)idx[n_valid] & 63u);
+      p_end = base + n_valid * SPAN_G + ((uint32_t)lidx[n_valid] & 63u);
       end_stop = true;
     } else {  // the walk of the lane before went through the whole region, or met a real stop there
       const uint32_t kind = wv::readlane(s_kind, f - 1u), kk = wv::readlane(s_k, f - 1u);
@@ -651,6 +652,11 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
 #ifdef SPAN_TRACE
   if (lane == 0) fprintf(stderr, "span: usable %u K %u TG %u lanes %u n_valid %u p_end-base %u stop %d\n", usable, K, TG, n_lanes, n_valid, p_end - base, (int)end_stop);
 #endif
+
+  // the index leaves LDS (phase B needs the tile's place): its verified part, to the stream's scratch
+  wv::sync();
+  for (uint32_t i = ulane; i < n_valid; i += 64u) idx[i] = lidx[i];
+  wv::fence_global();  // (read back below, by other lanes)
 
   // ---- phase B: the verified granules, a tile of output at a time
   uint32_t out_pos = out_pos0;
