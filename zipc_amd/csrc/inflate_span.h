@@ -16,7 +16,7 @@
 //            then one look for a granule boundary.  At every 256-bit boundary it crosses it
 //            records where the first symbol at or after the boundary starts (6 bits) and how
 //            many bytes the granule before produced (10 bits): the INDEX, one u16 per granule
-//            (global scratch).
+//            (in LDS, in the tile's place, until it is complete; then in the stream's scratch).
 //            Then lane i walks on into region i+1, overwriting that region's entries with
 //            its own, until it crosses a boundary at the very bit lane i+1 recorded: from
 //            there on the two walks are the same walk (MERGED).  Lane 0 started on a real
