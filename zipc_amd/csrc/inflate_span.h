@@ -782,193 +782,193 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // stream order, and when those are filled the rest -- nothing before a hole depends on it.)
     uint32_t my_open = mine ? nh : 0u;
     for (;;) {
-    const uint32_t hincl = wv::scan_incl(my_open), h_total = wv::readlane(hincl, 63u);
-    if (h_total == 0u) break;
-    uint32_t n_open = h_total < SPAN_LIST_MAX ? h_total : SPAN_LIST_MAX;
-    {
-      uint32_t cursor = mine ? o0 : 0u, at = hincl - my_open;
-      const uint32_t range_end = mine ? o_end : 0u;
-      for (;;) {
-        const uint32_t dp = span_bits_first(mbits, cursor, range_end);
-        const bool open = dp != 0xFFFFFFFFu;
-        if (!wv::any(open)) break;
-        if (open) {
-          if (at < SPAN_LIST_MAX) list[at] = (uint16_t)dp;
-          at++;
-          cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
-        }
-      }
-      wv::sync();
-    }
-    if (out_pos + 32u <= hard_cap && wv::any(has_far != 0u)) {  // (16-byte loads of far sources may read into the tile's place)
-      wv::Quad a0, a1;
-      a0.x = a0.y = a0.z = a0.w = a1.x = a1.y = a1.z = a1.w = 0;
-      uint32_t a_dp = 0, a_len = 0;  // what the step before requested
-      for (uint32_t c0 = 0;; c0 += 64u) {
-        const bool have = c0 + ulane < n_open;
-        const uint32_t dp = have ? (uint32_t)list[c0 + ulane] : 0u;
-        uint32_t dist = 1, len = 0;
-        if (have) {
-          const uint32_t rec = span_rec(tile, dp);
-          dist = (rec & 0x7FFFu) + 1u;
-          len = (rec >> 16) + 3u;
-        }
-        const bool far = have && len <= SPAN_LONG && dp + len <= dist;
-        const uint32_t goff = far ? out_pos + dp - dist : 0u;  // (lanes with nothing to fetch: the output's first bytes)
-        const wv::Quad q0 = wv::load_quad(dst + goff), q1 = wv::load_quad(dst + (goff + 16u));
-        if (a_len != 0u) {
-          uint8_t *t = tile + a_dp;
-          const uint32_t w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-#pragma unroll
-          for (uint32_t i = 0; i < 8u; i++) {
-            if (4u * i + 4u <= a_len) store_u32_le(t + 4u * i, w[i]);
-            else if (4u * i < a_len) {
-              t[4u * i] = (uint8_t)w[i];
-              if (4u * i + 1u < a_len) t[4u * i + 1u] = (uint8_t)(w[i] >> 8);
-              if (4u * i + 2u < a_len) t[4u * i + 2u] = (uint8_t)(w[i] >> 16);
-            }
-          }
-          span_bits_clear(mbits, a_dp, a_len);
-        }
-        if (far) list[c0 + ulane] = 0xFFFFu;  // done
-        a0 = q0; a1 = q1; a_dp = dp; a_len = far ? len : 0u;
-        if (c0 >= n_open) break;  // (one step behind the last holes: what they requested is written)
-      }
-      wv::sync();
-    }
-    ZD_SPAN_PH(4);
-    for (;;) {
-      uint32_t kept = 0;
-#ifdef SPAN_TRACE
-      if (lane == 0) span_trace_steps[3]++;
-#endif
-      for (uint32_t c0 = 0; c0 < n_open; c0 += 64u) {
-#ifdef SPAN_TRACE
-        if (lane == 0) span_trace_steps[7]++;
-#endif
-        const uint32_t dp = c0 + ulane < n_open ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
-        const bool open = dp != 0xFFFFu;
-        uint32_t dist = 1, len = 0;
-        if (open) {
-          const uint32_t rec = span_rec(tile, dp);
-          dist = (rec & 0x7FFFu) + 1u;
-          len = (rec >> 16) + 3u;
-        }
-        const int sp = (int)dp - (int)dist;
-        bool ready = false;
-        if (open) {
-          const int a = sp > 0 ? sp : 0;
-          const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
-          ready = b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
-        }
-        const bool go = ready && len <= SPAN_LONG;
-        // a period of 1, 2 or 3 bytes: twelve bytes of it in registers
-        uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
-        const bool pat = go && dist < 4u;
-        if (pat) {
-          const uint32_t b0 = span_byte_at(tile, gbase, sp), b1 = span_byte_at(tile, gbase, sp + (dist > 1u ? 1 : 0)),
-                         b2 = span_byte_at(tile, gbase, sp + (dist > 2u ? 2 : 0));
-          if (dist == 3u) {
-            pw0 = b0 | b1 << 8 | b2 << 16 | b0 << 24;
-            pw1 = b1 | b2 << 8 | b0 << 16 | b1 << 24;
-            pw2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
-          } else {
-            pw0 = pw1 = pw2 = (b0 | b1 << 8) * 0x00010001u;  // (dist 1: b1 is b0)
+      const uint32_t hincl = wv::scan_incl(my_open), h_total = wv::readlane(hincl, 63u);
+      if (h_total == 0u) break;
+      uint32_t n_open = h_total < SPAN_LIST_MAX ? h_total : SPAN_LIST_MAX;
+      {
+        uint32_t cursor = mine ? o0 : 0u, at = hincl - my_open;
+        const uint32_t range_end = mine ? o_end : 0u;
+        for (;;) {
+          const uint32_t dp = span_bits_first(mbits, cursor, range_end);
+          const bool open = dp != 0xFFFFFFFFu;
+          if (!wv::any(open)) break;
+          if (open) {
+            if (at < SPAN_LIST_MAX) list[at] = (uint16_t)dp;
+            at++;
+            cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
           }
         }
-        wv::sync();  // records and bits are read before anybody writes bytes over them
-        // three ways to move the bytes: four at a time inside the tile (distance >= 4), the period's
-        // words, byte by byte (what reaches before the tile from close to its start: rare)
-        const bool words = go && !pat && sp >= 0;
-        if (words || pat) {
-          uint8_t *t = tile + dp;
-          const uint8_t *f = tile + (sp >= 0 ? sp : 0);
-#pragma unroll
-          for (uint32_t i = 0; i < 8u; i++) {
-            if (4u * i + 4u <= len) {
-              const uint32_t pv = i % 3u == 0u ? pw0 : i % 3u == 1u ? pw1 : pw2;
-              store_u32_le(t + 4u * i, pat ? pv : load_u32_le(f + 4u * i));
-            }
-          }
-          if ((len & 3u) != 0u) {
-            const uint32_t k = len >> 2, pv = k % 3u == 0u ? pw0 : k % 3u == 1u ? pw1 : pw2;
-            if (!pat && len >= 4u) store_u32_le(t + (len - 4u), load_u32_le(f + (len - 4u)));  // (over bytes just written)
-            else {
-              const uint32_t v = pat ? pv : load_u32_le(f + 4u * k);  // len 3: (the tile has 16 bytes behind it)
-              t[4u * k] = (uint8_t)v;
-              if ((len & 3u) >= 2u) t[4u * k + 1u] = (uint8_t)(v >> 8);
-              if ((len & 3u) == 3u) t[4u * k + 2u] = (uint8_t)(v >> 16);
-            }
-          }
-        }
-        if (wv::any(go && !words && !pat)) {
-          for (uint32_t i = 0;; i++) {
-            const bool g = go && !words && !pat && i < len;
-            if (!wv::any(g)) break;
-            if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
-          }
-        }
-        // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
-        for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
-          const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-          const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
-          span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
-        }
-        if (ready) span_bits_clear(mbits, dp, len);
-        // what is still open moves up in the list
-        const uint64_t km = wv::ballot(open && !ready);
-        if (open && !ready) list[kept + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
-        kept += (uint32_t)__builtin_popcountll(km);
         wv::sync();
       }
-      if (kept == 0u) break;
-      // A round that filled one or two of many open holes: they form a chain (each
-      // copying from the one before: hand-made streams, short periods cut into short matches), and
-      // rounds would take as many passes as it has links.  In stream order every hole's source is
-      // final when its turn comes: the rest one after the other, each by the whole wave.
-      // (Holes that follow each other at one distance -- a period cut into short matches -- are one
-      // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
-      if (n_open - kept <= 2u && kept >= 64u) {
-        for (uint32_t h = 0; h < kept;) {
-          const bool have = h + ulane < kept;
-          const uint32_t dp = have ? (uint32_t)list[h + ulane] : 0u;
-          uint32_t dist = 0, len = 0;
+      if (out_pos + 32u <= hard_cap && wv::any(has_far != 0u)) {  // (16-byte loads of far sources may read into the tile's place)
+        wv::Quad a0, a1;
+        a0.x = a0.y = a0.z = a0.w = a1.x = a1.y = a1.z = a1.w = 0;
+        uint32_t a_dp = 0, a_len = 0;  // what the step before requested
+        for (uint32_t c0 = 0;; c0 += 64u) {
+          const bool have = c0 + ulane < n_open;
+          const uint32_t dp = have ? (uint32_t)list[c0 + ulane] : 0u;
+          uint32_t dist = 1, len = 0;
           if (have) {
             const uint32_t rec = span_rec(tile, dp);
             dist = (rec & 0x7FFFu) + 1u;
             len = (rec >> 16) + 3u;
           }
-          const uint32_t pdp = wv::shfl(dp, ulane - 1u), plen = wv::shfl(len, ulane - 1u), pdist = wv::shfl(dist, ulane - 1u);
-          const bool joins = ulane == 0u || (have && dp == pdp + plen && dist == pdist);
-          const uint64_t jm = wv::ballot(joins);
-          const uint32_t run = ~jm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~jm);  // >= 1: lane 0 has a hole
-          const uint32_t total = wv::readlane(wv::scan_incl(len), run - 1u);
-          const uint32_t dp0 = wv::readlane(dp, 0u), dist0 = wv::readlane(dist, 0u);
-          wv::sync();  // (the records are read before any lane writes over them)
-          span_fill_by_wave(tile, gbase, dp0, dist0, total, ulane);
-          if (ulane == 0u) span_bits_mark<false>(mbits, dp0, total);
-          wv::sync();
-          h += run;
+          const bool far = have && len <= SPAN_LONG && dp + len <= dist;
+          const uint32_t goff = far ? out_pos + dp - dist : 0u;  // (lanes with nothing to fetch: the output's first bytes)
+          const wv::Quad q0 = wv::load_quad(dst + goff), q1 = wv::load_quad(dst + (goff + 16u));
+          if (a_len != 0u) {
+            uint8_t *t = tile + a_dp;
+            const uint32_t w[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) {
+              if (4u * i + 4u <= a_len) store_u32_le(t + 4u * i, w[i]);
+              else if (4u * i < a_len) {
+                t[4u * i] = (uint8_t)w[i];
+                if (4u * i + 1u < a_len) t[4u * i + 1u] = (uint8_t)(w[i] >> 8);
+                if (4u * i + 2u < a_len) t[4u * i + 2u] = (uint8_t)(w[i] >> 16);
+              }
+            }
+            span_bits_clear(mbits, a_dp, a_len);
+          }
+          if (far) list[c0 + ulane] = 0xFFFFu;  // done
+          a0 = q0; a1 = q1; a_dp = dp; a_len = far ? len : 0u;
+          if (c0 >= n_open) break;  // (one step behind the last holes: what they requested is written)
         }
-        break;
+        wv::sync();
       }
-      n_open = kept;
-    }
-    if (h_total <= SPAN_LIST_MAX) break;
-    {  // what is still open of my own holes
-      uint32_t cursor = mine ? o0 : 0u, cnt = 0;
-      const uint32_t range_end = mine ? o_end : 0u;
+      ZD_SPAN_PH(4);
       for (;;) {
-        const uint32_t dp = span_bits_first(mbits, cursor, range_end);
-        const bool open = dp != 0xFFFFFFFFu;
-        if (!wv::any(open)) break;
-        if (open) {
-          cnt++;
-          cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
+        uint32_t kept = 0;
+#ifdef SPAN_TRACE
+        if (lane == 0) span_trace_steps[3]++;
+#endif
+        for (uint32_t c0 = 0; c0 < n_open; c0 += 64u) {
+#ifdef SPAN_TRACE
+          if (lane == 0) span_trace_steps[7]++;
+#endif
+          const uint32_t dp = c0 + ulane < n_open ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
+          const bool open = dp != 0xFFFFu;
+          uint32_t dist = 1, len = 0;
+          if (open) {
+            const uint32_t rec = span_rec(tile, dp);
+            dist = (rec & 0x7FFFu) + 1u;
+            len = (rec >> 16) + 3u;
+          }
+          const int sp = (int)dp - (int)dist;
+          bool ready = false;
+          if (open) {
+            const int a = sp > 0 ? sp : 0;
+            const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
+            ready = b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
+          }
+          const bool go = ready && len <= SPAN_LONG;
+          // a period of 1, 2 or 3 bytes: twelve bytes of it in registers
+          uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
+          const bool pat = go && dist < 4u;
+          if (pat) {
+            const uint32_t b0 = span_byte_at(tile, gbase, sp), b1 = span_byte_at(tile, gbase, sp + (dist > 1u ? 1 : 0)),
+                           b2 = span_byte_at(tile, gbase, sp + (dist > 2u ? 2 : 0));
+            if (dist == 3u) {
+              pw0 = b0 | b1 << 8 | b2 << 16 | b0 << 24;
+              pw1 = b1 | b2 << 8 | b0 << 16 | b1 << 24;
+              pw2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
+            } else {
+              pw0 = pw1 = pw2 = (b0 | b1 << 8) * 0x00010001u;  // (dist 1: b1 is b0)
+            }
+          }
+          wv::sync();  // records and bits are read before anybody writes bytes over them
+          // three ways to move the bytes: four at a time inside the tile (distance >= 4), the period's
+          // words, byte by byte (what reaches before the tile from close to its start: rare)
+          const bool words = go && !pat && sp >= 0;
+          if (words || pat) {
+            uint8_t *t = tile + dp;
+            const uint8_t *f = tile + (sp >= 0 ? sp : 0);
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) {
+              if (4u * i + 4u <= len) {
+                const uint32_t pv = i % 3u == 0u ? pw0 : i % 3u == 1u ? pw1 : pw2;
+                store_u32_le(t + 4u * i, pat ? pv : load_u32_le(f + 4u * i));
+              }
+            }
+            if ((len & 3u) != 0u) {
+              const uint32_t k = len >> 2, pv = k % 3u == 0u ? pw0 : k % 3u == 1u ? pw1 : pw2;
+              if (!pat && len >= 4u) store_u32_le(t + (len - 4u), load_u32_le(f + (len - 4u)));  // (over bytes just written)
+              else {
+                const uint32_t v = pat ? pv : load_u32_le(f + 4u * k);  // len 3: (the tile has 16 bytes behind it)
+                t[4u * k] = (uint8_t)v;
+                if ((len & 3u) >= 2u) t[4u * k + 1u] = (uint8_t)(v >> 8);
+                if ((len & 3u) == 3u) t[4u * k + 2u] = (uint8_t)(v >> 16);
+              }
+            }
+          }
+          if (wv::any(go && !words && !pat)) {
+            for (uint32_t i = 0;; i++) {
+              const bool g = go && !words && !pat && i < len;
+              if (!wv::any(g)) break;
+              if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+            }
+          }
+          // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
+          for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+            const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
+            span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
+          }
+          if (ready) span_bits_clear(mbits, dp, len);
+          // what is still open moves up in the list
+          const uint64_t km = wv::ballot(open && !ready);
+          if (open && !ready) list[kept + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
+          kept += (uint32_t)__builtin_popcountll(km);
+          wv::sync();
         }
+        if (kept == 0u) break;
+        // A round that filled one or two of many open holes: they form a chain (each
+        // copying from the one before: hand-made streams, short periods cut into short matches), and
+        // rounds would take as many passes as it has links.  In stream order every hole's source is
+        // final when its turn comes: the rest one after the other, each by the whole wave.
+        // (Holes that follow each other at one distance -- a period cut into short matches -- are one
+        // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
+        if (n_open - kept <= 2u && kept >= 64u) {
+          for (uint32_t h = 0; h < kept;) {
+            const bool have = h + ulane < kept;
+            const uint32_t dp = have ? (uint32_t)list[h + ulane] : 0u;
+            uint32_t dist = 0, len = 0;
+            if (have) {
+              const uint32_t rec = span_rec(tile, dp);
+              dist = (rec & 0x7FFFu) + 1u;
+              len = (rec >> 16) + 3u;
+            }
+            const uint32_t pdp = wv::shfl(dp, ulane - 1u), plen = wv::shfl(len, ulane - 1u), pdist = wv::shfl(dist, ulane - 1u);
+            const bool joins = ulane == 0u || (have && dp == pdp + plen && dist == pdist);
+            const uint64_t jm = wv::ballot(joins);
+            const uint32_t run = ~jm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~jm);  // >= 1: lane 0 has a hole
+            const uint32_t total = wv::readlane(wv::scan_incl(len), run - 1u);
+            const uint32_t dp0 = wv::readlane(dp, 0u), dist0 = wv::readlane(dist, 0u);
+            wv::sync();  // (the records are read before any lane writes over them)
+            span_fill_by_wave(tile, gbase, dp0, dist0, total, ulane);
+            if (ulane == 0u) span_bits_mark<false>(mbits, dp0, total);
+            wv::sync();
+            h += run;
+          }
+          break;
+        }
+        n_open = kept;
       }
-      my_open = cnt;
-    }
+      if (h_total <= SPAN_LIST_MAX) break;
+      {  // what is still open of my own holes
+        uint32_t cursor = mine ? o0 : 0u, cnt = 0;
+        const uint32_t range_end = mine ? o_end : 0u;
+        for (;;) {
+          const uint32_t dp = span_bits_first(mbits, cursor, range_end);
+          const bool open = dp != 0xFFFFFFFFu;
+          if (!wv::any(open)) break;
+          if (open) {
+            cnt++;
+            cursor = dp + (span_rec(tile, dp) >> 16) + 3u;
+          }
+        }
+        my_open = cnt;
+      }
     }
     ZD_SPAN_PH(5);
     // the tile leaves
