@@ -107,3 +107,25 @@ def test_more_holes_than_a_tile_lists(gpu_ctx, oracle):
                                  [len(p) for _, p, _ in cases], 2)
     for i, (comp, plain, c0) in enumerate(cases):
         assert got[i] == (0, plain, c0), i
+
+
+def test_random_hand_made_blocks(gpu_ctx, oracle):
+    """blocks of random literals and matches at every mix of short and long lengths, near and far
+    distances (util.random_fixed_block): dense near matches, chains of them, runs -- the shapes the
+    hole filling and the run copy have special paths for, at random"""
+    cases = []
+    for seed in range(96):
+        comp, plain = util.random_fixed_block(seed, 12000, max_dist=[1, 3, 4, 16, 64, 300, 5000, 32768][seed % 8],
+                                              max_len=[3, 4, 10, 40, 258][(seed // 8) % 5], lit_share=[0.0, 0.05, 0.5][seed % 3])
+        assert zlib.decompress(comp, -15) == plain
+        cases.append((comp, plain))
+    got = util.gpu_inflate_batch(gpu_ctx, [c for c, _ in cases], [len(p) for _, p in cases], [True] * len(cases),
+                                 [len(p) for _, p in cases], 1)
+    for i, (comp, plain) in enumerate(cases):
+        assert got[i][0] == 0 and got[i][1] == plain and got[i][2] == zlib.crc32(plain), i
+    # and with the size limit inside: same accept / reject as the oracle
+    lims = [len(p) - 1 - (i * 37) % 300 for i, (_, p) in enumerate(cases)]
+    got = util.gpu_inflate_batch(gpu_ctx, [c for c, _ in cases], [len(p) for _, p in cases], [True] * len(cases), lims, 1)
+    for i, (comp, plain) in enumerate(cases):
+        st0, _, _ = oracle.inflate(comp, decompressed_size=lims[i])
+        assert got[i][0] == st0 != 0, i

@@ -213,6 +213,13 @@ def test_inflate_span_model(sim, oracle, monkeypatch):
             st0, d0, a0 = oracle.inflate(c, decompressed_size=len(data), crc_op=2)
             st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
             assert (st0, d0) == (0, data) and (st, d, a) == (0, data, a0), (length, dist, order)
+        # random literals and matches at every mix of lengths and distances, hand-made
+        for seed in range(8 if order == "a" else 3):
+            c, data = util.random_fixed_block(seed, 5000, max_dist=[1, 4, 64, 300, 5000, 3, 16, 32768][seed], max_len=[3, 4, 10, 40, 258][seed % 5],
+                                              lit_share=[0.0, 0.05, 0.5][seed % 3])
+            st0, d0, a0 = oracle.inflate(c, decompressed_size=len(data), crc_op=2)
+            st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
+            assert (st0, d0) == (0, data) and (st, d, a) == (0, data, a0), (seed, order)
         # random complete codes (long codes, odd alphabets), thousands of symbols; then damaged
         seen = {}
         for k, s in enumerate(long_random):

@@ -379,3 +379,46 @@ def fixed_block_of_short_matches(n_matches, length, dist, lead=b"abcdefgh", seed
             plain.append(plain[-d])
     w.code(0, 7)                              # end of block
     return w.bytes(), bytes(plain)
+
+
+_DIST_BASE = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145,
+              8193, 12289, 16385, 24577]
+_LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+
+
+def random_fixed_block(seed, n_symbols, max_dist=300, max_len=20, lit_share=0.3):
+    """one fixed-Huffman block of random literals and matches (any legal length up to max_len, any
+    distance up to max_dist that the output so far allows): streams no encoder writes -- dense near
+    matches, chains of them -- but every decoder must read.  Returns (compressed, plain)."""
+    r = random.Random(seed)
+    w = BitWriter()
+    w.field(1, 1); w.field(1, 2)
+    plain = bytearray()
+
+    def lit(c):
+        if c < 144: w.code(0x30 + c, 8)
+        else: w.code(0x190 + c - 144, 9)
+        plain.append(c)
+
+    for c in b"seed":
+        lit(c)
+    for _ in range(n_symbols):
+        if r.random() < lit_share:
+            lit(r.randrange(256))
+            continue
+        ln = r.randrange(3, max_len + 1)
+        d = r.randrange(1, min(max_dist, len(plain)) + 1)
+        li = max(i for i, b in enumerate(_LEN_BASE) if b <= ln)
+        if li == 28 and ln != 258: li = 27
+        sym = 257 + li
+        if sym < 280: w.code(sym - 256, 7)
+        else: w.code(0xC0 + sym - 280, 8)
+        ebits = 0 if li < 8 or li == 28 else (li - 4) // 4
+        w.field(ln - _LEN_BASE[li], ebits)
+        di = max(i for i, b in enumerate(_DIST_BASE) if b <= d)
+        w.code(di, 5)
+        w.field(d - _DIST_BASE[di], 0 if di < 4 else (di - 2) // 2)
+        for _ in range(ln):
+            plain.append(plain[-d])
+    w.code(0, 7)
+    return w.bytes(), bytes(plain)
