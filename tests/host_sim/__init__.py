@@ -23,6 +23,8 @@ def lib():
     L.sim_deflate.restype = C.c_int
     L.sim_deflate.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
                               C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]
+    L.sim_huff_lengths.restype = C.c_int
+    L.sim_huff_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.sim_crc_advance.restype = C.c_uint32
     L.sim_crc_advance.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64]
     L.sim_chain.restype = None

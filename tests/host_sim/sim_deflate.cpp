@@ -178,6 +178,17 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       }
       for (uint32_t p = 0; p + 4 <= len; p++)
         if (match2[p] != match[p] || match3[p] != match[p]) return 98;
+      // the walk the window kernel runs now: byte at best_len first, cheap steps, compares together
+      std::vector<uint64_t> match4(len + 8, 0), match5(len + 8, 0);
+      for (uint32_t wbeg = 0; wbeg + 4 <= len; wbeg += 1024) {
+        const uint32_t wend = wbeg + 1024 < len - 3 ? wbeg + 1024 : len - 3;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+          lz_match_scan_serial<true>(padded.data(), len, wbeg + lane, 64, wend, prev.data(), K, K / 4, match4.data());
+          lz_match_scan_serial<false>(src, len, wbeg + lane, 64, wend, prev.data(), K, K / 4, match5.data());
+        }
+      }
+      for (uint32_t p = 0; p + 4 <= len; p++)
+        if (match4[p] != match[p] || match5[p] != match[p]) return 97;
     }
     // macro step of every position (+ literal runs), then the walk in small
     // resumable slices like the kernel's ring, then the symbol emission
@@ -275,5 +286,17 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
   *n_kinds = nk;
   if (w.out.size() > dst_cap) return 16;
   memcpy(dst, w.out.data(), w.out.size());
+  return 0;
+}
+
+// Huffman.lengths_of_freqs two ways: the reference's heap (huff_lengths_of_freqs) and the two
+// queues the kernel uses (huff_lengths_of_freqs_tq).  Returns 0 when the lengths are equal.
+extern "C" int sim_huff_lengths(const uint32_t *freqs, int max_sym, int max_code_len, uint32_t *out_heap,
+                                uint32_t *out_tq) {
+  std::vector<uint32_t> heap(2 * (max_sym + 1) + 8, 0), scratch(4 * (max_sym + 1) + 8, 0);
+  huff_lengths_of_freqs(heap.data(), out_heap, freqs, max_sym, max_code_len);
+  huff_lengths_of_freqs_tq(scratch.data(), out_tq, freqs, max_sym, max_code_len);
+  for (int i = 0; i <= max_sym; i++)
+    if (out_heap[i] != out_tq[i]) return 1 + i;
   return 0;
 }

@@ -30,3 +30,24 @@ def test_randomized_parity_bounded(gpu_ctx, oracle):
             break
     assert bad == 0, lines[:10]
     assert total > 1000
+
+
+@pytest.mark.parametrize("env", [
+    {"ZIPC_HIP_MATCH_FORM": "2"},                                   # the byte-first walk on every tile (default: chosen per tile)
+    {"ZIPC_HIP_MATCH_FORM": "1"},                                   # the first walk on every tile
+    {"ZIPC_HIP_SLICES": "3", "ZIPC_HIP_SLICE_MIN": "1"},            # batches cut into slices on side queues
+    {"ZIPC_HIP_MATCH_FORM": "2", "ZIPC_HIP_MATCH_TILES_PER_GROUP": "3", "ZIPC_HIP_SLICES": "2", "ZIPC_HIP_SLICE_MIN": "1"},
+], ids=["scan-walk", "first-walk", "slices", "scan-walk+groups+slices"])
+def test_randomized_parity_under_overrides(env):
+    """The same loop in a process of its own under the library's overrides (read once per process), so that
+    the paths a 120-stream batch would not reach by itself are compared with the oracle too."""
+    import subprocess
+    import sys
+
+    day = datetime.date.today().timetuple().tm_yday
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), str(70000 + 10 * day), "2"],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-600:]
+    assert r.returncode == 0 and "FUZZ ok" in tail, tail

@@ -52,7 +52,37 @@ hipEvent_t zipc_hip_ctx::get_event() {
 
 void zipc_hip_ctx::begin(const char *, hipEvent_t &start) {
   start = get_event();
-  (void)hipEventRecord(start, stream);
+  (void)hipEventRecord(start, cur);
+}
+
+hipError_t zipc_hip_ctx::fork(size_t k) {
+  while (side.size() < k) {
+    hipStream_t s = nullptr;
+    hipEvent_t e = nullptr;
+    hipError_t r = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (r != hipSuccess) return r;
+    r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (r != hipSuccess) { (void)hipStreamDestroy(s); return r; }
+    side.push_back(s);
+    side_done.push_back(e);
+  }
+  if (!fork_ev) {
+    const hipError_t r = hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming);
+    if (r != hipSuccess) return r;
+  }
+  hipError_t r = hipEventRecord(fork_ev, stream);
+  for (size_t i = 0; i < k && r == hipSuccess; i++) r = hipStreamWaitEvent(side[i], fork_ev, 0);
+  return r;
+}
+
+hipError_t zipc_hip_ctx::join(size_t k) {
+  hipError_t r = hipSuccess;
+  for (size_t i = 0; i < k && r == hipSuccess; i++) {
+    r = hipEventRecord(side_done[i], side[i]);
+    if (r == hipSuccess) r = hipStreamWaitEvent(stream, side_done[i], 0);
+  }
+  cur = stream;
+  return r;
 }
 
 void zipc_hip_ctx::end(const char *name, hipEvent_t start) {
@@ -60,7 +90,7 @@ void zipc_hip_ctx::end(const char *name, hipEvent_t start) {
   p.name_idx = name_index(name);
   p.start = start;
   p.stop = get_event();
-  (void)hipEventRecord(p.stop, stream);
+  (void)hipEventRecord(p.stop, cur);
   pending.push_back(p);
 }
 
@@ -172,6 +202,60 @@ struct EventSet {
   }
 };
 
+namespace zd {
+size_t batch_slices(size_t n_streams) {
+  static const long env = [] { const char *e = getenv("ZIPC_HIP_SLICES"); return e ? atol(e) : 0L; }();
+  static const long env_min = [] { const char *e = getenv("ZIPC_HIP_SLICE_MIN"); return e ? atol(e) : 0L; }();  // tests
+  size_t k = env > 0 ? (size_t)env : 1;
+  if (k > 8) k = 8;
+  const size_t least = env_min > 0 ? (size_t)env_min : 2048;
+  while (k > 1 && n_streams / k < least) k--;
+  return k;
+}
+size_t crc32_segs(size_t max_len) {
+  const size_t segs = (max_len + CRC_SEG_BYTES - 1) / CRC_SEG_BYTES;
+  return segs ? segs : 1;
+}
+hipError_t crc32_segments_launch(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
+                                 const StreamResult *d_results, size_t n_ranges, uint64_t single_off,
+                                 uint64_t single_len, size_t max_len, uint32_t *partials) {
+  const size_t segs = crc32_segs(max_len);
+  if (n_ranges * segs > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  ZD_LAUNCH(ctx, "crc32_segments", crc32_segments_kernel, dim3((unsigned)(n_ranges * segs)), dim3(256), 0,
+            base, mode, d_descs, d_results, single_off, single_len, (uint32_t)segs, (const uint32_t *)ctx->crc_nib.p,
+            partials);
+  return hipGetLastError();
+}
+hipError_t crc32_finish_launch(zipc_hip_ctx *ctx, int mode, const StreamDesc *d_descs, StreamResult *d_results,
+                               size_t n_ranges, uint64_t single_len, size_t max_len, const uint32_t *partials,
+                               uint32_t *d_single_out) {
+  const size_t segs = crc32_segs(max_len);
+  if (mode != RANGE_SINGLE && segs <= 16)  // a batch of short streams: one per thread
+    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_streams_kernel, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0,
+              mode, d_descs, d_results, (uint32_t)n_ranges, (uint32_t)segs, ctx->crc_consts, partials);
+  else
+    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
+              d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts, (const uint32_t *)ctx->crc_nib.p,
+              partials, d_single_out);
+  return hipGetLastError();
+}
+}  // namespace zd
+
+// the whole CRC-32 pass on ctx->cur; partials: the context's buffer from word `partials_at` on
+static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
+                      StreamResult *d_results, size_t n_ranges, uint64_t single_off,
+                      uint64_t single_len, size_t max_len, uint32_t *d_single_out, size_t partials_at = 0,
+                      bool ensured = false) {
+  const size_t segs = crc32_segs(max_len);
+  if (n_ranges * segs > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (!ensured) HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, (partials_at + n_ranges * segs) * sizeof(uint32_t)));
+  uint32_t *partials = (uint32_t *)ctx->crc_partials.p + partials_at;
+  HIP_TRY(ctx, crc32_segments_launch(ctx, base, mode, d_descs, (const StreamResult *)d_results, n_ranges, single_off,
+                                     single_len, max_len, partials));
+  HIP_TRY(ctx, crc32_finish_launch(ctx, mode, d_descs, d_results, n_ranges, single_len, max_len, partials, d_single_out));
+  return ZIPC_HIP_OK;
+}
+
 extern "C" {
 
 int zipc_hip_abi_version(void) { return ZIPC_HIP_ABI_VERSION; }
@@ -214,6 +298,7 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
     delete ctx;
     return ZIPC_HIP_ERR_HIP;
   }
+  ctx->cur = ctx->stream;
   // CRC merge constants (zd_common.h), computed with the same GF(2) routines the
   // kernels use
   uint32_t x = gf2_xpow8n(CRC_PIECE_BYTES);
@@ -250,6 +335,9 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   if (ctx->pin_res.p) (void)hipHostFree(ctx->pin_res.p);
   if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
   if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
+  for (auto s : ctx->side) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+  for (auto e : ctx->side_done) (void)hipEventDestroy(e);
+  if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -312,29 +400,6 @@ size_t zipc_hip_deflate_bound(size_t len) {
 size_t zipc_hip_zlib_bound(size_t len) { return zipc_hip_deflate_bound(len) + 6; }
 
 // ---- batch forms ---------------------------------------------------------------
-
-static int crc32_pass(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
-                      StreamResult *d_results, size_t n_ranges, uint64_t single_off,
-                      uint64_t single_len, size_t max_len, uint32_t *d_single_out) {
-  size_t segs = (max_len + CRC_SEG_BYTES - 1) / CRC_SEG_BYTES;
-  if (segs == 0) segs = 1;
-  if (n_ranges * segs > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
-  HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_ranges * segs * sizeof(uint32_t)));
-  uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
-  ZD_LAUNCH(ctx, "crc32_segments", crc32_segments_kernel, dim3((unsigned)(n_ranges * segs)), dim3(256), 0,
-            base, mode, d_descs, (const StreamResult *)d_results, single_off, single_len,
-            (uint32_t)segs, (const uint32_t *)ctx->crc_nib.p, partials);
-  if (mode != RANGE_SINGLE && segs <= 16)  // a batch of short streams: one per thread
-    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_streams_kernel, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0,
-              mode, d_descs, d_results, (uint32_t)n_ranges, (uint32_t)segs, ctx->crc_consts,
-              (const uint32_t *)partials);
-  else
-    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
-              d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts, (const uint32_t *)ctx->crc_nib.p,
-              (const uint32_t *)partials, d_single_out);
-  HIP_TRY(ctx, hipGetLastError());
-  return ZIPC_HIP_OK;
-}
 
 // One stream beyond ZIPC_HIP_MAX_STREAM_LEN: the chain of equal stored blocks it has to start with
 // (inflate.hip) is found and copied with 64-bit offsets, what follows goes through the batch kernel
@@ -410,16 +475,35 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_streams == 1 && max_dst_cap > MAX_STREAM_LEN)
     return inflate_huge_stream(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op);
-  // one wave per stream
+  // one wave per stream (ZIPC_HIP_SLICES > 1: in slices on queues of their own, the CRC pass of one slice
+  // beside the inflate kernel of the next; measured, not the default: deflate.hip)
   HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));
-  ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)n_streams), dim3(64), 0,
-            (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
-            (StreamResult *)d_results, (uint32_t)n_streams, (uint16_t *)ctx->inflate_scratch.p, crc_op);
-  HIP_TRY(ctx, hipGetLastError());
-  if (crc_op == ZIPC_HIP_CRC_CRC32)
-    return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs,
-                      (StreamResult *)d_results, n_streams, 0, 0, max_dst_cap, nullptr);
-  return ZIPC_HIP_OK;
+  const size_t segs = crc32_segs(max_dst_cap);
+  if (crc_op == ZIPC_HIP_CRC_CRC32) {
+    if (n_streams * segs > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+    HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_streams * segs * sizeof(uint32_t)));
+  }
+  const size_t k = crc_op == ZIPC_HIP_CRC_CRC32 ? batch_slices(n_streams) : 1;
+  if (k > 1) HIP_TRY(ctx, ctx->fork(k));
+  int st = ZIPC_HIP_OK;
+  for (size_t i = 0; i < k && st == ZIPC_HIP_OK; i++) {
+    const size_t lo = n_streams * i / k, hi = n_streams * (i + 1) / k;
+    if (k > 1) ctx->use_slice_stream(i);
+    const StreamDesc *dd = (const StreamDesc *)d_descs + lo;
+    StreamResult *dr = (StreamResult *)d_results + lo;
+    ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
+              (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
+              (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
+    if (hipGetLastError() != hipSuccess) { ctx->last_error = "inflate_batch launch failed"; st = ZIPC_HIP_ERR_HIP; break; }
+    if (crc_op == ZIPC_HIP_CRC_CRC32)
+      st = crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, dd, dr, hi - lo, 0, 0, max_dst_cap, nullptr,
+                      lo * segs, true);
+  }
+  if (k > 1) {
+    const hipError_t e = ctx->join(k);
+    if (st == ZIPC_HIP_OK) HIP_TRY(ctx, e);
+  }
+  return st;
 }
 
 int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
@@ -434,12 +518,13 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, ctx->ensure(ctx->deflate_scratch,
                            deflate_scratch_bytes(n_streams, max_src_len, total_src_len, level)));
+  if (crc_op == ZIPC_HIP_CRC_CRC32) {  // (launch_deflate runs the pass, group by group)
+    if (n_streams * crc32_segs(max_src_len) > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+    HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, n_streams * crc32_segs(max_src_len) * sizeof(uint32_t)));
+  }
   HIP_TRY(ctx, launch_deflate(ctx, (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena,
                               (const StreamDesc *)d_descs, (StreamResult *)d_results, n_streams,
                               max_src_len, total_src_len, level, crc_op));
-  if (crc_op == ZIPC_HIP_CRC_CRC32)
-    return crc32_pass(ctx, (const uint8_t *)d_src_arena, RANGE_DEFLATE_SRC, (const StreamDesc *)d_descs,
-                      (StreamResult *)d_results, n_streams, 0, 0, max_src_len, nullptr);
   return ZIPC_HIP_OK;
 }
 

@@ -11,6 +11,16 @@
 struct zipc_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // The stream ZD_LAUNCH enqueues on: `stream`, or one of `side` while a batch call has its
+  // slices in flight (fork()/join() below).
+  hipStream_t cur = nullptr;
+  // Side streams of the batch forms (ZIPC_HIP_SLICES > 1, not the default: deflate.hip has the
+  // measurement).  A large batch is cut into slices of consecutive streams and every slice's kernels
+  // go to a queue of their own.  Work is still ordered behind everything enqueued on `stream` before
+  // the call (fork) and everything enqueued on `stream` after the call is ordered behind the slices (join).
+  std::vector<hipStream_t> side;
+  std::vector<hipEvent_t> side_done;
+  hipEvent_t fork_ev = nullptr;
   bool profiling = false;
   bool adler_rfc1950 = false;  // zipc_hip_set_adler_rfc1950: the zlib forms and checksum_device use RFC 1950's Adler-32
   std::string last_error;
@@ -43,6 +53,12 @@ struct zipc_hip_ctx {
   hipError_t ensure(Buf &b, size_t bytes);
   hipError_t ensure_pinned(Buf &b, size_t bytes);
   hipError_t collect_times();
+  // side streams [0, k) wait for what `stream` holds now / `stream` waits for side streams [0, k)
+  // (join also points `cur` back at `stream`; every fork is followed by a join on every path)
+  hipError_t fork(size_t k);
+  hipError_t join(size_t k);
+  // slice i of a batch call goes to: `stream` for i = 0, side[i] above
+  void use_slice_stream(size_t i) { cur = i == 0 ? stream : side[i]; }
 };
 
 // Launch `kernel<<<grid, block, lds, ctx->stream>>>(args...)`, bracketed by HIP
@@ -51,11 +67,23 @@ struct zipc_hip_ctx {
   do {                                                                            \
     hipEvent_t _zd_start = nullptr;                                               \
     if ((ctx)->profiling) (ctx)->begin(name, _zd_start);                          \
-    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);     \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->cur, __VA_ARGS__);        \
     if ((ctx)->profiling) (ctx)->end(name, _zd_start);                            \
   } while (0)
 
 namespace zd {
+// api.hip: into how many slices of consecutive streams a batch of n is cut (1: no side streams).
+// ZIPC_HIP_SLICES overrides the default; a slice holds at least 2048 streams.
+size_t batch_slices(size_t n_streams);
+// api.hip: the two halves of the CRC-32 pass over n_ranges ranges of up to max_len bytes, on ctx->cur.
+// partials: n_ranges * crc32_segs(max_len) words.
+size_t crc32_segs(size_t max_len);
+hipError_t crc32_segments_launch(zipc_hip_ctx *ctx, const uint8_t *base, int mode, const StreamDesc *d_descs,
+                                 const StreamResult *d_results, size_t n_ranges, uint64_t single_off,
+                                 uint64_t single_len, size_t max_len, uint32_t *partials);
+hipError_t crc32_finish_launch(zipc_hip_ctx *ctx, int mode, const StreamDesc *d_descs, StreamResult *d_results,
+                               size_t n_ranges, uint64_t single_len, size_t max_len, const uint32_t *partials,
+                               uint32_t *d_single_out);
 // deflate.hip: bytes of scratch the pipeline needs, and the pipeline itself
 size_t deflate_scratch_bytes(size_t n_streams, size_t max_src_len, size_t total_src_len, int level);
 hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,

@@ -422,14 +422,16 @@ constexpr int MATCHW_NP = 2;  // run slots per lane.  3 and 4 measured on C2 wit
                                // +6 % on real text: the loop is nearer its vector bound than latency-bound
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
+#ifndef ZD_SCAN_STEPS
+#define ZD_SCAN_STEPS 6
+#endif
+// run-slot steps per position (iterations x lanes x slots / positions) from which the second form of the walk
+// pays: 4-bit symbols take 2.7 of the first form's (1.56 chain steps at 0.58 lane use), 3-bit symbols ~12, text ~48
+constexpr uint32_t MATCHW_SCAN_STEPS = ZD_SCAN_STEPS;
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
 static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
 static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
 
-#ifdef ZD_MATCH_UTIL  // counting build (experiments): [0] wave steps (iterations x slots) [1] lane steps that walked a candidate
-// [2] long compares [3] their lengths / 8 [4] iterations with a handout [5] positions handed out
-__device__ unsigned long long zd_match_util[8];
-#endif
 #ifdef ZD_MATCH_PHASES  // timing-only build (tools/exp_match_phases.py): clock deltas, data paths untouched
 // Slot = workgroup index mod ZD_PH_SLOTS (plain atomics on one address from every workgroup
 // cost more than the kernel), 8 words each, s_memtime (shader clock) ticks unless noted:
@@ -475,10 +477,12 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
-                                                                         uint32_t tiles_per_group, int K, int Kq) {
+                                                                         uint32_t tiles_per_group, int K, int Kq,
+                                                                         int form) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
   __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
+  __shared__ uint32_t tile_iters[2];  // loop iterations of the workgroup's waves in the tile they walk (by tile parity)
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
   unsigned long long ph0 = __builtin_readcyclecounter();
@@ -546,8 +550,16 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   MatchTile g = match_tile(tile, len);
   issue(g.w0, g.n_src, g.n_links);
   store(g);
-  if (tid == 0) pool_next = 0;
+  if (tid == 0) { pool_next = 0; tile_iters[0] = 0; tile_iters[1] = 0; }
   __syncthreads();
+  // Two forms of the walk (deflate_lane.h): the first reads every candidate's 8 bytes and is the
+  // faster one where chains hold a candidate or two (the benchmark's 4-bit symbols: 1.2 per
+  // position); the second looks at one byte first and compares in bulk, and is the faster one on
+  // long chains (3-bit symbols 8.5, text 34 per position: -14 % and -39 % of the kernel; +8 % on the
+  // 4-bit symbols).  Same results; a workgroup takes the second form for a tile when the tile
+  // before it took more than MATCHW_SCAN_STEPS run-slot steps per position (its first tile: the first form).
+  // form: 0 that rule, 1 / 2 always the first / second form (ZIPC_HIP_MATCH_FORM: tests and tuning).
+  bool scan_form = form == 2;
   for (;;) {
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
@@ -566,7 +578,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     {
       const uint64_t tend64 = (uint64_t)g.t0 + MATCHW_TILE < (uint64_t)len - 3 ? (uint64_t)g.t0 + MATCHW_TILE : (uint64_t)len - 3;
-      lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base)
+                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
+      if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
     }
 #ifdef ZD_MATCH_PHASES
     {
@@ -596,8 +610,10 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if (!has_next) break;
     issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
+    // run-slot steps the tile took per position (a tile with a successor is a full one): chain steps / lane use
+    if (form == 0) scan_form = tile_iters[tile & 1u] * (64u * MATCHW_NP) > MATCHW_SCAN_STEPS * MATCHW_TILE;
     store(gn);
-    if (tid == 0) pool_next = 0;
+    if (tid == 0) { pool_next = 0; tile_iters[(tile + 1) & 1u] = 0; }  // the next tile's counter: nobody touches it now
     __syncthreads();
     tile++;
     g = gn;
@@ -896,44 +912,68 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// Huffman.lengths_of_freqs zd.ml:404-473 (huff_lengths_of_freqs)
+// Huffman.lengths_of_freqs zd.ml:404-473 on two queues (huff_tree_two_queues, deflate_lane.h, has
+// why that is the reference's tree).  The leaves are keyed and sorted by all lanes (rank by counting:
+// the keys are distinct), ONE lane merges -- n - 1 steps of a few LDS reads each, where the heap
+// took 2 (n - 1) sift-downs of log n dependent levels -- and all lanes climb from their leaves.
+// heap: 2 n + 2 words of LDS (n <= max_sym + 1): n queue words, then the parents as u16.
 __device__ __forceinline__ void wave_lengths_of_freqs(uint32_t *heap, uint32_t *e, const uint32_t *freqs, int max_sym,
                                                       int max_code_len, int lane) {
   uint32_t freq_cap = 65535;
   for (;;) {
-    int max = 0;
+    // keys of the used symbols in symbol order, at tmp[rank - 1]
+    int n = 0;
 #pragma unroll 1
-    for (int c = 0; c <= max_sym; c += 64) {  // leaves, in symbol order
+    for (int c = 0; c <= max_sym; c += 64) {
+      const int sym = c + lane;
+      const uint32_t f = sym <= max_sym ? freqs[sym] : 0u;
+      n += __popcll(__builtin_amdgcn_ballot_w64(f != 0));
+    }
+    if (n < 2) {  // trivial_codeword_lengths zd.ml:462-466
+      for (int sym = lane; sym <= max_sym; sym += 64) e[sym] = freqs[sym] == 0 ? 0u : 1u;
+      return;
+    }
+    uint32_t *q = heap, *tmp = heap + n;          // tmp: where the parents go later
+    uint16_t *par = (uint16_t *)(heap + n);
+    int rank0 = 0;
+#pragma unroll 1
+    for (int c = 0; c <= max_sym; c += 64) {
       const int sym = c + lane;
       uint32_t f = sym <= max_sym ? freqs[sym] : 0u;
       const unsigned long long m = __builtin_amdgcn_ballot_w64(f != 0);
       if (f != 0) {
         if (f > freq_cap) f = freq_cap;
-        const int at = max + 1 + (int)lanes_below(m);
-        heap[at] = (f << 10) | (uint32_t)(max_sym + 1 + at);
+        const int rank = rank0 + 1 + (int)lanes_below(m);
+        tmp[rank - 1] = (f << 10) | (uint32_t)rank;
       }
-      max += __popcll(m);
-    }
-    if (max < 2) {  // trivial_codeword_lengths zd.ml:462-466
-      for (int sym = lane; sym <= max_sym; sym += 64) e[sym] = freqs[sym] == 0 ? 0u : 1u;
-      return;
+      rank0 += __popcll(m);
     }
     wave_sync();
-#pragma unroll 1
-    for (int i = max / 2; i >= 1; i--) huff_heapdown(heap, max, i);
-#pragma unroll 1
-    for (int m = max; m > 1; m--) {  // make_huffman_tree zd.ml:432-445
-      const int new_max = m - 1;
-      const uint32_t p = heap[1];
-      heap[1] = heap[m];
-      huff_heapdown(heap, new_max, 1);
-      const uint32_t q = heap[1];
-      const uint32_t f = (p >> 10) + (q >> 10);
-      heap[1] = (f << 10) | (uint32_t)m;
-      heap[p & 0x3FF] = (uint32_t)m;
-      heap[q & 0x3FF] = (uint32_t)m;
-      huff_heapdown(heap, new_max, 1);
+    // sorted place of a key = number of smaller keys; a lane's keys (up to 5) take one pass together
+    {
+      constexpr int MAXC = (LITLEN_SYM_MAX + 64) / 64;
+      uint32_t key[MAXC], below[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; c++) {
+        const int i = c * 64 + lane;
+        key[c] = i < n ? tmp[i] : 0u;  // 0: below every real key, counts nothing
+        below[c] = 0;
+      }
+      const int chunks = (n + 63) / 64;  // wave-uniform
+#pragma unroll 2
+      for (int j = 0; j < n; j++) {
+        const uint32_t kj = tmp[j];
+#pragma unroll
+        for (int c = 0; c < MAXC; c++)
+          if (c < chunks) below[c] += kj < key[c] ? 1u : 0u;
+      }
+      wave_sync();  // (q does not overlap tmp)
+#pragma unroll
+      for (int c = 0; c < MAXC; c++)
+        if (c * 64 + lane < n) q[below[c]] = key[c];
     }
+    wave_sync();
+    if (lane == 0) huff_tree_two_queues(q, n, par);
     wave_sync();
     bool overflow = false;  // code_lengths_of_tree zd.ml:446-461: every leaf climbs to the root
     int rank = 0;
@@ -944,9 +984,9 @@ __device__ __forceinline__ void wave_lengths_of_freqs(uint32_t *heap, uint32_t *
       const unsigned long long m = __builtin_amdgcn_ballot_w64(nz);
       uint32_t l = 0;
       if (nz) {
-        uint32_t p = heap[max_sym + 1 + rank + 1 + (int)lanes_below(m)];
+        uint32_t p = par[n + rank + 1 + (int)lanes_below(m)];
         l = 1;
-        while (p != 2) { l++; p = heap[p]; }
+        while (p != 2) { l++; p = par[p]; }
       }
       if (sym <= max_sym) e[sym] = l;
       overflow |= l > (uint32_t)max_code_len;
@@ -1038,8 +1078,10 @@ __device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scrat
   if (lane < dist_count) l[litlen_count + lane] = c.dyn_dist[lane] & 0x1F;
   wave_sync();
   // compute_codelen_syms zd.ml:989-1030 (in place: the encoding never expands)
+  // (one lane: the scan is serial, and 64 lanes bumping the same counter were 64 stores to one address)
   const int len_max = litlen_count + dist_count - 1;
   int k = 0, i = 0;
+  if (lane == 0) {
 #pragma unroll 1
   while (i <= len_max) {
     if (l[i] == 0) {
@@ -1068,7 +1110,8 @@ __device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scrat
       }
     }
   }
-  c.codelen_syms_len = k;
+  }
+  c.codelen_syms_len = __builtin_amdgcn_readfirstlane(k);
   wave_sync();
   wave_lengths_of_freqs(c.heap, c.dyn_codelen, c.codelen_freq, CODELEN_SYM_MAX, 7, lane);
   wave_sync();
@@ -1403,7 +1446,14 @@ hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_ds
   if (level == LEVEL_NONE) {
     ZD_LAUNCH(ctx, "deflate_stored", deflate_stored_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst,
               d_descs, d_results, crc_op);
-    return hipGetLastError();
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && crc_op == CRC_CRC32) {
+      uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
+      e = crc32_segments_launch(ctx, d_src, RANGE_DEFLATE_SRC, d_descs, nullptr, n, 0, 0, max_src_len, partials);
+      if (e == hipSuccess)
+        e = crc32_finish_launch(ctx, RANGE_DEFLATE_SRC, d_descs, d_results, n, 0, max_src_len, partials, nullptr);
+    }
+    return e;
   }
   size_t per_group, group_total;
   deflate_grouping(n, max_src_len, total_src_len, per_group, group_total);
@@ -1424,30 +1474,63 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   level_params(level, good_match, K);
   ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S,
             (uint64_t)max_src_len);
-  ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
-  if (max_src_len <= MATCHW_SMALL) {  // short streams: a whole-CU window per tile would sit mostly idle
-    const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
-    if (n * cps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((n * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
-              d_src, d_descs, S, (uint32_t)n, (uint32_t)cps, K, K / 4);
+  // The pipeline of a slice of the group's streams: the slices share the scratch arrays (one
+  // scan above gave every stream its base) and the error word, and differ in where their
+  // per-stream arrays start.
+  const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
+  const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
+  if (n * (max_src_len <= MATCHW_SMALL ? cps : tps) > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  // consecutive tiles of a stream per workgroup: as many as leave the grid >= 8192
+  // workgroups (32 per CU: with 2048 a group of 2048 long streams had one workgroup per stream
+  // and a long tail), so few long streams still spread over the chip
+  // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
+  static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
+  static const int form_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_FORM"); const long v = e ? atol(e) : 0L; return v == 1 || v == 2 ? (int)v : 0; }();
+  size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
+  tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
+  const size_t gps = (tps + tpg - 1) / tpg;
+  auto slice = [&](size_t lo, size_t hi) {
+    const size_t m = hi - lo;
+    DeflateScratch Q = S;
+    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo;
+    const StreamDesc *dd = d_descs + lo;
+    ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
+    if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
+      ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((m * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
+                d_src, dd, Q, (uint32_t)m, (uint32_t)cps, K, K / 4);
+    else
+      ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((m * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
+                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env);
+    ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
+    ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
+              d_results + lo, Q, crc_op);
+  };
+  // ZIPC_HIP_SLICES > 1: the group goes out in slices on queues of their own (ctx.h).  Measured on the
+  // three shapes of tools/exp_wall.py and NOT the default: the kernels are each near their issue bound and
+  // share the chip by workgroup, so slices change the time by -4 .. +3 % (2 slices) or lose (more).  The
+  // CRC-32 pass over the source (deflated_block_src_crc, zd.ml:1081-1086: exact across blocks for CRC-32)
+  // follows the pipeline: its second half writes the checksums into the results deflate_emit wrote.
+  const size_t k = batch_slices(n);
+  hipError_t e = hipSuccess;
+  if (k > 1) {
+    e = ctx->fork(k);
+    if (e != hipSuccess) return e;
+    for (size_t i = 0; i < k; i++) {
+      ctx->use_slice_stream(i);
+      slice(n * i / k, n * (i + 1) / k);
+    }
+    e = ctx->join(k);
   } else {
-    const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
-    if (n * tps > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    // consecutive tiles of a stream per workgroup: as many as leave the grid >= 8192
-    // workgroups (32 per CU: with 2048 a group of 2048 long streams had one workgroup per stream
-    // and a long tail), so few long streams still spread over the chip
-    // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
-    static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
-    size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
-    tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
-    const size_t gps = (tps + tpg - 1) / tpg;
-    ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((n * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-              0, d_src, d_descs, S, (uint32_t)n, (uint32_t)tps, (uint32_t)tpg, K, K / 4);
+    slice(0, n);
   }
-  ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_descs, S, good_match);
-  ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)n), dim3(64), 0, d_src, d_dst, d_descs,
-            d_results, S, crc_op);
-  return hipGetLastError();
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e == hipSuccess && crc_op == CRC_CRC32) {
+    uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
+    e = crc32_segments_launch(ctx, d_src, RANGE_DEFLATE_SRC, d_descs, nullptr, n, 0, 0, max_src_len, partials);
+    if (e == hipSuccess)
+      e = crc32_finish_launch(ctx, RANGE_DEFLATE_SRC, d_descs, d_results, n, 0, max_src_len, partials, nullptr);
+  }
+  return e;
 }
 
 }  // namespace zd
@@ -1465,18 +1548,6 @@ extern "C" int zipc_hip_debug_match_phases(unsigned long long *out8, int reset) 
   if (reset) {
     for (auto &h : host) h = 0;
     if (hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_phases), host, sizeof host) != hipSuccess) return 1;
-  }
-  return 0;
-}
-#endif
-
-#ifdef ZD_MATCH_UTIL
-extern "C" int zipc_hip_debug_match_util(unsigned long long *out8, int reset) {
-  static unsigned long long host[8];
-  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(zd::zd_match_util), sizeof host) != hipSuccess) return 1;
-  if (reset) {
-    for (auto &h : host) h = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_util), host, sizeof host) != hipSuccess) return 1;
   }
   return 0;
 }

@@ -182,9 +182,6 @@ struct MatchRun {
   uint32_t dn;  // prev[q], read ahead: whether the chain goes on is known before the next step
   bool alive, snapped;
   uint64_t pw;
-#ifdef ZD_MATCH_UTIL
-  uint32_t u_walk, u_cmp, u_cmp8;
-#endif
 };
 template <bool WORDS>
 ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend,
@@ -232,13 +229,7 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
       compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
     }
     if (compare) l = common_prefix(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);  // (maxlen >= 8 here means x == 0: the first 8 agree)
-#ifdef ZD_MATCH_UTIL
-    if (compare) { r.u_cmp++; r.u_cmp8 += l >> 3; }
-#endif
   }
-#ifdef ZD_MATCH_UTIL
-  r.u_walk += walk ? 1u : 0u;
-#endif
   r.q = qc;
   r.steps += walk ? 1u : 0u;
   if (walk && l > r.best_len) {
@@ -301,6 +292,135 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
   return iters;
 }
 
+// ---------------------------------------------------------------------------
+// The chain walk of the window kernel (lz_match_window_kernel), second form.  A candidate can only
+// become the best match if it is LONGER than the best so far, which takes agreement in the byte
+// at offset best_len -- so that byte is looked at first (one byte of the LDS window, any
+// alignment) and a candidate that differs there is passed over without reading its 8 bytes:
+// its common prefix is <= best_len, it changes neither the best match nor -- being shorter than
+// maxlen -- the end of the walk (zd.ml:1190-1194), and it still counts as one of the K
+// candidates.  On 3-bit symbols 7 of 8 candidates go that way, on text about as many.  What makes
+// this pay on a wave is the shape of the loop: lanes do up to SCAN_ROUNDS cheap steps (link, byte,
+// compare) until they stand on a candidate that passes -- or their chain ends -- and only then
+// all lanes with such a candidate go through the full compare TOGETHER.  In the first form every
+// step of every lane paid for the long-compare branches, because some lane of the 64 always
+// took them.
+//   state WALK: the next candidate (q - dn) exists and is in range; HIT: q passed the byte test
+//   and waits for the compare; FIN: the position is done and waits for its store; DEAD: no position.
+enum : uint32_t { RUN_WALK = 0, RUN_HIT = 1, RUN_FIN = 2, RUN_DEAD = 3 };
+constexpr uint32_t SNAP_NONE = 0xFFFFFFFFu;  // no snapshot yet (a real one has length bits <= 258)
+struct ScanRun {
+  uint32_t p, q, best_len, best, maxlen, steps;
+  uint32_t snap;   // best after Kq candidates, SNAP_NONE before
+  uint32_t dn;     // prev[q], read with the candidate
+  uint32_t pb;     // s[p + best_len]
+  uint32_t state;  // RUN_*
+  uint64_t pw;     // s[p .. p+8)
+};
+// is there a candidate behind q (whose link is dn)?  zd.ml:1185-1187
+ZD_HD bool scan_next_ok(uint32_t p, uint32_t steps, uint32_t q, uint32_t dn, uint32_t K) {
+  return dn != 0 && steps != K && p - q + dn <= (uint32_t)MAX_MATCH_DIST;
+}
+template <bool WORDS>
+ZD_HD void scan_run_start(ScanRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend, const uint16_t *prev,
+                          uint32_t K) {
+  const bool alive = p < pend;
+  r.p = alive ? p : (pend ? pend - 1u : 0u);  // a run without a position parks on a valid one
+  r.q = r.p;
+  r.best_len = MIN_MATCH_LEN - 1;
+  r.best = 0; r.snap = SNAP_NONE; r.steps = 0;
+  r.maxlen = len - r.p < (uint32_t)MAX_MATCH_LEN ? len - r.p : (uint32_t)MAX_MATCH_LEN;
+  r.pw = 0;
+  if (WORDS) r.pw = load_u64_words(s, r.p);
+  else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
+  else for (uint32_t i = 0; i < r.maxlen; i++) r.pw |= (uint64_t)s[r.p + i] << (8 * i);
+  r.pb = (uint32_t)(r.pw >> 24) & 0xFFu;  // s[p + 3]
+  r.dn = prev[r.p];
+  // zd.ml:1181: no search when even the shortest match does not fit
+  const bool walk = r.best_len < r.maxlen && scan_next_ok(r.p, 0, r.p, r.dn, K);
+  r.state = !alive ? RUN_DEAD : walk ? RUN_WALK : RUN_FIN;
+}
+// One cheap step of a walking run: on to the next candidate, its link and its byte at best_len.
+// Straight-line on purpose (selects, no branches, flags as integers): the workgroup's 16 waves
+// share the CU's one scalar issue per clock, and a divergent branch costs 4-8 scalar instructions
+// (the first form of this step had 20 of them per 14 vector ones and the kernel sat on its
+// scalar bound on text and on 3-bit symbols).  Runs in another state read the bytes of the
+// candidate they stand on again and keep everything.
+ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
+  const bool w = r.state == RUN_WALK;
+  const uint32_t q = w ? r.q - r.dn : r.q;
+  const uint32_t steps = r.steps + (w ? 1u : 0u);
+  const uint32_t b = s[q + r.best_len];  // best_len < maxlen: inside both strings
+  const uint32_t dn = prev[q];
+  const bool hit = b == r.pb;
+  const uint32_t after = hit ? (uint32_t)RUN_HIT : scan_next_ok(r.p, steps, q, dn, K) ? (uint32_t)RUN_WALK : (uint32_t)RUN_FIN;
+  r.snap = (w && !hit && steps == Kq) ? r.best : r.snap;
+  r.q = q;
+  r.steps = steps;
+  r.dn = dn;
+  r.state = w ? after : r.state;
+}
+// the full compare of a run that stands on a candidate which passed the byte test
+template <bool WORDS>
+ZD_HD void scan_run_compare(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
+  if (r.state != RUN_HIT) return;
+  const uint32_t q = r.q;
+  uint32_t l;
+  if (r.maxlen >= 8) {
+    const uint64_t x = (WORDS ? load_u64_words(s, q) : load_u64_le(s + q)) ^ r.pw;
+    l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+    if (x == 0) {
+      // the first 8 bytes agree: before the long compare, the 8 bytes that END at best_len
+      // (they include the byte already tested); what fails here is at most best_len long
+      bool compare = true;
+      if (r.best_len >= 8u) {
+        const uint32_t toff = r.best_len - 7u;
+        compare = WORDS ? load_u64_words(s, q + toff) == load_u64_words(s, r.p + toff)
+                        : load_u64_le(s + q + toff) == load_u64_le(s + r.p + toff);
+      }
+      if (compare) l = common_prefix(s, q, r.p, r.maxlen, 8u);
+    }
+  } else {
+    l = common_prefix(s, q, r.p, r.maxlen, 0u);
+  }
+  const bool better = l > r.best_len;
+  r.best_len = better ? l : r.best_len;
+  r.best = better ? (((r.p - q) << 9) | l) : r.best;
+  if (better && l < r.maxlen) r.pb = s[r.p + l];
+  r.snap = r.steps == Kq ? r.best : r.snap;
+  // zd.ml:1194: after l == maxlen nothing later can be longer
+  r.state = (l != r.maxlen && scan_next_ok(r.p, r.steps, q, r.dn, K)) ? RUN_WALK : RUN_FIN;
+}
+ZD_HD uint64_t scan_run_result(const ScanRun &r, uint32_t Kq) {
+  const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : r.best);
+  return (uint64_t)r.best | ((uint64_t)snap << 32);
+}
+#ifndef ZD_SCAN_ROUNDS
+#define ZD_SCAN_ROUNDS 4
+#endif
+#ifndef ZD_SCAN_MIN_WALKERS
+#define ZD_SCAN_MIN_WALKERS 16
+#endif
+constexpr int SCAN_ROUNDS = ZD_SCAN_ROUNDS;  // cheap steps between two compares, at most
+constexpr int SCAN_MIN_WALKERS = ZD_SCAN_MIN_WALKERS;  // ... and only while this many lanes of the wave still walk
+
+// The same walk for one lane's positions first, first + step, ... < pend, serially (the host
+// model's form; the device runs lz_match_scan_pool below on the same pieces).
+template <bool WORDS>
+ZD_HD void lz_match_scan_serial(const uint8_t *s, uint32_t len, uint32_t first, uint32_t step, uint32_t pend,
+                                const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  for (uint32_t p = first; p < pend; p += step) {
+    ScanRun r;
+    scan_run_start<WORDS>(r, s, len, p, pend, prev, (uint32_t)K);
+    while (r.state != RUN_FIN) {
+      for (int i = 0; i < SCAN_ROUNDS; i++) scan_run_step(r, s, prev, (uint32_t)K, (uint32_t)Kq);
+      scan_run_compare<WORDS>(r, s, prev, (uint32_t)K, (uint32_t)Kq);
+    }
+    out[p] = scan_run_result(r, (uint32_t)Kq);
+    if (pend - p <= step) break;  // (no wrap near 2^32)
+  }
+}
+
 #if defined(__HIPCC__)  // device code of the HIP build only (the host models walk one lane at a time)
 // The window kernel's schedule: ONE pool of a tile's positions [*, pend) for the whole workgroup,
 // behind a counter in LDS.  A wave fetches chunks of POOL_CHUNK positions from it, and inside its
@@ -315,6 +435,8 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 // iteration count.
 constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any one handout.  Measured, same box, 128 / 256 / 512:
                                       // C2 5.58 / 5.44-5.48 / 5.83 ms, real text 145.5 / 150.1 / 167.5 ms
+// first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
+// where chains are a candidate or two long.  Returns the wave's iterations: x 64 NP / positions = steps per position / lane use.
 template <int NP>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
                                                         uint32_t pbeg, uint32_t pend, uint32_t lane,
@@ -322,10 +444,6 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
-#ifdef ZD_MATCH_UTIL
-  for (int i = 0; i < NP; i++) { r[i].u_walk = 0; r[i].u_cmp = 0; r[i].u_cmp8 = 0; }
-  uint32_t u_hand = 0, u_fin = 0;
-#endif
   // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
   // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
   auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
@@ -353,9 +471,6 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
       const bool fin = match_run_step<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out);
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
-#ifdef ZD_MATCH_UTIL
-        u_hand++; u_fin += (uint32_t)__builtin_popcountll(fm);
-#endif
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;
@@ -376,21 +491,87 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
     }
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
   }
-#ifdef ZD_MATCH_UTIL
-  {
-    extern __device__ unsigned long long zd_match_util[8];
-    uint32_t w = 0, c = 0, c8 = 0;
-    for (int i = 0; i < NP; i++) { w += r[i].u_walk; c += r[i].u_cmp; c8 += r[i].u_cmp8; }
-    atomicAdd(&zd_match_util[1], (unsigned long long)w);
-    atomicAdd(&zd_match_util[2], (unsigned long long)c);
-    atomicAdd(&zd_match_util[3], (unsigned long long)c8);
-    if (lane == 0) {
-      atomicAdd(&zd_match_util[0], (unsigned long long)iters * NP);
-      atomicAdd(&zd_match_util[4], (unsigned long long)u_hand);
-      atomicAdd(&zd_match_util[5], (unsigned long long)u_fin);
-    }
+  return iters;
+}
+
+// second form (scan_run_*): the faster one on long chains.  Returns the wave's rounds of cheap steps.
+template <int NP>
+__device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
+                                                        uint32_t pbeg, uint32_t pend, uint32_t lane,
+                                                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  static_assert(64u * NP <= POOL_CHUNK, "chunk");
+  ScanRun r[NP];
+  uint32_t iters = 0;  // rounds of cheap steps (what is returned: the same measure as the first form's iterations)
+  // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
+  // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
+  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
+    uint32_t c = 0;
+    if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
+    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    return c < pend - pbeg ? pbeg + c : pend;
+  };
+  uint32_t next = fetch();  // my chunk is [next, cend)
+  uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
+  bool empty = next >= pend;
+  // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
+  // may end within a chunk of 2^32 and a sum must not wrap into a position that looks valid)
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
+    const uint32_t off = lane + 64u * (uint32_t)i;
+    scan_run_start<true>(r[i], s, len, off < cend - next ? next + off : cend, cend, prev, (uint32_t)K);
   }
-#endif
+  next = cend - next > 64u * NP ? next + 64u * NP : cend;
+  for (;;) {
+    // cheap steps: every walking run goes from candidate to candidate until one passes the byte test
+#pragma unroll 1
+    for (int round = 0; round < SCAN_ROUNDS; round++) {
+      bool walking = false;
+      iters++;
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        scan_run_step(r[i], s, prev, (uint32_t)K, (uint32_t)Kq);
+        walking |= r[i].state == RUN_WALK;
+      }
+      if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < SCAN_MIN_WALKERS) break;
+    }
+    // the compares of all runs that stand on such a candidate, together
+    {
+      bool hit = false;
+#pragma unroll
+      for (int i = 0; i < NP; i++) hit |= r[i].state == RUN_HIT;
+      if (__builtin_amdgcn_ballot_w64(hit)) {
+#pragma unroll
+        for (int i = 0; i < NP; i++) scan_run_compare<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq);
+      }
+    }
+    // finished positions are stored and their slots take the pool's next positions
+    bool alive = false;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const bool fin = r[i].state == RUN_FIN;
+      const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
+      if (fm) {  // wave-uniform
+        if (fin) out[r[i].p] = scan_run_result(r[i], (uint32_t)Kq);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+        const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
+        const uint32_t rem = cend - next;
+        uint32_t np = rank < rem ? next + rank : cend, lim = cend;
+        if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
+          const uint32_t c = fetch();
+          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
+          empty = c >= pend;
+          if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
+          next = ce - c > taken - rem ? c + (taken - rem) : ce;
+          cend = ce;
+        } else {
+          next = rem > taken ? next + taken : cend;
+        }
+        if (fin) scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K);
+      }
+      alive |= r[i].state != RUN_DEAD;
+    }
+    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+  }
   return iters;
 }
 #endif
@@ -516,6 +697,104 @@ ZD_HD void huff_lengths_of_freqs(uint32_t *heap, uint32_t *e, const uint32_t *fr
       uint32_t p = heap[max_sym + 1 + rank];
       int l = 1;
       while (p != 2) { l++; p = heap[p]; }
+      if (l > max_code_len) { overflow = true; break; }
+      e[sym] = (uint32_t)l;
+    }
+    if (!overflow) return;
+    freq_cap >>= 1;  // flatten and retry zd.ml:470-473
+  }
+}
+
+// The tree of Huffman.lengths_of_freqs (make_huffman_tree zd.ml:432-445) without the heap.
+// The reference pops the two smallest nodes of a binary heap whose keys (freq << 10) | link are
+// all distinct, so WHICH nodes meet is a function of the key order alone:
+//   * a leaf's link is max_sym + 1 + rank (rank: 1-based among the used symbols, in symbol
+//     order), a merged node's link is the heap size m at its creation (n, n-1, .., 2): at equal
+//     frequency merged nodes come before leaves, later merged nodes before earlier ones, lower
+//     symbols before higher ones;
+//   * the frequencies of merged nodes never decrease in creation order (both popped nodes are
+//     at least as large as the larger one popped before, all frequencies are >= 1), and a node
+//     created while a group of equal merged nodes is being popped is strictly larger than them.
+// So the leaves sorted by (freq, rank) form one queue that is read front to back, and the
+// merged nodes, in creation order, a second one whose front GROUP of equal frequencies is
+// popped last-created first: n - 1 steps of O(1) instead of 2 (n - 1) sift-downs of depth
+// log n, each level a dependent LDS round trip on the device.  Same tree, same lengths
+// (tests/test_host_sim.py compares the two on ties of every kind and on the flatten-and-retry path).
+//   q[0, n): in: the leaf keys (freq << 10) | rank, ascending (n >= 2, rank 1..n); the merged nodes'
+//            frequencies overwrite them in creation order (node c, link n - c, at q[c]): when node c
+//            is created at least c + 2 leaves have been taken -- 2 (c + 1) pops, at most c of them
+//            merged nodes -- so the slot is free.
+//   par[0, 2n + 2): out, par[m] = link of the parent of the merged node with link m (2 < m <= n),
+//                   par[n + rank] = link of the parent of leaf `rank`.  The root has link 2.
+template <typename Par>
+ZD_HD void huff_tree_two_queues(uint32_t *q, int n, Par *par) {
+  int li = 0;                   // next leaf
+  int cnt = 0;                  // merged nodes created
+  int lo = 0, top = -1, hi = -1;  // front group of the merged queue: nodes [lo, hi], not yet popped [lo, top]
+  for (int t = 0; t + 1 < n; t++) {
+    const uint32_t m = (uint32_t)(n - t);
+    uint32_t fsum = 0;
+    for (int pop = 0; pop < 2; pop++) {
+      if (top < lo && hi + 1 < cnt) {  // the group is used up: the next one starts behind it
+        lo = hi + 1;
+        hi = lo;
+        while (hi + 1 < cnt && q[hi + 1] == q[lo]) hi++;
+        top = hi;
+      }
+      const bool have_node = top >= lo, have_leaf = li < n;
+      const uint32_t lkey = have_leaf ? q[li] : 0u;
+      const uint32_t lf = lkey >> 10;
+      if (have_node && (!have_leaf || q[top] <= lf)) {  // equal frequencies: the merged node's link is smaller
+        fsum += q[top];
+        par[n - top] = (Par)m;
+        top--;
+      } else {
+        fsum += lf;
+        par[n + (lkey & 0x3FF)] = (Par)m;
+        li++;
+      }
+    }
+    q[cnt] = fsum;
+    if (top >= lo && top == hi && hi == cnt - 1 && q[lo] == fsum) { hi = cnt; top = cnt; }  // joins the untouched front group
+    cnt++;
+  }
+}
+
+// Huffman.lengths_of_freqs zd.ml:404-473 on the two queues (the device form: wave_lengths_of_freqs
+// in deflate.hip sorts and climbs with all lanes and runs the merge on one).  scratch: 2 n + 2 words.
+ZD_HD void huff_lengths_of_freqs_tq(uint32_t *scratch, uint32_t *e, const uint32_t *freqs, int max_sym,
+                                    int max_code_len) {
+  uint32_t freq_cap = 65535;
+  for (;;) {
+    int n = 0;
+    uint32_t *lk = scratch;
+    for (int sym = 0; sym <= max_sym; sym++) {
+      uint32_t f = freqs[sym];
+      if (f == 0) continue;
+      if (f > freq_cap) f = freq_cap;
+      n++;
+      lk[n - 1] = (f << 10) | (uint32_t)n;
+    }
+    if (n < 2) {  // trivial_codeword_lengths zd.ml:462-466
+      for (int sym = 0; sym <= max_sym; sym++) e[sym] = freqs[sym] == 0 ? 0u : 1u;
+      return;
+    }
+    for (int i = 1; i < n; i++) {  // insertion sort: keys are distinct
+      const uint32_t v = lk[i];
+      int j = i;
+      while (j > 0 && lk[j - 1] > v) { lk[j] = lk[j - 1]; j--; }
+      lk[j] = v;
+    }
+    uint16_t *par = (uint16_t *)(scratch + n);
+    huff_tree_two_queues(lk, n, par);
+    bool overflow = false;
+    int rank = 0;
+    for (int sym = 0; sym <= max_sym; sym++) {
+      if (freqs[sym] == 0) { e[sym] = 0; continue; }
+      rank++;
+      uint32_t p = par[n + rank];
+      int l = 1;
+      while (p != 2) { l++; p = par[p]; }
       if (l > max_code_len) { overflow = true; break; }
       e[sym] = (uint32_t)l;
     }
