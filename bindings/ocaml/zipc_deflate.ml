@@ -44,9 +44,17 @@ let crc_nop = 0 and crc_crc32 = 1 and crc_adler32 = 2
    [start, start + len) here; the reference's Lz77.compress does not when start > 0 -- see
    INTEGRATION.md.  And Adler_32 is the reference's signed-remainder value unless
    zipc_hip_set_adler_rfc1950 is called on the context.) *)
+(* The device: ZIPC_HIP_DEVICE from the environment (a process per GPU is how a node's GPUs are used through
+   this seam: members are independent, test/zipc_tool.ml:6-8; the C++ host layer of this repository also
+   spreads one batch of members over all devices from one process, include/zipc_host.h), else device 0. *)
+let device =
+  match Sys.getenv_opt "ZIPC_HIP_DEVICE" with
+  | None -> 0
+  | Some v -> (try int_of_string (String.trim v) with Failure _ -> 0)
+
 let ctx = lazy begin
   let p = allocate ctx_t null in
-  let st = c_create p 0 in
+  let st = c_create p device in
   if st <> ok then failwith ("zipc_hip_create: " ^ c_strerror st);
   !@ p
 end

@@ -96,6 +96,20 @@ int zipc_host_member_to_binary_string(const zipc_host_archive *a, size_t index, 
  * Results are read back per file member, in path order. */
 typedef struct zipc_host_extraction zipc_host_extraction;
 int zipc_host_extract_all(const zipc_host_archive *a, zipc_host_extraction **out, char *err, size_t errcap);
+
+/* ---- devices.  The reference handles one member per call on one core; its tool notes that the members of an
+ * archive are "trivially parallelizable" (test/zipc_tool.ml:6-8).  zipc_host_add_files_deflate and
+ * zipc_host_extract_all hand ALL members to the GPUs as one batch: with several devices the members are cut into
+ * contiguous ranges of about equal bytes (the order Zipc writes them, src/zipc.ml:575-581), one range per
+ * device, each through a context and a host thread of its own; nothing is exchanged between the devices.
+ * The list is every visible device by default, ZIPC_HIP_DEVICES="0,2,3" from the environment, or this call
+ * (n = 0: back to the default).  A device may be named twice (two contexts on it). */
+int zipc_host_set_devices(const int *devices, size_t n);
+size_t zipc_host_devices(int *devices, size_t cap);
+/* the device of the calling thread's single-stream calls (the first of the list unless set) */
+void zipc_host_set_thread_device(int device);
+/* bounds[0 .. n_devices] of the ranges n sizes are cut into (what the two calls above use) */
+void zipc_host_partition(const size_t *sizes, size_t n, size_t n_devices, size_t *bounds);
 size_t zipc_host_extraction_count(const zipc_host_extraction *x);
 /* ok != 0: data/len are the member's bytes; else data/len are the error message */
 int zipc_host_extraction_at(const zipc_host_extraction *x, size_t i, const char **path, size_t *path_len, int *ok,

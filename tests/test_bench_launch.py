@@ -25,8 +25,26 @@ def test_gpus_n_spawns_n_ranks_and_fails_cleanly_without_a_gpu():
         ranks = sorted(int(m.group(1)) for m in re.finditer(r"\[bench\] rank (\d+) of %d " % n, err))
         assert ranks == list(range(n)), err  # the spawned world size equals --gpus
         assert r.returncode != 0 and "workers failed" in err
-        assert err.count("ZIPC_HIP_ERR_NO_DEVICE") == n  # every rank says why; nothing falls back to the CPU
+        # the rank that fails first says why (the launcher stops the others at once); nothing falls back to the CPU
+        assert 1 <= err.count("ZIPC_HIP_ERR_NO_DEVICE") <= n
         assert r.stdout.decode().strip() == ""  # and no JSON line is made up
+
+
+def test_a_dead_rank_stops_the_others_at_once():
+    """Rank 1 never arrives (it sleeps for an hour), rank 0 dies without a GPU: the launcher must not wait for
+    rank 1 -- on a GPU node the survivors would sit in the rendezvous until the RCCL timeout -- but stop it."""
+    import time
+
+    t0 = time.time()
+    r = run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"], {"ZIPC_BENCH_TEST_HANG_RANK": "1"},
+            timeout=120)
+    took = time.time() - t0
+    err = r.stderr.decode()
+    assert r.returncode != 0 and "workers failed" in err and "the others were stopped" in err
+    assert took < 60, took
+    # nothing of the run is left behind
+    ps = subprocess.run(["ps", "-eo", "pid,args"], stdout=subprocess.PIPE).stdout.decode()
+    assert not [l for l in ps.splitlines() if "bench.py" in l and "--gpus 2" in l and str(os.getpid()) not in l.split()[0:1]], ps
 
 
 def test_gpus_must_agree_with_world_size():

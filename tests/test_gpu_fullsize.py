@@ -54,6 +54,14 @@ def test_config2_full_1gib_default_round_trip(gpu_ctx, oracle):
     assert 0.5 < ratio < 0.6  # SURVEY.md 8d expects ~0.545
 
 
+def test_config2_full_1gib_level_best(gpu_ctx, oracle):
+    """The same 16 384 streams at `Best -- the level a caller of the seam gets who passes none
+    (make_encoder ?(level = `Best), zd.ml:817): K = 4096 chain steps, good_match 32."""
+    res = _c2_round_trip(gpu_ctx, oracle, 16384, 4, 3, 2, sample=6)
+    ratio = res["out_len"].sum() / (16384 * 65536)
+    assert 0.5 < ratio < 0.6
+
+
 def test_config5_stored_heavy(gpu_ctx, oracle):
     """C5 shape at 1/16 scale: uniform random bytes -> stored 65534 + 2-literal fixed block."""
     res = _c2_round_trip(gpu_ctx, oracle, 8192, 8, 2, 5, sample=3)
@@ -273,11 +281,44 @@ def test_config5_single_8gib_stream_of_stored_blocks(gpu_ctx, oracle):
     comp[at] = saved
 
 
+def test_huge_stored_stream_through_the_host_form(gpu_ctx):
+    """The same kind of stream -- equal stored blocks beyond 4 GiB, a short final block -- through the HOST form
+    zipc_hip_inflate with a CRC-32: the host forms keep the stream's descriptor and result in the context's
+    staging slots, which the remainder's pass through the batch kernel must not reuse (it did: the CRC-32 then
+    covered the wrong range of the output)."""
+    import ctypes as C
+
+    import torch
+
+    from zipc_amd import _lib, batch, synth
+
+    dev = torch.device("cuda", 0)
+    n = (1 << 32) + 3 * 65534 + 22  # a multiple of 8 (the generator), a 26-byte final block
+    src = synth.batch_bytes_torch(5, 7, 1, n, 8, dev)
+    comp, J = _stored_stream(src)
+    crc, _ = batch.checksum_device(gpu_ctx, src, want_adler32=False)
+    plain = src.cpu().numpy()
+    comp_h = comp.cpu().numpy()
+    del src, comp
+    torch.cuda.empty_cache()
+    out = np.zeros(n + 64, np.uint8)
+    out_len, ck = C.c_size_t(0), C.c_uint32(0)
+    st = _lib.lib().zipc_hip_inflate(gpu_ctx.handle, comp_h.ctypes.data, comp_h.size, 1, n, 1, out.ctypes.data, n,
+                                     C.byref(out_len), C.byref(ck))
+    assert st == 0 and out_len.value == n
+    assert ck.value == crc
+    assert np.array_equal(out[:n], plain)
+    # a limit one byte short: the reference's message, from the remainder's pass
+    st = _lib.lib().zipc_hip_inflate(gpu_ctx.handle, comp_h.ctypes.data, comp_h.size, 1, n - 1, 1, out.ctypes.data, n,
+                                     C.byref(out_len), C.byref(ck))
+    assert st == 2
+
+
 def test_real_text_at_16384_streams(gpu_ctx, oracle):
     """The reference's own documents (tests/golden/zip-docs.zip: APPNOTE.TXT, rfc1951.txt) as 16 384
     chunks of 64 KiB: long hash chains, long matches, long Huffman codes, many dynamic blocks per
     stream -- what the synthetic configs do not have.  Round trip of every byte, per-stream
-    checksums, and every distinct chunk's compressed bytes against the oracle at `Fast and `Default."""
+    checksums, and every distinct chunk's compressed bytes against the oracle at `Fast, `Default and `Best."""
     import zipfile
     import zlib
 
@@ -302,7 +343,7 @@ def test_real_text_at_16384_streams(gpu_ctx, oracle):
     comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
     out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
     d_descs = batch.to_device(descs, dev)
-    for level in (1, 2):
+    for level in (1, 2, 3):  # 3 = `Best, the seam's default: up to 4096 candidates per position (about 300 on this text)
         d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
         batch.deflate_batch(gpu_ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
         res = batch.results_from_device(d_res)
@@ -318,4 +359,49 @@ def test_real_text_at_16384_streams(gpu_ctx, oracle):
         ires = batch.results_from_device(d_ires)
         assert (ires["status"] == 0).all() and (ires["out_len"] == L).all()
         assert torch.equal(out[:n * L], src)
+        assert (ires["checksum"] == res["checksum"]).all()
+
+
+def test_corpus_every_chunk_against_the_oracle(gpu_ctx, oracle):
+    """tools/corpus.py: the reference's documents and this repository's own files (text, code, ELF and gfx950
+    binaries, fixtures) as distinct 64 KiB streams -- every one of them against the oracle's bytes and CRC-32 at
+    `Default and `Best, and back through inflate."""
+    import os
+    import sys
+    import zlib
+
+    import torch
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from tools import corpus
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    L = 65536
+    chunks = corpus.chunks(L)
+    n = len(chunks)
+    assert n >= 40
+    src = torch.from_numpy(np.frombuffer(b"".join(chunks), np.uint8).copy()).to(dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    slot = int(descs["dst_off"][1])
+    comp = torch.zeros(n * slot + 256, dtype=torch.uint8, device=dev)
+    out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    for level in (2, 3):
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        batch.deflate_batch(gpu_ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
+        res = batch.results_from_device(d_res)
+        assert (res["status"] == 0).all()
+        host = comp.cpu().numpy()
+        for j, c in enumerate(chunks):
+            st, c0, crc0 = oracle.deflate(c, level=level, crc_op=oracle.CRC_CRC32)
+            o = int(descs["dst_off"][j])
+            assert host[o:o + int(res["out_len"][j])].tobytes() == c0, (level, j)
+            assert int(res["checksum"][j]) == crc0 == zlib.crc32(c)
+        d_ires = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+        out.fill_(0x5A)
+        batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(batch.compact_descs(res, descs, L), dev), d_ires, n, L, 1)
+        ires = batch.results_from_device(d_ires)
+        assert (ires["status"] == 0).all() and torch.equal(out[:n * L], src)
         assert (ires["checksum"] == res["checksum"]).all()

@@ -192,6 +192,33 @@ def test_config4_like_archive_validates_with_unzip(host, tmp_path):
     assert dict(host.Archive.of_binary_string(enc).extract_all()) == dict(files)
 
 
+def test_members_sharded_over_devices_equal_one_device(host):
+    """The member loop over several devices (zipc_host_set_devices; SURVEY 8(e): contiguous ranges of about
+    equal bytes, one context and one host thread per device, nothing exchanged).  A box with one GPU names it
+    three times -- three contexts, three threads, the same code path as three GPUs -- and the archive must be
+    the one a single device writes, byte for byte; extraction likewise."""
+    from zipc_amd import synth
+
+    n, size = 192, 1 << 18  # 48 MiB: above the size from which a batch is spread
+    files = [(b"m/%05d.bin" % j, synth.stream_bytes_np(4, j, size if j % 7 else size // 3, 3).tobytes()) for j in range(n)]
+    try:
+        host.set_devices([0])
+        one = host.Archive()
+        one.add_files_deflate(files, level=2)
+        enc_one = one.to_binary_string()
+        host.set_devices([0, 0, 0])
+        assert host.devices() == [0, 0, 0]
+        parts = host.partition([len(d) for _, d in files], 3)
+        assert parts[0][0] == 0 and parts[-1][1] == n and all(hi > lo for lo, hi in parts)
+        three = host.Archive()
+        three.add_files_deflate(files, level=2)
+        assert three.to_binary_string() == enc_one
+        assert dict(host.Archive.of_binary_string(enc_one).extract_all()) == dict(files)
+    finally:
+        host.set_devices([])
+    assert host.devices() == list(range(max(1, len(host.devices()))))
+
+
 def test_command_line_like_the_reference_tool(host, oracle, tmp_path):
     """zipc-hip (zipc_amd/host/zipc_tool.cpp, after test/zipc_tool.ml): crc, compress / decompress,
     zip, list, unzip -t / extract, recode -- each checked against the oracle or an independent tool"""

@@ -245,3 +245,47 @@ def test_inflate_span_model(sim, oracle, monkeypatch):
                 assert st == st0 and (st != 0 or (d == d0 and a == a0)), s["name"]
                 seen[st] = seen.get(st, 0) + 1
         assert seen.get(0, 0) > 5 and seen.get(1, 0) > 20, seen
+
+
+def test_huffman_two_queues_equal_the_heap(sim):
+    """Huffman.lengths_of_freqs (zd.ml:404-473) two ways: the reference's heap (huff_lengths_of_freqs, what the
+    oracle restates) and the two queues deflate_emit runs (huff_lengths_of_freqs_tq).  The tree is a function
+    of the order of the keys (freq << 10) | link, so frequency ties -- merged nodes before leaves, later merged
+    nodes first -- and the flatten-and-retry path are what must agree."""
+    import numpy as np
+
+    r = random.Random(20261003)
+
+    def fib(n):
+        a, b, out = 1, 1, []
+        for _ in range(n):
+            out.append(a)
+            a, b = b, a + b
+        return out
+
+    for it in range(20000):
+        kind = it % 9
+        max_sym, max_len = ((285, 15), (29, 15), (18, 7))[it % 3]
+        n = max_sym + 1
+        if kind == 0: fr = [r.choice([0, 1]) for _ in range(n)]
+        elif kind == 1: fr = [r.choice([0, 1, 2]) for _ in range(n)]
+        elif kind == 2: fr = [r.choice([0, 1, 2, 4, 8, 16]) for _ in range(n)]
+        elif kind == 3: fr = [r.randrange(0, 5) for _ in range(n)]
+        elif kind == 4: fr = [r.randrange(0, 70000) if r.random() < 0.5 else 0 for _ in range(n)]
+        elif kind == 5:
+            fr = [0] * n
+            fb = fib(min(n, 30))
+            for i, v in zip(r.sample(range(n), len(fb)), fb):
+                fr[i] = min(v, 65535)
+        elif kind == 6:
+            fr = [0] * n
+            for i in r.sample(range(n), r.randrange(0, min(n, 6) + 1)):
+                fr[i] = r.randrange(1, 4)
+        elif kind == 7: fr = [int(2 ** r.uniform(0, 16)) if r.random() < 0.7 else 0 for _ in range(n)]
+        else:
+            base = r.randrange(1, 1000)
+            fr = [base * r.choice([0, 1, 1, 2, 3]) for _ in range(n)]
+        f = np.array(fr, np.uint32)
+        a = np.zeros(n, np.uint32)
+        b = np.zeros(n, np.uint32)
+        assert sim.sim_huff_lengths(f.ctypes.data, max_sym, max_len, a.ctypes.data, b.ctypes.data) == 0, (it, fr)

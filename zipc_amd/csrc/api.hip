@@ -421,7 +421,7 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
   uint64_t blocks = 0;
   bool done = false;
   if (st.len0 != 0 && st.candidates != 0) {
-    ZD_LAUNCH(ctx, "stored_chain_scan", stored_chain_scan_kernel, dim3((st.candidates + 255) / 256), dim3(256), 0,
+    ZD_LAUNCH(ctx, "stored_chain_scan", stored_chain_scan_kernel, dim3((unsigned)(((uint64_t)st.candidates + 255) / 256)), dim3(256), 0,
               (const uint8_t *)d_src_arena, (const StreamDesc *)d_descs, d_st);
     HIP_TRY(ctx, hipMemcpyAsync(&st, d_st, sizeof st, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -446,13 +446,17 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
     if (rest.flags & STREAM_HAS_LIMIT) rest.limit -= made;
     if (rest.src_len <= MAX_STREAM_LEN) {
       if (rest.dst_cap > MAX_STREAM_LEN) rest.dst_cap = MAX_STREAM_LEN;  // (the rest is an ordinary stream: it may produce up to that much)
-      HIP_TRY(ctx, ctx->ensure(ctx->io_desc, sizeof(StreamDesc)));
-      HIP_TRY(ctx, ctx->ensure(ctx->io_res, sizeof(StreamResult)));
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->io_desc.p, &rest, sizeof rest, hipMemcpyHostToDevice, ctx->stream));
-      const int stb = zipc_hip_inflate_batch(ctx, d_src_arena, d_dst_arena, (const zipc_hip_stream_desc *)ctx->io_desc.p,
-                                             (zipc_hip_stream_result *)ctx->io_res.p, 1, (size_t)rest.dst_cap, ZIPC_HIP_CRC_NOP);
+      // the remainder's descriptor and result live in io_small, behind the StoredChain: the host forms hand
+      // THEIR descriptors in io_desc / io_res to this function (d_descs, d_results), which must stay as they are
+      // for the CRC pass below
+      zipc_hip_stream_desc *d_rest = (zipc_hip_stream_desc *)((uint8_t *)ctx->io_small.p + 64);
+      zipc_hip_stream_result *d_rest_res = (zipc_hip_stream_result *)((uint8_t *)ctx->io_small.p + 128);
+      static_assert(sizeof(StoredChain) <= 64 && sizeof(StreamDesc) <= 64 && 128 + sizeof(StreamResult) <= 256, "io_small layout");
+      HIP_TRY(ctx, hipMemcpyAsync(d_rest, &rest, sizeof rest, hipMemcpyHostToDevice, ctx->stream));
+      const int stb = zipc_hip_inflate_batch(ctx, d_src_arena, d_dst_arena, d_rest, d_rest_res, 1, (size_t)rest.dst_cap,
+                                             ZIPC_HIP_CRC_NOP);
       if (stb) return stb;
-      HIP_TRY(ctx, hipMemcpyAsync(&res, ctx->io_res.p, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipMemcpyAsync(&res, d_rest_res, sizeof res, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if (res.status == ZIPC_HIP_OK) res.out_len += made;
       else res.out_len = 0;
@@ -738,6 +742,8 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (!is_inflate) {
     const int st = zipc_hip_reserve(ctx, n_max, max_src, total_max);
     if (st) return st;
+  } else {
+    HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_max * INFLATE_SCRATCH_PER_STREAM));
   }
   if (crc_op == ZIPC_HIP_CRC_CRC32) {
     const size_t longest = is_inflate ? max_cap : max_src;

@@ -420,6 +420,10 @@ constexpr uint32_t MATCHW_TILE = 16384;
 constexpr int MATCHW_NP = 2;  // run slots per lane.  3 and 4 measured on C2 with the shared cursor: +3 % and +7.5 % (and
                                // +3 % / +8 % on 1 MiB streams of 3-bit symbols); 3 again under the tile-wide pool: +9 % on C2,
                                // +6 % on real text: the loop is nearer its vector bound than latency-bound
+#ifndef ZD_SCAN_NP
+#define ZD_SCAN_NP 2
+#endif
+constexpr int MATCHW_SCAN_NP = ZD_SCAN_NP;  // run slots per lane of the second form of the walk
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
 #ifndef ZD_SCAN_STEPS
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     {
       const uint64_t tend64 = (uint64_t)g.t0 + MATCHW_TILE < (uint64_t)len - 3 ? (uint64_t)g.t0 + MATCHW_TILE : (uint64_t)len - 3;
-      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base)
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base)
                                        : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
       if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
     }
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     // run-slot steps the tile took per position (a tile with a successor is a full one): chain steps / lane use
-    if (form == 0) scan_form = tile_iters[tile & 1u] * (64u * MATCHW_NP) > MATCHW_SCAN_STEPS * MATCHW_TILE;
+    if (form == 0) scan_form = tile_iters[tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > MATCHW_SCAN_STEPS * MATCHW_TILE;
     store(gn);
     if (tid == 0) { pool_next = 0; tile_iters[(tile + 1) & 1u] = 0; }  // the next tile's counter: nobody touches it now
     __syncthreads();

@@ -294,9 +294,10 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 
 // ---------------------------------------------------------------------------
 // The chain walk of the window kernel (lz_match_window_kernel), second form.  A candidate can only
-// become the best match if it is LONGER than the best so far, which takes agreement in the byte
-// at offset best_len -- so that byte is looked at first (one byte of the LDS window, any
-// alignment) and a candidate that differs there is passed over without reading its 8 bytes:
+// become the best match if it is LONGER than the best so far, which takes agreement in the bytes
+// at offsets best_len - 1 and best_len -- so those two are looked at first (two single bytes of the
+// LDS window, any alignment; on text one byte lets about a quarter of the candidates through, two
+// a sixteenth) and a candidate that differs there is passed over without reading its 8 bytes:
 // its common prefix is <= best_len, it changes neither the best match nor -- being shorter than
 // maxlen -- the end of the walk (zd.ml:1190-1194), and it still counts as one of the K
 // candidates.  On 3-bit symbols 7 of 8 candidates go that way, on text about as many.  What makes
@@ -313,7 +314,7 @@ struct ScanRun {
   uint32_t p, q, best_len, best, maxlen, steps;
   uint32_t snap;   // best after Kq candidates, SNAP_NONE before
   uint32_t dn;     // prev[q], read with the candidate
-  uint32_t pb;     // s[p + best_len]
+  uint32_t pb;     // s[p + best_len - 1] | s[p + best_len] << 8
   uint32_t state;  // RUN_*
   uint64_t pw;     // s[p .. p+8)
 };
@@ -334,7 +335,7 @@ ZD_HD void scan_run_start(ScanRun &r, const uint8_t *s, uint32_t len, uint32_t p
   if (WORDS) r.pw = load_u64_words(s, r.p);
   else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
   else for (uint32_t i = 0; i < r.maxlen; i++) r.pw |= (uint64_t)s[r.p + i] << (8 * i);
-  r.pb = (uint32_t)(r.pw >> 24) & 0xFFu;  // s[p + 3]
+  r.pb = (uint32_t)(r.pw >> 16) & 0xFFFFu;  // s[p + 2], s[p + 3]
   r.dn = prev[r.p];
   // zd.ml:1181: no search when even the shortest match does not fit
   const bool walk = r.best_len < r.maxlen && scan_next_ok(r.p, 0, r.p, r.dn, K);
@@ -350,7 +351,7 @@ ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uin
   const bool w = r.state == RUN_WALK;
   const uint32_t q = w ? r.q - r.dn : r.q;
   const uint32_t steps = r.steps + (w ? 1u : 0u);
-  const uint32_t b = s[q + r.best_len];  // best_len < maxlen: inside both strings
+  const uint32_t b = (uint32_t)s[q + r.best_len - 1u] | ((uint32_t)s[q + r.best_len] << 8);  // 2 <= best_len - 1, best_len < maxlen: inside both strings
   const uint32_t dn = prev[q];
   const bool hit = b == r.pb;
   const uint32_t after = hit ? (uint32_t)RUN_HIT : scan_next_ok(r.p, steps, q, dn, K) ? (uint32_t)RUN_WALK : (uint32_t)RUN_FIN;
@@ -386,7 +387,7 @@ ZD_HD void scan_run_compare(ScanRun &r, const uint8_t *s, const uint16_t *prev, 
   const bool better = l > r.best_len;
   r.best_len = better ? l : r.best_len;
   r.best = better ? (((r.p - q) << 9) | l) : r.best;
-  if (better && l < r.maxlen) r.pb = s[r.p + l];
+  if (better && l < r.maxlen) r.pb = (uint32_t)s[r.p + l - 1u] | ((uint32_t)s[r.p + l] << 8);
   r.snap = r.steps == Kq ? r.best : r.snap;
   // zd.ml:1194: after l == maxlen nothing later can be longer
   r.state = (l != r.maxlen && scan_next_ok(r.p, r.steps, q, r.dn, K)) ? RUN_WALK : RUN_FIN;

@@ -290,9 +290,12 @@ ZD_WV void span_lengths(uint32_t xlo, uint32_t xhi, const LaneLds &L, uint32_t &
 // entry of 0: long codes, stops) is a divergent branch the wave skips when no lane takes it.  A
 // granule boundary is looked for once per four steps -- four symbols are at most 192 bits, so it
 // is one boundary at most -- from the positions the steps left behind: some lane crosses one in
-// nearly every step, and handling it there would be paid by all 64.  The up to three steps a walk
-// takes behind the end of its region, or behind the granule it merges in, change nothing that is
-// used: a stop met there is booked on the granule before, which ends the span a granule early.
+// nearly every step, and handling it there would be paid by all 64.  A stop met in the up to three
+// steps a walk takes behind the granule it merges in is booked on the granule before and masked off
+// with it: phase A's stop bookkeeping is NOT exact there, and entries behind such a stop may be
+// accepted as verified.  What makes the result exact is phase B: it decodes every granule again from
+// its real start with every check of lane_one_symbol's, and requires that each granule ends exactly
+// where the next one's entry says it starts -- inside a tile and across tiles -- or refuses the tile.
 template <bool STITCH>
 ZD_WV void span_walk_loop(SpanWalk &W, SpanReader &R, const SpanEnv &E, const LaneLds &L, uint16_t *idx,
                           int lit_max_sym, int dist_max_sym) {
@@ -666,6 +669,8 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     const uint32_t ent = e + ulane;
     const bool have = ent < n_valid;
     const uint32_t iv = have ? (uint32_t)idx[ent] : 0u;
+    // where the granule behind mine starts (also across the end of the tile: the next tile's first)
+    const uint32_t next_epd = ent + 1u < n_valid ? (uint32_t)idx[ent + 1u] & 63u : 0u;
     const uint32_t eod = iv >> 6, epd = iv & 63u;
     const uint32_t incl = wv::scan_incl(eod);
     const bool fit = have && eod != SPAN_OD_BIG && incl <= SPAN_TILE && incl <= cap_min - out_pos;
@@ -751,12 +756,9 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
 #pragma unroll
     for (int u = 0; u < SPAN_FLY; u++) span_land(tile, f_meta[u], f_a[u], f_b[u]);
     // both phases must have walked the same symbols
-    {
-      const uint32_t next_start = wv::shfl(p0, ulane + 1u);
-      if (mine && err == 0u) {
-        if (o != o_end) err = 1;
-        if (ent + 1u == n_valid ? p != p_end : (ulane + 1u < n && p != next_start)) err = 1;
-      }
+    if (mine && err == 0u) {
+      if (o != o_end) err = 1;
+      if (p != (ent + 1u == n_valid ? p_end : base + (ent + 1u) * SPAN_G + next_epd)) err = 1;
     }
     if (wv::any(err != 0u)) {  // leave the tile's symbols to the plain decoder: it finds what is wrong
       p_end = tile_start_p;

@@ -34,7 +34,11 @@ __device__ __forceinline__ uint32_t shfl(uint32_t v, uint32_t src) {
 }
 __device__ __forceinline__ uint32_t scan_incl(uint32_t v) { return wave_scan_incl(v); }
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-__device__ __forceinline__ void sync() { __builtin_amdgcn_wave_barrier(); }
+// (the fence emits no instruction: it tells the compiler that LDS accesses do not move across this point)
+__device__ __forceinline__ void sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 // global stores of this wave before, its global loads after
 __device__ __forceinline__ void fence_global() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }

@@ -2,26 +2,104 @@
 #include "zipc_deflate.hpp"
 
 #include <cstdio>
+#include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <thread>
 
 namespace zipc_deflate {
 
 // One context PER HOST THREAD (include/zipc_hip.h: a context owns one HIP stream and staging
 // buffers that every call reuses, so it serves one thread at a time).  The reference module is
 // re-entrant and a drop-in caller may well call it from several threads: each gets its own
-// context on first use, destroyed when the thread exits.
+// context on first use, on the device it chose (set_thread_device; the first of devices() otherwise),
+// destroyed when the thread exits.  The many-stream forms spread a batch over ALL of devices().
 namespace {
+std::mutex g_devices_mu;
+std::vector<int> g_devices;      // empty: not decided yet
+bool g_devices_set = false;
+
+std::vector<int> default_devices() {
+  std::vector<int> d;
+  if (const char *e = getenv("ZIPC_HIP_DEVICES")) {
+    const char *p = e;
+    while (*p) {
+      char *end = nullptr;
+      const long v = strtol(p, &end, 10);
+      if (end == p) break;
+      if (v >= 0) d.push_back((int)v);
+      p = *end == ',' ? end + 1 : end;
+      if (*end && *end != ',') break;
+    }
+  }
+  if (d.empty()) {
+    if (const char *one = getenv("ZIPC_HIP_DEVICE")) {  // a process pinned to one GPU (one process per GPU)
+      const int v = atoi(one);
+      if (v >= 0) return std::vector<int>(1, v);
+    }
+    const int n = zipc_hip_device_count();
+    for (int i = 0; i < (n > 0 ? n : 1); i++) d.push_back(i);
+  }
+  return d;
+}
+
 struct ThreadContext {
   zipc_hip_ctx *ctx = nullptr;
+  int device = -1;  // -1: the first of devices()
+  int made_on = -1;
   int status = 0;
-  ThreadContext() { status = zipc_hip_create(&ctx, 0); }
   ~ThreadContext() {
     if (ctx) zipc_hip_destroy(ctx);
   }
 };
+thread_local ThreadContext tc;
+
+// One more context per entry of devices() for the many-stream forms: made on first use, kept for the
+// life of the process (a context pins its staging buffers: ~100 ms the first time), one user at a time.
+struct PoolContext {
+  std::mutex mu;
+  zipc_hip_ctx *ctx = nullptr;
+  int device = -1;
+};
+std::mutex g_pool_mu;
+std::vector<std::unique_ptr<PoolContext>> g_pool;
+PoolContext &pool_context(std::size_t slot, int device) {
+  std::lock_guard<std::mutex> g(g_pool_mu);
+  while (g_pool.size() <= slot) g_pool.emplace_back(new PoolContext());
+  PoolContext &pc = *g_pool[slot];
+  if (pc.ctx && pc.device != device) {  // the device list changed under it
+    std::lock_guard<std::mutex> u(pc.mu);
+    zipc_hip_destroy(pc.ctx);
+    pc.ctx = nullptr;
+  }
+  pc.device = device;
+  return pc;
+}
 }  // namespace
+
+std::vector<int> devices() {
+  std::lock_guard<std::mutex> g(g_devices_mu);
+  if (!g_devices_set) { g_devices = default_devices(); g_devices_set = true; }
+  return g_devices;
+}
+void set_devices(const std::vector<int> &list) {
+  std::lock_guard<std::mutex> g(g_devices_mu);
+  g_devices = list.empty() ? default_devices() : list;
+  g_devices_set = true;
+}
+void set_thread_device(int device) { tc.device = device; }
+int thread_device() { return tc.device >= 0 ? tc.device : devices().front(); }
+
 zipc_hip_ctx *context() {
-  thread_local ThreadContext tc;
+  const int want = thread_device();
+  if (tc.ctx && tc.made_on != want) {
+    zipc_hip_destroy(tc.ctx);
+    tc.ctx = nullptr;
+  }
+  if (!tc.ctx) {
+    tc.status = zipc_hip_create(&tc.ctx, want);
+    tc.made_on = want;
+  }
   if (!tc.ctx) throw std::runtime_error(std::string("zipc_hip_create: ") + zipc_hip_strerror(tc.status));
   return tc.ctx;
 }
@@ -215,6 +293,64 @@ Result<std::string> zlib_compress(const std::string &s, std::optional<level> lvl
   return Result<std::string>::Ok(std::move(out));
 }
 
+std::vector<std::pair<std::size_t, std::size_t>> partition_items(const std::vector<ManyItem> &items, std::size_t n_devices) {
+  // contiguous ranges balanced by bytes: boundary k is the first index where the running byte count reaches
+  // k / n_devices of the total (zipc_amd/shard.partition is the same rule for bench.py's ranks)
+  const std::size_t n = items.size();
+  if (n_devices < 1) n_devices = 1;
+  std::vector<unsigned long long> csum(n + 1, 0);
+  for (std::size_t i = 0; i < n; i++) csum[i + 1] = csum[i] + items[i].len;
+  const unsigned __int128 total = csum[n];
+  std::vector<std::size_t> bounds(1, 0);
+  for (std::size_t k = 1; k < n_devices; k++) {
+    std::size_t b = bounds.back();
+    while (b < n && (unsigned __int128)csum[b] * n_devices < total * k) b++;
+    bounds.push_back(b);
+  }
+  bounds.push_back(n);
+  std::vector<std::pair<std::size_t, std::size_t>> out;
+  for (std::size_t k = 0; k < n_devices; k++) out.push_back({bounds[k], bounds[k + 1]});
+  return out;
+}
+
+// a batch smaller than this stays on one device: a second context costs a launch chain and staging of its own
+static const std::size_t SHARD_MIN_BYTES = 32u << 20;
+
+// runs call(ctx, first, last) for the ranges of the items, one range per device of devices()
+template <class Call>
+static void over_devices(const std::vector<ManyItem> &items, Call call) {
+  const std::vector<int> devs = devices();
+  unsigned long long total = 0;
+  for (const auto &it : items) total += it.len;
+  if (devs.size() < 2 || items.size() < 2 * devs.size() || total < SHARD_MIN_BYTES) {
+    call(context(), (std::size_t)0, items.size());
+    return;
+  }
+  const auto parts = partition_items(items, devs.size());
+  std::vector<std::thread> workers;
+  std::vector<std::string> failed(devs.size());
+  for (std::size_t r = 0; r < devs.size(); r++) {
+    if (parts[r].first == parts[r].second) continue;
+    workers.emplace_back([&, r] {
+      try {
+        PoolContext &pc = pool_context(r, devs[r]);
+        std::lock_guard<std::mutex> g(pc.mu);
+        if (!pc.ctx) {
+          const int st = zipc_hip_create(&pc.ctx, devs[r]);
+          if (st) throw std::runtime_error(std::string("zipc_hip_create (device ") + std::to_string(devs[r]) + "): " + zipc_hip_strerror(st));
+        }
+        call(pc.ctx, parts[r].first, parts[r].second);
+      } catch (const std::exception &e) {
+        failed[r] = e.what();
+        if (failed[r].empty()) failed[r] = "failed";
+      }
+    });
+  }
+  for (auto &w : workers) w.join();
+  for (const auto &f : failed)
+    if (!f.empty()) throw std::runtime_error(f);
+}
+
 std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &items, std::optional<level> lvl) {
   const std::size_t n = items.size();
   std::vector<ManyResult> out(n);
@@ -229,9 +365,11 @@ std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &ite
     dst[i] = &out[i].value[0];
   }
   std::vector<zipc_hip_stream_result> res(n);
-  const int st = zipc_hip_deflate_many(context(), n, src.data(), len.data(), level_of(lvl), ZIPC_HIP_CRC_CRC32, dst.data(),
-                                       cap.data(), res.data());
-  if (st) throw std::runtime_error(std::string("zipc_hip_deflate_many: ") + message(st));
+  over_devices(items, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
+    const int st = zipc_hip_deflate_many(ctx, hi - lo, src.data() + lo, len.data() + lo, level_of(lvl), ZIPC_HIP_CRC_CRC32,
+                                         dst.data() + lo, cap.data() + lo, res.data() + lo);
+    if (st) throw std::runtime_error(std::string("zipc_hip_deflate_many: ") + message(st));
+  });
   for (std::size_t i = 0; i < n; i++) {
     throw_if_library_failure((int)res[i].status);
     out[i].ok = res[i].status == ZIPC_HIP_OK;
@@ -248,6 +386,7 @@ std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &ite
   std::vector<const void *> src(n);
   std::vector<void *> dst(n);
   std::vector<std::size_t> len(n), cap(n), limit(n);
+  std::vector<ManyItem> by_output(n);  // the work of inflate goes by what it produces
   for (std::size_t i = 0; i < n; i++) {
     if (!items[i].decompressed_size) throw std::invalid_argument("inflate_and_crc_32_many: decompressed_size missing");
     src[i] = items[i].data;
@@ -255,11 +394,14 @@ std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &ite
     cap[i] = limit[i] = *items[i].decompressed_size;
     out[i].value.resize(cap[i]);
     dst[i] = cap[i] ? &out[i].value[0] : nullptr;
+    by_output[i].len = cap[i];
   }
   std::vector<zipc_hip_stream_result> res(n);
-  const int st = zipc_hip_inflate_many(context(), n, src.data(), len.data(), limit.data(), ZIPC_HIP_CRC_CRC32, dst.data(),
-                                       cap.data(), res.data());
-  if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many: ") + message(st));
+  over_devices(by_output, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
+    const int st = zipc_hip_inflate_many(ctx, hi - lo, src.data() + lo, len.data() + lo, limit.data() + lo, ZIPC_HIP_CRC_CRC32,
+                                         dst.data() + lo, cap.data() + lo, res.data() + lo);
+    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many: ") + message(st));
+  });
   for (std::size_t i = 0; i < n; i++) {
     throw_if_library_failure((int)res[i].status);
     out[i].ok = res[i].status == ZIPC_HIP_OK;

@@ -42,11 +42,20 @@ struct Unit {};
 typedef std::uint16_t uint16;  // zipc_deflate.mli:17
 typedef std::uint32_t uint32;  // zipc_deflate.mli:20
 
-// The context the calling THREAD's calls go through (device 0, created on the thread's first
-// use, destroyed when it exits): a zipc_hip context serves one thread at a time, and like the
-// reference module these functions may be called from several threads at once.  Throws
+// The context the calling THREAD's calls go through (created on the thread's first use on the
+// thread's device, destroyed when it exits): a zipc_hip context serves one thread at a time, and
+// like the reference module these functions may be called from several threads at once.  Throws
 // std::runtime_error when the library cannot create one.
 zipc_hip_ctx *context();
+// The device of the calling thread's context: the first of devices() unless set_thread_device() chose
+// another (a context made on the earlier device is replaced).
+void set_thread_device(int device);
+int thread_device();
+// The devices the many-stream forms below spread a batch over, one host thread and one context per
+// entry: every visible device (zipc_hip_device_count()) by default, ZIPC_HIP_DEVICES="0,2,3" from the
+// environment, or set_devices().  A device may be named more than once (two contexts on it).
+std::vector<int> devices();
+void set_devices(const std::vector<int> &list);
 
 // (start, len) of the reference's optional arguments -> the checked range
 inline std::pair<std::size_t, std::size_t> range(const std::string &s, std::size_t start, std::size_t len) {
@@ -125,9 +134,15 @@ struct ManyResult {
   uint32 checksum = 0;
   std::string error;
 };
-// crc_32_and_deflate of every item, one launch of the batch kernels
+// crc_32_and_deflate of every item through the batch kernels.  The items are independent streams (archive
+// members: "trivially parallelizable", test/zipc_tool.ml:6-8), so with several devices() they are cut into
+// contiguous ranges of about equal bytes, one range per device, each through its own context on a host
+// thread of its own -- no exchange between the devices, results in the order of the items.
 std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &items,
                                                 std::optional<level> lvl = std::nullopt);
+// the ranges [first, last) the items are cut into for n_devices (what the sharded forms use; bench.py's
+// zipc_amd/shard.partition is the same rule)
+std::vector<std::pair<std::size_t, std::size_t>> partition_items(const std::vector<ManyItem> &items, std::size_t n_devices);
 // inflate_and_crc_32 of every item; items need decompressed_size (the members of
 // an archive have it)
 std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &items);

@@ -278,4 +278,26 @@ size_t zipc_host_fpath(int which, const char *p, size_t len, char *out, size_t c
 }
 size_t zipc_host_fpath_pp_mode(int mode, char *buf, size_t cap) { return put_str(zipc::Fpath::pp_mode(mode), buf, cap); }
 
+int zipc_host_set_devices(const int *devices, size_t n) {
+  try {
+    zipc_deflate::set_devices(std::vector<int>(devices, devices + (devices ? n : 0)));
+    return ZIPC_HOST_OK;
+  } catch (...) {
+    return ZIPC_HOST_FAILURE;
+  }
+}
+size_t zipc_host_devices(int *devices, size_t cap) {
+  const std::vector<int> d = zipc_deflate::devices();
+  for (size_t i = 0; i < d.size() && i < cap && devices; i++) devices[i] = d[i];
+  return d.size();
+}
+void zipc_host_set_thread_device(int device) { zipc_deflate::set_thread_device(device); }
+void zipc_host_partition(const size_t *sizes, size_t n, size_t n_devices, size_t *bounds) {
+  std::vector<zipc_deflate::ManyItem> items(n);
+  for (size_t i = 0; i < n; i++) items[i].len = sizes[i];
+  const auto parts = zipc_deflate::partition_items(items, n_devices ? n_devices : 1);
+  bounds[0] = 0;
+  for (size_t k = 0; k < parts.size(); k++) bounds[k + 1] = parts[k].second;
+}
+
 }  // extern "C"

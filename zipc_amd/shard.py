@@ -79,3 +79,53 @@ def archive_offsets(records: np.ndarray, header_sizes) -> np.ndarray:
     sum of (header + compressed payload) sizes."""
     sizes = records["compressed_size"].astype(np.uint64) + np.asarray(header_sizes, dtype=np.uint64)
     return np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+
+
+def gather_payloads(local: bytes, dst: int = 0, group=None):
+    """Every rank's compressed members (its part of the arena, members back to back) to rank `dst`: one
+    point-to-point payload gather, SURVEY 8(e)'s CG2 (RCCL over xGMI on GPU ranks -- about 0.43 GiB per peer
+    at C4 -- gloo on CPU).  Returns the list of parts in rank order on `dst`, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [local]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(local)], dtype=torch.int64, device=dev), group=group)
+    sizes = [int(t.item()) for t in sizes]
+    width = max(max(sizes), 1)
+    mine = torch.zeros(width, dtype=torch.uint8)
+    if local:
+        mine[:len(local)] = torch.from_numpy(np.frombuffer(local, np.uint8).copy())
+    mine = mine.to(dev)
+    if rank == dst:
+        out = [torch.empty(width, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.gather(mine, out, dst=dst, group=group)
+        return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+    dist.gather(mine, None, dst=dst, group=group)
+    return None
+
+
+def assemble_archive(paths, records: np.ndarray, parts, counts, member_len) -> bytes:
+    """The ZIP archive of the sharded members on the rank that holds all parts (zipc_amd/host: Zipc.add +
+    Zipc.to_binary_string, src/zipc.ml:568-588): member j is `paths[j]`, Deflate, its compressed bytes the
+    next records['compressed_size'][j] bytes of its rank's part, its CRC-32 and size from the records.  The
+    archive depends on the members only, not on how they were spread over ranks."""
+    from . import zipc_host
+
+    a = zipc_host.Archive()
+    j = 0
+    for r, part in enumerate(parts):
+        at = 0
+        for _ in range(int(counts[r])):
+            size = int(records["compressed_size"][j])
+            a.add_file_made(paths[j], 8, part[at:at + size], int(member_len), int(records["crc32"][j]))  # 8: Deflate
+            at += size
+            j += 1
+        assert at == len(part), "part %d: %d bytes of members, %d bytes received" % (r, at, len(part))
+    assert j == len(paths)
+    return a.to_binary_string()
+

@@ -47,6 +47,10 @@ SYMBOLS = [
     ("zipc_host_member_to_binary_string", C.c_int,
      [_P, _SZ, C.c_int, _P, _SZ, C.POINTER(_SZ), C.POINTER(C.c_uint32), C.c_char_p, _SZ]),
     ("zipc_host_extract_all", C.c_int, [_P, C.POINTER(_P), C.c_char_p, _SZ]),
+    ("zipc_host_set_devices", C.c_int, [C.POINTER(C.c_int), _SZ]),
+    ("zipc_host_devices", _SZ, [C.POINTER(C.c_int), _SZ]),
+    ("zipc_host_set_thread_device", None, [C.c_int]),
+    ("zipc_host_partition", None, [C.POINTER(_SZ), _SZ, _SZ, C.POINTER(_SZ)]),
     ("zipc_host_extraction_count", _SZ, [_P]),
     ("zipc_host_extraction_at", C.c_int,
      [_P, _SZ, C.POINTER(C.POINTER(C.c_char)), C.POINTER(_SZ), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_char)),
@@ -263,3 +267,27 @@ def fpath_pp_mode(m):
     b = C.create_string_buffer(16)
     n = lib().zipc_host_fpath_pp_mode(m, b, 16)
     return b.raw[:n].decode()
+
+
+def set_devices(devices=()):
+    """The devices add_files_deflate / extract_all spread the members of an archive over (empty: every visible one)."""
+    arr = (C.c_int * max(len(devices), 1))(*devices)
+    if lib().zipc_host_set_devices(arr, len(devices)) != 0:
+        raise RuntimeError("zipc_host_set_devices failed")
+
+
+def devices():
+    n = lib().zipc_host_devices(None, 0)
+    arr = (C.c_int * max(n, 1))()
+    lib().zipc_host_devices(arr, n)
+    return list(arr[:n])
+
+
+def partition(sizes, n_devices):
+    """[(lo, hi)] per device: the ranges a batch of members with these sizes is cut into"""
+    n = len(sizes)
+    arr = (_SZ * max(n, 1))(*sizes)
+    bounds = (_SZ * (n_devices + 1))()
+    lib().zipc_host_partition(arr, n, n_devices, bounds)
+    return [(int(bounds[k]), int(bounds[k + 1])) for k in range(n_devices)]
+
