@@ -219,11 +219,18 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
         }
         if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
       } else if (d.phase == PH_SYMBOLS) {
-        if (span && !d.span_off) {  // as inflate.hip
+        if (span && !d.span_off && d.in_word >= d.span_retry_word) {  // as inflate.hip
           if (d.q_count) break;
+          const uint32_t out_before = d.out_pos;
           const int sr = span_model(d, L, src, dst, span_desc);
           if (sr != SPAN_NONE) {
             d.span_off = sr == SPAN_OFF;
+            if (sr == SPAN_LATER) {
+              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
+              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
+            } else {
+              d.span_fails = 0;
+            }
             break;
           }
           d.span_off = 1;

@@ -207,6 +207,22 @@ def test_inflate_span_model(sim, oracle, monkeypatch):
             st0, d0, a0 = oracle.inflate(s["raw"], crc_op=oracle.CRC_ADLER32)
             st, d, a = sim_inflate(sim, s["raw"], s["plain_len"] + 100, crc_op=2, budget=24)
             assert (st, d, a) == (st0, d0, a0), s["name"]
+        # binary-like: stretches a span cannot take (zeros, short periods: granules too rich for a tile) between
+        # stretches it can -- the span steps aside for the wide turns and comes back (SPAN_LATER), again and again
+        rb = random.Random(77)
+        for shape in range(3):
+            parts = []
+            while sum(map(len, parts)) < 150000:
+                parts.append(bytes(rb.randrange(256 if shape else 16) for _ in range(rb.randrange(200, 6000))))
+                parts.append(bytes([0, 0xFF, 0x90][shape]) * rb.randrange(300, 9000) if rb.random() < 0.7
+                             else bytes(rb.randrange(256) for _ in range(rb.randrange(1, 9))) * rb.randrange(100, 1500))
+                parts.append(util.deflate_cases()["text150k"][rb.randrange(0, 100000):][:rb.randrange(500, 8000)])
+            data = b"".join(parts)
+            spans_before = stats[0]
+            st0, c, a0 = oracle.deflate(data, level=2, crc_op=oracle.CRC_ADLER32)
+            st, d, a = sim_inflate(sim, c, len(data), limit=len(data), crc_op=2, budget=24)
+            assert (st, d, a) == (0, data, a0), (shape, order)
+            assert stats[0] - spans_before > 6, (shape, list(stats))  # spans kept coming back after the runs
         # more holes than a tile lists (SPAN_LIST_MAX): thousands of 3-byte matches in a row, hand-made
         for length, dist, n, seed in ((3, 3, 6000, None), (3, 1, 3000, None), (3, 4, 8000, 1), (4, 4, 8000, 2), (4, 2, 5000, 3)):
             c, data = util.fixed_block_of_short_matches(n, length, dist, seed=seed)

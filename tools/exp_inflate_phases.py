@@ -15,6 +15,10 @@ if os.environ.get("ZEROS"):
 elif os.environ.get("DOC"):  # tools/bench_single.py's text: this repo's SURVEY.md over and over
     doc = open(os.path.join(ROOT, "SURVEY.md"), "rb").read()
     src = torch.from_numpy(np.frombuffer((doc * (n * L // len(doc) + 1))[:n * L], np.uint8).copy()).to(dev)
+elif os.environ.get("CORPUS_CHUNK"):  # one chunk of tools/corpus.py, n copies
+    from tools import corpus
+    c = corpus.chunks(L)[int(os.environ["CORPUS_CHUNK"])]
+    src = torch.from_numpy(np.frombuffer(c * n, np.uint8).copy()).to(dev)
 elif os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
     import zipfile
     z = zipfile.ZipFile(os.path.join(ROOT, "tests/golden/zip-docs.zip"))

@@ -63,7 +63,7 @@ __device__ __forceinline__ void uniformize(InflateLane &d) {
   ZD_U(phase); ZD_U(final_block); ZD_U(lit_max_sym); ZD_U(dist_max_sym); ZD_U(blk_out_start);
   ZD_U(req_src); ZD_U(req_len); ZD_U(req_dist); ZD_U(q_count); ZD_U(hole_min); ZD_U(hdr_num);
   ZD_U(hdr_hlit); ZD_U(hdr_hdist); ZD_U(hdr_cl_max); ZD_U(hdr_hclen); ZD_U(hdr_fixed); ZD_U(adler); ZD_U(levels);
-  ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off); ZD_U(fixed_lazy);
+  ZD_U(blk_in_word); ZD_U(blk_boff); ZD_U(prev_block_bits); ZD_U(span_off); ZD_U(span_retry_word); ZD_U(span_fails); ZD_U(fixed_lazy);
 #undef ZD_U
 }
 
@@ -540,8 +540,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         }
         if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
       } else if (d.phase == PH_SYMBOLS) {
-        if (!d.span_off) {  // the block's symbols by regions, all lanes busy (inflate_span.h)
+        if (!d.span_off && d.in_word >= d.span_retry_word) {  // the block's symbols by regions, all lanes busy (inflate_span.h)
           if (d.q_count) break;  // queued copies first: the span reads its match sources from memory
+          const uint32_t out_before = d.out_pos;
           ZD_PH_START();
 #ifdef ZD_INFLATE_PHASES
           const int sr = span_decode(d, L, src, dst, span_idx, lane, span_ph);
@@ -551,6 +552,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           if (sr != SPAN_NONE) {
             uniformize(d);
             d.span_off = sr == SPAN_OFF;
+            if (sr == SPAN_LATER) {
+              // the wide turns take the next granule at least; a span that committed nothing costs about what
+              // 150 bytes cost them, so the wait doubles while spans keep failing (runs of runs) up to 1 Ki words
+              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
+              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
+            } else {
+              d.span_fails = 0;
+            }
             ZD_PH(ph_plain);  // (timing build: the span's clocks are booked as "plain")
             break;  // the input ring starts over at the new position
           }

@@ -173,6 +173,8 @@ struct InflateLane {
   uint32_t blk_in_word, blk_boff;  // where the current block's symbols start
   uint32_t prev_block_bits;        // bits of the previous compressed block's symbols (0: none yet): sizes the regions
   int32_t span_off;                // the rest of this block is left to the wide turns
+  uint32_t span_retry_word;        // no span before the input has reached this word (after one that met a stretch it cannot take)
+  uint32_t span_fails;             // such spans in a row that committed nothing: the wait doubles with each
   int32_t fixed_lazy;              // > 0: a fixed block whose tables are not built yet; symbols left before they are
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }
@@ -713,6 +715,8 @@ ZD_HD void lane_begin_symbols(InflateLane &d) {
   d.blk_in_word = d.in_word;
   d.blk_boff = d.boff;
   d.span_off = 0;
+  d.span_retry_word = 0;
+  d.span_fails = 0;
   d.fixed_lazy = 0;
 }
 
@@ -909,6 +913,8 @@ ZD_HD void lane_init(InflateLane &d, const StreamDesc &s) {
   d.blk_in_word = d.blk_boff = 0;
   d.prev_block_bits = 0;
   d.span_off = 0;
+  d.span_retry_word = 0;
+  d.span_fails = 0;
   d.fixed_lazy = 0;
   if (s.src_len > MAX_STREAM_LEN || s.dst_cap > MAX_STREAM_LEN) {
     d.src_len = 0; d.hard_cap = 0; d.limit = 0; d.cap_min = 0;

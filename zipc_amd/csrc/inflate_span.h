@@ -77,7 +77,8 @@ constexpr uint32_t SPAN_BITS_OFF = LDS_SPAN_BITS_BYTE;   // u32[128 + 2]: a bit 
 constexpr uint32_t SPAN_IDX_ENTRIES = 64 * SPAN_K_MAX;
 static_assert(SPAN_TILE + 16 == LDS_SPAN_TILE_BYTES && SPAN_RING * 64 * 4 <= LDS_WIDE_LIT * 4 && SPAN_IDX_ENTRIES * 2 <= SPAN_TILE, "inflate_lane.h's map");
 
-enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_OFF = 3 };
+enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_LATER = 2, SPAN_OFF = 3 };
+constexpr uint32_t SPAN_RETRY_WORDS = 8;  // input words (a granule) the wide turns take before a span is tried again
 enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERGE = 5 };
 
 // ---- one symbol, from the next 64 bits
@@ -472,7 +473,9 @@ ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, u
 }
 // The span.  d.phase == PH_SYMBOLS, nothing queued; returns SPAN_NONE when it did not run
 // (nothing changed), else the stream position, out_pos and ring_wr are those after the
-// symbols it committed: SPAN_AGAIN (more of the block may follow the same way) or SPAN_OFF
+// symbols it committed: SPAN_AGAIN (more of the block may follow the same way), SPAN_LATER (it met a
+// stretch it cannot take -- a granule too rich for a tile, walks that do not fall into step: runs of long
+// matches, zeros, periods; the wide turns and match_run take that stretch, then a span is tried again) or SPAN_OFF
 // (leave the rest of this block to the wide turns).
 #ifdef ZD_INFLATE_PHASES  // timing-only build (tools/exp_inflate_phases.py): clocks per phase of the span
 #define ZD_SPAN_PH(i) do { const uint64_t now_ = __builtin_readcyclecounter(); span_ph[i] += now_ - span_t; span_t = now_; } while (0)
@@ -602,7 +605,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   ZD_SPAN_PH(0);
   if (wv::any(lane == 0 && W.kind == WK_NONE)) {  // gave up (see the walk loop): nothing committed,
     d.ring_wr = d.in_word;                         // but the wide path's input ring was this walk's
-    return SPAN_OFF;
+    return SPAN_LATER;
   }
   const uint32_t m_p = W.rp, m_stops = W.stops;  // (every walk of a region ends at the region's end: WK_END)
   wv::sync();  // entries written by one lane are read by others below
@@ -665,6 +668,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   uint32_t out_pos = out_pos0;
   uint32_t e = 0;
   bool cut = false;  // the span ends before n_valid: size limit reached, a granule too rich, or a tile refused
+  bool limit_cut = false;  // ... the first of these
   while (e < n_valid) {
     const uint32_t ent = e + ulane;
     const bool have = ent < n_valid;
@@ -680,6 +684,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     if (n == 0u) {  // the output limit (the symbol that crosses it is lane_one_symbol's), or a granule too rich for a tile
       p_end = tile_start_p;
       cut = true;
+      limit_cut = wv::readlane(eod, 0u) != SPAN_OD_BIG;
       break;
     }
     const uint32_t tile_len = wv::readlane(incl, n - 1u);
@@ -1008,7 +1013,12 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   // (a chain that held for less than a quarter of the span: walks that do not fall into step -- a bit
   // stream with a period does that -- make every further span of the block as poor: leave it)
   const bool poor = n_valid * 4u < TG && !end_stop;
-  return !progress || cut || end_stop || poor ? SPAN_OFF : SPAN_AGAIN;
+  // the block ends here (a real stop), or the output's limit is near: the rest is the plain decoder's.  A rich
+  // granule, a refused tile, a chain that broke early: such stretches are short (binaries: a run of zeros
+  // between code and tables); leaving the whole block to the wide turns for one of them made ELF files
+  // inflate 10 x slower than text.
+  if (end_stop || limit_cut) return SPAN_OFF;
+  return !progress || cut || poor ? SPAN_LATER : SPAN_AGAIN;
 }
 
 }  // namespace zd
