@@ -37,10 +37,12 @@ extern "C" {
 
 /* Longest single stream, and largest destination capacity, in bytes: 4 GiB - 64 KiB (positions are
  * 32-bit inside the kernels).  The reference's own limit is OCaml's string length.
- * One exception, for inflate: a batch of ONE stream that begins with a chain of stored blocks of
- * equal length -- what the reference's encoder makes of incompressible data -- may be of any size
- * (zipc_hip_inflate_batch with max_dst_cap above this limit; checksum none or CRC-32): the chain is
- * copied with 64-bit offsets and what follows it has to fit the limit as a stream of its own. */
+ * One exception, for inflate: a batch of ONE stream that begins with stored blocks -- what the
+ * reference's encoder makes of incompressible data -- may be of any size (zipc_hip_inflate_batch with
+ * max_dst_cap above this limit; checksum none or CRC-32): stored blocks of any lengths are copied with
+ * 64-bit offsets (a run of equal blocks all at once, others by a walk over their headers), with the
+ * reference's messages for a damaged header and for a block beyond ?decompressed_size; the first block
+ * of another kind and what follows it has to fit the limit as a stream of its own. */
 #define ZIPC_HIP_MAX_STREAM_LEN 0xFFFF0000ull
 
 /* ---- status codes --------------------------------------------------------
@@ -219,7 +221,10 @@ typedef struct zipc_hip_stream_result_s {
 
 /* All pointers are DEVICE pointers (descs and results too).  Work is enqueued
  * on the context stream and NOT synchronised: call zipc_hip_synchronize (or
- * synchronise the stream) before reading results. */
+ * synchronise the stream) before reading results.  One exception: zipc_hip_inflate_batch
+ * of ONE stream with max_dst_cap above ZIPC_HIP_MAX_STREAM_LEN (a stream of stored blocks
+ * beyond 4 GiB, below) reads a few words back between its steps and so synchronises the
+ * stream itself. */
 /* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream
  * whose output is longer than that reports ZIPC_HIP_ERR_INVALID_ARG in its result when a
  * CRC-32 is asked for (its checksum would cover only a part). A descriptor with src_len or

@@ -273,12 +273,99 @@ def test_config5_single_8gib_stream_of_stored_blocks(gpu_ctx, oracle):
     res = run(n)
     assert int(res["status"][0]) == 1 and int(res["out_len"][0]) == 0  # "Corrupted data stream"
     comp[at] = saved
-    # damaged early: what follows is itself beyond the kernel's range: refused as an argument
+    # damaged early: the reference's message here too (the walk over the headers finds it; round 2 refused the
+    # stream as an argument because what follows the damage is beyond the batch kernel's range)
     at = 1000 * 65539 + 3
     saved = int(comp[at])
     comp[at] = saved ^ 0x40
+    res = run(n)
+    assert int(res["status"][0]) == 1 and int(res["out_len"][0]) == 0
+    comp[at] = saved
+    # a compressed block early in a stream this long cannot be taken (32-bit positions): refused as an argument
+    at = 1000 * 65539
+    saved = int(comp[at])
+    comp[at] = saved | 2  # BTYPE 01
     assert int(run(n)["status"][0]) == 18
     comp[at] = saved
+
+
+def _stored_stream_of(src, lens):
+    """src as stored blocks of the given lengths (their sum = len(src)), the last one final, on the device"""
+    import torch
+
+    parts = []
+    at = 0
+    for k, L in enumerate(lens):
+        h = torch.tensor([1 if k + 1 == len(lens) else 0, L & 255, L >> 8, (~L) & 255, ((~L) >> 8) & 255], dtype=torch.uint8, device=src.device)
+        parts += [h, src[at:at + L]]
+        at += L
+    assert at == src.numel()
+    return torch.cat(parts)
+
+
+def test_huge_stream_of_stored_blocks_of_any_lengths(gpu_ctx, oracle):
+    """Beyond 4 GiB with blocks of MIXED lengths: runs of equal blocks of several lengths, single odd blocks,
+    empty blocks, a short final one -- the walk over the headers (inflate.hip, stored_walk_kernel) lists what the
+    all-at-once check of equal blocks cannot take.  Bytes, CRC-32, the reference's statuses; the first blocks as
+    a stream of their own against the oracle."""
+    import random
+
+    import torch
+
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    r = random.Random(9)
+    lens = []
+    total = 0
+    target = (1 << 32) + (1 << 27)
+    while total < target:
+        kind = r.randrange(5)
+        run = [65534] * r.randrange(200, 6000) if kind < 2 else [r.choice([65535, 40000, 1, 17, 65534])] * r.randrange(1, 900) if kind < 4 \
+            else [r.randrange(0, 65536) for _ in range(r.randrange(1, 30))] + [0, 0]
+        lens += run
+        total += sum(run)
+    while total % 8:
+        lens.append(1)
+        total += 1
+    src = synth.batch_bytes_torch(5, 11, 1, total, 8, dev)
+    comp = _stored_stream_of(src, lens)
+    out = torch.zeros(total + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+
+    def run_(limit, cap=total):
+        descs = batch.make_descs([0], [comp.numel()], [0], [cap], limit=None if limit is None else [limit])
+        batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(descs, dev), d_res, 1, cap, 1)
+        return batch.results_from_device(d_res)
+
+    res = run_(total)
+    assert int(res["status"][0]) == 0 and int(res["out_len"][0]) == total
+    assert torch.equal(out[:total], src)
+    crc, _ = batch.checksum_device(gpu_ctx, src, want_adler32=False)
+    assert int(res["checksum"][0]) == crc
+    assert int(run_(total - 1)["status"][0]) == 2   # "Expected decompression size exceeded"
+    assert int(run_(None, cap=total - 1)["status"][0]) == 16  # no ?decompressed_size: the caller's buffer is what is short
+    # a damaged NLEN in a block of an odd length, far into the stream
+    pos = 0
+    k = len(lens) * 2 // 3
+    for L in lens[:k]:
+        pos += 5 + L
+    saved = int(comp[pos + 4])
+    comp[pos + 4] = saved ^ 1
+    res = run_(total)
+    assert int(res["status"][0]) == 1 and int(res["out_len"][0]) == 0
+    comp[pos + 4] = saved
+    # cut short inside the last block's bytes: "Corrupted data stream" (zd.ml:676)
+    descs = batch.make_descs([0], [comp.numel() - 1], [0], [total], limit=[total])
+    batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(descs, dev), d_res, 1, total, 1)
+    assert int(batch.results_from_device(d_res)["status"][0]) == 1
+    # the oracle on the first blocks (made final)
+    n_head = 40
+    end = sum(5 + L for L in lens[:n_head])
+    head = bytearray(comp[:end].cpu().numpy().tobytes())
+    head[end - 5 - lens[n_head - 1]] |= 1
+    st0, d0, _ = oracle.inflate(bytes(head))
+    assert st0 == 0 and d0 == src[:sum(lens[:n_head])].cpu().numpy().tobytes()
 
 
 def test_huge_stored_stream_through_the_host_form(gpu_ctx):

@@ -330,6 +330,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch);
   free_buf(ctx->inflate_scratch);
+  free_buf(ctx->stored_list);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
   if (ctx->pin_res.p) (void)hipHostFree(ctx->pin_res.p);
@@ -401,9 +402,12 @@ size_t zipc_hip_zlib_bound(size_t len) { return zipc_hip_deflate_bound(len) + 6;
 
 // ---- batch forms ---------------------------------------------------------------
 
-// One stream beyond ZIPC_HIP_MAX_STREAM_LEN: the chain of equal stored blocks it has to start with
-// (inflate.hip) is found and copied with 64-bit offsets, what follows goes through the batch kernel
-// as a stream of its own, and the two results are put together.
+// One stream beyond ZIPC_HIP_MAX_STREAM_LEN: the stored blocks it has to start with (inflate.hip) are found
+// and copied with 64-bit offsets -- a chain of equal blocks all at once, blocks of other lengths by a walk over
+// their headers -- and what follows, if anything, goes through the batch kernel as a stream of its own; the
+// results are put together.  A damaged or cut-short stored header, and a block that does not fit the limit,
+// get the reference's messages.  This path copies a few words to the host between its steps: it SYNCHRONISES
+// the context's stream, unlike the rest of zipc_hip_inflate_batch.
 static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                                const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results, int crc_op) {
   if (crc_op == ZIPC_HIP_CRC_ADLER32 || crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950) return ZIPC_HIP_ERR_INVALID_ARG;
@@ -427,19 +431,56 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     blocks = st.first_bad;
     if (st.final_at < blocks) { blocks = (uint64_t)st.final_at + 1; done = true; }  // the final block is one of the chain
-    // blocks that would overrun the destination are the remainder's: it reports the reference's error
-    const uint64_t limit = (sd.flags & STREAM_HAS_LIMIT) ? sd.limit : ~0ull;
-    const uint64_t room = limit < sd.dst_cap ? limit : sd.dst_cap;
-    if (blocks * st.len0 > room) { blocks = room / st.len0; done = false; }
+    // blocks that would overrun the destination are left to the walk below: it reports the reference's error
+    {
+      const uint64_t lim = (sd.flags & STREAM_HAS_LIMIT) ? sd.limit : ~0ull;
+      const uint64_t room = lim < sd.dst_cap ? lim : sd.dst_cap;
+      if (blocks * st.len0 > room) { blocks = room / st.len0; done = false; }
+    }
     if (blocks)
       ZD_LAUNCH(ctx, "stored_chain_copy", stored_chain_copy_kernel, dim3((unsigned)blocks), dim3(256), 0,
                 (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs, st.len0);
   }
-  const uint64_t used_src = blocks * (5ull + st.len0), made = blocks * (uint64_t)st.len0;
+  uint64_t used_src = blocks * (5ull + st.len0), made = blocks * (uint64_t)st.len0;
+  const uint64_t limit = (sd.flags & STREAM_HAS_LIMIT) ? sd.limit : ~0ull;
+  const uint64_t room_all = limit < sd.dst_cap ? limit : sd.dst_cap;
+  bool settled = done;  // the result is known without the batch kernel
   if (done) {
     res.status = ZIPC_HIP_OK;
     res.out_len = made;
-  } else {
+  }
+  if (!settled) {
+    // stored blocks of other lengths: walked header by header (64 at a time while the length stays), listed and
+    // copied, a list at a time
+    constexpr uint32_t LIST_CAP = 1u << 20;
+    HIP_TRY(ctx, ctx->ensure(ctx->stored_list, (size_t)LIST_CAP * sizeof(StoredBlock)));
+    StoredWalk *d_walk = (StoredWalk *)((uint8_t *)ctx->io_small.p + 192);
+    static_assert(192 + sizeof(StoredWalk) <= 256, "io_small layout");
+    for (;;) {
+      StoredWalk w;
+      w.src_pos = used_src; w.dst_pos = made; w.room = room_all - made; w.n_blocks = 0; w.stop = WALK_MORE;
+      HIP_TRY(ctx, hipMemcpyAsync(d_walk, &w, sizeof w, hipMemcpyHostToDevice, ctx->stream));
+      ZD_LAUNCH(ctx, "stored_walk", stored_walk_kernel, dim3(1), dim3(64), 0, (const uint8_t *)d_src_arena,
+                (const StreamDesc *)d_descs, d_walk, (StoredBlock *)ctx->stored_list.p, LIST_CAP);
+      HIP_TRY(ctx, hipMemcpyAsync(&w, d_walk, sizeof w, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+      if (w.n_blocks)
+        ZD_LAUNCH(ctx, "stored_list_copy", stored_list_copy_kernel, dim3(w.n_blocks < 65536u ? w.n_blocks : 65536u), dim3(256), 0,
+                  (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
+                  (const StoredBlock *)ctx->stored_list.p, w.n_blocks);
+      used_src = w.src_pos;
+      made = w.dst_pos;
+      if (w.stop == WALK_MORE && w.n_blocks) continue;  // the list was full
+      if (w.stop == WALK_FINAL) { res.status = ZIPC_HIP_OK; res.out_len = made; settled = true; }
+      else if (w.stop == WALK_CORRUPT) { res.status = ZIPC_HIP_ERR_CORRUPTED; settled = true; }  // zd.ml:672-677
+      else if (w.stop == WALK_ROOM) {  // Buf.add_string past the fixed size (zd.ml:29), or the caller's buffer is full
+        res.status = (sd.flags & STREAM_HAS_LIMIT) && limit <= sd.dst_cap ? ZIPC_HIP_ERR_SIZE_EXCEEDED : ZIPC_HIP_ERR_DST_TOO_SMALL;
+        settled = true;
+      }
+      break;  // WALK_OTHER: a block of another kind follows
+    }
+  }
+  if (!settled) {
     StreamDesc rest = sd;
     rest.src_off += used_src; rest.src_len -= used_src;
     rest.dst_off += made; rest.dst_cap -= made;
@@ -451,7 +492,7 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
       // for the CRC pass below
       zipc_hip_stream_desc *d_rest = (zipc_hip_stream_desc *)((uint8_t *)ctx->io_small.p + 64);
       zipc_hip_stream_result *d_rest_res = (zipc_hip_stream_result *)((uint8_t *)ctx->io_small.p + 128);
-      static_assert(sizeof(StoredChain) <= 64 && sizeof(StreamDesc) <= 64 && 128 + sizeof(StreamResult) <= 256, "io_small layout");
+      static_assert(sizeof(StoredChain) <= 64 && sizeof(StreamDesc) <= 64 && 128 + sizeof(StreamResult) <= 192, "io_small layout");
       HIP_TRY(ctx, hipMemcpyAsync(d_rest, &rest, sizeof rest, hipMemcpyHostToDevice, ctx->stream));
       const int stb = zipc_hip_inflate_batch(ctx, d_src_arena, d_dst_arena, d_rest, d_rest_res, 1, (size_t)rest.dst_cap,
                                              ZIPC_HIP_CRC_NOP);
@@ -460,7 +501,7 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
       HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
       if (res.status == ZIPC_HIP_OK) res.out_len += made;
       else res.out_len = 0;
-    }  // else: the chain ends too early for the rest to be one ordinary stream: INVALID_ARG stands
+    }  // else: compressed blocks begin too early for the rest to be one ordinary stream (32-bit positions): INVALID_ARG stands
   }
   HIP_TRY(ctx, hipMemcpyAsync(d_results, &res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -45,6 +45,7 @@ struct zipc_hip_ctx {
   Buf crc_nib;                                    // nibble tables of the CRC merge constants (kernels.h)
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)
   Buf inflate_scratch;                            // inflate: the span decoder's index, 2304 bytes per stream
+  Buf stored_list;                                // inflate of one stream beyond 4 GiB: the stored blocks a walk listed
 
   int name_index(const char *name);
   hipEvent_t get_event();

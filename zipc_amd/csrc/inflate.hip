@@ -700,4 +700,79 @@ __global__ __launch_bounds__(256) void stored_chain_copy_kernel(const uint8_t *_
   if (threadIdx.x < (len0 & 15u)) o[body + threadIdx.x] = s[body + threadIdx.x];
 }
 
+// The same for stored blocks of any lengths (a stream some other encoder made, or the reference's own
+// behind a run of shorter blocks).  A block's length says where the next header is, so the headers are a
+// chain of dependent loads; but runs of equal blocks are the rule, so the wave guesses that the next 64
+// blocks have the length of the last one seen and checks 64 headers per step: all that hold in a row are
+// listed, the first that does not (another length: it becomes the next guess) ends the step.
+__global__ __launch_bounds__(64) void stored_walk_kernel(const uint8_t *__restrict__ src_arena,
+                                                         const StreamDesc *__restrict__ descs,
+                                                         StoredWalk *__restrict__ walk, StoredBlock *__restrict__ list,
+                                                         uint32_t list_cap) {
+  const StreamDesc sd = descs[0];
+  const uint8_t *s = src_arena + sd.src_off;
+  const uint32_t lane = threadIdx.x;
+  uint64_t p = walk->src_pos, o = walk->dst_pos, room = walk->room;  // wave-uniform
+  uint32_t n = 0, stop = WALK_MORE;
+  uint32_t guess = 0xFFFFFFFFu;  // no guess: only lane 0's header counts
+  while (n + 64u <= list_cap) {
+    // lane k: the header that starts k blocks of the guessed length further on
+    const uint64_t q = p + (uint64_t)lane * (5ull + (guess == 0xFFFFFFFFu ? 0u : guess));
+    const bool here = guess != 0xFFFFFFFFu || lane == 0;
+    uint32_t len = 0, kind = 0;  // kind: 0 a stored header that holds, 1 another kind of block, 2 damaged / cut short
+    bool final = false;
+    if (here) {
+      if (q + 1u > sd.src_len) kind = 2;  // (no byte left for the block's 3 header bits: the reference's read fails)
+      else if ((s[q] & 6u) != 0u) kind = 1;
+      else if (q + 5u > sd.src_len) kind = 2;
+      else {
+        len = s[q + 1] | ((uint32_t)s[q + 2] << 8);
+        const uint32_t nlen = s[q + 3] | ((uint32_t)s[q + 4] << 8);
+        if (len != ((~nlen) & 0xFFFFu) || q + 5u + len > sd.src_len) kind = 2;
+        final = (s[q] & 1u) != 0u;
+      }
+    }
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+    const uint32_t kind0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)kind);
+    if (kind0 != 0u) { stop = kind0 == 1u ? WALK_OTHER : WALK_CORRUPT; break; }
+    if (guess != len0) {  // the guess was wrong for lane 0 already (or there was none): only lane 0 stands
+      guess = len0;
+      if (lane != 0) kind = 3;
+    }
+    // the lanes that hold in a row: good header, the guessed length, room for their bytes, no final block before them
+    const bool good = here && kind == 0u && len == guess && (uint64_t)(lane + 1u) * guess <= room;
+    const unsigned long long gm = __builtin_amdgcn_ballot_w64(good);
+    const unsigned long long fm = __builtin_amdgcn_ballot_w64(good && final);
+    uint32_t m = ~gm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~gm);
+    if (fm) { const uint32_t f = (uint32_t)__builtin_ctzll(fm); if (f < m) { m = f + 1u; stop = WALK_FINAL; } }
+    if (m == 0u) { stop = WALK_ROOM; break; }  // lane 0 holds but does not fit
+    if (lane < m) {
+      StoredBlock b;
+      b.src = q + 5u; b.dst = o + (uint64_t)lane * guess; b.len = guess; b.pad = 0;
+      list[n + lane] = b;
+    }
+    n += m;
+    p += (uint64_t)m * (5ull + guess);
+    o += (uint64_t)m * guess;
+    room -= (uint64_t)m * guess;
+    if (stop == WALK_FINAL) break;
+    if (m < 64u) guess = 0xFFFFFFFFu;  // the run ended: the next header's own length
+  }
+  if (lane == 0) { walk->src_pos = p; walk->dst_pos = o; walk->room = room; walk->n_blocks = n; walk->stop = stop; }
+}
+__global__ __launch_bounds__(256) void stored_list_copy_kernel(const uint8_t *__restrict__ src_arena,
+                                                              uint8_t *__restrict__ dst_arena,
+                                                              const StreamDesc *__restrict__ descs,
+                                                              const StoredBlock *__restrict__ list, uint32_t n_blocks) {
+  const StreamDesc sd = descs[0];
+  for (uint32_t j = blockIdx.x; j < n_blocks; j += gridDim.x) {
+    const StoredBlock b = list[j];
+    const uint8_t *s = src_arena + sd.src_off + b.src;
+    uint8_t *o = dst_arena + sd.dst_off + b.dst;
+    const uint32_t body = b.len & ~15u;
+    for (uint32_t i = threadIdx.x * 16u; i < body; i += 256u * 16u) store16_unaligned(o + i, load16_unaligned(s + i));
+    if (threadIdx.x < (b.len & 15u)) o[body + threadIdx.x] = s[body + threadIdx.x];
+  }
+}
+
 }  // namespace zd

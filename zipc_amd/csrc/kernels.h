@@ -27,6 +27,23 @@ __global__ void stored_chain_scan_kernel(const uint8_t *__restrict__ src_arena, 
                                          StoredChain *__restrict__ st);
 __global__ void stored_chain_copy_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                          const StreamDesc *__restrict__ descs, uint32_t len0);
+// ... and of stored blocks of ANY lengths: one wave walks the headers (64 at a time while the blocks keep
+// their length) and lists the blocks; a second kernel copies the listed blocks
+struct StoredBlock { uint64_t src, dst; uint32_t len, pad; };  // offsets inside the stream's source / destination
+enum : uint32_t { WALK_MORE = 0, WALK_FINAL = 1, WALK_OTHER = 2, WALK_CORRUPT = 3, WALK_ROOM = 4 };
+struct StoredWalk {
+  uint64_t src_pos, dst_pos;  // in: where the walk starts; out: where it stopped (a header's first byte)
+  uint64_t room;              // output bytes the walk may still list
+  uint32_t n_blocks;          // out: blocks listed
+  uint32_t stop;              // out: WALK_* -- the list is full / the final block is listed / the next block is not a
+                              // stored one / its header is damaged or cut short (the reference's "Corrupted data
+                              // stream", zd.ml:672-677) / the next block does not fit the room
+};
+__global__ void stored_walk_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                   StoredWalk *__restrict__ walk, StoredBlock *__restrict__ list, uint32_t list_cap);
+__global__ void stored_list_copy_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                        const StreamDesc *__restrict__ descs, const StoredBlock *__restrict__ list,
+                                        uint32_t n_blocks);
 
 // ---- checksum.hip
 constexpr uint32_t CRC_PIECE_BYTES = 128;  // bytes per thread of crc32_segments_kernel
