@@ -657,6 +657,16 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   uint32_t *syms = S.syms + base;
   BlockDesc *blocks = S.blocks + S.blk_base[stream];
 
+  if (len != 0 && !has_match) {  // 1 to 3 bytes: literals, one block (and the loop below may load whole words of source)
+    if ((uint32_t)lane < len) syms[lane] = s[lane];
+    if (lane == 0) {
+      BlockDesc b;
+      b.src_start = 0; b.src_len = len; b.sym_start = 0; b.n_syms = len;
+      blocks[0] = b;
+      S.n_blocks[stream] = 1;
+    }
+    return;
+  }
   uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
   uint32_t B = 0;
   // Table entries and source bytes of three tiles are kept in registers: the current
@@ -668,28 +678,44 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   // the table is read without a range test; source bytes past the end are never used)
   // (addresses are a wave-uniform base, made scalar explicitly, plus a small lane part:
   // per-lane 64-bit address arithmetic costs vector instructions this kernel is bound by)
+  // (no branch and no select around a load: the compiler waits for EVERYTHING in flight at the join of a
+  // conditional load, and a select on the loaded value is an instruction it may place early)
   auto load_match = [&](uint32_t tile) -> uint64_t {
     const uint64_t *mt = match + (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);  // the tile's entries
-    return has_match ? mt[lane] : 0ull;  // uniform condition
+    return mt[lane];
   };
-  auto load_lit = [&](uint32_t tile) -> uint32_t {
+  // A lane's source byte travels as the 4-byte word it was loaded in and is extracted where it is used
+  // (lit_byte) -- NOT loaded as a byte: a byte load is zero-extended by an instruction the compiler put at
+  // the end of the iteration that issued the load (where the value moves into the next iteration's variable),
+  // and with it an s_waitcnt vmcnt(0): every tile waited for the loads it had just requested for two tiles
+  // ahead, and for its own symbol stores.
+  auto lit_index = [&](uint32_t tile, uint32_t &i, uint32_t &c) {
     const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
     const uint32_t tc = t < len ? t : len - 1;  // len >= 1 inside the loop; len <= MAX_STREAM_LEN: no wrap below
-    const uint32_t i = tc + (uint32_t)lane;
-    return s[i < len ? i : len - 1];
+    i = tc + (uint32_t)lane;
+    i = i < len ? i : len - 1;
+    c = i < len - 4u ? i : len - 4u;  // where an in-bounds word that holds byte i starts (len >= 4 here)
   };
-  uint64_t m_cur = 0, m_nxt = 0;
-  uint32_t lit_cur = 0, lit_nxt = 0;
-  if (len) {
-    m_cur = load_match(0);
-    lit_cur = load_lit(0);
-    m_nxt = load_match(PARSE_TILE);
-    lit_nxt = load_lit(PARSE_TILE);
-  }
-  while (B < len) {
+  auto load_lit = [&](uint32_t tile) -> uint32_t {
+    uint32_t i, c;
+    lit_index(tile, i, c);
+    return load_u32_le(s + c);
+  };
+  auto lit_byte = [&](uint32_t raw, uint32_t tile) -> uint32_t {
+    uint32_t i, c;
+    lit_index(tile, i, c);
+    return (raw >> 8u * (i - c)) & 0xFFu;
+  };
+  // One tile.  The three sets of registers -- current tile, next tile, the one requested now -- change
+  // roles from tile to tile BY NAME (the loop below calls this three times with the sets rotated): moved from
+  // variable to variable at the end of an iteration, a value that had just been requested had to arrive first
+  // (s_waitcnt vmcnt(0) before the v_mov), and every tile waited a full memory round trip for loads it would
+  // only need two tiles later.
+  auto tile_step = [&](uint64_t &m_cur, uint64_t &m_nxt, uint64_t &m_nx2, uint32_t &lit_cur, uint32_t &lit_nxt,
+                       uint32_t &lit_nx2) {
     uint32_t Bn = B + PARSE_TILE;
-    const uint64_t m_nx2 = load_match(Bn + PARSE_TILE);
-    const uint32_t lit_nx2 = load_lit(Bn + PARSE_TILE);
+    m_nx2 = load_match(Bn + PARSE_TILE);
+    lit_nx2 = load_lit(Bn + PARSE_TILE);
 
     const uint32_t p = B + (uint32_t)lane;
     const bool valid = p < len;
@@ -779,15 +805,16 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     // position its deferral literals -- the bytes of the next positions, taken
     // from their lanes -- then its match
     {
+      const uint32_t byte_cur = lit_byte(lit_cur, B), byte_nxt = lit_byte(lit_nxt, Bn);
       const bool lit_run = visited && br != 0 && lits != 0;
       uint32_t k = 0;
       while (__builtin_amdgcn_ballot_w64(lit_run && k < lits)) {  // rarely more than one turn
         const uint32_t at = (uint32_t)lane + k;
-        const uint32_t a = lane_value((at & 63u) * 4u, lit_cur), b2 = lane_value((at & 63u) * 4u, lit_nxt);
+        const uint32_t a = lane_value((at & 63u) * 4u, byte_cur), b2 = lane_value((at & 63u) * 4u, byte_nxt);
         if (lit_run && k < lits) tsyms[first_rel + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
         k++;
       }
-      if (visited) tsyms[first_rel + (br ? lits : 0u)] = br ? br : lit_cur;
+      if (visited) tsyms[first_rel + (br ? lits : 0u)] = br ? br : byte_cur;
     }
     // block cut: the first visited node that ends past blk_start + 65534
     // (a visited position is at or behind blk_start, so the test runs on 32-bit
@@ -816,19 +843,30 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     entry = next_entry;
     // tiles the parse jumps over entirely are skipped
     const uint32_t Be = entry & ~63u;
-    if (Be > Bn) {
+    if (Be > Bn) {  // (into the sets that are "current" and "next" for the call that follows)
       B = Be;
-      m_cur = load_match(Be);
-      lit_cur = load_lit(Be);
-      m_nxt = load_match(Be + PARSE_TILE);
-      lit_nxt = load_lit(Be + PARSE_TILE);
+      m_nxt = load_match(Be);
+      lit_nxt = load_lit(Be);
+      m_nx2 = load_match(Be + PARSE_TILE);
+      lit_nx2 = load_lit(Be + PARSE_TILE);
     } else {
       B = Bn;
-      m_cur = m_nxt;
-      lit_cur = lit_nxt;
-      m_nxt = m_nx2;
-      lit_nxt = lit_nx2;
     }
+  };
+  uint64_t ma = 0, mb = 0, mc = 0;
+  uint32_t la = 0, lb = 0, lc = 0;
+  if (len) {
+    ma = load_match(0);
+    la = load_lit(0);
+    mb = load_match(PARSE_TILE);
+    lb = load_lit(PARSE_TILE);
+  }
+  while (B < len) {
+    tile_step(ma, mb, mc, la, lb, lc);
+    if (B >= len) break;
+    tile_step(mb, mc, ma, lb, lc, la);
+    if (B >= len) break;
+    tile_step(mc, ma, mb, lc, la, lb);
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
@@ -1223,23 +1261,28 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
           v[u] = syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
         }
       };
-      uint32_t cur[4], nxt[4];
-      load4(0, cur);
-      for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 256) {
-        load4(k0 + 256u, nxt);
+      // (two sets of registers that swap roles by name: copied from "next" to "current" at the end of a turn,
+      // the values just requested had to arrive first, and nothing was in flight while a turn was counted)
+      auto count4 = [&](uint32_t k0, const uint32_t *v) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
           if (k < bd.n_syms) {
-            if ((cur[u] >> 9) == 0) atomicAdd(&lit_freq[cur[u]], 1u);
+            if ((v[u] >> 9) == 0) atomicAdd(&lit_freq[v[u]], 1u);
             else {
-              atomicAdd(&lit_freq[heap[cur[u] & 0x1FF]], 1u);
-              atomicAdd(&dist_freq[dist_to_sym((int)(cur[u] >> 9))], 1u);
+              atomicAdd(&lit_freq[heap[v[u] & 0x1FF]], 1u);
+              atomicAdd(&dist_freq[dist_to_sym((int)(v[u] >> 9))], 1u);
             }
           }
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+      };
+      uint32_t va[4], vb[4];
+      load4(0, va);
+      for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 512) {
+        load4(k0 + 256u, vb);
+        count4(k0, va);
+        load4(k0 + 512u, va);
+        count4(k0 + 256u, vb);  // (past the block's end: nothing is counted)
       }
     }
     wave_sync();
@@ -1322,14 +1365,10 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
       const uint32_t k = idx > n_hdr ? idx - 1u - n_hdr : 0u;
       return syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
     };
-    uint32_t sref_cur[PACK_TILES], sref_next[PACK_TILES];
-#pragma unroll
-    for (int u = 0; u < PACK_TILES; u++) sref_cur[u] = fetch((uint32_t)(64 * u + lane));
-    for (uint32_t base = 0; base < n_items; base += 64 * PACK_TILES) {
+    // one turn: PACK_TILES tiles of items from `base` on, their symbols in sref (requested a turn ago)
+    auto pack_turn = [&](uint32_t base, const uint32_t *sref) {
       uint64_t value[PACK_TILES];
       int nbits[PACK_TILES];
-#pragma unroll
-      for (int u = 0; u < PACK_TILES; u++) sref_next[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
 #pragma unroll
       for (int u = 0; u < PACK_TILES; u++) {
         const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
@@ -1344,9 +1383,9 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
             dyn_header_item(c, (int)idx - 1, v, nbits[u]);
             value[u] = v;
           } else {
-            const uint32_t sref = idx - 1u - n_hdr < bd.n_syms ? sref_cur[u] : (uint32_t)LITLEN_EOB;
+            const uint32_t sr = idx - 1u - n_hdr < bd.n_syms ? sref[u] : (uint32_t)LITLEN_EOB;
             // write_block_symbols zd.ml:879-910 (symbol_bits), by table
-            const uint32_t dist = sref >> 9, len = sref & 0x1FF;
+            const uint32_t dist = sr >> 9, len = sr & 0x1FF;
             if (dist == 0) {
               const uint32_t si = hl[len];
               value[u] = si >> 5;
@@ -1363,8 +1402,20 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
         }
       }
       pack_tiles(bo, stage, value, nbits, lane);
+    };
+    // (two sets of registers that swap roles by name, as in the histogram loop)
+    uint32_t sref_a[PACK_TILES], sref_b[PACK_TILES];
 #pragma unroll
-      for (int u = 0; u < PACK_TILES; u++) sref_cur[u] = sref_next[u];
+    for (int u = 0; u < PACK_TILES; u++) sref_a[u] = fetch((uint32_t)(64 * u + lane));
+    for (uint32_t base = 0; base < n_items; base += 2u * 64u * PACK_TILES) {
+#pragma unroll
+      for (int u = 0; u < PACK_TILES; u++) sref_b[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
+      pack_turn(base, sref_a);
+      const uint32_t base2 = base + 64u * PACK_TILES;
+      if (base2 >= n_items) break;  // uniform
+#pragma unroll
+      for (int u = 0; u < PACK_TILES; u++) sref_a[u] = fetch(base2 + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
+      pack_turn(base2, sref_b);
     }
   }
 
