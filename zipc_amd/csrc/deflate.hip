@@ -724,26 +724,27 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     uint32_t br = 0, st = 1u | (1u << 16);
     {
       uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
-      bool chaining = (pend & 0x1FF) != 0;
+      // (flags as integers and selects instead of branches: a loop-carried bool lives in a scalar mask that
+      // costs three scalar instructions per update, and the CU's ONE scalar issue per clock is what this
+      // kernel's 32 waves per CU queue for)
+      uint32_t chaining = (pend & 0x1FF) != 0 ? 1u : 0u;
       uint32_t n_lits = 0, j = p + 1;
       const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
       const uint32_t nxt_lo = (uint32_t)m_nxt, nxt_hi = (uint32_t)(m_nxt >> 32);
       // one step of a lane's lazy chain with the entry mj of position j
-      auto chain_step = [&](uint32_t mj_lo, uint32_t mj_hi, bool use_hi) {
-        if (j > max_pos) { chaining = false; return; }
+      auto chain_step = [&](uint32_t mj_lo, uint32_t mj_hi, uint32_t use_hi) {
         const uint32_t pl = pend & 0x1FF;
-        const uint32_t rem = len - j;
+        const uint32_t rem = len - j;  // (j > max_pos: the value is not used)
         const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
-        uint32_t nb = 0;
-        if (pl < maxlen) {
-          const uint32_t c = use_hi ? mj_hi : mj_lo;
-          if ((c & 0x1FF) > pl) nb = c;
-        }
-        if (nb == 0) chaining = false;
-        else { n_lits++; pend = nb; j++; }
+        const uint32_t c = use_hi ? mj_hi : mj_lo;
+        const uint32_t take = (chaining != 0 && j <= max_pos && pl < maxlen && (c & 0x1FF) > pl) ? 1u : 0u;
+        n_lits += take;
+        pend = take ? c : pend;
+        j += take;
+        chaining = take;
       };
       // chains within the staged tiles (all but pathological ones): entries by shuffle
-      for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining); ahead++) {
+      for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining != 0); ahead++) {
         // every chaining lane looks at the same distance ahead: lane + ahead (< 128)
         const uint32_t off = (uint32_t)lane + ahead;
         const uint32_t addr = (off & 63u) * 4u;
@@ -753,19 +754,19 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
         const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
         const uint32_t mj_lo = in_cur ? a_lo : b_lo;
         uint32_t mj_hi = 0;
-        const bool want_hi = chaining && (pend & 0x1FF) >= (uint32_t)good_match;
-        if (__builtin_amdgcn_ballot_w64(want_hi)) {
+        const uint32_t want_hi = (chaining != 0 && (pend & 0x1FF) >= (uint32_t)good_match) ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(want_hi != 0)) {
           const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
           mj_hi = in_cur ? a_hi : b_hi;
         }
-        if (chaining) chain_step(mj_lo, mj_hi, want_hi);
+        chain_step(mj_lo, mj_hi, want_hi);
       }
       // a chain of 64 strictly growing matches and more: straight from the table
       // (kept out of the loop above: its load would make that loop wait for memory)
-      if (__builtin_amdgcn_ballot_w64(chaining)) {
+      if (__builtin_amdgcn_ballot_w64(chaining != 0)) {
         while (chaining) {
           const uint64_t mj = j <= max_pos ? match[j] : 0ull;
-          chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match);
+          chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
         }
       }
       if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
