@@ -178,19 +178,21 @@ ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p,
 // over-read by 11 bytes) -- the LDS window.  out is indexed by position.  Same
 // results as lz_match_position.
 struct MatchRun {
-  uint32_t p, q, best_len, best, snap, maxlen, steps;
-  uint32_t dn;  // prev[q], read ahead: whether the chain goes on is known before the next step
-  bool alive, snapped;
+  uint32_t p, q, best_len, best, maxlen, steps;
+  uint32_t snap;   // best after Kq candidates, SNAP_NONE before
+  uint32_t dn;     // prev[q], read ahead: whether the chain goes on is known before the next step
+  uint32_t alive;  // 0 / 1 (an integer, like every flag of the step: see match_run_step)
   uint64_t pw;
 };
+constexpr uint32_t SNAP_NONE = 0xFFFFFFFFu;  // no snapshot yet (a real one has length bits <= 258)
 template <bool WORDS>
 ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend,
                            const uint16_t *prev) {
-  r.alive = p < pend;
+  r.alive = p < pend ? 1u : 0u;
   r.p = r.alive ? p : (pend ? pend - 1u : 0u);  // a finished run parks on a valid position
   r.q = r.p;
   r.best_len = MIN_MATCH_LEN - 1;
-  r.best = 0; r.snap = 0; r.steps = 0; r.snapped = false;
+  r.best = 0; r.snap = SNAP_NONE; r.steps = 0;
   r.maxlen = len - r.p < (uint32_t)MAX_MATCH_LEN ? len - r.p : (uint32_t)MAX_MATCH_LEN;
   r.pw = 0;
   if (WORDS) r.pw = load_u64_words(s, r.p);
@@ -202,16 +204,16 @@ ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t
 // starts the run's next position.  The step that compares a candidate also reads
 // that candidate's link, so a position ends in the step of its LAST candidate
 // (max(1, chain length) steps per position, not chain length + 1).
-// (A form with the predicates as integers and selects instead of ifs -- what paid in
-// the inflate kernel -- was measured here and lost: 8.85 ms against 7.27 on C2.  The
-// branches skip work that selects execute, and this loop is nearer its vector bound
-// than its scalar one.)
+// Flags are integers and updates are selects (round 3): the workgroup's 16 waves share the CU's one
+// scalar issue per clock -- this kernel's tighter bound -- and a loop-carried bool costs three scalar
+// instructions per update, a divergent `if` four to eight.  A run without a position goes through the
+// step like any other (it parks on a valid position and never walks); only the long compare and
+// the store of a finished position stay behind branches.
 template <bool WORDS>
 ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
                           uint64_t *out) {
-  if (!r.alive) return false;
   const uint32_t qn = r.q - r.dn;
-  const bool walk = r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
+  const bool walk = r.alive != 0 && r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
   const uint32_t qc = walk ? qn : r.p;
   uint64_t x = 0;
   if (WORDS) x = load_u64_words(s, qc) ^ r.pw;
@@ -230,24 +232,24 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
     }
     if (compare) l = common_prefix(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);  // (maxlen >= 8 here means x == 0: the first 8 agree)
   }
+  const uint32_t steps = r.steps + (walk ? 1u : 0u);
+  const bool better = walk && l > r.best_len;
+  const uint32_t best = better ? (((r.p - qc) << 9) | l) : r.best;
+  r.best_len = better ? l : r.best_len;
+  r.best = best;
+  r.snap = (walk && steps == Kq) ? best : r.snap;
   r.q = qc;
-  r.steps += walk ? 1u : 0u;
-  if (walk && l > r.best_len) {
-    r.best_len = l;
-    r.best = ((r.p - qc) << 9) | l;
-  }
-  if (walk && r.steps == Kq) { r.snap = r.best; r.snapped = true; }
+  r.steps = steps;
   r.dn = d2;
   // would the next step walk?  (l < maxlen implies best_len < maxlen; zd.ml:1194:
   // after l == maxlen nothing later can be longer)
-  const bool more = walk && l != r.maxlen && d2 != 0 && r.steps != K && r.p - (qc - d2) <= (uint32_t)MAX_MATCH_DIST;
-  if (!more) {
-    if (!r.snapped) r.snap = r.best;
-    if (Kq == 0) r.snap = 0;
-    out[r.p] = (uint64_t)r.best | ((uint64_t)r.snap << 32);
-    return true;
+  const bool more = walk && l != r.maxlen && d2 != 0 && steps != K && r.p - qc + d2 <= (uint32_t)MAX_MATCH_DIST;
+  const bool fin = r.alive != 0 && !more;
+  if (fin) {
+    const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : best);
+    out[r.p] = (uint64_t)best | ((uint64_t)snap << 32);
   }
-  return false;
+  return fin;
 }
 // A lane's positions are first, first + step, first + 2 step, ... < pend.  Its NP run
 // slots draw from ONE cursor over them: a slot that finishes a position takes the
@@ -309,7 +311,6 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 //   state WALK: the next candidate (q - dn) exists and is in range; HIT: q passed the byte test
 //   and waits for the compare; FIN: the position is done and waits for its store; DEAD: no position.
 enum : uint32_t { RUN_WALK = 0, RUN_HIT = 1, RUN_FIN = 2, RUN_DEAD = 3 };
-constexpr uint32_t SNAP_NONE = 0xFFFFFFFFu;  // no snapshot yet (a real one has length bits <= 258)
 struct ScanRun {
   uint32_t p, q, best_len, best, maxlen, steps;
   uint32_t snap;   // best after Kq candidates, SNAP_NONE before
