@@ -42,6 +42,34 @@ def test_checksums_match_oracle(gpu_ctx, oracle):
     assert Adler_32.string(b"\xff" * 4200) == 0xA2045889  # not RFC 1950's a2d65889
 
 
+def test_both_checksums_in_one_pass_match_oracle(gpu_ctx, oracle):
+    """checksum_device with both checksums wanted reads the bytes once (crc32_adler_segments_kernel): every
+    length around the grids involved (16-byte units, 128-byte pieces, 5552-byte chunks, 32 KiB segments), at
+    odd starting addresses, on bytes that make the largest sums."""
+    import numpy as np
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+    big = 3 * 32768 + 5552 * 7 + 300
+    pools = {"rand": rng.integers(0, 256, big + 64, dtype=np.uint8), "ff": np.full(big + 64, 255, np.uint8),
+             "text": np.frombuffer(util.text(big + 64, 5), np.uint8).copy()}
+    d_pools = {k: torch.from_numpy(v).to(dev) for k, v in pools.items()}
+    lens = set(range(0, 300)) | {big}
+    for base in (5552, 2 * 5552, 32768, 32768 + 5552, 65536, 3 * 32768, 6 * 5552):
+        lens |= set(range(base - 20, base + 21))
+    lens |= {int(x) for x in rng.integers(300, big, 60)}
+    for n in sorted(lens):
+        for kind in (("ff", "rand") if n % 3 else ("ff", "rand", "text")):
+            off = int(rng.integers(0, 64))
+            crc, adler = batch.checksum_device(gpu_ctx, d_pools[kind][off:off + n])
+            d = pools[kind][off:off + n].tobytes()
+            assert crc == oracle.crc32(d), (n, kind, off)
+            assert adler == oracle.adler32(d), (n, kind, off)
+
+
 def _chunk_with_s2(target_s2, n=5552):
     """n bytes whose position-weighted sum S2 = sum (n - i) b_i equals target_s2"""
     full = n * (n + 1) // 2
@@ -71,6 +99,9 @@ def test_adler_chain_ambiguous_chunks(gpu_ctx, oracle):
     right at 2^31, where the reference's signed remainder (zipc_deflate.ml:95,196)
     depends on the sign of the running s2: the parallel chain must replay those
     chunks exactly."""
+    import torch
+
+    from zipc_amd import batch
     from zipc_amd.zipc_deflate import Adler_32
 
     n = 5552
@@ -90,6 +121,8 @@ def test_adler_chain_ambiguous_chunks(gpu_ctx, oracle):
             assert len(data) % n == 0
             assert Adler_32.string(data) == oracle.adler32(data), (deltas, len(lead))
             assert Adler_32.string(data + b"xyz") == oracle.adler32(data + b"xyz")
+            both = batch.checksum_device(gpu_ctx, torch.frombuffer(bytearray(data + b"xyz"), dtype=torch.uint8).cuda())
+            assert both == (oracle.crc32(data + b"xyz"), oracle.adler32(data + b"xyz"))  # the one-pass form
 
 
 def test_deflate_trip_like_reference(gpu_ctx, oracle):  # test/test.ml:28-43,123-126

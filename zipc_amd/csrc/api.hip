@@ -587,25 +587,28 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
                              int want_adler32, uint32_t *d_out) {
   if (!ctx || !d_out || (!d_buf && len)) return ZIPC_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // Both checksums of a large buffer: the two passes on two queues.  The CRC pass is bound by its table
-  // walks (4.1 TB/s), the Adler pass by memory (6.3 TB/s); side by side they share the reads that are still
-  // in the caches and the chip's idle halves (C3, 4 GiB: 2.1 ms one after the other).
+  // Both checksums: ONE pass over the bytes (crc32_adler_segments_kernel leaves the CRC partials and the
+  // Adler chunk sums), then the two finishes -- on two queues for a large buffer.  ZIPC_HIP_CHECKSUM_FUSED=0
+  // keeps the two passes of rounds 1-3 (CRC on a side queue from 64 MiB on) for comparison and for the tests.
+  static const bool fused_ok = [] { const char *e = getenv("ZIPC_HIP_CHECKSUM_FUSED"); return !e || atoi(e) != 0; }();
   static const bool c3_two_queues = [] { const char *e = getenv("ZIPC_HIP_CHECKSUM_QUEUES"); return !e || atoi(e) != 1; }();
+  const bool fused = want_crc32 && want_adler32 && len > 0 && fused_ok;
   const bool side = want_crc32 && want_adler32 && len >= (64u << 20) && c3_two_queues;
-  if (side) {
-    HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, crc32_segs(len) * sizeof(uint32_t)));  // (before the fork: growing a buffer synchronises)
+  if (side || fused)  // (before any fork: growing a buffer synchronises)
+    HIP_TRY(ctx, ctx->ensure(ctx->crc_partials, crc32_segs(len) * sizeof(uint32_t)));
+  if (side && !fused) {
     HIP_TRY(ctx, ctx->fork(1));
     ctx->cur = ctx->side[0];
   }
-  if (want_crc32) {
+  if (want_crc32 && !fused) {
     int st = crc32_pass(ctx, (const uint8_t *)d_buf, RANGE_SINGLE, nullptr, nullptr, 1, 0, len, len, d_out);
     if (side) ctx->cur = ctx->stream;
     if (st != ZIPC_HIP_OK) { if (side) (void)ctx->join(1); return st; }
   }
   struct Joiner {  // the side queue is joined on every way out of the Adler half
     zipc_hip_ctx *c; bool on;
-    ~Joiner() { if (on) (void)c->join(1); }
-  } joiner{ctx, side};
+    ~Joiner() { if (on) { c->cur = c->stream; (void)c->join(1); } }
+  } joiner{ctx, side && !fused};
   if (want_adler32) {
     const uint64_t n_chunks = len ? len / ADLER_CHUNK + 1 : 0;
     // chunk sums, then the ambiguous-chunk list and the per-run arrays of the chain kernels
@@ -624,7 +627,23 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
     R.last_hi = (uint32_t *)q; q += run_bytes;
     R.res_before = (uint32_t *)q; q += run_bytes;
     R.amb_count = (uint32_t *)q;
-    if (n_chunks) {
+    if (fused) {
+      const size_t segs = crc32_segs(len);
+      if (segs > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+      uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
+      HIP_TRY(ctx, hipMemsetAsync(sums, 0, (size_t)n_chunks * sizeof(uint2), ctx->stream));
+      ZD_LAUNCH(ctx, "crc32_adler_segments", crc32_adler_segments_kernel, dim3((unsigned)segs), dim3(256), 0,
+                (const uint8_t *)d_buf, (uint64_t)len, (uint32_t)segs, (const uint32_t *)ctx->crc_nib.p, partials,
+                sums, n_chunks);
+      HIP_TRY(ctx, hipGetLastError());
+      if (side) {  // the CRC's finish beside the Adler chain
+        HIP_TRY(ctx, ctx->fork(1));
+        ctx->cur = ctx->side[0];
+        joiner.on = true;
+      }
+      HIP_TRY(ctx, crc32_finish_launch(ctx, RANGE_SINGLE, nullptr, nullptr, 1, len, len, partials, d_out));
+      ctx->cur = ctx->stream;
+    } else if (n_chunks) {
       if ((n_chunks + 3) / 4 > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
       ZD_LAUNCH(ctx, "adler_chunks", adler_chunks_kernel, dim3((unsigned)((n_chunks + 3) / 4)), dim3(256), 0,
                 (const uint8_t *)d_buf, (uint64_t)len, n_chunks, sums);

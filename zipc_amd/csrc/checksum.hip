@@ -60,10 +60,18 @@ __device__ __forceinline__ void build_crc_tables(uint32_t (*T)[256], int t) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
+// ADLER: the same pass also leaves the Adler-32 chunk sums of the range (RANGE_SINGLE only): the chunk grid
+// (first chunk = len mod 5552, then 5552 each) and the right-aligned piece grid agree mod 16 -- 5552 = 16 * 347
+// and both are congruent to len -- so a chunk boundary falls between two 16-byte units of a thread's piece,
+// never inside one.  A thread sums its 8 units (S1 = sum b, S2 = sum (end - i) b, two dot products per word),
+// splits them at the boundary if its piece holds one, and the wave adds what it has of at most three chunks
+// to `adler_sums` (zeroed by the caller; integer adds: any order gives the same sums).
+template <bool ADLER>
+__device__ __forceinline__ void crc32_segment(
     const uint8_t *__restrict__ base, int mode, const StreamDesc *__restrict__ descs,
     const StreamResult *__restrict__ results, uint64_t single_off, uint64_t single_len,
-    uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials) {
+    uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials,
+    uint32_t *__restrict__ adler_sums, uint64_t n_chunks) {
   __shared__ uint32_t T[4][256];
   __shared__ __attribute__((aligned(16))) uint32_t N[8 * GF2_NIB_WORDS];  // xpiece[0..7] as nibble tables (4 KiB)
   static_assert(8 * GF2_NIB_WORDS == 4 * CRC_THREADS, "one 16-byte load per thread");
@@ -124,9 +132,36 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
   // zero bytes leave c = 0)
   uint32_t c = 0;
   const u32x4 *mine = (const u32x4 *)(stage + (uint32_t)t * CRC_PIECE_STRIDE);
+  // Adler: the chunk that holds the piece's first byte, and the unit at which the next chunk starts (8: none)
+  uint32_t cut = 8, s1 = 0, s2 = 0, A1 = 0, A2 = 0;
+  uint64_t kA = 0;
+  int64_t to_end = 0;  // from the piece's start to the end of chunk kA: a positive multiple of 16
+  if constexpr (ADLER) {
+    const int64_t ps = seg0 + (int64_t)((uint32_t)t * CRC_PIECE);
+    const uint64_t r = len % ADLER_CHUNK;
+    const uint64_t pos0 = ps > 0 ? (uint64_t)ps : 0;
+    uint64_t eA = r;
+    if (pos0 >= r) { kA = (pos0 - r) / ADLER_CHUNK + 1; eA = r + kA * ADLER_CHUNK; }
+    to_end = (int64_t)eA - ps;
+    cut = to_end < (int64_t)CRC_PIECE ? (uint32_t)to_end / 16u : 8u;
+  }
 #pragma unroll
   for (int j = 0; j < (int)(CRC_PIECE / 16); j++) {
     const u32x4 w = mine[j];
+    if constexpr (ADLER) {
+      A1 = cut == (uint32_t)j ? s1 : A1;  // the sums of the units before the boundary
+      A2 = cut == (uint32_t)j ? s2 : A2;
+      uint32_t u1 = __builtin_amdgcn_udot4(w.x, 0x01010101u, 0u, false);
+      u1 = __builtin_amdgcn_udot4(w.y, 0x01010101u, u1, false);
+      u1 = __builtin_amdgcn_udot4(w.z, 0x01010101u, u1, false);
+      u1 = __builtin_amdgcn_udot4(w.w, 0x01010101u, u1, false);
+      uint32_t u2 = __builtin_amdgcn_udot4(w.x, 0x0D0E0F10u, 0u, false);  // byte i of the unit weighs 16 - i
+      u2 = __builtin_amdgcn_udot4(w.y, 0x090A0B0Cu, u2, false);
+      u2 = __builtin_amdgcn_udot4(w.z, 0x05060708u, u2, false);
+      u2 = __builtin_amdgcn_udot4(w.w, 0x01020304u, u2, false);
+      s2 += 16u * s1 + u2;
+      s1 += u1;
+    }
     uint32_t u = c ^ w.x;
     c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
     u = c ^ w.y;
@@ -151,6 +186,46 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
     const uint32_t b = gf2_mul_nib(wave_part[2], N + 6 * GF2_NIB_WORDS) ^ wave_part[3];
     partials[(uint64_t)range * segs_per_range + seg] = gf2_mul_nib(a, N + 7 * GF2_NIB_WORDS) ^ b;
   }
+  if constexpr (ADLER) {
+    if (cut == 8u) { A1 = s1; A2 = s2; }
+    // what the piece adds to chunk kA (units before the boundary) and to chunk kA + 1 (the rest): S2 counts a
+    // byte by its distance to the end of ITS CHUNK, the piece sums count it to the end of the part
+    const uint32_t B1 = s1 - A1, B2 = s2 - A2 - (CRC_PIECE - 16u * cut) * A1;
+    const uint32_t a2 = A2 + (cut == 8u ? (uint32_t)(to_end - (int64_t)CRC_PIECE) * A1 : 0u);
+    const uint32_t b2 = B2 + ((uint32_t)to_end + ADLER_CHUNK - CRC_PIECE) * B1;  // (B1 = 0 when there is no boundary)
+    // the wave's 8 KiB touch at most three chunks: three sums of each kind, lane 63 of a scan holds the total
+    const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kA >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)kA);
+    const uint32_t dk = (uint32_t)(kA - k0);
+    uint32_t tot[6];
+#pragma unroll
+    for (uint32_t k = 0; k < 3; k++) {
+      const uint32_t v1 = (dk == k ? A1 : 0u) + (dk + 1u == k ? B1 : 0u);
+      const uint32_t v2 = (dk == k ? a2 : 0u) + (dk + 1u == k ? b2 : 0u);
+      tot[2 * k] = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v1), 63);
+      tot[2 * k + 1] = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(v2), 63);
+    }
+    const uint32_t ln = (uint32_t)t & 63u;
+    uint32_t mine_v = tot[0];
+#pragma unroll
+    for (uint32_t m = 1; m < 6; m++) mine_v = ln == m ? tot[m] : mine_v;
+    const uint64_t kc = k0 + (ln >> 1);
+    if (ln < 6u && kc < n_chunks && mine_v) atomicAdd(adler_sums + 2 * kc + (ln & 1u), mine_v);
+  }
+}
+
+__global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
+    const uint8_t *__restrict__ base, int mode, const StreamDesc *__restrict__ descs,
+    const StreamResult *__restrict__ results, uint64_t single_off, uint64_t single_len,
+    uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials) {
+  crc32_segment<false>(base, mode, descs, results, single_off, single_len, segs_per_range, nib, partials, nullptr, 0);
+}
+
+// CRC-32 partials and Adler-32 chunk sums of ONE buffer in one pass over its bytes
+__global__ __launch_bounds__(CRC_THREADS) void crc32_adler_segments_kernel(
+    const uint8_t *__restrict__ p, uint64_t len, uint32_t n_segs, const uint32_t *__restrict__ nib,
+    uint32_t *__restrict__ partials, uint2 *__restrict__ adler_sums, uint64_t n_chunks) {
+  crc32_segment<true>(p, RANGE_SINGLE, nullptr, nullptr, 0, len, n_segs, nib, partials, (uint32_t *)adler_sums, n_chunks);
 }
 
 // One workgroup per range: folds the segment partials (Horner runs per thread,
@@ -312,19 +387,25 @@ __global__ __launch_bounds__(1024) void adler_rfc_finish_kernel(const uint2 *__r
 //   order, by one thread, each replay shifting all later residues by a constant.
 constexpr uint32_t CHAIN_THREADS_A = 1024;
 
-__device__ __forceinline__ uint64_t block_excl_scan_mod(uint64_t v, uint64_t *sh, int t) {
+// (a + b) mod p for a, b <= p
+__device__ __forceinline__ uint32_t addmod(uint32_t a, uint32_t b) {
+  const uint32_t s = a + b;
+  return s >= ADLER_BASE ? s - ADLER_BASE : s;
+}
+
+__device__ __forceinline__ uint32_t block_excl_scan_mod(uint32_t v, uint32_t *sh, int t) {
   // exclusive scan of per-thread values (each < 65521) over the 1024 threads, mod p
   sh[t] = v;
   __syncthreads();
   for (int o = 1; o < (int)CHAIN_THREADS_A; o <<= 1) {
-    const uint64_t u = t >= o ? sh[t - o] : 0;
+    const uint32_t u = t >= o ? sh[t - o] : 0;
     __syncthreads();
-    sh[t] = (sh[t] + u) % ADLER_BASE;
+    sh[t] = addmod(sh[t], u);
     __syncthreads();
   }
-  const uint64_t incl = sh[t];
+  const uint32_t incl = sh[t];
   __syncthreads();
-  return (incl + ADLER_BASE - v % ADLER_BASE) % ADLER_BASE;
+  return incl >= v ? incl - v : incl + ADLER_BASE - v;
 }
 
 // what pass 2 already knows about an ambiguous chunk, kept for the replay
@@ -355,20 +436,43 @@ __global__ __launch_bounds__(256) void adler_runs_s1_kernel(const uint2 *__restr
   R.sum[run] = (uint32_t)(acc % ADLER_BASE);
 }
 
-// out[run] = (first + exclusive prefix of in[0 .. run)) mod p; total[0] = the same over all runs
+// out[run] = (first + exclusive prefix of in[0 .. run)) mod p; the inputs are < p.  A thread owns `each`
+// consecutive runs (1, 2, 4 .. 64 of them: 16-byte loads from 4 on) and everything is 32-bit: a run of 64
+// values sums below 2^22, and a sum of two residues needs one conditional subtraction.
 __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_scan_runs_kernel(const uint32_t *__restrict__ in,
                                                                           uint32_t *__restrict__ out,
                                                                           uint32_t n_runs, uint32_t first) {
-  __shared__ uint64_t sh[CHAIN_THREADS_A];
+  __shared__ uint32_t sh[CHAIN_THREADS_A];
   const int t = threadIdx.x;
-  const uint32_t each = n_runs / CHAIN_THREADS_A;  // n_runs is a multiple of 1024
-  uint64_t acc = 0;
-  for (uint32_t j = 0; j < each; j++) acc += in[(uint32_t)t * each + j];
-  uint64_t pre = (first + block_excl_scan_mod(acc % ADLER_BASE, sh, t)) % ADLER_BASE;
-  for (uint32_t j = 0; j < each; j++) {
-    const uint32_t v = in[(uint32_t)t * each + j];
-    out[(uint32_t)t * each + j] = (uint32_t)pre;
-    pre = (pre + v) % ADLER_BASE;
+  const uint32_t each = n_runs / CHAIN_THREADS_A;  // n_runs is 1024 times a power of two
+  const uint32_t *mine = in + (uint32_t)t * each;
+  uint32_t *mine_out = out + (uint32_t)t * each;
+  uint32_t acc = 0;
+  if (each >= 4) {
+    for (uint32_t j = 0; j < each; j += 4) {
+      const u32x4 v = *(const u32x4 *)(mine + j);
+      acc += v.x + v.y + v.z + v.w;
+    }
+  } else {
+    for (uint32_t j = 0; j < each; j++) acc += mine[j];
+  }
+  uint32_t pre = addmod(first % ADLER_BASE, block_excl_scan_mod(acc % ADLER_BASE, sh, t));
+  if (each >= 4) {
+    for (uint32_t j = 0; j < each; j += 4) {
+      const u32x4 v = *(const u32x4 *)(mine + j);
+      u32x4 o;
+      o.x = pre; pre = addmod(pre, v.x);
+      o.y = pre; pre = addmod(pre, v.y);
+      o.z = pre; pre = addmod(pre, v.z);
+      o.w = pre; pre = addmod(pre, v.w);
+      *(u32x4 *)(mine_out + j) = o;
+    }
+  } else {
+    for (uint32_t j = 0; j < each; j++) {
+      const uint32_t v = mine[j];
+      mine_out[j] = pre;
+      pre = addmod(pre, v);
+    }
   }
 }
 
@@ -417,11 +521,14 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_replay_kernel(const uin
   // everything the serial replay reads is gathered into LDS by the whole
   // workgroup first: one thread walking global memory pays a full memory latency
   // per access
+  // -- and everything that does not depend on the chunks before a record is worked out by the thread that
+  // ranks it: the one thread's loop is a handful of 32-bit operations per record.
   __shared__ uint32_t keys[REPLAY_MAX];
-  __shared__ AmbRecord recs[REPLAY_MAX];  // sorted by chunk index
-  __shared__ uint2 rec_sums[REPLAY_MAX];
-  __shared__ uint32_t rec_res[REPLAY_MAX];
-  __shared__ uint8_t rec_prev[REPLAY_MAX];
+  __shared__ uint32_t r_k[REPLAY_MAX];     // sorted by chunk index: the chunk,
+  __shared__ uint32_t r_res[REPLAY_MAX];   // the predicted residue of s2 before it,
+  __shared__ uint32_t r_C[REPLAY_MAX];     // C = n * s1 + S2 (< 2^32),
+  __shared__ uint32_t r_pc[REPLAY_MAX];    // what the prediction adds for the chunk: (C - 225 * hi) mod p,
+  __shared__ uint8_t r_prev[REPLAY_MAX];   // the branch of the chunk before it as C alone decides it
   const AmbRecord *amb = (const AmbRecord *)amb_raw;
   const int t = threadIdx.x;
   const uint32_t r = (uint32_t)(n % ADLER_CHUNK);
@@ -451,38 +558,32 @@ __global__ __launch_bounds__(CHAIN_THREADS_A) void adler_replay_kernel(const uin
     const AmbRecord rec = amb[i];
     uint32_t rank = 0;
     for (uint32_t j = 0; j < n_amb; j++) rank += keys[j] < rec.k ? 1u : 0u;
-    recs[rank] = rec;
-    rec_sums[rank] = sums[rec.k];
-    rec_res[rank] = run_res[rec.k / per];
-    rec_prev[rank] = prev_branch(rec.k, rec.prev_hi) ? 1 : 0;
+    const uint2 sm = sums[rec.k];
+    const uint32_t len = rec.k == 0 ? r : ADLER_CHUNK;
+    const uint32_t C = len * rec.s1 + sm.y;  // < 2^32
+    r_k[rank] = rec.k;
+    r_res[rank] = addmod(run_res[rec.k / per], rec.a_partial);
+    r_C[rank] = C;
+    r_pc[rank] = addmod(C % ADLER_BASE, C >= 0x80000000u ? ADLER_BASE - 225u : 0u);
+    r_prev[rank] = prev_branch(rec.k, rec.prev_hi) ? 1 : 0;
   }
   __syncthreads();
   if (t != 0) return;
   // ---- replay of the ambiguous chunks, in order, by one thread
-  uint64_t delta = 0;          // correction (mod p) of every predicted residue from here on
-  int64_t exact_next = 0;      // exact s2 after the last replayed chunk ...
-  uint64_t exact_at = ~0ull;   // ... valid as the input of chunk `exact_at`
+  uint32_t delta = 0;            // correction (mod p) of every predicted residue from here on
+  int32_t exact_next = 0;        // exact s2 after the last replayed chunk ...
+  uint64_t exact_at = ~0ull;     // ... valid as the input of chunk `exact_at`
   for (uint32_t i = 0; i < n_amb; i++) {
-    const AmbRecord rec = recs[i];
-    const uint64_t k = rec.k;
-    const uint64_t resk = ((uint64_t)rec_res[i] + rec.a_partial) % ADLER_BASE;
-    int64_t x;
-    if (k == exact_at) x = exact_next;
-    else {
-      const uint64_t rr = (resk + delta) % ADLER_BASE;
-      x = rec_prev[i] ? (rr == 0 ? 0 : (int64_t)rr - ADLER_BASE) : (int64_t)rr;
-    }
-    const uint2 sm = rec_sums[i];
-    const uint32_t len = k == 0 ? r : ADLER_CHUNK;
-    const uint64_t C = (uint64_t)len * rec.s1 + sm.y;
-    const uint32_t t2 = (uint32_t)((int64_t)C + x);
+    const uint32_t k = r_k[i];
+    const uint32_t rr = addmod(r_res[i], delta);
+    const int32_t x = k == exact_at ? exact_next : (r_prev[i] ? (rr == 0 ? 0 : (int32_t)rr - (int32_t)ADLER_BASE) : (int32_t)rr);
+    const uint32_t t2 = r_C[i] + (uint32_t)x;                 // wraps like the reference's int32
     const int32_t outv = (int32_t)t2 % (int32_t)ADLER_BASE;  // the reference's signed rem
-    const uint64_t ro = (uint64_t)(((int64_t)outv % ADLER_BASE + ADLER_BASE) % ADLER_BASE);
-    const bool hi_k = C >= 0x80000000ull;
-    const uint64_t predicted = (resk + delta + C % ADLER_BASE + (hi_k ? ADLER_BASE - 225u : 0u)) % ADLER_BASE;
-    delta = (delta + ro + ADLER_BASE - predicted) % ADLER_BASE;
+    const uint32_t ro = (uint32_t)(outv < 0 ? outv + (int32_t)ADLER_BASE : outv);
+    const uint32_t predicted = addmod(rr, r_pc[i]);
+    delta = addmod(addmod(delta, ro), ADLER_BASE - predicted);
     exact_next = outv;
-    exact_at = k + 1;
+    exact_at = (uint64_t)k + 1;
   }
   // state after the last chunk
   uint32_t final_s2;

@@ -64,6 +64,9 @@ __global__ void crc32_segments_kernel(const uint8_t *__restrict__ base, int mode
                                       uint64_t single_off, uint64_t single_len,
                                       uint32_t segs_per_range, const uint32_t *__restrict__ nib,
                                       uint32_t *__restrict__ partials);
+__global__ void crc32_adler_segments_kernel(const uint8_t *__restrict__ p, uint64_t len, uint32_t n_segs,
+                                            const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials,
+                                            uint2 *__restrict__ adler_sums, uint64_t n_chunks);
 __global__ void crc32_finish_kernel(int mode, const StreamDesc *__restrict__ descs,
                                     StreamResult *__restrict__ results, uint64_t single_len,
                                     uint32_t segs_per_range, CrcConsts K, const uint32_t *__restrict__ nib,
