@@ -324,6 +324,66 @@ def test_deflate_batch_ragged_equals_oracle(gpu_ctx, oracle):
                 assert res["checksum"][i] == k0, (names[i], level, crc_op)
 
 
+def _long_streams_for_segments(seed):
+    """Streams of many parse segments (4096 positions each): text, symbols of several entropies, and the data on
+    which a parse started at a segment boundary does NOT fall in with the true one -- runs of one byte and
+    periods around the longest match -- with lengths around the segment and block sizes."""
+    from zipc_amd import synth
+
+    rnd = random.Random(seed)
+    out = []
+    lens = [4096 * 8, 4096 * 8 + 1, 65534, 65535, 65536 + 4095, 2 * 65534 + 3, 200000, 300001, (1 << 20) + 77]
+    for i, ln in enumerate(lens):
+        out.append(util.text(ln, seed + i))
+        out.append(synth.stream_bytes_np(9, seed + i, ln, (1, 2, 3, 4, 8)[i % 5]).tobytes())
+    for k in (1, 2, 3, 7, 64, 257, 258, 259, 260, 515, 1000, 4095, 4096, 4097, 5000):
+        ln = rnd.choice([70000, 131072 + 5, 300000])
+        pat = synth.stream_bytes_np(9, seed + k, k, 8).tobytes()
+        out.append((pat * (ln // k + 1))[:ln])
+    out.append(b"\0" * ((1 << 20) + 5))
+    # a periodic stretch inside text, so that paths part and meet again
+    t = bytearray(util.text(400000, seed + 99))
+    t[100000:180000] = b"ab" * 40000
+    t[250000:300000] = bytes(50000)
+    out.append(bytes(t))
+    return out
+
+
+def test_deflate_long_streams_by_segments_equal_oracle(gpu_ctx, oracle):
+    """Few long streams: lz_parse runs as a wave per segment with a stitch (deflate.hip lz_parse_spec_kernel ...);
+    bytes, block by block, against the oracle at every level."""
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    streams = _long_streams_for_segments(5)
+    src_off = np.cumsum([0] + [(len(s) + 63) // 64 * 64 for s in streams[:-1]]).astype(np.uint64)
+    caps = [batch.deflate_bound(len(s)) for s in streams]
+    slots = [(c + 255) // 256 * 256 for c in caps]
+    dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+    descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+    arena = bytearray(int(src_off[-1]) + len(streams[-1]) + 64)
+    for o, st in zip(src_off, streams):
+        arena[int(o):int(o) + len(st)] = st
+    src = torch.from_numpy(np.frombuffer(bytes(arena), dtype=np.uint8).copy()).to(dev)
+    d_descs = batch.to_device(descs, dev)
+    total = int(sum(len(s) for s in streams))
+    for level in (1, 2, 3):
+        dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(len(streams) * 16, dtype=torch.uint8, device=dev)
+        batch.deflate_batch(gpu_ctx, src, dst, d_descs, d_res, len(streams), max(len(s) for s in streams), total, level, 1)
+        res = batch.results_from_device(d_res)
+        out = dst.cpu().numpy()
+        for i, st in enumerate(streams):
+            st0, c0, k0 = oracle.deflate(st, level=level, crc_op=1)
+            assert res["status"][i] == 0, (i, level)
+            o = int(dst_off[i])
+            assert int(res["out_len"][i]) == len(c0), (i, level, len(st))
+            assert out[o:o + len(c0)].tobytes() == c0, (i, level, len(st))
+            assert res["checksum"][i] == k0, (i, level)
+
+
 def _grouped_tile_streams(n, max_len, seed):
     """Ragged streams for the window kernel's grouped form: lengths around the multiples of
     its 16 384-position tile, data of several entropies (numpy-generated: tens of MB)."""

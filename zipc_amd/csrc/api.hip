@@ -328,7 +328,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
-  free_buf(ctx->deflate_scratch);
+  free_buf(ctx->deflate_scratch); free_buf(ctx->parse_scratch);
   free_buf(ctx->inflate_scratch);
   free_buf(ctx->stored_list);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);

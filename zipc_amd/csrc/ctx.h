@@ -44,6 +44,7 @@ struct zipc_hip_ctx {
   Buf crc_partials, adler_sums;                   // checksum kernels
   Buf crc_nib;                                    // nibble tables of the CRC merge constants (kernels.h)
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)
+  Buf parse_scratch;                              // lz_parse by segments: their symbols, paths and verdicts (deflate.hip ParseSegs)
   Buf inflate_scratch;                            // inflate: the span decoder's index, 2304 bytes per stream
   Buf stored_list;                                // inflate of one stream beyond 4 GiB: the stored blocks a walk listed
 

@@ -637,15 +637,88 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 // between tiles is the entry position.
 constexpr int PARSE_TILE = 64;
 
-__global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
-                                                      const StreamDesc *__restrict__ descs,
-                                                      DeflateScratch S, int good_match) {
+// The macro step of the 64 positions of a tile, one per lane (lz_macro_position, with the following
+// positions' entries taken from the neighbouring lanes: m_cur is this tile's entry of the lane, m_nxt the
+// next tile's).  br: the match the step ends with (0: the position is a literal), st: advance | literals << 16.
+__device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool valid, bool has_match, uint32_t max_pos,
+                                               uint32_t len, uint64_t m_cur, uint64_t m_nxt,
+                                               const uint64_t *__restrict__ match, int good_match, uint32_t &br,
+                                               uint32_t &st) {
+  br = 0; st = 1u | (1u << 16);
+  uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
+  // (flags as integers and selects instead of branches: a loop-carried bool lives in a scalar mask that
+  // costs three scalar instructions per update, and the CU's ONE scalar issue per clock is what this
+  // kernel's 32 waves per CU queue for)
+  uint32_t chaining = (pend & 0x1FF) != 0 ? 1u : 0u;
+  uint32_t n_lits = 0, j = p + 1;
+  const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
+  const uint32_t nxt_lo = (uint32_t)m_nxt, nxt_hi = (uint32_t)(m_nxt >> 32);
+  // one step of a lane's lazy chain with the entry mj of position j
+  auto chain_step = [&](uint32_t mj_lo, uint32_t mj_hi, uint32_t use_hi) {
+    const uint32_t pl = pend & 0x1FF;
+    const uint32_t rem = len - j;  // (j > max_pos: the value is not used)
+    const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
+    const uint32_t c = use_hi ? mj_hi : mj_lo;
+    const uint32_t take = (chaining != 0 && j <= max_pos && pl < maxlen && (c & 0x1FF) > pl) ? 1u : 0u;
+    n_lits += take;
+    pend = take ? c : pend;
+    j += take;
+    chaining = take;
+  };
+  // chains within the staged tiles (all but pathological ones): entries by shuffle
+  for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining != 0); ahead++) {
+    // every chaining lane looks at the same distance ahead: lane + ahead (< 128)
+    const uint32_t off = (uint32_t)lane + ahead;
+    const uint32_t addr = (off & 63u) * 4u;
+    const bool in_cur = off < 64u;
+    // best-of-K of position j; best-of-K/4 only if a pending match is that long
+    // (all lanes take part in every shuffle: a lane is also somebody's source)
+    const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
+    const uint32_t mj_lo = in_cur ? a_lo : b_lo;
+    uint32_t mj_hi = 0;
+    const uint32_t want_hi = (chaining != 0 && (pend & 0x1FF) >= (uint32_t)good_match) ? 1u : 0u;
+    if (__builtin_amdgcn_ballot_w64(want_hi != 0)) {
+      const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
+      mj_hi = in_cur ? a_hi : b_hi;
+    }
+    chain_step(mj_lo, mj_hi, want_hi);
+  }
+  // a chain of 64 strictly growing matches and more: straight from the table
+  // (kept out of the loop above: its load would make that loop wait for memory)
+  if (__builtin_amdgcn_ballot_w64(chaining != 0)) {
+    while (chaining) {
+      const uint64_t mj = j <= max_pos ? match[j] : 0ull;
+      chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
+    }
+  }
+  if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
+}
+
+// Streams parsed by several waves (lz_parse_spec_kernel / lz_parse_stitch_kernel / lz_parse_gather_kernel below):
+// what the waves leave for each other, per stream at the stream's position base (tiles: base / 64, segments: seg_base).
+constexpr uint32_t PARSE_SEG = 4096;  // positions per segment: a multiple of the tile, far above the longest step (63 + 512)
+constexpr uint32_t PARSE_SEG_SYMS = PARSE_SEG + 576;  // symbols of a segment at most: one per position before its last step, and that step's
+struct ParseSegs {
+  uint32_t *spec_syms;            // [segments * PARSE_SEG_SYMS] a segment's symbols as parsed from its first position
+  unsigned long long *vis;        // [P / 64] per tile: the positions on the path (zeroed per call: a tile jumped over has none)
+  uint32_t *tile_sym0;            // [P / 64] per tile: symbols of its segment before it
+  uint32_t *seg_exit, *seg_total; // [segments] where the segment's parse left it (>= its end), and its symbols
+  uint32_t *seg_dst, *seg_from, *seg_n;  // [segments] the stitch's verdict: spec symbols [from, from + n) go to the stream's symbols at dst
+  uint32_t segs_per_stream;       // of the longest stream: segment slot of (stream, k) = stream * segs_per_stream + k
+};
+
+// MODE 0: one wave parses a whole stream and cuts its blocks.  MODE 1: one wave parses ONE SEGMENT of a stream as if
+// a symbol started at the segment's first position, into ParseSegs (no blocks: lz_parse_stitch_kernel).
+template <int MODE>
+__device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_arena,
+                                              const StreamDesc *__restrict__ descs,
+                                              DeflateScratch S, int good_match, uint32_t stream, uint32_t seg,
+                                              ParseSegs G) {
   if (S.error[0]) return;
-  const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (sd.src_len > MAX_STREAM_LEN) {
-    if (lane == 0) S.n_blocks[stream] = 0;
+    if (MODE == 0 && lane == 0) S.n_blocks[stream] = 0;
     return;
   }
   const uint32_t len = (uint32_t)sd.src_len;
@@ -654,10 +727,18 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   const uint64_t *match = S.match + base;
   const bool has_match = len >= (uint32_t)MIN_MATCH_LEN;
   const uint32_t max_pos = has_match ? len - MIN_MATCH_LEN : 0;  // positions <= max_pos have a match entry
-  uint32_t *syms = S.syms + base;
-  BlockDesc *blocks = S.blocks + S.blk_base[stream];
+  const uint32_t B0 = MODE == 1 ? seg * PARSE_SEG : 0u;        // where this wave starts,
+  if (MODE == 1 && B0 >= len && !(len == 0 && seg == 0)) return;
+  const uint32_t lim = MODE == 1 ? (len - B0 > PARSE_SEG ? B0 + PARSE_SEG : len) : len;  // and the tiles it takes: those below lim
+  const size_t seg_slot = (size_t)stream * G.segs_per_stream + seg;
+  uint32_t *syms = MODE == 1 ? G.spec_syms + seg_slot * PARSE_SEG_SYMS : S.syms + base;
+  BlockDesc *blocks = MODE == 1 ? nullptr : S.blocks + S.blk_base[stream];
 
-  if (len != 0 && !has_match) {  // 1 to 3 bytes: literals, one block (and the loop below may load whole words of source)
+  if (MODE == 1 && len < 4u) {  // (the stitch handles streams this short itself)
+    if (lane == 0) { G.seg_exit[seg_slot] = len; G.seg_total[seg_slot] = 0; }
+    return;
+  }
+  if (MODE == 0 && len != 0 && !has_match) {  // 1 to 3 bytes: literals, one block (and the loop below may load whole words of source)
     if ((uint32_t)lane < len) syms[lane] = s[lane];
     if (lane == 0) {
       BlockDesc b;
@@ -667,8 +748,8 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     }
     return;
   }
-  uint32_t entry = 0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
-  uint32_t B = 0;
+  uint32_t entry = B0, nsym = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;  // wave-uniform
+  uint32_t B = B0;
   // Table entries and source bytes of three tiles are kept in registers: the current
   // one, the next one (the lazy chains look into it) and the one after, which is
   // requested while the current tile is worked on -- two tiles ahead of its first use.
@@ -721,56 +802,8 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     const bool valid = p < len;
     // macro step of every position of the tile (lz_macro_position, with the
     // following positions' matches taken from the neighbouring lanes)
-    uint32_t br = 0, st = 1u | (1u << 16);
-    {
-      uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
-      // (flags as integers and selects instead of branches: a loop-carried bool lives in a scalar mask that
-      // costs three scalar instructions per update, and the CU's ONE scalar issue per clock is what this
-      // kernel's 32 waves per CU queue for)
-      uint32_t chaining = (pend & 0x1FF) != 0 ? 1u : 0u;
-      uint32_t n_lits = 0, j = p + 1;
-      const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
-      const uint32_t nxt_lo = (uint32_t)m_nxt, nxt_hi = (uint32_t)(m_nxt >> 32);
-      // one step of a lane's lazy chain with the entry mj of position j
-      auto chain_step = [&](uint32_t mj_lo, uint32_t mj_hi, uint32_t use_hi) {
-        const uint32_t pl = pend & 0x1FF;
-        const uint32_t rem = len - j;  // (j > max_pos: the value is not used)
-        const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
-        const uint32_t c = use_hi ? mj_hi : mj_lo;
-        const uint32_t take = (chaining != 0 && j <= max_pos && pl < maxlen && (c & 0x1FF) > pl) ? 1u : 0u;
-        n_lits += take;
-        pend = take ? c : pend;
-        j += take;
-        chaining = take;
-      };
-      // chains within the staged tiles (all but pathological ones): entries by shuffle
-      for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining != 0); ahead++) {
-        // every chaining lane looks at the same distance ahead: lane + ahead (< 128)
-        const uint32_t off = (uint32_t)lane + ahead;
-        const uint32_t addr = (off & 63u) * 4u;
-        const bool in_cur = off < 64u;
-        // best-of-K of position j; best-of-K/4 only if a pending match is that long
-        // (all lanes take part in every shuffle: a lane is also somebody's source)
-        const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
-        const uint32_t mj_lo = in_cur ? a_lo : b_lo;
-        uint32_t mj_hi = 0;
-        const uint32_t want_hi = (chaining != 0 && (pend & 0x1FF) >= (uint32_t)good_match) ? 1u : 0u;
-        if (__builtin_amdgcn_ballot_w64(want_hi != 0)) {
-          const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
-          mj_hi = in_cur ? a_hi : b_hi;
-        }
-        chain_step(mj_lo, mj_hi, want_hi);
-      }
-      // a chain of 64 strictly growing matches and more: straight from the table
-      // (kept out of the loop above: its load would make that loop wait for memory)
-      if (__builtin_amdgcn_ballot_w64(chaining != 0)) {
-        while (chaining) {
-          const uint64_t mj = j <= max_pos ? match[j] : 0ull;
-          chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
-        }
-      }
-      if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
-    }
+    uint32_t br, st;
+    parse_tile_macro(lane, p, valid, has_match, max_pos, len, m_cur, m_nxt, match, good_match, br, st);
     const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
     const uint32_t lits = br ? macro_lits(st) : 0u;
     const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
@@ -792,6 +825,10 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
       if (y <= lane4) v = y;
     }
     const bool visited = valid && v == lane4;
+    if (MODE == 1) {
+      const unsigned long long vm = __builtin_amdgcn_ballot_w64(visited);
+      if (lane == 0) { G.vis[(base + B) >> 6] = vm; G.tile_sym0[(base + B) >> 6] = nsym; }
+    }
     // the path leaves the tile after the last visited position (lane 63's answer)
     const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
     uint32_t next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
@@ -821,8 +858,8 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     // (a visited position is at or behind blk_start, so the test runs on 32-bit
     // distances from it; lanes that are not visited are masked out)
     const uint32_t rel = p - blk_start;
-    const unsigned long long cb = __ballot(visited && rel + adv > (uint32_t)MAX_BLOCK_SRC_LEN);
-    if (cb) {
+    const unsigned long long cb = MODE == 0 ? __ballot(visited && rel + adv > (uint32_t)MAX_BLOCK_SRC_LEN) : 0ull;
+    if (MODE == 0 && cb) {
       const int c = __ffsll((long long)cb) - 1;
       uint32_t cutpos, symidx;
       if (br == 0) { cutpos = p; symidx = first; }
@@ -857,17 +894,21 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
   uint64_t ma = 0, mb = 0, mc = 0;
   uint32_t la = 0, lb = 0, lc = 0;
   if (len) {
-    ma = load_match(0);
-    la = load_lit(0);
-    mb = load_match(PARSE_TILE);
-    lb = load_lit(PARSE_TILE);
+    ma = load_match(B0);
+    la = load_lit(B0);
+    mb = load_match(B0 + PARSE_TILE);
+    lb = load_lit(B0 + PARSE_TILE);
   }
-  while (B < len) {
+  while (B < lim) {
     tile_step(ma, mb, mc, la, lb, lc);
-    if (B >= len) break;
+    if (B >= lim) break;
     tile_step(mb, mc, ma, lb, lc, la);
-    if (B >= len) break;
+    if (B >= lim) break;
     tile_step(mc, ma, mb, lc, la, lb);
+  }
+  if (MODE == 1) {
+    if (lane == 0) { G.seg_exit[seg_slot] = entry; G.seg_total[seg_slot] = nsym; }
+    return;
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
@@ -876,6 +917,225 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
     blocks[nblk] = b;
     S.n_blocks[stream] = nblk + 1;
   }
+}
+
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
+                                                      const StreamDesc *__restrict__ descs,
+                                                      DeflateScratch S, int good_match) {
+  lz_parse_wave<0>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
+}
+
+// ---------------------------------------------------------------------------------
+// One stream parsed by many waves.  Between two positions where the reference has no pending match the parse is
+// a function of the position alone (above), so a wave can start anywhere -- at a position the true parse may
+// never visit -- and once the two paths share ONE position they are the same from there on; they do within a
+// few symbols on anything but periodic data.
+//   lz_parse_spec_kernel    a wave per segment of 4096 positions: the parse from the segment's first position
+//                           (true for segment 0), symbols to the segment's own buffer, per tile the positions
+//                           visited and the symbol count before it, per segment where the path left it;
+//   lz_parse_stitch_kernel  a wave per stream, segment by segment: from the true entry (where the segment
+//                           before was left) tiles are parsed again until the path meets the segment's own
+//                           (a common position in a tile); those symbols go straight to the stream's symbol
+//                           array, the rest of the segment is a range of its buffer, and the segment is left
+//                           where its own parse left it.  No meeting before the segment ends: the whole
+//                           segment was parsed again and is left where that parse says (the serial order, at
+//                           worst for every segment: a long run of one byte parsed at the wrong phase).
+//                           Blocks are cut here, at the step that holds source byte 65534 of the block;
+//   lz_parse_gather_kernel  a wave per segment copies the segment's range to its place in the symbol array.
+__global__ __launch_bounds__(64) void lz_parse_spec_kernel(const uint8_t *__restrict__ src_arena,
+                                                           const StreamDesc *__restrict__ descs,
+                                                           DeflateScratch S, int good_match, ParseSegs G) {
+  lz_parse_wave<1>(src_arena, descs, S, good_match, blockIdx.x / G.segs_per_stream, blockIdx.x % G.segs_per_stream, G);
+}
+
+__global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__restrict__ src_arena,
+                                                             const StreamDesc *__restrict__ descs,
+                                                             DeflateScratch S, int good_match, ParseSegs G) {
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x;
+  const int lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len > MAX_STREAM_LEN) {
+    if (lane == 0) S.n_blocks[stream] = 0;
+    return;
+  }
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint8_t *s = src_arena + sd.src_off;
+  const uint64_t base = S.pos_base[stream];
+  const uint64_t *match = S.match + base;
+  uint32_t *syms = S.syms + base;
+  BlockDesc *blocks = S.blocks + S.blk_base[stream];
+  if (len < (uint32_t)MIN_MATCH_LEN) {  // 0 to 3 bytes: literals, one block
+    if ((uint32_t)lane < len) syms[lane] = s[lane];
+    if (lane == 0) {
+      BlockDesc b;
+      b.src_start = 0; b.src_len = len; b.sym_start = 0; b.n_syms = len;
+      blocks[0] = b;
+      S.n_blocks[stream] = 1;
+    }
+    return;
+  }
+  const uint32_t max_pos = len - MIN_MATCH_LEN;
+  const size_t slot0 = (size_t)stream * G.segs_per_stream;
+  const uint32_t nseg = (len + PARSE_SEG - 1) / PARSE_SEG;
+  unsigned long long *vis = G.vis + (base >> 6);
+  uint32_t *tile_sym0 = G.tile_sym0 + (base >> 6);
+
+  // A tile's steps, counts and scan: the path from `entry` (use_mask false) or the positions of `mask`.
+  struct Tile {
+    uint32_t br, adv, lits, cnt, first_rel, total, next_entry;
+    bool visited;
+    unsigned long long vm;
+  };
+  auto eval_tile = [&](uint32_t B, uint32_t entry, bool use_mask, unsigned long long mask) -> Tile {
+    Tile t;
+    const uint32_t p = B + (uint32_t)lane;
+    const bool valid = p < len;
+    const uint64_t m_cur = match[p], m_nxt = match[p + PARSE_TILE];  // (PARSE_PAD zero entries behind the last position)
+    uint32_t st;
+    parse_tile_macro(lane, p, valid, true, max_pos, len, m_cur, m_nxt, match, good_match, t.br, st);
+    t.adv = valid ? (t.br ? macro_advance(st) : 1u) : 0u;
+    t.lits = t.br ? macro_lits(st) : 0u;
+    t.cnt = valid ? (t.br ? t.lits + 1u : 1u) : 0u;
+    const uint32_t lane4 = (uint32_t)lane * 4u;
+    const uint32_t j0 = (uint32_t)lane + t.adv;
+    if (use_mask) {
+      t.visited = valid && ((mask >> lane) & 1ull);
+      t.next_entry = 0;
+    } else {
+      uint32_t J[7];
+      J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
+#pragma unroll
+      for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+      uint32_t v = (entry - B) * 4u;
+#pragma unroll
+      for (int k = 6; k >= 0; k--) {
+        const uint32_t y = lane_value(v, J[k]);
+        if (y <= lane4) v = y;
+      }
+      t.visited = valid && v == lane4;
+      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+      t.next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
+      if (t.next_entry > len) t.next_entry = len;
+    }
+    t.vm = __builtin_amdgcn_ballot_w64(t.visited);
+    const uint32_t incl = wave_scan_incl(t.visited ? t.cnt : 0u);
+    t.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    t.first_rel = incl - (t.visited ? t.cnt : 0u);
+    return t;
+  };
+
+  uint32_t off = 0;        // symbols of the stream so far
+  uint32_t exit_prev = 0;  // where the segment before was left: this segment's true entry
+  uint32_t blk_start = 0, blk_sym_start = 0, nblk = 0;
+  for (uint32_t k = 0; k < nseg; k++) {
+    const uint32_t seg_start = k * PARSE_SEG;
+    const uint32_t seg_end = len - seg_start > PARSE_SEG ? seg_start + PARSE_SEG : len;
+    const uint32_t spec_total = G.seg_total[slot0 + k], spec_exit = G.seg_exit[slot0 + k];
+    const uint32_t e = exit_prev;
+    uint32_t f = 0;                // symbols parsed again here (written at syms[off ..))
+    uint32_t from = 0;             // the segment's own symbols from this one on follow them
+    uint32_t exit_k = spec_exit;
+    uint32_t again_end = seg_start;  // tiles in [tile of e, again_end) were parsed again: their tile_sym0 counts from `off`
+    if (k != 0 && e >= seg_end) {  // (a step over a short last segment)
+      from = spec_total; exit_k = e; again_end = seg_end;
+    } else if (k != 0) {
+      uint32_t B = e & ~63u, entry = e;
+      for (;;) {
+        const Tile t = eval_tile(B, entry, false, 0ull);
+        const unsigned long long own = vis[B >> 6];  // the segment's own path through this tile (0: it jumped over it)
+        // symbols (lz_emit_position)
+        {
+          uint32_t *out = syms + off + f;
+          const uint32_t p = B + (uint32_t)lane;
+          if (t.visited) {
+            for (uint32_t i = 0; i < t.lits; i++) out[t.first_rel + i] = s[p + i];
+            out[t.first_rel + t.lits] = t.br ? t.br : (uint32_t)s[p];
+          }
+        }
+        if (lane == 0) { vis[B >> 6] = t.vm; tile_sym0[B >> 6] = f; }
+        f += t.total;
+        entry = t.next_entry;
+        const uint32_t Be = entry & ~63u;
+        const uint32_t Bn = Be > B + PARSE_TILE ? Be : B + PARSE_TILE;
+        const bool met = (t.vm & own) != 0ull;
+        // tiles this path jumps over are not on it, whatever the segment's own parse did there (the block cut
+        // below looks for the last visited position at or before a given one)
+        if (Bn > B + PARSE_TILE) {
+          const uint32_t tz = B + PARSE_TILE * (1u + (uint32_t)lane);
+          if (tz < Bn && tz < seg_end) vis[tz >> 6] = 0ull;
+        }
+        if (met || Bn >= seg_end) {
+          again_end = Bn;
+          if (met && Bn < seg_end) from = tile_sym0[Bn >> 6];  // (the segment's own parse went on with tile Bn too)
+          else from = spec_total;
+          exit_k = met ? spec_exit : entry;
+          break;
+        }
+        B = Bn;
+      }
+    }
+    const uint32_t n_own = spec_total - from;
+    if (lane == 0) {
+      G.seg_dst[slot0 + k] = off + f;
+      G.seg_from[slot0 + k] = from;
+      G.seg_n[slot0 + k] = n_own;
+    }
+    // block cut (write_block_symbol zd.ml:1118-1123): the step that holds source byte blk_start + 65534 --
+    // the first one that ends behind it -- closes the block
+    while (exit_k - blk_start > (uint32_t)MAX_BLOCK_SRC_LEN) {
+      const uint32_t T = blk_start + (uint32_t)MAX_BLOCK_SRC_LEN;
+      // the last visited position <= T; it lies in this segment (behind its end the tiles still hold the next
+      // segment's own path, and the step that leaves this segment started inside it)
+      const uint32_t Ts = T < seg_end ? T : seg_end - 1u;
+      uint32_t Bt = Ts & ~63u;
+      unsigned long long w = vis[Bt >> 6] & (~0ull >> (63u - (Ts & 63u)));
+      while (w == 0ull) { Bt -= PARSE_TILE; w = vis[Bt >> 6]; }  // (the step started in an earlier tile: at most 9 back)
+      const int c = 63 - __builtin_clzll(w);
+      const Tile t = eval_tile(Bt, 0, true, vis[Bt >> 6]);
+      const bool again = k != 0 && Bt >= (e & ~63u) && Bt < again_end;
+      const uint32_t tile0 = again ? off + tile_sym0[Bt >> 6] : off + f - from + tile_sym0[Bt >> 6];
+      const uint32_t p = Bt + (uint32_t)lane;
+      const uint32_t rel = p - blk_start, first = tile0 + t.first_rel;
+      uint32_t cutpos, symidx;
+      if (t.br == 0) { cutpos = p; symidx = first; }
+      else if (rel + t.lits > (uint32_t)MAX_BLOCK_SRC_LEN) { const uint32_t i = (uint32_t)MAX_BLOCK_SRC_LEN - rel; cutpos = p + i; symidx = first + i; }
+      else { cutpos = p + t.lits; symidx = first + t.lits; }
+      cutpos = (uint32_t)__builtin_amdgcn_readlane((int)cutpos, c);
+      symidx = (uint32_t)__builtin_amdgcn_readlane((int)symidx, c);
+      if (lane == 0) {
+        BlockDesc b;
+        b.src_start = blk_start; b.src_len = cutpos - blk_start;
+        b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
+        blocks[nblk] = b;
+      }
+      nblk++;
+      blk_start = cutpos;
+      blk_sym_start = symidx;
+    }
+    off += f + n_own;
+    exit_prev = exit_k;
+  }
+  if (lane == 0) {
+    BlockDesc b;  // the final block, always present (zd.ml:1216)
+    b.src_start = blk_start; b.src_len = len - blk_start;
+    b.sym_start = blk_sym_start; b.n_syms = off - blk_sym_start;
+    blocks[nblk] = b;
+    S.n_blocks[stream] = nblk + 1;
+  }
+}
+
+__global__ __launch_bounds__(64) void lz_parse_gather_kernel(const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                             ParseSegs G) {
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x / G.segs_per_stream, seg = blockIdx.x % G.segs_per_stream;
+  const uint64_t len = descs[stream].src_len;
+  if (len > MAX_STREAM_LEN || len < (uint64_t)MIN_MATCH_LEN || (uint64_t)seg * PARSE_SEG >= len) return;
+  const size_t slot = (size_t)stream * G.segs_per_stream + seg;
+  const uint32_t n = G.seg_n[slot];
+  const uint32_t *from = G.spec_syms + slot * PARSE_SEG_SYMS + G.seg_from[slot];
+  uint32_t *to = S.syms + S.pos_base[stream] + G.seg_dst[slot];
+  for (uint32_t i = threadIdx.x; i < n; i += 64u) to[i] = from[i];
 }
 
 // ---------------------------------------------------------------------------------
@@ -1545,6 +1805,31 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
   tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
   const size_t gps = (tps + tpg - 1) / tpg;
+  // Few long streams: lz_parse by a wave per segment (lz_parse_spec_kernel); many streams fill the chip with a
+  // wave each.  ZIPC_HIP_PARSE_SEGMENTS=0 never, =1 whenever a stream has more than one segment (tests).
+  static const long segs_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEGMENTS"); return e ? atol(e) : -1L; }();
+  const size_t sps = (max_src_len + PARSE_SEG - 1) / PARSE_SEG;
+  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 2048 && sps >= 8);
+  if (segmented && n * sps > 0x7FFFFFFFull) segmented = false;
+  ParseSegs segs{};
+  if (segmented) {
+    const size_t n_slots = n * sps, tiles = (size_t)(S.cap_positions / 64) + 4;
+    const size_t bytes = align_up(n_slots * PARSE_SEG_SYMS * 4, 256) + align_up(tiles * 8, 256) + align_up(tiles * 4, 256) +
+                         5 * align_up(n_slots * 4, 256);
+    if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) return hipErrorOutOfMemory;
+    uint8_t *q = (uint8_t *)ctx->parse_scratch.p;
+    segs.spec_syms = (uint32_t *)q; q += align_up(n_slots * PARSE_SEG_SYMS * 4, 256);
+    segs.vis = (unsigned long long *)q; q += align_up(tiles * 8, 256);
+    segs.tile_sym0 = (uint32_t *)q; q += align_up(tiles * 4, 256);
+    segs.seg_exit = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.seg_total = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.seg_dst = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.seg_from = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.seg_n = (uint32_t *)q;
+    segs.segs_per_stream = (uint32_t)sps;
+    const hipError_t me = hipMemsetAsync(segs.vis, 0, tiles * 8, ctx->cur);
+    if (me != hipSuccess) return me;
+  }
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;
     DeflateScratch Q = S;
@@ -1557,7 +1842,19 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     else
       ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((m * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
                 0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env);
-    ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
+    if (segmented) {
+      ParseSegs G = segs;
+      const size_t o = lo * sps;  // the slice's segment slots
+      G.spec_syms += o * PARSE_SEG_SYMS;
+      G.seg_exit += o; G.seg_total += o; G.seg_dst += o; G.seg_from += o; G.seg_n += o;
+      ZD_LAUNCH(ctx, "lz_parse_spec", lz_parse_spec_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, d_src, dd, Q,
+                good_match, G);
+      ZD_LAUNCH(ctx, "lz_parse_stitch", lz_parse_stitch_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q,
+                good_match, G);
+      ZD_LAUNCH(ctx, "lz_parse_gather", lz_parse_gather_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, dd, Q, G);
+    } else {
+      ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
+    }
     ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
               d_results + lo, Q, crc_op);
   };
