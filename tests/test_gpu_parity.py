@@ -569,6 +569,27 @@ def test_deflate_dst_too_small_is_reported(gpu_ctx):
     assert st == _lib.ERR_DST_TOO_SMALL
 
 
+def test_deflate_dst_too_small_is_reported_for_a_long_stream(gpu_ctx, oracle):
+    """the same through the forms a long stream takes (blocks coded by a wave each, deflate_scan_kernel decides):
+    a capacity below the output fails the stream and leaves the bytes behind the capacity alone; the exact size fits
+    when the reference's own estimates let it (they run high: the code-length counts are never reset)"""
+    import ctypes as C
+
+    from zipc_amd import _lib
+
+    d = util.text(300000, 3)
+    st0, c0, k0 = oracle.deflate(d, level=2, crc_op=1)
+    for cap, ok in ((len(c0) // 2, False), (len(c0) - 1, False), (len(c0) + 600, True)):
+        dst = C.create_string_buffer(b"\xA5" * (cap + 64), cap + 64)
+        ol, ck = C.c_size_t(), C.c_uint32()
+        st = _lib.lib().zipc_hip_deflate(gpu_ctx.handle, d, len(d), 2, 1, dst, cap, C.byref(ol), C.byref(ck))
+        assert dst.raw[cap:] == b"\xA5" * 64, cap
+        if ok:
+            assert st == 0 and dst.raw[:ol.value] == c0 and ck.value == k0
+        else:
+            assert st == _lib.ERR_DST_TOO_SMALL, cap
+
+
 def test_deflate_start_offset_is_the_requested_range(gpu_ctx, oracle):
     """`?start ?len` on the encode side: the reference's Lz77.compress mixes absolute and relative
     indices when start > 0 (zipc_deflate.ml:1206,1215,1220: it would encode [start, len) instead of

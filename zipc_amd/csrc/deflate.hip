@@ -214,22 +214,33 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
-__global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
-                                                                 const StreamDesc *__restrict__ descs,
-                                                                 DeflateScratch S) {
+// A link is the distance to the nearest earlier position with the same hash if that is within 32768, else 0:
+// a function of the 32 KiB before the position and nothing else.  So a long stream's links can be made by
+// several workgroups (SEG): each takes CHAIN_SEG positions, starts with an empty table at the sweep boundary at
+// least 32768 before its first one, and stores the links of its own positions only.
+constexpr uint32_t CHAIN_SEG = 8 * SWEEP_PERIOD;  // 128 Ki positions, after 32 - 48 Ki of run-up
+template <bool SEG>
+__device__ __forceinline__ void lz_chain_workgroup(const uint8_t *__restrict__ src_arena,
+                                                   const StreamDesc *__restrict__ descs,
+                                                   DeflateScratch S, uint32_t stream, uint32_t seg) {
   __shared__ uint16_t head[32768];
   __shared__ uint16_t hs[CHAIN_ROUND + 2 * NEAR];
   __shared__ uint32_t peel_more[2];
   __shared__ uint32_t head_spare;
   if (S.error[0]) return;
-  const uint32_t stream = blockIdx.x;
   const uint32_t t = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
   const uint8_t *s = src_arena + sd.src_off;
   uint16_t *prev = S.prev + S.pos_base[stream];
-  const uint32_t max_pos = len - 4;
+  const uint32_t stream_max_pos = len - 4;
+  // SEG: links of [own_lo, own_hi], rounds from B_first on
+  const uint32_t own_lo = SEG ? seg * CHAIN_SEG : 0u;
+  if (SEG && own_lo > stream_max_pos) return;
+  const uint32_t own_hi = SEG ? (stream_max_pos - own_lo >= CHAIN_SEG ? own_lo + CHAIN_SEG - 1u : stream_max_pos) : stream_max_pos;
+  const uint32_t B_first = SEG ? (own_lo > 2u * SWEEP_PERIOD ? own_lo - 2u * SWEEP_PERIOD : 0u) : 0u;  // (own_lo is a multiple of the period)
+  const uint32_t max_pos = own_hi;  // the last position inserted
   if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_ROUND + NEAR + t] = 0xFFFF; }
   if (t < 2) peel_more[t] = 0;
 
@@ -238,10 +249,10 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
   uint32_t word_next[CHAIN_PPT];
 #pragma unroll
   for (int i = 0; i < CHAIN_PPT; i++) {
-    const uint32_t p = t + CHAIN_THREADS * (uint32_t)i;
+    const uint32_t p = B_first + t + CHAIN_THREADS * (uint32_t)i;
     word_next[i] = load_u32_le(s + (p <= max_pos ? p : max_pos));  // unconditional: the wait counts stay exact
   }
-  for (uint32_t B = 0; B <= max_pos; B += CHAIN_ROUND) {
+  for (uint32_t B = B_first; B <= max_pos; B += CHAIN_ROUND) {
     uint32_t word[CHAIN_PPT];
 #pragma unroll
     for (int i = 0; i < CHAIN_PPT; i++) {
@@ -253,7 +264,7 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
       const uint16_t mark = (uint16_t)(B + SWEEP_MARK);
       for (uint32_t i = t; i < 32768; i += CHAIN_THREADS) {
         bool keep = false;
-        if (B != 0) {
+        if (B != B_first) {
           const uint32_t d = (B - head[i]) & 0xFFFFu;
           keep = d >= 1 && d <= 32768;
         }
@@ -359,11 +370,23 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *
           d = (p - e_old[i]) & 0xFFFFu;
           if (d > 32768) d = 0;
         }
-        prev[p] = (uint16_t)d;
+        if (!SEG || p >= own_lo) prev[p] = (uint16_t)d;
       }
     }
     lds_barrier();
   }
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
+                                                                 const StreamDesc *__restrict__ descs,
+                                                                 DeflateScratch S) {
+  lz_chain_workgroup<false>(src_arena, descs, S, blockIdx.x, 0);
+}
+
+__global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_segments_kernel(const uint8_t *__restrict__ src_arena,
+                                                                          const StreamDesc *__restrict__ descs,
+                                                                          DeflateScratch S, uint32_t segs_per_stream) {
+  lz_chain_workgroup<true>(src_arena, descs, S, blockIdx.x / segs_per_stream, blockIdx.x % segs_per_stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -1350,8 +1373,9 @@ __device__ __forceinline__ uint64_t wave_symbols_bits(const BlockCoder &c, const
   return wave_sum64(acc);
 }
 
-// make_dynamic_huffman + make_dynamic_huffman_encoding zd.ml:953-1043 (coder_make_dynamic)
-__device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scratch, int lane) {
+// make_dynamic_huffman + make_dynamic_huffman_encoding zd.ml:953-1043 (coder_make_dynamic), in two halves:
+// the codes of the block's own symbols and their code-length symbols (counted into c.codelen_freq) ...
+__device__ __forceinline__ void wave_make_dynamic_syms(BlockCoder &c, uint32_t *scratch, int lane) {
   wave_lengths_of_freqs(c.heap, c.dyn_lit, c.lit_freq, LITLEN_SYM_MAX, 15, lane);
   wave_sync();
   wave_init_with_lengths(c.dyn_lit, LITLEN_SYM_MAX, scratch, lane);
@@ -1416,6 +1440,10 @@ __device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scrat
   }
   c.codelen_syms_len = __builtin_amdgcn_readfirstlane(k);
   wave_sync();
+}
+// ... and the code of the code-length symbols, from counts that are never reset between the blocks of a
+// stream (Q1, zd.ml:849-854): it depends on every block before
+__device__ __forceinline__ void wave_make_dynamic_codelen(BlockCoder &c, uint32_t *scratch, int lane) {
   wave_lengths_of_freqs(c.heap, c.dyn_codelen, c.codelen_freq, CODELEN_SYM_MAX, 7, lane);
   wave_sync();
   wave_init_with_lengths(c.dyn_codelen, CODELEN_SYM_MAX, scratch, lane);
@@ -1423,6 +1451,11 @@ __device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scrat
   int o = CODELEN_SYM_MAX;  // codelen_length_count zd.ml:1032-1036
   while (o > 0 && (c.dyn_codelen[k_codelen_order[o]] & 0x1F) == 0) o--;
   c.hclen = (o + 1) - 4;
+}
+
+__device__ __forceinline__ void wave_make_dynamic(BlockCoder &c, uint32_t *scratch, int lane) {
+  wave_make_dynamic_syms(c, scratch, lane);
+  wave_make_dynamic_codelen(c, scratch, lane);
 }
 
 // write_block's three estimates and its choice (coder_choose)
@@ -1441,29 +1474,54 @@ __device__ __forceinline__ int wave_choose(const BlockCoder &c, uint32_t block_s
   return 2;
 }
 
-__global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
-                                                          uint8_t *__restrict__ dst_arena,
-                                                          const StreamDesc *__restrict__ descs,
-                                                          StreamResult *__restrict__ results,
-                                                          DeflateScratch S, int crc_op) {
+// The blocks of a stream coded by a wave each (deflate_plan_kernel / deflate_scan_kernel / deflate_pack_kernel /
+// deflate_seal_kernel below): what they leave for each other, one record per block at the block's slot.
+constexpr uint32_t EMIT_SKIP = 0xFFu;  // kind of every block of a stream whose output does not fit
+struct EmitPlan {
+  uint64_t flen;          // plan: bits of the block as a fixed block,
+  uint64_t dyn_sym_bits;  //   and of its symbols under its own dynamic code
+  uint64_t bit_start, bit_end;  // scan: the block's bits in the stream's output
+  uint32_t kind;          // scan: 0 stored, 1 fixed, 2 dynamic, EMIT_SKIP
+  uint32_t tail;          // pack: the bits behind the block's last whole byte
+  int32_t codelen_syms_len, hlit, hdist;  // plan
+  int32_t hclen;          // scan
+  uint32_t n_chunks;      // plan (Adler-32): the block's chunks, first = len mod 5552 (possibly empty), then 5552 each
+  uint32_t codelen_freq[19];  // plan: the block's own code-length symbols, counted
+  uint2 adler[13];        // plan: (S1, S2) per chunk
+  uint32_t dyn_lit[288], dyn_dist[32], codelen_syms[320];  // plan
+  uint32_t dyn_codelen[32];                                // scan
+};
+
+// MODE 0: a wave codes a whole stream, block after block.  MODE 1 (plan): a wave takes ONE block as far as its
+// bits do not depend on the blocks before it -- histogram, the codes of its symbols, its code-length symbols, the
+// fixed and dynamic sizes, its Adler-32 chunk sums.  MODE 2 (pack): a wave writes one block where the scan put it.
+template <int MODE>
+__device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ src_arena,
+                                                  uint8_t *__restrict__ dst_arena,
+                                                  const StreamDesc *__restrict__ descs,
+                                                  StreamResult *__restrict__ results,
+                                                  DeflateScratch S, int crc_op, uint32_t stream, uint32_t only_block,
+                                                  EmitPlan *__restrict__ plans) {
   __shared__ uint32_t lit_freq[288], dist_freq[32], codelen_freq[32];
   __shared__ uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], fix_lit[288], fix_dist[32];
   __shared__ uint32_t codelen_syms[320], heap[580];
   __shared__ uint32_t stage[STAGE_WORDS];
   __shared__ uint32_t coder_scratch[32];
 
-  const uint32_t stream = blockIdx.x;
   const int lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
-    if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
+    if (MODE == 0 && lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
     return;
   }
   const uint8_t *src = src_arena + sd.src_off;
   const uint32_t dst_cap = (uint32_t)sd.dst_cap;
   const uint32_t nblk = S.n_blocks[stream];
+  if (MODE != 0 && only_block >= nblk) return;
   const BlockDesc *blocks = S.blocks + S.blk_base[stream];
   const uint32_t *syms = S.syms + S.pos_base[stream];
+  EmitPlan *plan = MODE != 0 ? plans + S.blk_base[stream] + only_block : nullptr;
+  if (MODE == 2 && plan->kind == EMIT_SKIP) return;
 
   BlockCoder c;
   c.lit_freq = lit_freq; c.dist_freq = dist_freq; c.codelen_freq = codelen_freq;
@@ -1494,11 +1552,34 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
   const uint64_t ph_begin = __builtin_readcyclecounter();
 #endif
 
-  for (uint32_t b = 0; b < nblk && status == ST_OK; b++) {
+  if (MODE == 2) {  // where the scan put the block; the bits of the block before it come from the seal
+    bo.out_pos = (uint32_t)(plan->bit_start >> 3);
+    bo.acc_bits = (int)(plan->bit_start & 7u);
+  }
+  const uint32_t b_first = MODE == 0 ? 0u : only_block, b_end = MODE == 0 ? nblk : only_block + 1u;
+  for (uint32_t b = b_first; b < b_end && status == ST_OK; b++) {
     const BlockDesc bd = blocks[b];
     const bool final = b + 1 == nblk;
     // deflated_block_src_crc zd.ml:1081-1086 (Adler: one update call per block)
-    if (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane, crc_op == CRC_ADLER32_RFC);
+    if (MODE == 0 && (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC)) adler = wave_adler_update(adler, src + bd.src_start, bd.src_len, lane, crc_op == CRC_ADLER32_RFC);
+    if (MODE == 1) {  // the chunk sums of that call (wave_adler_update's loop), applied in order by the scan
+      uint32_t n_chunks = 0;
+      if (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC) {
+        uint32_t start = 0, chunk_len = bd.src_len % ADLER_CHUNK;
+        while (start < bd.src_len) {
+          uint32_t S1, S2;
+          wave_adler_chunk_sums(src + bd.src_start + start, chunk_len, lane, S1, S2);
+          if (lane == 0) plan->adler[n_chunks] = make_uint2(S1, S2);
+          n_chunks++;
+          start += chunk_len;
+          chunk_len = ADLER_CHUNK;
+        }
+      }
+      if (lane == 0) plan->n_chunks = n_chunks;
+    }
+    int kind = 0;
+    uint64_t block_bits = 0;
+    if (MODE != 2) {
 
 #ifdef ZD_EMIT_PHASES
     const uint64_t ph0 = __builtin_readcyclecounter();
@@ -1552,23 +1633,47 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
 #endif
     if (lane == 0) lit_freq[LITLEN_EOB] = 1;  // add_end_of_block_sym zd.ml:1088-1092
     wave_sync();
+    if (MODE == 1) {
+      wave_make_dynamic_syms(c, coder_scratch, lane);
+      const uint64_t flen = 3 + wave_symbols_bits(c, c.fix_lit, c.fix_dist, lane);
+      const uint64_t dsb = wave_symbols_bits(c, c.dyn_lit, c.dyn_dist, lane);
+      for (int i = lane; i < 288; i += 64) plan->dyn_lit[i] = dyn_lit[i];
+      if (lane < 32) plan->dyn_dist[lane] = dyn_dist[lane];
+      for (int i = lane; i < c.codelen_syms_len; i += 64) plan->codelen_syms[i] = codelen_syms[i];
+      if (lane < 19) plan->codelen_freq[lane] = codelen_freq[lane];
+      if (lane == 0) {
+        plan->flen = flen; plan->dyn_sym_bits = dsb;
+        plan->codelen_syms_len = c.codelen_syms_len; plan->hlit = c.hlit; plan->hdist = c.hdist;
+      }
+      return;
+    }
     wave_make_dynamic(c, coder_scratch, lane);
     uint64_t flen, dlen;
-    const int kind = wave_choose(c, bd.src_len, bo.acc_bits, flen, dlen, lane);
-    const uint64_t block_bits = kind == 1 ? flen : dlen;
+    kind = wave_choose(c, bd.src_len, bo.acc_bits, flen, dlen, lane);
+    block_bits = kind == 1 ? flen : dlen;
     wave_sync();
 #ifdef ZD_EMIT_PHASES
     const uint64_t ph2 = __builtin_readcyclecounter();
     ph_hist += ph1 - ph0;
     ph_code += ph2 - ph1;
 #endif
+    } else {  // MODE 2: the plan's codes
+      kind = (int)plan->kind;
+      if (kind == 2) {
+        for (int i = lane; i < 288; i += 64) dyn_lit[i] = plan->dyn_lit[i];
+        if (lane < 32) { dyn_dist[lane] = plan->dyn_dist[lane]; dyn_codelen[lane] = plan->dyn_codelen[lane]; }
+        c.codelen_syms_len = plan->codelen_syms_len; c.hlit = plan->hlit; c.hdist = plan->hdist; c.hclen = plan->hclen;
+        for (int i = lane; i < c.codelen_syms_len; i += 64) codelen_syms[i] = plan->codelen_syms[i];
+      }
+      wave_sync();
+    }
 
     if (kind == 0) {
       // write_non_compressed_block zd.ml:873-877
       const uint32_t hdr_bits = (uint32_t)bo.acc_bits + 3;
       const uint32_t hdr_bytes = (hdr_bits + 7) >> 3;
       const uint64_t need = (uint64_t)bo.out_pos + hdr_bytes + 4 + bd.src_len;
-      if (need > dst_cap) { status = ST_DST_TOO_SMALL; break; }
+      if (MODE == 0 && need > dst_cap) { status = ST_DST_TOO_SMALL; break; }
       uint8_t *o = bo.dst + bo.out_pos;
       if (lane == 0) {
         const uint32_t v = bo.acc | ((final ? 1u : 0u) << bo.acc_bits);
@@ -1590,7 +1695,7 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     }
 
     // fixed (zd.ml:912-916) or dynamic (zd.ml:918-945) block
-    {
+    if (MODE == 0) {
       const uint64_t need = (uint64_t)bo.out_pos + (((uint64_t)bo.acc_bits + block_bits + 7) >> 3);
       if (need > dst_cap) { status = ST_DST_TOO_SMALL; break; }
     }
@@ -1680,6 +1785,10 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
     }
   }
 
+  if (MODE == 2) {  // what the block leaves of its last byte: the seal puts it there
+    if (lane == 0) plan->tail = bo.acc;
+    return;
+  }
   if (status == ST_OK && bo.acc_bits > 0) {  // flush zd.ml:856-858
     if (bo.out_pos + 1 > dst_cap) status = ST_DST_TOO_SMALL;
     else {
@@ -1698,6 +1807,132 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
 #endif
     results[stream] = r;
   }
+}
+
+__global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__restrict__ src_arena,
+                                                          uint8_t *__restrict__ dst_arena,
+                                                          const StreamDesc *__restrict__ descs,
+                                                          StreamResult *__restrict__ results,
+                                                          DeflateScratch S, int crc_op) {
+  deflate_emit_wave<0>(src_arena, dst_arena, descs, results, S, crc_op, blockIdx.x, 0, nullptr);
+}
+
+// ---------------------------------------------------------------------------------
+// A stream's blocks by a wave each.  A block's bits depend on the blocks before it in three ways only: where it
+// starts (and, through the padding of a stored block, which kind is smallest), the code-length code (its counts
+// are never reset, Q1) and the running Adler-32.  So: deflate_plan_kernel does per block everything else;
+// deflate_scan_kernel, a wave per stream, walks the blocks' records -- counts added up, the 19-symbol code
+// built, the three sizes compared, bit offsets, the Adler-32 chunk steps, the stream's result;
+// deflate_pack_kernel writes every block from its first bit on (whole bytes; the low bits of its first byte
+// are the block's before, left zero) and deflate_seal_kernel ORs those bits in and writes the stream's last byte.
+__global__ __launch_bounds__(64, 4) void deflate_plan_kernel(const uint8_t *__restrict__ src_arena,
+                                                          const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                          int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
+  deflate_emit_wave<1>(src_arena, nullptr, descs, nullptr, S, crc_op, blockIdx.x / blocks_per_stream,
+                       blockIdx.x % blocks_per_stream, plans);
+}
+
+__global__ __launch_bounds__(64, 4) void deflate_pack_kernel(const uint8_t *__restrict__ src_arena,
+                                                          uint8_t *__restrict__ dst_arena,
+                                                          const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                          int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
+  deflate_emit_wave<2>(src_arena, dst_arena, descs, nullptr, S, crc_op, blockIdx.x / blocks_per_stream,
+                       blockIdx.x % blocks_per_stream, plans);
+}
+
+__global__ __launch_bounds__(64) void deflate_scan_kernel(const StreamDesc *__restrict__ descs,
+                                                          StreamResult *__restrict__ results, DeflateScratch S,
+                                                          int crc_op, EmitPlan *__restrict__ plans) {
+  __shared__ uint32_t codelen_freq[32], dyn_codelen[32], heap[580], coder_scratch[32];
+  const uint32_t stream = blockIdx.x;
+  const int lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
+    if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
+    return;
+  }
+  const uint32_t nblk = S.n_blocks[stream];
+  const BlockDesc *blocks = S.blocks + S.blk_base[stream];
+  EmitPlan *P = plans + S.blk_base[stream];
+  BlockCoder c{};
+  c.codelen_freq = codelen_freq; c.dyn_codelen = dyn_codelen; c.heap = heap;
+  if (lane < 32) { codelen_freq[lane] = 0; dyn_codelen[lane] = 0; }
+  wave_sync();
+  const bool want_adler = crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC;
+  uint32_t adler = 1;  // Adler_32.init
+  uint64_t bits = 0;
+  bool fits = true;
+  for (uint32_t b = 0; b < nblk; b++) {
+    const BlockDesc bd = blocks[b];
+    EmitPlan *p = P + b;
+    if (want_adler) {  // wave_adler_update's chunk steps, with the sums the plan left
+      uint32_t a1, a2;
+      adler_unpack(adler, a1, a2);  // (one update call per block: the value is packed and unpacked between two, zd.ml:178,198)
+      const uint32_t nc = p->n_chunks;
+      for (uint32_t i = 0; i < nc; i++) {
+        const uint2 sm = p->adler[i];
+        adler_chunk_step(a1, a2, i == 0 ? bd.src_len % ADLER_CHUNK : ADLER_CHUNK, sm.x, sm.y, crc_op == CRC_ADLER32_RFC);
+      }
+      adler = adler_pack(a1, a2);
+    }
+    if (lane < 19) codelen_freq[lane] += p->codelen_freq[lane];
+    wave_sync();
+    wave_make_dynamic_codelen(c, coder_scratch, lane);
+    wave_sync();
+    // wave_choose's estimates and choice, with the plan's sums
+    const uint32_t pending = (uint32_t)(bits & 7u);
+    const uint64_t nlen = 3 + (uint64_t)(8 - ((pending + 3) % 8)) + (4 + (uint64_t)bd.src_len) * 8;
+    const uint64_t flen = p->flen;
+    // (the dynamic estimate counts the code-length symbols of every block so far -- that is the reference's,
+    // and what the choice and the capacity test go by; the block itself holds its own)
+    uint64_t acc = 0, own = 0;
+    if (lane <= CODELEN_SYM_MAX) {
+      const uint32_t rb = lane == 16 ? 2 : lane == 17 ? 3 : lane == 18 ? 7 : 0;
+      acc = (uint64_t)codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
+      own = (uint64_t)p->codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
+    }
+    const uint64_t dhead = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4) + p->dyn_sym_bits;
+    const uint64_t dlen = dhead + wave_sum64(acc), dbits = dhead + wave_sum64(own);
+    const uint32_t kind = (nlen <= dlen && nlen <= flen) ? 0u : flen <= dlen ? 1u : 2u;
+    // a stored block: its type bits, zeros up to the next byte, LEN, NLEN, the bytes (nlen above is the
+    // reference's estimate: 8 too many when the type bits end a byte, Q3)
+    const uint64_t sbits = (uint64_t)(((pending + 3u + 7u) & ~7u) - pending) + (4 + (uint64_t)bd.src_len) * 8;
+    const uint64_t block_bits = kind == 0 ? sbits : kind == 1 ? flen : dbits;
+    if (((bits + (kind == 2 ? dlen : block_bits) + 7) >> 3) > sd.dst_cap) fits = false;  // deflate_emit_kernel's test per block
+    if (lane < 32) p->dyn_codelen[lane] = dyn_codelen[lane];
+    if (lane == 0) { p->bit_start = bits; p->bit_end = bits + block_bits; p->kind = kind; p->hclen = c.hclen; }
+    bits += block_bits;
+    wave_sync();
+  }
+  const uint64_t out_len = (bits + 7) >> 3;
+  const uint32_t status = (!fits || out_len > sd.dst_cap) ? (uint32_t)ST_DST_TOO_SMALL : (uint32_t)ST_OK;
+  if (status != ST_OK)
+    for (uint32_t b = (uint32_t)lane; b < nblk; b += 64) P[b].kind = EMIT_SKIP;
+  if (lane == 0) {
+    StreamResult r;
+    r.status = status;
+    r.out_len = status == ST_OK ? out_len : 0;
+    r.checksum = (want_adler && status == ST_OK) ? adler : 0u;  // CRC-32: checksum pass
+    results[stream] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void deflate_seal_kernel(uint8_t *__restrict__ dst_arena,
+                                                           const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                           uint32_t n_streams, uint32_t blocks_per_stream,
+                                                           const EmitPlan *__restrict__ plans) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t stream = (uint32_t)(i / blocks_per_stream), b = (uint32_t)(i % blocks_per_stream);
+  if (stream >= n_streams || S.error[0]) return;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) return;
+  const uint32_t nblk = S.n_blocks[stream];
+  if (b >= nblk) return;
+  const EmitPlan *p = plans + S.blk_base[stream] + b;
+  if (p->kind == EMIT_SKIP) return;
+  uint8_t *dst = dst_arena + sd.dst_off;
+  if (b != 0 && (p->bit_start & 7u)) dst[p->bit_start >> 3] |= (uint8_t)p[-1].tail;
+  if (b + 1 == nblk && (p->bit_end & 7u)) dst[p->bit_end >> 3] = (uint8_t)p->tail;  // flush zd.ml:856-858
 }
 
 // ---------------------------------------------------------------------------------
@@ -1805,19 +2040,25 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
   tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
   const size_t gps = (tps + tpg - 1) / tpg;
-  // Few long streams: lz_parse by a wave per segment (lz_parse_spec_kernel); many streams fill the chip with a
-  // wave each.  ZIPC_HIP_PARSE_SEGMENTS=0 never, =1 whenever a stream has more than one segment (tests).
+  // Few long streams: lz_parse by a wave per segment (lz_parse_spec_kernel) and the blocks coded by a wave each
+  // (deflate_plan_kernel); many streams fill the chip with a wave each.  ZIPC_HIP_PARSE_SEGMENTS=0 never, =1
+  // whenever a stream has more than one segment (tests).
   static const long segs_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEGMENTS"); return e ? atol(e) : -1L; }();
   const size_t sps = (max_src_len + PARSE_SEG - 1) / PARSE_SEG;
   bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 2048 && sps >= 8);
-  if (segmented && n * sps > 0x7FFFFFFFull) segmented = false;
+  const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
+  const size_t csegs = (max_src_len + CHAIN_SEG - 1) / CHAIN_SEG;  // lz_chain: workgroups of the longest stream
+  if (segmented && (n * sps > 0x7FFFFFFFull || n * bps > 0x7FFFFFFFull)) segmented = false;
   ParseSegs segs{};
+  EmitPlan *plans = nullptr;
   if (segmented) {
     const size_t n_slots = n * sps, tiles = (size_t)(S.cap_positions / 64) + 4;
-    const size_t bytes = align_up(n_slots * PARSE_SEG_SYMS * 4, 256) + align_up(tiles * 8, 256) + align_up(tiles * 4, 256) +
-                         5 * align_up(n_slots * 4, 256);
+    const size_t plan_bytes = align_up((size_t)S.cap_blocks * sizeof(EmitPlan), 256);
+    const size_t bytes = plan_bytes + align_up(n_slots * PARSE_SEG_SYMS * 4, 256) + align_up(tiles * 8, 256) +
+                         align_up(tiles * 4, 256) + 5 * align_up(n_slots * 4, 256);
     if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) return hipErrorOutOfMemory;
     uint8_t *q = (uint8_t *)ctx->parse_scratch.p;
+    plans = (EmitPlan *)q; q += plan_bytes;
     segs.spec_syms = (uint32_t *)q; q += align_up(n_slots * PARSE_SEG_SYMS * 4, 256);
     segs.vis = (unsigned long long *)q; q += align_up(tiles * 8, 256);
     segs.tile_sym0 = (uint32_t *)q; q += align_up(tiles * 4, 256);
@@ -1835,7 +2076,11 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     DeflateScratch Q = S;
     Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo;
     const StreamDesc *dd = d_descs + lo;
-    ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
+    if (segmented && csegs > 1 && m <= 128)  // (the run-up is a quarter more work: only while workgroups are what is missing)
+      ZD_LAUNCH(ctx, "lz_chain", lz_chain_segments_kernel, dim3((unsigned)(m * csegs)), dim3(CHAIN_THREADS), 0, d_src, dd,
+                Q, (uint32_t)csegs);
+    else
+      ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
     if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
       ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((m * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
                 d_src, dd, Q, (uint32_t)m, (uint32_t)cps, K, K / 4);
@@ -1855,8 +2100,19 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     } else {
       ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
     }
-    ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
-              d_results + lo, Q, crc_op);
+    if (segmented) {
+      ZD_LAUNCH(ctx, "deflate_plan", deflate_plan_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, dd, Q, crc_op,
+                (uint32_t)bps, plans);
+      ZD_LAUNCH(ctx, "deflate_scan", deflate_scan_kernel, dim3((unsigned)m), dim3(64), 0, dd, d_results + lo, Q, crc_op,
+                plans);
+      ZD_LAUNCH(ctx, "deflate_pack", deflate_pack_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, d_dst, dd, Q,
+                crc_op, (uint32_t)bps, plans);
+      ZD_LAUNCH(ctx, "deflate_seal", deflate_seal_kernel, dim3((unsigned)((m * bps + 255) / 256)), dim3(256), 0, d_dst,
+                dd, Q, (uint32_t)m, (uint32_t)bps, (const EmitPlan *)plans);
+    } else {
+      ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
+                d_results + lo, Q, crc_op);
+    }
   };
   // ZIPC_HIP_SLICES > 1: the group goes out in slices on queues of their own (ctx.h).  Measured on the
   // three shapes of tools/exp_wall.py and NOT the default: the kernels are each near their issue bound and
