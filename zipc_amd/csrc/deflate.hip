@@ -719,15 +719,19 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
 
 // Streams parsed by several waves (lz_parse_spec_kernel / lz_parse_stitch_kernel / lz_parse_gather_kernel below):
 // what the waves leave for each other, per stream at the stream's position base (tiles: base / 64, segments: seg_base).
-constexpr uint32_t PARSE_SEG = 4096;  // positions per segment: a multiple of the tile, far above the longest step (63 + 512)
-constexpr uint32_t PARSE_SEG_SYMS = PARSE_SEG + 576;  // symbols of a segment at most: one per position before its last step, and that step's
+// positions per segment (ParseSegs::seg_positions): a multiple of the tile, far above the longest step (63 + 512);
+// chosen per call -- the stitch takes a couple of microseconds per segment, one after the other, the waves of
+// lz_parse_spec_kernel a third of a microsecond per tile, side by side
+constexpr uint32_t PARSE_SEG_MIN = 4096;
+constexpr uint32_t PARSE_SEG_SLACK = 576;  // symbols of a segment at most: one per position before its last step, and that step's
 struct ParseSegs {
-  uint32_t *spec_syms;            // [segments * PARSE_SEG_SYMS] a segment's symbols as parsed from its first position
+  uint32_t *spec_syms;            // [segments * seg_syms] a segment's symbols as parsed from its first position
   unsigned long long *vis;        // [P / 64] per tile: the positions on the path (zeroed per call: a tile jumped over has none)
   uint32_t *tile_sym0;            // [P / 64] per tile: symbols of its segment before it
   uint32_t *seg_exit, *seg_total; // [segments] where the segment's parse left it (>= its end), and its symbols
   uint32_t *seg_dst, *seg_from, *seg_n;  // [segments] the stitch's verdict: spec symbols [from, from + n) go to the stream's symbols at dst
   uint32_t segs_per_stream;       // of the longest stream: segment slot of (stream, k) = stream * segs_per_stream + k
+  uint32_t seg_positions, seg_syms;  // positions per segment; symbol slots per segment (seg_positions + PARSE_SEG_SLACK)
 };
 
 // MODE 0: one wave parses a whole stream and cuts its blocks.  MODE 1: one wave parses ONE SEGMENT of a stream as if
@@ -750,11 +754,11 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   const uint64_t *match = S.match + base;
   const bool has_match = len >= (uint32_t)MIN_MATCH_LEN;
   const uint32_t max_pos = has_match ? len - MIN_MATCH_LEN : 0;  // positions <= max_pos have a match entry
-  const uint32_t B0 = MODE == 1 ? seg * PARSE_SEG : 0u;        // where this wave starts,
-  if (MODE == 1 && B0 >= len && !(len == 0 && seg == 0)) return;
-  const uint32_t lim = MODE == 1 ? (len - B0 > PARSE_SEG ? B0 + PARSE_SEG : len) : len;  // and the tiles it takes: those below lim
+  if (MODE == 1 && (uint64_t)seg * G.seg_positions >= len && !(len == 0 && seg == 0)) return;
+  const uint32_t B0 = MODE == 1 ? seg * G.seg_positions : 0u;  // where this wave starts,
+  const uint32_t lim = MODE == 1 ? (len - B0 > G.seg_positions ? B0 + G.seg_positions : len) : len;  // and the tiles it takes: those below lim
   const size_t seg_slot = (size_t)stream * G.segs_per_stream + seg;
-  uint32_t *syms = MODE == 1 ? G.spec_syms + seg_slot * PARSE_SEG_SYMS : S.syms + base;
+  uint32_t *syms = MODE == 1 ? G.spec_syms + seg_slot * G.seg_syms : S.syms + base;
   BlockDesc *blocks = MODE == 1 ? nullptr : S.blocks + S.blk_base[stream];
 
   if (MODE == 1 && len < 4u) {  // (the stitch handles streams this short itself)
@@ -1000,7 +1004,8 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
   }
   const uint32_t max_pos = len - MIN_MATCH_LEN;
   const size_t slot0 = (size_t)stream * G.segs_per_stream;
-  const uint32_t nseg = (len + PARSE_SEG - 1) / PARSE_SEG;
+  const uint32_t PARSE_SEG = G.seg_positions;
+  const uint32_t nseg = (uint32_t)(((uint64_t)len + PARSE_SEG - 1) / PARSE_SEG);
   unsigned long long *vis = G.vis + (base >> 6);
   uint32_t *tile_sym0 = G.tile_sym0 + (base >> 6);
 
@@ -1064,6 +1069,7 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
       from = spec_total; exit_k = e; again_end = seg_end;
     } else if (k != 0) {
       uint32_t B = e & ~63u, entry = e;
+      uint32_t rest = 0;  // tiles until a run of equal steps is tried again
       for (;;) {
         const Tile t = eval_tile(B, entry, false, 0ull);
         const unsigned long long own = vis[B >> 6];  // the segment's own path through this tile (0: it jumped over it)
@@ -1094,6 +1100,46 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
           else from = spec_total;
           exit_k = met ? spec_exit : entry;
           break;
+        }
+        // One long step through the tile and no meeting: a run of one byte, or a short period -- the data on which
+        // this path and the segment's own stay out of phase to the segment's end.  Then the next steps are probably
+        // the same: every lane takes the position i steps on and works out ITS step (lz_macro_position); the lanes
+        // before the first one that steps differently are on the path -- up to 64 steps for the price of a tile.
+        const uint32_t node_pos = B + (uint32_t)__builtin_ctzll(t.vm | (1ull << 63));
+        const uint32_t stride = entry - node_pos;
+        if (rest != 0) rest--;
+        else if (__builtin_popcountll(t.vm) == 1 && stride >= (uint32_t)PARSE_TILE) {
+          const uint64_t ahead = (uint64_t)lane * stride;
+          const bool in = ahead < (uint64_t)(seg_end - entry);
+          const uint32_t p = in ? entry + (uint32_t)ahead : entry;
+          const MacroStep m = lz_macro_position(p, len, good_match, [&](uint32_t j) -> uint64_t { return match[j]; });
+          const uint32_t adv = m.bref ? macro_advance(m.step) : 1u;
+          const unsigned long long go = __builtin_amdgcn_ballot_w64(in && adv == stride);
+          const uint32_t lead = ~go ? (uint32_t)__builtin_ctzll(~go) : 64u;  // lanes [0, lead) are on the path, and step alike
+          if (lead == 0) rest = 8;
+          else {
+            const bool on = (uint32_t)lane < lead;
+            const uint32_t cnt = on ? macro_sym_count(m) : 0u;
+            const uint32_t incl = wave_scan_incl(cnt);
+            const uint32_t first_rel = incl - cnt;
+            if (on) {
+              lz_emit_position(s, p, m, syms + off + f, first_rel);
+              // the path's marks for the block cut: this step's tile holds it alone, the tiles it jumps over nothing
+              vis[p >> 6] = 1ull << (p & 63u);
+              tile_sym0[p >> 6] = f + first_rel;
+              for (uint32_t tz = (p & ~63u) + PARSE_TILE; tz < ((p + stride) & ~63u) && tz < seg_end; tz += PARSE_TILE) vis[tz >> 6] = 0ull;
+            }
+            f += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            entry += lead * stride;  // (< seg_end + stride: lane lead - 1 was inside)
+            if (entry > len) entry = len;
+            const uint32_t Bs = entry & ~63u;
+            if (Bs >= seg_end) {
+              again_end = Bs; from = spec_total; exit_k = entry;
+              break;
+            }
+            B = Bs;
+            continue;
+          }
         }
         B = Bn;
       }
@@ -1153,10 +1199,10 @@ __global__ __launch_bounds__(64) void lz_parse_gather_kernel(const StreamDesc *_
   if (S.error[0]) return;
   const uint32_t stream = blockIdx.x / G.segs_per_stream, seg = blockIdx.x % G.segs_per_stream;
   const uint64_t len = descs[stream].src_len;
-  if (len > MAX_STREAM_LEN || len < (uint64_t)MIN_MATCH_LEN || (uint64_t)seg * PARSE_SEG >= len) return;
+  if (len > MAX_STREAM_LEN || len < (uint64_t)MIN_MATCH_LEN || (uint64_t)seg * G.seg_positions >= len) return;
   const size_t slot = (size_t)stream * G.segs_per_stream + seg;
   const uint32_t n = G.seg_n[slot];
-  const uint32_t *from = G.spec_syms + slot * PARSE_SEG_SYMS + G.seg_from[slot];
+  const uint32_t *from = G.spec_syms + slot * G.seg_syms + G.seg_from[slot];
   uint32_t *to = S.syms + S.pos_base[stream] + G.seg_dst[slot];
   for (uint32_t i = threadIdx.x; i < n; i += 64u) to[i] = from[i];
 }
@@ -1480,16 +1526,18 @@ constexpr uint32_t EMIT_SKIP = 0xFFu;  // kind of every block of a stream whose 
 struct EmitPlan {
   uint64_t flen;          // plan: bits of the block as a fixed block,
   uint64_t dyn_sym_bits;  //   and of its symbols under its own dynamic code
+  uint64_t dlen, dbits;   // codelen: the reference's estimate of the block as a dynamic block, and its bits
   uint64_t bit_start, bit_end;  // scan: the block's bits in the stream's output
   uint32_t kind;          // scan: 0 stored, 1 fixed, 2 dynamic, EMIT_SKIP
   uint32_t tail;          // pack: the bits behind the block's last whole byte
   int32_t codelen_syms_len, hlit, hdist;  // plan
-  int32_t hclen;          // scan
+  int32_t hclen;          // codelen
   uint32_t n_chunks;      // plan (Adler-32): the block's chunks, first = len mod 5552 (possibly empty), then 5552 each
   uint32_t codelen_freq[19];  // plan: the block's own code-length symbols, counted
+  uint32_t cum_freq[19];      // counts: ... and with those of the blocks before
   uint2 adler[13];        // plan: (S1, S2) per chunk
   uint32_t dyn_lit[288], dyn_dist[32], codelen_syms[320];  // plan
-  uint32_t dyn_codelen[32];                                // scan
+  uint32_t dyn_codelen[32];                                // codelen
 };
 
 // MODE 0: a wave codes a whole stream, block after block.  MODE 1 (plan): a wave takes ONE block as far as its
@@ -1821,10 +1869,12 @@ __global__ __launch_bounds__(64, 4) void deflate_emit_kernel(const uint8_t *__re
 // A stream's blocks by a wave each.  A block's bits depend on the blocks before it in three ways only: where it
 // starts (and, through the padding of a stored block, which kind is smallest), the code-length code (its counts
 // are never reset, Q1) and the running Adler-32.  So: deflate_plan_kernel does per block everything else;
-// deflate_scan_kernel, a wave per stream, walks the blocks' records -- counts added up, the 19-symbol code
-// built, the three sizes compared, bit offsets, the Adler-32 chunk steps, the stream's result;
-// deflate_pack_kernel writes every block from its first bit on (whole bytes; the low bits of its first byte
-// are the block's before, left zero) and deflate_seal_kernel ORs those bits in and writes the stream's last byte.
+// deflate_counts_kernel adds the code-length counts up along each stream (a wave scan per symbol over 64 blocks a
+// turn); deflate_codelen_kernel, a wave per block again, builds the 19-symbol code and the block's dynamic sizes;
+// deflate_scan_kernel, a wave per stream, is what is left of the chain: the three sizes compared, bit offsets, the
+// Adler-32 chunk steps, the stream's result -- a few dozen scalar operations per block; deflate_pack_kernel writes
+// every block from its first bit on (whole bytes; the low bits of its first byte are the block's before, left zero)
+// and deflate_seal_kernel ORs those bits in and writes the stream's last byte.
 __global__ __launch_bounds__(64, 4) void deflate_plan_kernel(const uint8_t *__restrict__ src_arena,
                                                           const StreamDesc *__restrict__ descs, DeflateScratch S,
                                                           int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
@@ -1840,12 +1890,69 @@ __global__ __launch_bounds__(64, 4) void deflate_pack_kernel(const uint8_t *__re
                        blockIdx.x % blocks_per_stream, plans);
 }
 
+// the counts of the code-length symbols as block b's code sees them: its own and those of every block before (Q1)
+__global__ __launch_bounds__(64) void deflate_counts_kernel(const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                            EmitPlan *__restrict__ plans) {
+  const uint32_t stream = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) return;
+  const uint32_t nblk = S.n_blocks[stream];
+  EmitPlan *P = plans + S.blk_base[stream];
+  uint32_t carry[19];
+#pragma unroll
+  for (int k = 0; k < 19; k++) carry[k] = 0;
+  for (uint32_t c = 0; c < nblk; c += 64) {  // 64 blocks a turn, one per lane: a wave scan per symbol
+    const bool mine = c + lane < nblk;
+    EmitPlan *p = P + (mine ? c + lane : nblk - 1);
+#pragma unroll
+    for (int k = 0; k < 19; k++) {
+      const uint32_t incl = wave_scan_incl(mine ? p->codelen_freq[k] : 0u) + carry[k];
+      if (mine) p->cum_freq[k] = incl;
+      carry[k] = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+  }
+}
+
+// the code of the code-length symbols of ONE block from those counts, the block's size as a dynamic block and
+// the reference's estimate of it (wave_choose's dlen)
+__global__ __launch_bounds__(64) void deflate_codelen_kernel(const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                             uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
+  __shared__ uint32_t codelen_freq[32], dyn_codelen[32], heap[580], coder_scratch[32];
+  const uint32_t stream = blockIdx.x / blocks_per_stream, b = blockIdx.x % blocks_per_stream;
+  const int lane = threadIdx.x;
+  const StreamDesc sd = descs[stream];
+  if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) return;
+  if (b >= S.n_blocks[stream]) return;
+  EmitPlan *p = plans + S.blk_base[stream] + b;
+  BlockCoder c{};
+  c.codelen_freq = codelen_freq; c.dyn_codelen = dyn_codelen; c.heap = heap;
+  if (lane < 32) { codelen_freq[lane] = lane < 19 ? p->cum_freq[lane] : 0u; dyn_codelen[lane] = 0; }
+  wave_sync();
+  wave_make_dynamic_codelen(c, coder_scratch, lane);
+  wave_sync();
+  // (the estimate counts the code-length symbols of every block so far -- that is the reference's, and what the
+  // choice and the capacity test go by; the block itself holds its own)
+  uint64_t acc = 0, own = 0;
+  if (lane <= CODELEN_SYM_MAX) {
+    const uint32_t rb = lane == 16 ? 2 : lane == 17 ? 3 : lane == 18 ? 7 : 0;
+    acc = (uint64_t)codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
+    own = (uint64_t)p->codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
+  }
+  const uint64_t dhead = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4) + p->dyn_sym_bits;
+  const uint64_t dlen = dhead + wave_sum64(acc), dbits = dhead + wave_sum64(own);
+  if (lane < 32) p->dyn_codelen[lane] = dyn_codelen[lane];
+  if (lane == 0) { p->dlen = dlen; p->dbits = dbits; p->hclen = c.hclen; }
+}
+
+// what is left of the chain through a stream's blocks: the choice (a stored block's size depends on the bit
+// it starts at), the bit offsets, the Adler-32 steps, the result.  64 blocks a turn: the lanes fetch their
+// block's numbers together, then the turn's blocks are gone through in order on wave-uniform values.
 __global__ __launch_bounds__(64) void deflate_scan_kernel(const StreamDesc *__restrict__ descs,
                                                           StreamResult *__restrict__ results, DeflateScratch S,
                                                           int crc_op, EmitPlan *__restrict__ plans) {
-  __shared__ uint32_t codelen_freq[32], dyn_codelen[32], heap[580], coder_scratch[32];
   const uint32_t stream = blockIdx.x;
-  const int lane = threadIdx.x;
+  const uint32_t lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
     if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
@@ -1854,60 +1961,54 @@ __global__ __launch_bounds__(64) void deflate_scan_kernel(const StreamDesc *__re
   const uint32_t nblk = S.n_blocks[stream];
   const BlockDesc *blocks = S.blocks + S.blk_base[stream];
   EmitPlan *P = plans + S.blk_base[stream];
-  BlockCoder c{};
-  c.codelen_freq = codelen_freq; c.dyn_codelen = dyn_codelen; c.heap = heap;
-  if (lane < 32) { codelen_freq[lane] = 0; dyn_codelen[lane] = 0; }
-  wave_sync();
   const bool want_adler = crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC;
   uint32_t adler = 1;  // Adler_32.init
   uint64_t bits = 0;
   bool fits = true;
-  for (uint32_t b = 0; b < nblk; b++) {
-    const BlockDesc bd = blocks[b];
-    EmitPlan *p = P + b;
-    if (want_adler) {  // wave_adler_update's chunk steps, with the sums the plan left
-      uint32_t a1, a2;
-      adler_unpack(adler, a1, a2);  // (one update call per block: the value is packed and unpacked between two, zd.ml:178,198)
-      const uint32_t nc = p->n_chunks;
-      for (uint32_t i = 0; i < nc; i++) {
-        const uint2 sm = p->adler[i];
-        adler_chunk_step(a1, a2, i == 0 ? bd.src_len % ADLER_CHUNK : ADLER_CHUNK, sm.x, sm.y, crc_op == CRC_ADLER32_RFC);
+  for (uint32_t c = 0; c < nblk; c += 64) {
+    const bool mine = c + lane < nblk;
+    EmitPlan *p = P + (mine ? c + lane : nblk - 1);
+    const uint64_t my_flen = p->flen, my_dlen = p->dlen, my_dbits = p->dbits;
+    const uint32_t my_src_len = blocks[mine ? c + lane : nblk - 1].src_len;
+    uint64_t my_start = 0, my_end = 0;
+    uint32_t my_kind = 0;
+    const uint32_t turn = nblk - c < 64u ? nblk - c : 64u;
+    for (uint32_t i = 0; i < turn; i++) {
+      const uint32_t src_len = (uint32_t)__builtin_amdgcn_readlane((int)my_src_len, (int)i);
+      auto lane64 = [&](uint64_t v) -> uint64_t {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), (int)i) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, (int)i);
+      };
+      const uint64_t flen = lane64(my_flen), dlen = lane64(my_dlen), dbits = lane64(my_dbits);
+      if (want_adler) {  // wave_adler_update's chunk steps, with the sums the plan left
+        const EmitPlan *q = P + c + i;
+        uint32_t a1, a2;
+        adler_unpack(adler, a1, a2);  // (one update call per block: the value is packed and unpacked between two, zd.ml:178,198)
+        const uint32_t nc = q->n_chunks;
+        for (uint32_t j = 0; j < nc; j++) {
+          const uint2 sm = q->adler[j];
+          adler_chunk_step(a1, a2, j == 0 ? src_len % ADLER_CHUNK : ADLER_CHUNK, sm.x, sm.y, crc_op == CRC_ADLER32_RFC);
+        }
+        adler = adler_pack(a1, a2);
       }
-      adler = adler_pack(a1, a2);
+      // wave_choose's estimates and choice
+      const uint32_t pending = (uint32_t)(bits & 7u);
+      const uint64_t nlen = 3 + (uint64_t)(8 - ((pending + 3) % 8)) + (4 + (uint64_t)src_len) * 8;
+      const uint32_t kind = (nlen <= dlen && nlen <= flen) ? 0u : flen <= dlen ? 1u : 2u;
+      // a stored block: its type bits, zeros up to the next byte, LEN, NLEN, the bytes (nlen is the reference's
+      // estimate: 8 too many when the type bits end a byte, Q3)
+      const uint64_t sbits = (uint64_t)(((pending + 3u + 7u) & ~7u) - pending) + (4 + (uint64_t)src_len) * 8;
+      const uint64_t block_bits = kind == 0 ? sbits : kind == 1 ? flen : dbits;
+      if (((bits + (kind == 2 ? dlen : block_bits) + 7) >> 3) > sd.dst_cap) fits = false;  // deflate_emit_kernel's test per block
+      if (lane == i) { my_start = bits; my_end = bits + block_bits; my_kind = kind; }
+      bits += block_bits;
     }
-    if (lane < 19) codelen_freq[lane] += p->codelen_freq[lane];
-    wave_sync();
-    wave_make_dynamic_codelen(c, coder_scratch, lane);
-    wave_sync();
-    // wave_choose's estimates and choice, with the plan's sums
-    const uint32_t pending = (uint32_t)(bits & 7u);
-    const uint64_t nlen = 3 + (uint64_t)(8 - ((pending + 3) % 8)) + (4 + (uint64_t)bd.src_len) * 8;
-    const uint64_t flen = p->flen;
-    // (the dynamic estimate counts the code-length symbols of every block so far -- that is the reference's,
-    // and what the choice and the capacity test go by; the block itself holds its own)
-    uint64_t acc = 0, own = 0;
-    if (lane <= CODELEN_SYM_MAX) {
-      const uint32_t rb = lane == 16 ? 2 : lane == 17 ? 3 : lane == 18 ? 7 : 0;
-      acc = (uint64_t)codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
-      own = (uint64_t)p->codelen_freq[lane] * ((dyn_codelen[lane] & 0x1F) + rb);
-    }
-    const uint64_t dhead = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4) + p->dyn_sym_bits;
-    const uint64_t dlen = dhead + wave_sum64(acc), dbits = dhead + wave_sum64(own);
-    const uint32_t kind = (nlen <= dlen && nlen <= flen) ? 0u : flen <= dlen ? 1u : 2u;
-    // a stored block: its type bits, zeros up to the next byte, LEN, NLEN, the bytes (nlen above is the
-    // reference's estimate: 8 too many when the type bits end a byte, Q3)
-    const uint64_t sbits = (uint64_t)(((pending + 3u + 7u) & ~7u) - pending) + (4 + (uint64_t)bd.src_len) * 8;
-    const uint64_t block_bits = kind == 0 ? sbits : kind == 1 ? flen : dbits;
-    if (((bits + (kind == 2 ? dlen : block_bits) + 7) >> 3) > sd.dst_cap) fits = false;  // deflate_emit_kernel's test per block
-    if (lane < 32) p->dyn_codelen[lane] = dyn_codelen[lane];
-    if (lane == 0) { p->bit_start = bits; p->bit_end = bits + block_bits; p->kind = kind; p->hclen = c.hclen; }
-    bits += block_bits;
-    wave_sync();
+    if (mine) { p->bit_start = my_start; p->bit_end = my_end; p->kind = my_kind; }
   }
   const uint64_t out_len = (bits + 7) >> 3;
   const uint32_t status = (!fits || out_len > sd.dst_cap) ? (uint32_t)ST_DST_TOO_SMALL : (uint32_t)ST_OK;
   if (status != ST_OK)
-    for (uint32_t b = (uint32_t)lane; b < nblk; b += 64) P[b].kind = EMIT_SKIP;
+    for (uint32_t b = lane; b < nblk; b += 64) P[b].kind = EMIT_SKIP;
   if (lane == 0) {
     StreamResult r;
     r.status = status;
@@ -2044,7 +2145,13 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // (deflate_plan_kernel); many streams fill the chip with a wave each.  ZIPC_HIP_PARSE_SEGMENTS=0 never, =1
   // whenever a stream has more than one segment (tests).
   static const long segs_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEGMENTS"); return e ? atol(e) : -1L; }();
-  const size_t sps = (max_src_len + PARSE_SEG - 1) / PARSE_SEG;
+  static const long segp_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEG"); return e ? atol(e) : 0L; }();  // positions per segment (tuning)
+  // segment size: the stitch's serial time per stream is segments x ~2 us, the parallel part's a segment's tiles x ~0.3 us
+  // (one stream alone, 4-bit symbols, whole deflate, ms at 4096 / 8192 / 16384 / 32768 / 65536 positions: 1 MiB 1.52 / 1.35 /
+  // 1.39 / 1.63 / 2.15, 16 MiB 11.8 / 8.0 / 6.3 / 5.6 / 5.7)
+  size_t segp = max_src_len <= ((size_t)256 << 10) ? 4096 : max_src_len <= ((size_t)2 << 20) ? 8192 : max_src_len <= ((size_t)8 << 20) ? 16384 : 32768;
+  if (segp_env >= (long)PARSE_SEG_MIN && segp_env % 64 == 0 && segp_env <= (1L << 20)) segp = (size_t)segp_env;
+  const size_t sps = (max_src_len + segp - 1) / segp;
   bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 2048 && sps >= 8);
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
   const size_t csegs = (max_src_len + CHAIN_SEG - 1) / CHAIN_SEG;  // lz_chain: workgroups of the longest stream
@@ -2054,12 +2161,13 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   if (segmented) {
     const size_t n_slots = n * sps, tiles = (size_t)(S.cap_positions / 64) + 4;
     const size_t plan_bytes = align_up((size_t)S.cap_blocks * sizeof(EmitPlan), 256);
-    const size_t bytes = plan_bytes + align_up(n_slots * PARSE_SEG_SYMS * 4, 256) + align_up(tiles * 8, 256) +
+    const size_t seg_syms = segp + PARSE_SEG_SLACK;
+    const size_t bytes = plan_bytes + align_up(n_slots * seg_syms * 4, 256) + align_up(tiles * 8, 256) +
                          align_up(tiles * 4, 256) + 5 * align_up(n_slots * 4, 256);
     if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) return hipErrorOutOfMemory;
     uint8_t *q = (uint8_t *)ctx->parse_scratch.p;
     plans = (EmitPlan *)q; q += plan_bytes;
-    segs.spec_syms = (uint32_t *)q; q += align_up(n_slots * PARSE_SEG_SYMS * 4, 256);
+    segs.spec_syms = (uint32_t *)q; q += align_up(n_slots * seg_syms * 4, 256);
     segs.vis = (unsigned long long *)q; q += align_up(tiles * 8, 256);
     segs.tile_sym0 = (uint32_t *)q; q += align_up(tiles * 4, 256);
     segs.seg_exit = (uint32_t *)q; q += align_up(n_slots * 4, 256);
@@ -2068,6 +2176,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     segs.seg_from = (uint32_t *)q; q += align_up(n_slots * 4, 256);
     segs.seg_n = (uint32_t *)q;
     segs.segs_per_stream = (uint32_t)sps;
+    segs.seg_positions = (uint32_t)segp; segs.seg_syms = (uint32_t)seg_syms;
     const hipError_t me = hipMemsetAsync(segs.vis, 0, tiles * 8, ctx->cur);
     if (me != hipSuccess) return me;
   }
@@ -2090,7 +2199,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     if (segmented) {
       ParseSegs G = segs;
       const size_t o = lo * sps;  // the slice's segment slots
-      G.spec_syms += o * PARSE_SEG_SYMS;
+      G.spec_syms += o * G.seg_syms;
       G.seg_exit += o; G.seg_total += o; G.seg_dst += o; G.seg_from += o; G.seg_n += o;
       ZD_LAUNCH(ctx, "lz_parse_spec", lz_parse_spec_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, d_src, dd, Q,
                 good_match, G);
@@ -2102,6 +2211,9 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     }
     if (segmented) {
       ZD_LAUNCH(ctx, "deflate_plan", deflate_plan_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, dd, Q, crc_op,
+                (uint32_t)bps, plans);
+      ZD_LAUNCH(ctx, "deflate_counts", deflate_counts_kernel, dim3((unsigned)m), dim3(64), 0, dd, Q, plans);
+      ZD_LAUNCH(ctx, "deflate_codelen", deflate_codelen_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, dd, Q,
                 (uint32_t)bps, plans);
       ZD_LAUNCH(ctx, "deflate_scan", deflate_scan_kernel, dim3((unsigned)m), dim3(64), 0, dd, d_results + lo, Q, crc_op,
                 plans);
