@@ -127,7 +127,10 @@ def launch_workers(n, argv):
 
 # ---- pieces of the JSON line -------------------------------------------------------------------------
 
-DEFLATE_KERNELS = ("deflate_offsets", "lz_chain", "lz_match", "lz_parse", "deflate_emit", "deflate_stored")
+DEFLATE_KERNELS = ("deflate_offsets", "lz_chain", "lz_match", "lz_parse", "deflate_emit", "deflate_stored",
+                   # few long streams (at most 4096 of 32 KiB and more): the parse by segments, the blocks by a wave each
+                   "lz_parse_spec", "lz_parse_stitch", "lz_parse_gather", "deflate_plan", "deflate_counts", "deflate_codelen",
+                   "deflate_scan", "deflate_pack", "deflate_seal")
 
 
 def algorithmic_bytes(kernel, N, C):
@@ -150,6 +153,10 @@ def design_bytes(kernel, N, C):
         "lz_match": N + 2 * N + 8 * N,     # source + links in, 8-byte match records out
         "lz_parse": 8 * N + N + 4 * N,     # match records + literals in, <= 4 B/symbol out
         "deflate_emit": 4 * N + C,         # symbols in, compressed out
+        "lz_parse_spec": 8 * N + N + 4 * N,    # as lz_parse, symbols to the segments' buffers
+        "lz_parse_gather": 4 * N + 4 * N,      # ... and from there to the stream's symbol array
+        "deflate_plan": 4 * N,                 # symbols in (histograms), a 3 KiB record per block out
+        "deflate_pack": 4 * N + C,             # symbols in, compressed out
     }.get(kernel, 0)
 
 
@@ -535,13 +542,24 @@ def extra_legs(ctx, dev, n, L):
                                      "and built libraries) repeated to %d streams (`Best: 2048), device-resident" % (k, m)}
     except Exception as e:
         out["corpus_gib_s"] = {"error": repr(e)}
+    try:  # one stream per call (what every value of the reference's .mli takes): C1's 1 MiB of zeros, 1 MiB and 16 MiB of the C2 symbols
+        one = {}
+        for name, ML, bits in (("c1_zeros_1mib", 1 << 20, 0), ("symbols_1mib", 1 << 20, 4), ("symbols_16mib", 16 << 20, 4)):
+            src = torch.zeros(ML, dtype=torch.uint8, device=dev) if bits == 0 else synth.batch_bytes_torch(2, 0, 1, ML, bits, dev)
+            gd, gi = device_round_trip(ctx, dev, src, 1, ML, 1 if bits == 0 else 2, reps=3)
+            one[name] = {"deflate_ms": ML / GIB / gd * 1e3, "inflate_ms": ML / GIB / gi * 1e3}
+        one["is"] = "ONE stream per call, device-resident: `Fast on 1 MiB of zeros (BASELINE C1's input), `Default on the C2 symbols; " \
+                    "deflate of a long stream runs as segments and blocks on many waves, inflate as one wave"
+        out["one_stream_ms"] = one
+    except Exception as e:
+        out["one_stream_ms"] = {"error": repr(e)}
     try:  # C4 shape on this GPU: 4096 members x 1 MiB of 3-bit symbols (a wave per member: half of them leaves the GPU half empty)
         m, ML = 4096, 1 << 20
         src = synth.batch_bytes_torch(4, 0, m, ML, 3, dev)
         gd, gi = device_round_trip(ctx, dev, src, m, ML, 2)
         out["c4_deflate_gib_s"] = gd
         out["c4_inflate_gib_s"] = gi
-        out["c4_leg_is"] = "%d members x 1 MiB of 3-bit symbols on this GPU, device-resident (bench.py --config c4 runs all 8192: fuller kernels, higher rates)" % m
+        out["c4_leg_is"] = "%d members x 1 MiB of 3-bit symbols on this GPU, device-resident (bench.py --config c4 runs all 8192)" % m
     except Exception as e:
         out["c4_deflate_gib_s"] = {"error": repr(e)}
     return out

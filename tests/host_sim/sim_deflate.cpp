@@ -112,6 +112,125 @@ static uint32_t parse_tiles_model(const uint8_t *s, uint32_t len, const uint32_t
   return nblk;
 }
 
+// Host model of lz_parse_spec_kernel / lz_parse_stitch_kernel / lz_parse_gather_kernel (deflate.hip): every
+// segment of SEG positions parsed from its first position, then segment by segment from the true entry until the
+// path shares a position OF THE SAME TILE with the segment's own (what the kernel's tile test sees), runs of
+// equal long steps taken 64 at a time, the block cut at the step that holds source byte blk_start + 65534.
+static uint32_t parse_segments_model(const uint8_t *s, uint32_t len, const uint32_t *brefs, const uint32_t *steps,
+                                     uint32_t SEG, uint32_t *syms, BlockDesc *blocks) {
+  auto adv = [&](uint32_t p) { return brefs[p] ? macro_advance(steps[p]) : 1u; };
+  auto step_of = [&](uint32_t p) { MacroStep m; m.bref = brefs[p]; m.step = steps[p]; return m; };
+  const uint32_t nseg = (len + SEG - 1) / SEG, ntiles = len / 64 + 2;
+  std::vector<uint64_t> vis(ntiles, 0);
+  std::vector<uint32_t> tsym0(ntiles, 0), sexit(nseg + 1, 0), stotal(nseg + 1, 0);
+  std::vector<std::vector<uint32_t>> spec(nseg + 1);
+  for (uint32_t k = 0; k < nseg; k++) {
+    const uint32_t lim = (k + 1) * SEG < len ? (k + 1) * SEG : len;
+    uint32_t p = k * SEG, n = 0, cur = 0xFFFFFFFFu;
+    spec[k].assign(SEG + 600, 0);
+    while (p < lim) {
+      if ((p >> 6) != cur) { cur = p >> 6; tsym0[cur] = n; }
+      vis[p >> 6] |= 1ull << (p & 63);
+      lz_emit_position(s, p, step_of(p), spec[k].data(), n);
+      n += macro_sym_count(step_of(p));
+      p += adv(p);
+    }
+    sexit[k] = p < len ? p : len;
+    stotal[k] = n;
+  }
+  uint32_t off = 0, exit_prev = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;
+  for (uint32_t k = 0; k < nseg; k++) {
+    const uint32_t seg_start = k * SEG, seg_end = (k + 1) * SEG < len ? (k + 1) * SEG : len;
+    const uint32_t e = exit_prev;
+    uint32_t f = 0, from = 0, exit_k = sexit[k], again_end = seg_start;
+    if (k != 0 && e >= seg_end) { from = stotal[k]; exit_k = e; again_end = seg_end; }
+    else if (k != 0) {
+      uint32_t B = e & ~63u, entry = e, rest = 0;
+      for (;;) {
+        const uint64_t own = vis[B >> 6];
+        uint64_t vm = 0;
+        const uint32_t f0 = f;
+        uint32_t p = entry;
+        while (p < B + 64 && p < len) {
+          vm |= 1ull << (p & 63);
+          lz_emit_position(s, p, step_of(p), syms + off, f);
+          f += macro_sym_count(step_of(p));
+          p += adv(p);
+        }
+        const uint32_t node_pos = B + (uint32_t)__builtin_ctzll(vm | (1ull << 63));
+        vis[B >> 6] = vm; tsym0[B >> 6] = f0;
+        entry = p < len ? p : len;
+        const uint32_t Be = entry & ~63u, Bn = Be > B + 64 ? Be : B + 64;
+        const bool met = (vm & own) != 0;
+        for (uint32_t tz = B + 64; tz < Bn && tz < seg_end; tz += 64) vis[tz >> 6] = 0;
+        if (met || Bn >= seg_end) {
+          again_end = Bn;
+          from = (met && Bn < seg_end) ? tsym0[Bn >> 6] : stotal[k];
+          exit_k = met ? sexit[k] : entry;
+          break;
+        }
+        const uint32_t stride = entry - node_pos;
+        if (rest != 0) rest--;
+        else if (__builtin_popcountll(vm) == 1 && stride >= 64) {
+          uint32_t lead = 0;
+          while (lead < 64 && (uint64_t)lead * stride < (uint64_t)(seg_end - entry) && adv(entry + lead * stride) == stride) lead++;
+          if (lead == 0) rest = 8;
+          else {
+            for (uint32_t i = 0; i < lead; i++) {
+              const uint32_t q = entry + i * stride;
+              lz_emit_position(s, q, step_of(q), syms + off, f);
+              vis[q >> 6] = 1ull << (q & 63);
+              tsym0[q >> 6] = f;
+              for (uint32_t tz = (q & ~63u) + 64; tz < ((q + stride) & ~63u) && tz < seg_end; tz += 64) vis[tz >> 6] = 0;
+              f += macro_sym_count(step_of(q));
+            }
+            entry += lead * stride;
+            if (entry > len) entry = len;
+            const uint32_t Bs = entry & ~63u;
+            if (Bs >= seg_end) { again_end = Bs; from = stotal[k]; exit_k = entry; break; }
+            B = Bs;
+            continue;
+          }
+        }
+        B = Bn;
+      }
+    }
+    const uint32_t n_own = stotal[k] - from;
+    for (uint32_t i = 0; i < n_own; i++) syms[off + f + i] = spec[k][from + i];  // the gather
+    while (exit_k - blk_start > (uint32_t)MAX_BLOCK_SRC_LEN) {
+      const uint32_t T = blk_start + MAX_BLOCK_SRC_LEN;
+      const uint32_t Ts = T < seg_end ? T : seg_end - 1;
+      uint32_t Bt = Ts & ~63u;
+      uint64_t w = vis[Bt >> 6] & (~0ull >> (63 - (Ts & 63)));
+      while (w == 0) { Bt -= 64; w = vis[Bt >> 6]; }
+      const uint32_t c = 63 - (uint32_t)__builtin_clzll(w);
+      const bool again = k != 0 && Bt >= (e & ~63u) && Bt < again_end;
+      uint32_t first = again ? off + tsym0[Bt >> 6] : off + f - from + tsym0[Bt >> 6];
+      for (uint32_t t = 0; t < c; t++)
+        if ((vis[Bt >> 6] >> t) & 1) first += macro_sym_count(step_of(Bt + t));
+      const uint32_t p = Bt + c, rel = p - blk_start;
+      const uint32_t br = brefs[p], lits = br ? macro_lits(steps[p]) : 0;
+      uint32_t cutpos, symidx;
+      if (br == 0) { cutpos = p; symidx = first; }
+      else if (rel + lits > (uint32_t)MAX_BLOCK_SRC_LEN) { const uint32_t i = MAX_BLOCK_SRC_LEN - rel; cutpos = p + i; symidx = first + i; }
+      else { cutpos = p + lits; symidx = first + lits; }
+      BlockDesc b;
+      b.src_start = blk_start; b.src_len = cutpos - blk_start;
+      b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
+      blocks[nblk++] = b;
+      blk_start = cutpos;
+      blk_sym_start = symidx;
+    }
+    off += f + n_own;
+    exit_prev = exit_k;
+  }
+  BlockDesc b;
+  b.src_start = blk_start; b.src_len = len - blk_start;
+  b.sym_start = blk_sym_start; b.n_syms = off - blk_sym_start;
+  blocks[nblk++] = b;
+  return nblk;
+}
+
 // kinds[] receives the block kinds (0 stored, 1 fixed, 2 dynamic), up to max_kinds
 extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t *dst, uint64_t dst_cap,
                            uint64_t *out_len, uint32_t *adler_out, int *kinds, int max_kinds,
@@ -219,8 +338,14 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       lz_walk_advance(ws, len, stop, 48, gets, bitmap.data(), tile_sym.data(), blocks.data());
     }
     uint32_t nblk = lz_walk_finish(ws, len, bitmap.data(), tile_sym.data(), blocks.data());
-    const bool use_tiles = getenv("SIM_PARSE_TILES") != nullptr;
+    bool use_tiles = getenv("SIM_PARSE_TILES") != nullptr;
     if (use_tiles) nblk = parse_tiles_model(src, len, brefs.data(), steps.data(), syms.data(), blocks.data());
+    if (const char *seg = getenv("SIM_PARSE_SEGMENTS")) {  // positions per segment
+      if (len >= 4) {
+        use_tiles = true;  // (the symbols are in place)
+        nblk = parse_segments_model(src, len, brefs.data(), steps.data(), (uint32_t)atoi(seg), syms.data(), blocks.data());
+      }
+    }
     for (uint32_t t = 0; !use_tiles && t * WALK_TILE < len; t++) {
       uint32_t idx = tile_sym[t];
       for (uint32_t p = t * WALK_TILE; p < len && p < (t + 1) * WALK_TILE; p++) {
@@ -241,10 +366,77 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
     c.dyn_lit = dyn_lit; c.dyn_dist = dyn_dist; c.dyn_codelen = dyn_codelen;
     c.fix_lit = fix_lit; c.fix_dist = fix_dist; c.codelen_syms = codelen_syms; c.heap = heap;
     huff_fixed_encoders(fix_lit, fix_dist);
+    // SIM_EMIT_BLOCKS: the blocks as deflate_plan / _counts / _codelen / _scan_kernel code them -- each block by
+    // itself as far as its bits do not depend on the blocks before, then the counts of the code-length symbols
+    // added up, the 19-symbol code, the choice and the offsets along the stream
+    struct Plan {
+      uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], codelen_syms[320], own_freq[19], cum_freq[19];
+      int codelen_syms_len, hlit, hdist, hclen, kind;
+      uint64_t flen, dsb, dlen, dbits, bit_start, bit_end;
+    };
+    const bool by_blocks = getenv("SIM_EMIT_BLOCKS") != nullptr;
+    std::vector<Plan> plans(by_blocks ? nblk : 0);
+    if (by_blocks) {
+      for (uint32_t b = 0; b < nblk; b++) {  // plan
+        const BlockDesc &bd = blocks[b];
+        Plan &P = plans[b];
+        memset(lit_freq, 0, sizeof lit_freq);
+        memset(dist_freq, 0, sizeof dist_freq);
+        memset(codelen_freq, 0, sizeof codelen_freq);
+        for (uint32_t k = 0; k < bd.n_syms; k++) {
+          uint32_t s = syms[bd.sym_start + k];
+          if ((s >> 9) == 0) lit_freq[s]++;
+          else { lit_freq[length_to_sym(s & 0x1FF)]++; dist_freq[dist_to_sym(s >> 9)]++; }
+        }
+        lit_freq[LITLEN_EOB] = 1;
+        coder_make_dynamic_syms(c);
+        P.flen = 3 + coder_symbols_bits(c, fix_lit, fix_dist);
+        P.dsb = coder_symbols_bits(c, dyn_lit, dyn_dist);
+        memcpy(P.dyn_lit, dyn_lit, sizeof dyn_lit); memcpy(P.dyn_dist, dyn_dist, sizeof dyn_dist);
+        memcpy(P.codelen_syms, codelen_syms, sizeof codelen_syms); memcpy(P.own_freq, codelen_freq, sizeof P.own_freq);
+        P.codelen_syms_len = c.codelen_syms_len; P.hlit = c.hlit; P.hdist = c.hdist;
+      }
+      uint32_t run[19] = {0};
+      for (uint32_t b = 0; b < nblk; b++)  // counts
+        for (int k = 0; k < 19; k++) { run[k] += plans[b].own_freq[k]; plans[b].cum_freq[k] = run[k]; }
+      for (uint32_t b = 0; b < nblk; b++) {  // codelen
+        Plan &P = plans[b];
+        memcpy(codelen_freq, P.cum_freq, sizeof P.cum_freq);
+        coder_make_dynamic_codelen(c);
+        uint64_t head = 3 + 5 + 5 + 4 + 3 * (uint64_t)(c.hclen + 4) + P.dsb, acc = 0, own = 0;
+        for (int sym = 0; sym <= CODELEN_SYM_MAX; sym++) {
+          const uint32_t rb = sym == 16 ? 2 : sym == 17 ? 3 : sym == 18 ? 7 : 0;
+          acc += (uint64_t)P.cum_freq[sym] * ((dyn_codelen[sym] & 0x1F) + rb);
+          own += (uint64_t)P.own_freq[sym] * ((dyn_codelen[sym] & 0x1F) + rb);
+        }
+        P.dlen = head + acc; P.dbits = head + own; P.hclen = c.hclen;
+        memcpy(P.dyn_codelen, dyn_codelen, sizeof dyn_codelen);
+      }
+      uint64_t bits = 0;
+      for (uint32_t b = 0; b < nblk; b++) {  // scan
+        Plan &P = plans[b];
+        const uint32_t pending = (uint32_t)(bits & 7), src_len = blocks[b].src_len;
+        const uint64_t nlen = 3 + (uint64_t)(8 - ((pending + 3) % 8)) + (4 + (uint64_t)src_len) * 8;
+        P.kind = (nlen <= P.dlen && nlen <= P.flen) ? 0 : P.flen <= P.dlen ? 1 : 2;
+        const uint64_t sbits = (uint64_t)(((pending + 3u + 7u) & ~7u) - pending) + (4 + (uint64_t)src_len) * 8;
+        P.bit_start = bits;
+        bits += P.kind == 0 ? sbits : P.kind == 1 ? P.flen : P.dbits;
+        P.bit_end = bits;
+      }
+    }
     for (uint32_t b = 0; b < nblk; b++) {
       const BlockDesc &bd = blocks[b];
       const bool final = b + 1 == nblk;
       adler = adler_update_serial(adler, src + bd.src_start, bd.src_len);
+      int kind;
+      if (by_blocks) {
+        const Plan &P = plans[b];
+        if (P.bit_start != (uint64_t)w.out.size() * 8 + (uint64_t)w.nbits) return 96;  // the scan's offsets are the real ones
+        kind = P.kind;
+        memcpy(dyn_lit, P.dyn_lit, sizeof dyn_lit); memcpy(dyn_dist, P.dyn_dist, sizeof dyn_dist);
+        memcpy(dyn_codelen, P.dyn_codelen, sizeof dyn_codelen); memcpy(codelen_syms, P.codelen_syms, sizeof codelen_syms);
+        c.codelen_syms_len = P.codelen_syms_len; c.hlit = P.hlit; c.hdist = P.hdist; c.hclen = P.hclen;
+      } else {
       memset(lit_freq, 0, sizeof lit_freq);
       memset(dist_freq, 0, sizeof dist_freq);
       for (uint32_t k = 0; k < bd.n_syms; k++) {
@@ -255,7 +447,8 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
       lit_freq[LITLEN_EOB] = 1;
       coder_make_dynamic(c);
       uint64_t flen, dlen;
-      int kind = coder_choose(c, bd.src_len, w.nbits, flen, dlen);
+      kind = coder_choose(c, bd.src_len, w.nbits, flen, dlen);
+      }
       if (nk < max_kinds) kinds[nk] = kind;
       nk++;
       if (kind == 0) {
@@ -278,6 +471,7 @@ extern "C" int sim_deflate(const uint8_t *src, uint32_t len, int level, uint8_t 
           w.put(v, n);
         }
       }
+      if (by_blocks && plans[b].bit_end != (uint64_t)w.out.size() * 8 + (uint64_t)w.nbits) return 95;
     }
     w.flush();
   }

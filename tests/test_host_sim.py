@@ -106,6 +106,49 @@ def test_parse_tiles_model_bytes_equal_oracle(sim, oracle, monkeypatch):
             assert st == 0 and c == c0 and a == a0, (name, lvl)
 
 
+def _sim_cases_for_segments():
+    """the deflate cases plus what the segment stitch is about: runs of one byte and short periods (paths that stay
+    out of phase), long enough for several segments and blocks"""
+    cases = dict(util.deflate_cases())
+    rnd = random.Random(5)
+    for k in (1, 2, 3, 7, 64, 257, 258, 259, 260, 515, 1000):
+        pat = bytes(rnd.randrange(256) for _ in range(k))
+        cases["period_%d" % k] = (pat * (150000 // k + 1))[:150000 + k]
+    t = bytearray(util.text(200000, 9))
+    t[50000:120000] = b"ab" * 35000
+    t[140000:170000] = bytes(30000)
+    cases["text_with_runs"] = bytes(t)
+    return cases
+
+
+@pytest.mark.parametrize("seg", [64, 4096, 8192])
+def test_parse_segments_model_bytes_equal_oracle(sim, oracle, monkeypatch, seg):
+    """lz_parse by segments (lz_parse_spec / _stitch / _gather_kernel): the algorithm on the host -- every segment
+    parsed from its first position, stitched where the true path meets it within a tile, runs of equal steps, the
+    block cut at the step that holds the block's byte 65534 -- gives the reference's bytes (64: a segment per tile,
+    every boundary case many times over)."""
+    monkeypatch.setenv("SIM_PARSE_SEGMENTS", str(seg))
+    for name, data in _sim_cases_for_segments().items():
+        for lvl in ((1, 2, 3) if seg != 64 else (2,)):
+            st0, c0, a0 = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+            st, c, a, _ = sim_deflate(sim, oracle, data, lvl)
+            assert st == 0 and c == c0 and a == a0, (name, lvl, seg)
+
+
+def test_blocks_coded_independently_model_bytes_equal_oracle(sim, oracle, monkeypatch):
+    """deflate_plan / _counts / _codelen / _scan_kernel's split of the block coder: what a block's bits owe to the
+    blocks before it is the bit it starts at, the counts of the code-length symbols (never reset, Q1) and nothing
+    else; the sizes the scan goes by are the real ones (a stored block's estimate runs 8 high when its type bits end
+    a byte, Q3; a dynamic block's counts every block's code-length symbols)."""
+    monkeypatch.setenv("SIM_EMIT_BLOCKS", "1")
+    monkeypatch.setenv("SIM_PARSE_SEGMENTS", "4096")
+    for name, data in _sim_cases_for_segments().items():
+        for lvl in (1, 2, 3):
+            st0, c0, a0 = oracle.deflate(data, level=lvl, crc_op=oracle.CRC_ADLER32)
+            st, c, a, _ = sim_deflate(sim, oracle, data, lvl)
+            assert st == 0 and c == c0 and a == a0, (name, lvl)
+
+
 def test_deflate_lane_logic_fuzz(sim, oracle):
     rnd = random.Random(11)
     for t in range(600):

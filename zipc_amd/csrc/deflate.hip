@@ -2152,7 +2152,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   size_t segp = max_src_len <= ((size_t)256 << 10) ? 4096 : max_src_len <= ((size_t)2 << 20) ? 8192 : max_src_len <= ((size_t)8 << 20) ? 16384 : 32768;
   if (segp_env >= (long)PARSE_SEG_MIN && segp_env % 64 == 0 && segp_env <= (1L << 20)) segp = (size_t)segp_env;
   const size_t sps = (max_src_len + segp - 1) / segp;
-  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 2048 && sps >= 8);
+  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 4096 && sps >= 8);  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 16 384 x 64 KiB: 15.6 -> 17.4)
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
   const size_t csegs = (max_src_len + CHAIN_SEG - 1) / CHAIN_SEG;  // lz_chain: workgroups of the longest stream
   if (segmented && (n * sps > 0x7FFFFFFFull || n * bps > 0x7FFFFFFFull)) segmented = false;

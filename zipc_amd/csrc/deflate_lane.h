@@ -851,7 +851,9 @@ struct BlockCoder {
 };
 
 // make_dynamic_huffman zd.ml:953-957 + make_dynamic_huffman_encoding zd.ml:959-1043
-ZD_HD void coder_make_dynamic(BlockCoder &c) {
+// (in two halves, like the kernels' wave_make_dynamic_syms / wave_make_dynamic_codelen: the second one depends on
+// the blocks before through c.codelen_freq)
+ZD_HD void coder_make_dynamic_syms(BlockCoder &c) {
   huff_lengths_of_freqs(c.heap, c.dyn_lit, c.lit_freq, LITLEN_SYM_MAX, 15);
   huff_init_with_lengths(c.dyn_lit, LITLEN_SYM_MAX);
   huff_lengths_of_freqs(c.heap, c.dyn_dist, c.dist_freq, DIST_SYM_MAX, 15);
@@ -903,11 +905,17 @@ ZD_HD void coder_make_dynamic(BlockCoder &c) {
     }
   }
   c.codelen_syms_len = k;
+}
+ZD_HD void coder_make_dynamic_codelen(BlockCoder &c) {
   huff_lengths_of_freqs(c.heap, c.dyn_codelen, c.codelen_freq, CODELEN_SYM_MAX, 7);
   huff_init_with_lengths(c.dyn_codelen, CODELEN_SYM_MAX);
   int o = CODELEN_SYM_MAX;  // codelen_length_count zd.ml:1032-1036
   while (o > 0 && (c.dyn_codelen[k_codelen_order[o]] & 0x1F) == 0) o--;
   c.hclen = (o + 1) - 4;
+}
+ZD_HD void coder_make_dynamic(BlockCoder &c) {
+  coder_make_dynamic_syms(c);
+  coder_make_dynamic_codelen(c);
 }
 
 ZD_HD int length_extra_bits(int sym) {
