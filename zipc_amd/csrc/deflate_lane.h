@@ -348,19 +348,39 @@ ZD_HD void scan_run_start(ScanRun &r, const uint8_t *s, uint32_t len, uint32_t p
 // (the first form of this step had 20 of them per 14 vector ones and the kernel sat on its
 // scalar bound on text and on 3-bit symbols).  Runs in another state read the bytes of the
 // candidate they stand on again and keep everything.
-ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
-  const bool w = r.state == RUN_WALK;
-  const uint32_t q = w ? r.q - r.dn : r.q;
-  const uint32_t steps = r.steps + (w ? 1u : 0u);
-  const uint32_t b = (uint32_t)s[q + r.best_len - 1u] | ((uint32_t)s[q + r.best_len] << 8);  // 2 <= best_len - 1, best_len < maxlen: inside both strings
-  const uint32_t dn = prev[q];
-  const bool hit = b == r.pb;
-  const uint32_t after = hit ? (uint32_t)RUN_HIT : scan_next_ok(r.p, steps, q, dn, K) ? (uint32_t)RUN_WALK : (uint32_t)RUN_FIN;
-  r.snap = (w && !hit && steps == Kq) ? r.best : r.snap;
-  r.q = q;
+// (in two halves, so that a lane's run slots can have their reads in flight TOGETHER: issued one slot after
+// the other with the slot's own use in between, every slot waited for its own LDS round trip -- and an `if` the
+// compiler made of the nested selects kept the second slot's reads behind the first one's exec mask)
+struct ScanProbe {
+  uint32_t q;       // the candidate looked at: the next one for a walking run, the one it stands on otherwise
+  uint32_t b0, b1;  // its bytes at best_len - 1 and best_len
+  uint32_t dn;      // its link
+};
+ZD_HD ScanProbe scan_run_probe(const ScanRun &r, const uint8_t *s, const uint16_t *prev) {
+  ScanProbe x;
+  x.q = r.q - (r.state == RUN_WALK ? r.dn : 0u);
+  x.b0 = s[x.q + r.best_len - 1u];  // 2 <= best_len - 1, best_len < maxlen: inside both strings
+  x.b1 = s[x.q + r.best_len];
+  x.dn = prev[x.q];
+  return x;
+}
+ZD_HD void scan_run_take(ScanRun &r, const ScanProbe &x, uint32_t K, uint32_t Kq) {
+  const uint32_t w = r.state == RUN_WALK ? 1u : 0u;
+  const uint32_t steps = r.steps + w;
+  const uint32_t hit = (x.b0 | (x.b1 << 8)) == r.pb ? 1u : 0u;
+  // is there a candidate behind this one (scan_next_ok)?  Worked out whether or not it is needed: no branch
+  const uint32_t ok = (x.dn != 0 ? 1u : 0u) & (steps != K ? 1u : 0u) & (r.p - x.q + x.dn <= (uint32_t)MAX_MATCH_DIST ? 1u : 0u);
+  static_assert(RUN_WALK == 0 && RUN_HIT == 1 && RUN_FIN == 2, "the arithmetic below");
+  const uint32_t after = hit | (((hit | ok) ^ 1u) << 1);  // hit: HIT; else a candidate behind: WALK; else FIN (arithmetic: the compiler made a branch of the selects)
+  r.snap = (w & (hit ^ 1u) & (steps == Kq ? 1u : 0u)) ? r.best : r.snap;
+  r.q = x.q;
   r.steps = steps;
-  r.dn = dn;
+  r.dn = x.dn;
   r.state = w ? after : r.state;
+}
+ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
+  const ScanProbe x = scan_run_probe(r, s, prev);
+  scan_run_take(r, x, K, Kq);
 }
 // the full compare of a run that stands on a candidate which passed the byte test
 template <bool WORDS>
@@ -529,9 +549,12 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_
     for (int round = 0; round < SCAN_ROUNDS; round++) {
       bool walking = false;
       iters++;
+      ScanProbe x[NP];
+#pragma unroll
+      for (int i = 0; i < NP; i++) x[i] = scan_run_probe(r[i], s, prev);
 #pragma unroll
       for (int i = 0; i < NP; i++) {
-        scan_run_step(r[i], s, prev, (uint32_t)K, (uint32_t)Kq);
+        scan_run_take(r[i], x[i], (uint32_t)K, (uint32_t)Kq);
         walking |= r[i].state == RUN_WALK;
       }
       if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < SCAN_MIN_WALKERS) break;
