@@ -401,6 +401,65 @@ def test_huge_stored_stream_through_the_host_form(gpu_ctx):
     assert st == 2
 
 
+def test_one_long_stream_deflates_on_many_waves_bytes_equal_oracle(gpu_ctx, oracle):
+    """ONE 40 MiB stream -- text, runs of one byte, short periods, symbols of several entropies, random bytes, in
+    stretches of odd lengths -- through the forms a long stream takes (chain links by 128 Ki-position workgroups,
+    parse by segments with the stitch and its runs of equal steps, ~650 blocks coded by a wave each): every byte
+    of the output against the oracle at `Fast and `Default, zlib inflates it, and the GPU inflates it back."""
+    import zlib
+
+    import torch
+
+    import util
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    rnd = np.random.default_rng(404)
+    parts, total, want = [], 0, 40 << 20
+    k = 0
+    while total < want:
+        ln = int(rnd.integers(1, 700000))
+        kind = k % 7
+        if kind == 0:
+            d = util.text(ln, k)
+        elif kind == 1:
+            d = bytes([int(rnd.integers(0, 256))]) * ln
+        elif kind == 2:
+            per = int(rnd.choice([2, 3, 7, 257, 258, 259, 1000, 4097]))
+            pat = synth.stream_bytes_np(9, k, per, 8).tobytes()
+            d = (pat * (ln // per + 1))[:ln]
+        elif kind == 6:
+            d = rnd.integers(0, 256, ln, dtype=np.uint8).tobytes()
+        else:
+            d = synth.stream_bytes_np(9, k, ln, (1, 2, 3, 4)[kind - 2 if kind - 2 < 4 else 3]).tobytes()
+        parts.append(d)
+        total += ln
+        k += 1
+    plain = b"".join(parts)[:want]
+    n = len(plain)
+    src = torch.from_numpy(np.frombuffer(plain, np.uint8).copy()).to(dev)
+    cap = batch.deflate_bound(n)
+    descs = batch.uniform_layout(1, n, cap)
+    comp = torch.zeros(cap + 256, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    for level in (1, 2):
+        batch.deflate_batch(gpu_ctx, src, comp, d_descs, d_res, 1, n, n, level, 1)
+        res = batch.results_from_device(d_res)
+        assert int(res["status"][0]) == 0
+        got = comp[:int(res["out_len"][0])].cpu().numpy().tobytes()
+        st0, c0, k0 = oracle.deflate(plain, level=level, crc_op=1)
+        assert len(got) == len(c0) and got == c0, level
+        assert int(res["checksum"][0]) == k0 == zlib.crc32(plain)
+        assert zlib.decompress(got, -15) == plain
+    out = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+    d_ires = torch.zeros(16, dtype=torch.uint8, device=dev)
+    d_id = batch.to_device(batch.compact_descs(res, descs, n), dev)
+    batch.inflate_batch(gpu_ctx, comp, out, d_id, d_ires, 1, n, 1)
+    ires = batch.results_from_device(d_ires)
+    assert int(ires["status"][0]) == 0 and int(ires["checksum"][0]) == k0 and torch.equal(out[:n], src)
+
+
 def test_real_text_at_16384_streams(gpu_ctx, oracle):
     """The reference's own documents (tests/golden/zip-docs.zip: APPNOTE.TXT, rfc1951.txt) as 16 384
     chunks of 64 KiB: long hash chains, long matches, long Huffman codes, many dynamic blocks per
