@@ -10,22 +10,40 @@
 
 using namespace zd;
 
+// B_first, own_lo, own_hi: lz_chain_segments_kernel's form -- rounds from B_first on with an empty table, the links of
+// [own_lo, own_hi] stored, nothing inserted behind own_hi (the whole stream: 0, 0, len - 4)
+static void chain_rounds(const uint8_t *s, uint32_t len, uint16_t *prev, uint32_t seed, int *max_turns,
+                         uint32_t B_first, uint32_t own_lo, uint32_t own_hi);
 extern "C" void sim_chain(const uint8_t *s, uint32_t len, uint16_t *prev, uint32_t seed, int *max_turns) {
+  *max_turns = 0;
+  if (len < 4) return;
+  chain_rounds(s, len, prev, seed, max_turns, 0, 0, len - 4);
+}
+// the stream's links made segment by segment of seg_positions (a multiple of 16384), each from 32768 positions before
+extern "C" void sim_chain_segments(const uint8_t *s, uint32_t len, uint16_t *prev, uint32_t seed, uint32_t seg_positions) {
+  if (len < 4) return;
+  int mt = 0;
+  for (uint32_t lo = 0; lo <= len - 4; lo += seg_positions) {
+    const uint32_t hi = len - 4 - lo >= seg_positions ? lo + seg_positions - 1 : len - 4;
+    chain_rounds(s, len, prev, seed + lo, &mt, lo > 32768 ? lo - 32768 : 0, lo, hi);
+  }
+}
+static void chain_rounds(const uint8_t *s, uint32_t len, uint16_t *prev, uint32_t seed, int *max_turns,
+                         uint32_t B_first, uint32_t own_lo, uint32_t own_hi) {
   const uint32_t T = 1024, SWEEP_PERIOD = 16384, SWEEP_MARK = 20000;  // CHAIN_ROUND positions per round
   const int PLAIN_TURNS = 4;
   const int NEAR = 8;
-  *max_turns = 0;
-  if (len < 4) return;
   std::vector<uint16_t> head(32768);
   std::vector<uint16_t> hs(T + 2 * NEAR, 0xFFFF);
-  const uint32_t max_pos = len - 4;
+  const uint32_t max_pos = own_hi;
+  (void)len;
   srand(seed);
-  for (uint32_t B = 0; B <= max_pos; B += T) {
+  for (uint32_t B = B_first; B <= max_pos; B += T) {
     if ((B % SWEEP_PERIOD) == 0) {
       const uint16_t mark = (uint16_t)(B + SWEEP_MARK);
       for (uint32_t i = 0; i < 32768; i++) {
         bool keep = false;
-        if (B != 0) { uint32_t d = (B - head[i]) & 0xFFFFu; keep = d >= 1 && d <= 32768; }
+        if (B != B_first) { uint32_t d = (B - head[i]) & 0xFFFFu; keep = d >= 1 && d <= 32768; }
         if (!keep) head[i] = mark;
       }
     }
@@ -79,7 +97,7 @@ extern "C" void sim_chain(const uint8_t *s, uint32_t len, uint16_t *prev, uint32
       if (near_pred[t]) d = near_pred[t];
       else if (pred_local[t] >= 0) d = t - (uint32_t)pred_local[t];
       else { d = (p - e_old[t]) & 0xFFFFu; if (d > 32768) d = 0; }
-      prev[p] = (uint16_t)d;
+      if (p >= own_lo) prev[p] = (uint16_t)d;
     }
   }
 }

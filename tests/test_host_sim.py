@@ -187,6 +187,25 @@ def test_chain_round_model_equals_serial_chain(sim):
             assert list(a[:max(0, n - 3)]) == list(b[:max(0, n - 3)]), name
 
 
+def test_chain_links_by_segments_equal_serial_chain(sim):
+    """lz_chain_segments_kernel's claim: a link is a function of the 32 KiB before its position, so a stream's links
+    can be made a segment at a time, each from an empty table 32 768 positions before its first one."""
+    cases = {
+        "text": util.text(200000, 5), "nib": util.rand_bytes(150000, 2, 4), "nib3": util.rand_bytes(150000, 3, 3),
+        "zeros": bytes(120000), "p300": util.rand_bytes(300, 4) * 500,
+        "old": util.rand_bytes(100, 8) + bytes(70000) + util.rand_bytes(100, 8) + bytes(70000),
+        "far": util.rand_bytes(40000, 9) + util.text(33000, 1) + util.rand_bytes(40000, 9) + util.text(70000, 2),
+    }
+    for name, d in cases.items():
+        n = len(d)
+        b = (C.c_uint16 * (n + 8))()
+        sim.sim_chain_serial(d, n, b)
+        for seg in (16384, 32768, 131072):
+            a = (C.c_uint16 * (n + 8))()
+            sim.sim_chain_segments(d, n, a, 3, seg)
+            assert list(a[:n - 3]) == list(b[:n - 3]), (name, seg)
+
+
 def test_symbol_value_closed_forms_equal_rfc_tables(sim):
     assert sim.sim_sym_values_match_tables() == 0
 
