@@ -216,13 +216,16 @@ __device__ __forceinline__ void lds_barrier() {
 
 // A link is the distance to the nearest earlier position with the same hash if that is within 32768, else 0:
 // a function of the 32 KiB before the position and nothing else.  So a long stream's links can be made by
-// several workgroups (SEG): each takes CHAIN_SEG positions, starts with an empty table at the sweep boundary at
+// several workgroups (SEG): each takes seg_positions of them, starts with an empty table at the sweep boundary at
 // least 32768 before its first one, and stores the links of its own positions only.
-constexpr uint32_t CHAIN_SEG = 8 * SWEEP_PERIOD;  // 128 Ki positions, after 32 - 48 Ki of run-up
+// (seg_positions: a multiple of the sweep period; 64 Ki while that leaves the chip workgroups to spare -- half
+// again the work for twice the workgroups -- else 128 Ki)
+constexpr uint32_t CHAIN_SEG_MIN = 4 * SWEEP_PERIOD, CHAIN_SEG_MAX = 8 * SWEEP_PERIOD;
 template <bool SEG>
 __device__ __forceinline__ void lz_chain_workgroup(const uint8_t *__restrict__ src_arena,
                                                    const StreamDesc *__restrict__ descs,
-                                                   DeflateScratch S, uint32_t stream, uint32_t seg) {
+                                                   DeflateScratch S, uint32_t stream, uint32_t seg,
+                                                   uint32_t seg_positions) {
   __shared__ uint16_t head[32768];
   __shared__ uint16_t hs[CHAIN_ROUND + 2 * NEAR];
   __shared__ uint32_t peel_more[2];
@@ -236,9 +239,9 @@ __device__ __forceinline__ void lz_chain_workgroup(const uint8_t *__restrict__ s
   uint16_t *prev = S.prev + S.pos_base[stream];
   const uint32_t stream_max_pos = len - 4;
   // SEG: links of [own_lo, own_hi], rounds from B_first on
-  const uint32_t own_lo = SEG ? seg * CHAIN_SEG : 0u;
+  const uint32_t own_lo = SEG ? seg * seg_positions : 0u;
   if (SEG && own_lo > stream_max_pos) return;
-  const uint32_t own_hi = SEG ? (stream_max_pos - own_lo >= CHAIN_SEG ? own_lo + CHAIN_SEG - 1u : stream_max_pos) : stream_max_pos;
+  const uint32_t own_hi = SEG ? (stream_max_pos - own_lo >= seg_positions ? own_lo + seg_positions - 1u : stream_max_pos) : stream_max_pos;
   const uint32_t B_first = SEG ? (own_lo > 2u * SWEEP_PERIOD ? own_lo - 2u * SWEEP_PERIOD : 0u) : 0u;  // (own_lo is a multiple of the period)
   const uint32_t max_pos = own_hi;  // the last position inserted
   if (t < NEAR) { hs[t] = 0xFFFF; hs[CHAIN_ROUND + NEAR + t] = 0xFFFF; }
@@ -380,13 +383,14 @@ __device__ __forceinline__ void lz_chain_workgroup(const uint8_t *__restrict__ s
 __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
                                                                  DeflateScratch S) {
-  lz_chain_workgroup<false>(src_arena, descs, S, blockIdx.x, 0);
+  lz_chain_workgroup<false>(src_arena, descs, S, blockIdx.x, 0, 0);
 }
 
 __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_segments_kernel(const uint8_t *__restrict__ src_arena,
                                                                           const StreamDesc *__restrict__ descs,
-                                                                          DeflateScratch S, uint32_t segs_per_stream) {
-  lz_chain_workgroup<true>(src_arena, descs, S, blockIdx.x / segs_per_stream, blockIdx.x % segs_per_stream);
+                                                                          DeflateScratch S, uint32_t segs_per_stream,
+                                                                          uint32_t seg_positions) {
+  lz_chain_workgroup<true>(src_arena, descs, S, blockIdx.x / segs_per_stream, blockIdx.x % segs_per_stream, seg_positions);
 }
 
 // ---------------------------------------------------------------------------------
@@ -730,6 +734,11 @@ struct ParseSegs {
   uint32_t *tile_sym0;            // [P / 64] per tile: symbols of its segment before it
   uint32_t *seg_exit, *seg_total; // [segments] where the segment's parse left it (>= its end), and its symbols
   uint32_t *seg_dst, *seg_from, *seg_n;  // [segments] the stitch's verdict: spec symbols [from, from + n) go to the stream's symbols at dst
+  unsigned long long *vis2;       // [P / 64] per tile that was parsed again: the true path, and
+  uint32_t *sym02;                // [P / 64]   the symbols parsed again before the tile
+  uint32_t *meet_syms;            // [segments * MEET_CAP] lz_parse_meet_kernel: the symbols parsed again from the expected entry
+  uint32_t *meet_f, *meet_from, *meet_exit, *meet_end;  // [segments] ... and what parse_again returned (f = ~0: no room)
+  uint32_t *fix_dst, *fix_n;      // [segments] the stitch's verdict on them: meet_syms[0, n) go to the stream's symbols at dst
   uint32_t segs_per_stream;       // of the longest stream: segment slot of (stream, k) = stream * segs_per_stream + k
   uint32_t seg_positions, seg_syms;  // positions per segment; symbol slots per segment (seg_positions + PARSE_SEG_SLACK)
 };
@@ -960,19 +969,214 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
 //   lz_parse_spec_kernel    a wave per segment of 4096 positions: the parse from the segment's first position
 //                           (true for segment 0), symbols to the segment's own buffer, per tile the positions
 //                           visited and the symbol count before it, per segment where the path left it;
-//   lz_parse_stitch_kernel  a wave per stream, segment by segment: from the true entry (where the segment
-//                           before was left) tiles are parsed again until the path meets the segment's own
-//                           (a common position in a tile); those symbols go straight to the stream's symbol
-//                           array, the rest of the segment is a range of its buffer, and the segment is left
-//                           where its own parse left it.  No meeting before the segment ends: the whole
-//                           segment was parsed again and is left where that parse says (the serial order, at
-//                           worst for every segment: a long run of one byte parsed at the wrong phase).
-//                           Blocks are cut here, at the step that holds source byte 65534 of the block;
-//   lz_parse_gather_kernel  a wave per segment copies the segment's range to its place in the symbol array.
+//   lz_parse_meet_kernel    a wave per segment again: from the entry the segment has IF the one before is left where
+//                           its own parse left it, tiles are parsed again until the path meets the segment's own
+//                           (a common position in a tile); the rest of the segment is then a range of its buffer,
+//                           and the segment is left where its own parse left it.  No meeting before the segment
+//                           ends: the whole segment was parsed again and is left where that parse says;
+//   lz_parse_stitch_kernel  a wave per stream, segment by segment: is the segment entered where the meet kernel
+//                           assumed?  Almost always -- then its numbers stand.  Else (behind a segment whose path
+//                           never met: a long run of one byte parsed at the wrong phase) it is parsed again here,
+//                           from the true entry; at worst that is the serial order.  Blocks are cut here, at the
+//                           step that holds source byte 65534 of the block;
+//   lz_parse_gather_kernel  a wave per segment copies the symbols parsed again and the segment's range to their
+//                           place in the symbol array.
 __global__ __launch_bounds__(64) void lz_parse_spec_kernel(const uint8_t *__restrict__ src_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            DeflateScratch S, int good_match, ParseSegs G) {
   lz_parse_wave<1>(src_arena, descs, S, good_match, blockIdx.x / G.segs_per_stream, blockIdx.x % G.segs_per_stream, G);
+}
+
+// What the waves that re-parse parts of a stream share (lz_parse_meet_kernel, lz_parse_stitch_kernel).
+struct ParseStream {
+  int lane;
+  uint32_t len, max_pos;
+  const uint8_t *s;
+  const uint64_t *match;
+  int good_match;
+  const unsigned long long *own_vis;  // per tile: the path of the segment's own parse (read only after lz_parse_spec_kernel),
+  const uint32_t *own_sym0;           //   and the segment's symbols before the tile
+  unsigned long long *vis2;           // per tile that was parsed again: the true path,
+  uint32_t *sym02;                    //   and the symbols parsed again before the tile
+};
+// A tile's steps, counts and scan: the path from `entry` (use_mask false) or the positions of `mask`.
+struct ParseTile {
+  uint32_t br, adv, lits, cnt, first_rel, total, next_entry;
+  bool visited;
+  unsigned long long vm;
+};
+__device__ __forceinline__ ParseTile parse_eval_tile(const ParseStream &P, uint32_t B, uint32_t entry, bool use_mask,
+                                                     unsigned long long mask) {
+  ParseTile t;
+  const int lane = P.lane;
+  const uint32_t p = B + (uint32_t)lane;
+  const bool valid = p < P.len;
+  const uint64_t m_cur = P.match[p], m_nxt = P.match[p + PARSE_TILE];  // (PARSE_PAD zero entries behind the last position)
+  uint32_t st;
+  parse_tile_macro(lane, p, valid, true, P.max_pos, P.len, m_cur, m_nxt, P.match, P.good_match, t.br, st);
+  t.adv = valid ? (t.br ? macro_advance(st) : 1u) : 0u;
+  t.lits = t.br ? macro_lits(st) : 0u;
+  t.cnt = valid ? (t.br ? t.lits + 1u : 1u) : 0u;
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  const uint32_t j0 = (uint32_t)lane + t.adv;
+  if (use_mask) {
+    t.visited = valid && ((mask >> lane) & 1ull);
+    t.next_entry = 0;
+  } else {
+    uint32_t J[7];
+    J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
+#pragma unroll
+    for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+    uint32_t v = (entry - B) * 4u;
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+      const uint32_t y = lane_value(v, J[k]);
+      if (y <= lane4) v = y;
+    }
+    t.visited = valid && v == lane4;
+    const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    t.next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
+    if (t.next_entry > P.len) t.next_entry = P.len;
+  }
+  t.vm = __builtin_amdgcn_ballot_w64(t.visited);
+  const uint32_t incl = wave_scan_incl(t.visited ? t.cnt : 0u);
+  t.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  t.first_rel = incl - (t.visited ? t.cnt : 0u);
+  return t;
+}
+
+// A segment parsed again from its true entry e (seg_start <= e < seg_end) until the path meets the segment's own --
+// a common position in a tile -- or the segment ends.  Symbols to out[0 .. f), the path's marks to vis2 / sym02.
+struct ParseAgain {
+  uint32_t f;          // symbols parsed again
+  uint32_t from;       // the segment's own symbols from this one on follow them
+  uint32_t exit;       // where the segment is left
+  uint32_t again_end;  // tiles in [tile of e, again_end) were parsed again (their marks are vis2 / sym02)
+  bool ok;             // false: out[] was too small (cap) -- nothing of the above holds
+};
+__device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t seg_end, uint32_t e, uint32_t spec_total,
+                                                  uint32_t spec_exit, uint32_t *__restrict__ out, uint32_t cap) {
+  const int lane = P.lane;
+  ParseAgain r;
+  r.f = 0; r.from = spec_total; r.exit = e; r.again_end = seg_end; r.ok = true;
+  uint32_t f = 0;
+  uint32_t B = e & ~63u, entry = e;
+  uint32_t rest = 0;  // tiles until a run of equal steps is tried again
+  for (;;) {
+    if (cap - f < 64u + 576u) { r.ok = false; return r; }  // (a tile's steps make at most a symbol per position they cover)
+    const ParseTile t = parse_eval_tile(P, B, entry, false, 0ull);
+    const unsigned long long own = P.own_vis[B >> 6];  // the segment's own path through this tile (0: it jumped over it)
+    // symbols (lz_emit_position)
+    {
+      const uint32_t p = B + (uint32_t)lane;
+      if (t.visited) {
+        for (uint32_t i = 0; i < t.lits; i++) out[f + t.first_rel + i] = P.s[p + i];
+        out[f + t.first_rel + t.lits] = t.br ? t.br : (uint32_t)P.s[p];
+      }
+    }
+    if (lane == 0) { P.vis2[B >> 6] = t.vm; P.sym02[B >> 6] = f; }
+    f += t.total;
+    entry = t.next_entry;
+    const uint32_t Be = entry & ~63u;
+    const uint32_t Bn = Be > B + PARSE_TILE ? Be : B + PARSE_TILE;
+    const bool met = (t.vm & own) != 0ull;
+    // tiles this path jumps over are not on it (the block cut looks for the last visited position at or before
+    // a given one)
+    if (Bn > B + PARSE_TILE) {
+      const uint32_t tz = B + PARSE_TILE * (1u + (uint32_t)lane);
+      if (tz < Bn && tz < seg_end) P.vis2[tz >> 6] = 0ull;
+    }
+    if (met || Bn >= seg_end) {
+      r.again_end = Bn;
+      r.from = (met && Bn < seg_end) ? P.own_sym0[Bn >> 6] : spec_total;  // (the segment's own parse went on with tile Bn too)
+      r.exit = met ? spec_exit : entry;
+      break;
+    }
+    // One long step through the tile and no meeting: a run of one byte, or a short period -- the data on which
+    // this path and the segment's own stay out of phase to the segment's end.  Then the next steps are probably
+    // the same: every lane takes the position i steps on and works out ITS step (lz_macro_position); the lanes
+    // before the first one that steps differently are on the path -- up to 64 steps for the price of a tile.
+    const uint32_t node_pos = B + (uint32_t)__builtin_ctzll(t.vm | (1ull << 63));
+    const uint32_t stride = entry - node_pos;
+    if (rest != 0) rest--;
+    else if (__builtin_popcountll(t.vm) == 1 && stride >= (uint32_t)PARSE_TILE) {
+      const uint64_t ahead = (uint64_t)lane * stride;
+      const bool in = ahead < (uint64_t)(seg_end - entry);
+      const uint32_t p = in ? entry + (uint32_t)ahead : entry;
+      const uint64_t *match = P.match;
+      const MacroStep m = lz_macro_position(p, P.len, P.good_match, [&](uint32_t j) -> uint64_t { return match[j]; });
+      const uint32_t adv = m.bref ? macro_advance(m.step) : 1u;
+      const unsigned long long go = __builtin_amdgcn_ballot_w64(in && adv == stride);
+      const uint32_t lead = ~go ? (uint32_t)__builtin_ctzll(~go) : 64u;  // lanes [0, lead) are on the path, and step alike
+      if (lead == 0) rest = 8;
+      else {
+        const bool on = (uint32_t)lane < lead;
+        const uint32_t cnt = on ? macro_sym_count(m) : 0u;
+        const uint32_t incl = wave_scan_incl(cnt);
+        const uint32_t first_rel = incl - cnt;
+        const uint32_t made = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (cap - f < made) { r.ok = false; return r; }
+        if (on) {
+          lz_emit_position(P.s, p, m, out + f, first_rel);
+          // the path's marks for the block cut: this step's tile holds it alone, the tiles it jumps over nothing
+          P.vis2[p >> 6] = 1ull << (p & 63u);
+          P.sym02[p >> 6] = f + first_rel;
+          for (uint32_t tz = (p & ~63u) + PARSE_TILE; tz < ((p + stride) & ~63u) && tz < seg_end; tz += PARSE_TILE) P.vis2[tz >> 6] = 0ull;
+        }
+        f += made;
+        entry += lead * stride;  // (< seg_end + stride: lane lead - 1 was inside)
+        if (entry > P.len) entry = P.len;
+        const uint32_t Bs = entry & ~63u;
+        if (Bs >= seg_end) {
+          r.again_end = Bs; r.from = spec_total; r.exit = entry;
+          break;
+        }
+        B = Bs;
+        continue;
+      }
+    }
+    B = Bn;
+  }
+  r.f = f;
+  return r;
+}
+
+// lz_parse_meet_kernel: a wave per segment k >= 1 does that for the entry the segment has if the one before is left
+// where its OWN parse left it -- true of all segments but the few whose path never meets -- into the segment's
+// own small buffer (MEET_CAP symbols; more: left to the stitch).  The stitch then only checks the chain of exits.
+constexpr uint32_t MEET_CAP = 2048;
+__global__ __launch_bounds__(64) void lz_parse_meet_kernel(const uint8_t *__restrict__ src_arena,
+                                                           const StreamDesc *__restrict__ descs,
+                                                           DeflateScratch S, int good_match, ParseSegs G) {
+  if (S.error[0]) return;
+  const uint32_t stream = blockIdx.x / G.segs_per_stream, k = blockIdx.x % G.segs_per_stream;
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len > MAX_STREAM_LEN || sd.src_len < (uint64_t)MIN_MATCH_LEN) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  if (k == 0 || (uint64_t)k * G.seg_positions >= len) return;
+  const uint64_t base = S.pos_base[stream];
+  const size_t slot = (size_t)stream * G.segs_per_stream + k;
+  ParseStream P;
+  P.lane = threadIdx.x; P.len = len; P.max_pos = len - MIN_MATCH_LEN; P.s = src_arena + sd.src_off;
+  P.match = S.match + base; P.good_match = good_match;
+  P.own_vis = G.vis + (base >> 6); P.own_sym0 = G.tile_sym0 + (base >> 6);
+  P.vis2 = G.vis2 + (base >> 6); P.sym02 = G.sym02 + (base >> 6);
+  const uint32_t seg_start = k * G.seg_positions;
+  const uint32_t seg_end = len - seg_start > G.seg_positions ? seg_start + G.seg_positions : len;
+  const uint32_t e = G.seg_exit[slot - 1];
+  const uint32_t spec_total = G.seg_total[slot], spec_exit = G.seg_exit[slot];
+  ParseAgain a;
+  if (e >= seg_end) {  // (a step over a short last segment)
+    a.f = 0; a.from = spec_total; a.exit = e; a.again_end = seg_end; a.ok = true;
+  } else {
+    a = parse_again(P, seg_end, e, spec_total, spec_exit, G.meet_syms + slot * MEET_CAP, MEET_CAP);
+  }
+  if (P.lane == 0) {
+    G.meet_f[slot] = a.ok ? a.f : 0xFFFFFFFFu;
+    G.meet_from[slot] = a.from;
+    G.meet_exit[slot] = a.exit;
+    G.meet_end[slot] = a.again_end;
+  }
 }
 
 __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__restrict__ src_arena,
@@ -989,7 +1193,6 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
   const uint32_t len = (uint32_t)sd.src_len;
   const uint8_t *s = src_arena + sd.src_off;
   const uint64_t base = S.pos_base[stream];
-  const uint64_t *match = S.match + base;
   uint32_t *syms = S.syms + base;
   BlockDesc *blocks = S.blocks + S.blk_base[stream];
   if (len < (uint32_t)MIN_MATCH_LEN) {  // 0 to 3 bytes: literals, one block
@@ -1002,188 +1205,97 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
     }
     return;
   }
-  const uint32_t max_pos = len - MIN_MATCH_LEN;
+  ParseStream P;
+  P.lane = lane; P.len = len; P.max_pos = len - MIN_MATCH_LEN; P.s = s;
+  P.match = S.match + base; P.good_match = good_match;
+  P.own_vis = G.vis + (base >> 6); P.own_sym0 = G.tile_sym0 + (base >> 6);
+  P.vis2 = G.vis2 + (base >> 6); P.sym02 = G.sym02 + (base >> 6);
   const size_t slot0 = (size_t)stream * G.segs_per_stream;
   const uint32_t PARSE_SEG = G.seg_positions;
   const uint32_t nseg = (uint32_t)(((uint64_t)len + PARSE_SEG - 1) / PARSE_SEG);
-  unsigned long long *vis = G.vis + (base >> 6);
-  uint32_t *tile_sym0 = G.tile_sym0 + (base >> 6);
-
-  // A tile's steps, counts and scan: the path from `entry` (use_mask false) or the positions of `mask`.
-  struct Tile {
-    uint32_t br, adv, lits, cnt, first_rel, total, next_entry;
-    bool visited;
-    unsigned long long vm;
-  };
-  auto eval_tile = [&](uint32_t B, uint32_t entry, bool use_mask, unsigned long long mask) -> Tile {
-    Tile t;
-    const uint32_t p = B + (uint32_t)lane;
-    const bool valid = p < len;
-    const uint64_t m_cur = match[p], m_nxt = match[p + PARSE_TILE];  // (PARSE_PAD zero entries behind the last position)
-    uint32_t st;
-    parse_tile_macro(lane, p, valid, true, max_pos, len, m_cur, m_nxt, match, good_match, t.br, st);
-    t.adv = valid ? (t.br ? macro_advance(st) : 1u) : 0u;
-    t.lits = t.br ? macro_lits(st) : 0u;
-    t.cnt = valid ? (t.br ? t.lits + 1u : 1u) : 0u;
-    const uint32_t lane4 = (uint32_t)lane * 4u;
-    const uint32_t j0 = (uint32_t)lane + t.adv;
-    if (use_mask) {
-      t.visited = valid && ((mask >> lane) & 1ull);
-      t.next_entry = 0;
-    } else {
-      uint32_t J[7];
-      J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
-#pragma unroll
-      for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
-      uint32_t v = (entry - B) * 4u;
-#pragma unroll
-      for (int k = 6; k >= 0; k--) {
-        const uint32_t y = lane_value(v, J[k]);
-        if (y <= lane4) v = y;
-      }
-      t.visited = valid && v == lane4;
-      const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-      t.next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
-      if (t.next_entry > len) t.next_entry = len;
-    }
-    t.vm = __builtin_amdgcn_ballot_w64(t.visited);
-    const uint32_t incl = wave_scan_incl(t.visited ? t.cnt : 0u);
-    t.total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    t.first_rel = incl - (t.visited ? t.cnt : 0u);
-    return t;
-  };
 
   uint32_t off = 0;        // symbols of the stream so far
   uint32_t exit_prev = 0;  // where the segment before was left: this segment's true entry
+  uint32_t spec_exit_prev = 0;  // ... and where its own parse left it: the entry lz_parse_meet_kernel went by
   uint32_t blk_start = 0, blk_sym_start = 0, nblk = 0;
-  for (uint32_t k = 0; k < nseg; k++) {
-    const uint32_t seg_start = k * PARSE_SEG;
-    const uint32_t seg_end = len - seg_start > PARSE_SEG ? seg_start + PARSE_SEG : len;
-    const uint32_t spec_total = G.seg_total[slot0 + k], spec_exit = G.seg_exit[slot0 + k];
-    const uint32_t e = exit_prev;
-    uint32_t f = 0;                // symbols parsed again here (written at syms[off ..))
-    uint32_t from = 0;             // the segment's own symbols from this one on follow them
-    uint32_t exit_k = spec_exit;
-    uint32_t again_end = seg_start;  // tiles in [tile of e, again_end) were parsed again: their tile_sym0 counts from `off`
-    if (k != 0 && e >= seg_end) {  // (a step over a short last segment)
-      from = spec_total; exit_k = e; again_end = seg_end;
-    } else if (k != 0) {
-      uint32_t B = e & ~63u, entry = e;
-      uint32_t rest = 0;  // tiles until a run of equal steps is tried again
-      for (;;) {
-        const Tile t = eval_tile(B, entry, false, 0ull);
-        const unsigned long long own = vis[B >> 6];  // the segment's own path through this tile (0: it jumped over it)
-        // symbols (lz_emit_position)
-        {
-          uint32_t *out = syms + off + f;
-          const uint32_t p = B + (uint32_t)lane;
-          if (t.visited) {
-            for (uint32_t i = 0; i < t.lits; i++) out[t.first_rel + i] = s[p + i];
-            out[t.first_rel + t.lits] = t.br ? t.br : (uint32_t)s[p];
-          }
+  for (uint32_t c0 = 0; c0 < nseg; c0 += 64) {
+    // 64 segments a turn: the lanes fetch their segment's numbers together, the turn's segments are gone through
+    // in order on wave-uniform values
+    const uint32_t mine = c0 + (uint32_t)lane < nseg ? c0 + (uint32_t)lane : nseg - 1;
+    const uint32_t my_total = G.seg_total[slot0 + mine], my_exit = G.seg_exit[slot0 + mine];
+    const uint32_t my_mf = mine ? G.meet_f[slot0 + mine] : 0u, my_mfrom = mine ? G.meet_from[slot0 + mine] : 0u;
+    const uint32_t my_mexit = mine ? G.meet_exit[slot0 + mine] : 0u, my_mend = mine ? G.meet_end[slot0 + mine] : 0u;
+    uint32_t out_dst = 0, out_from = 0, out_n = 0, out_fix_dst = 0, out_fix_n = 0;  // my segment's verdict, stored after the turn
+    const uint32_t turn = nseg - c0 < 64u ? nseg - c0 : 64u;
+    for (uint32_t i = 0; i < turn; i++) {
+      const uint32_t k = c0 + i;
+      auto of_lane = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); };
+      const uint32_t seg_start = k * PARSE_SEG;
+      const uint32_t seg_end = len - seg_start > PARSE_SEG ? seg_start + PARSE_SEG : len;
+      const uint32_t spec_total = of_lane(my_total), spec_exit = of_lane(my_exit);
+      const uint32_t e = exit_prev;
+      ParseAgain a;
+      a.f = 0; a.from = 0; a.exit = spec_exit; a.again_end = seg_start; a.ok = true;  // segment 0: its own parse is the true one
+      bool in_buffer = false;  // the symbols parsed again are in the segment's meet buffer (else at syms[off ..))
+      if (k != 0) {
+        const uint32_t mf = of_lane(my_mf);
+        if (e == spec_exit_prev && mf != 0xFFFFFFFFu) {  // as lz_parse_meet_kernel assumed
+          a.f = mf; a.from = of_lane(my_mfrom); a.exit = of_lane(my_mexit); a.again_end = of_lane(my_mend);
+          in_buffer = true;
+        } else if (e >= seg_end) {  // (a step over a short last segment)
+          a.from = spec_total; a.exit = e; a.again_end = seg_end;
+        } else {
+          a = parse_again(P, seg_end, e, spec_total, spec_exit, syms + off, 0xFFFFFFFFu);
         }
-        if (lane == 0) { vis[B >> 6] = t.vm; tile_sym0[B >> 6] = f; }
-        f += t.total;
-        entry = t.next_entry;
-        const uint32_t Be = entry & ~63u;
-        const uint32_t Bn = Be > B + PARSE_TILE ? Be : B + PARSE_TILE;
-        const bool met = (t.vm & own) != 0ull;
-        // tiles this path jumps over are not on it, whatever the segment's own parse did there (the block cut
-        // below looks for the last visited position at or before a given one)
-        if (Bn > B + PARSE_TILE) {
-          const uint32_t tz = B + PARSE_TILE * (1u + (uint32_t)lane);
-          if (tz < Bn && tz < seg_end) vis[tz >> 6] = 0ull;
-        }
-        if (met || Bn >= seg_end) {
-          again_end = Bn;
-          if (met && Bn < seg_end) from = tile_sym0[Bn >> 6];  // (the segment's own parse went on with tile Bn too)
-          else from = spec_total;
-          exit_k = met ? spec_exit : entry;
-          break;
-        }
-        // One long step through the tile and no meeting: a run of one byte, or a short period -- the data on which
-        // this path and the segment's own stay out of phase to the segment's end.  Then the next steps are probably
-        // the same: every lane takes the position i steps on and works out ITS step (lz_macro_position); the lanes
-        // before the first one that steps differently are on the path -- up to 64 steps for the price of a tile.
-        const uint32_t node_pos = B + (uint32_t)__builtin_ctzll(t.vm | (1ull << 63));
-        const uint32_t stride = entry - node_pos;
-        if (rest != 0) rest--;
-        else if (__builtin_popcountll(t.vm) == 1 && stride >= (uint32_t)PARSE_TILE) {
-          const uint64_t ahead = (uint64_t)lane * stride;
-          const bool in = ahead < (uint64_t)(seg_end - entry);
-          const uint32_t p = in ? entry + (uint32_t)ahead : entry;
-          const MacroStep m = lz_macro_position(p, len, good_match, [&](uint32_t j) -> uint64_t { return match[j]; });
-          const uint32_t adv = m.bref ? macro_advance(m.step) : 1u;
-          const unsigned long long go = __builtin_amdgcn_ballot_w64(in && adv == stride);
-          const uint32_t lead = ~go ? (uint32_t)__builtin_ctzll(~go) : 64u;  // lanes [0, lead) are on the path, and step alike
-          if (lead == 0) rest = 8;
-          else {
-            const bool on = (uint32_t)lane < lead;
-            const uint32_t cnt = on ? macro_sym_count(m) : 0u;
-            const uint32_t incl = wave_scan_incl(cnt);
-            const uint32_t first_rel = incl - cnt;
-            if (on) {
-              lz_emit_position(s, p, m, syms + off + f, first_rel);
-              // the path's marks for the block cut: this step's tile holds it alone, the tiles it jumps over nothing
-              vis[p >> 6] = 1ull << (p & 63u);
-              tile_sym0[p >> 6] = f + first_rel;
-              for (uint32_t tz = (p & ~63u) + PARSE_TILE; tz < ((p + stride) & ~63u) && tz < seg_end; tz += PARSE_TILE) vis[tz >> 6] = 0ull;
-            }
-            f += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            entry += lead * stride;  // (< seg_end + stride: lane lead - 1 was inside)
-            if (entry > len) entry = len;
-            const uint32_t Bs = entry & ~63u;
-            if (Bs >= seg_end) {
-              again_end = Bs; from = spec_total; exit_k = entry;
-              break;
-            }
-            B = Bs;
-            continue;
-          }
-        }
-        B = Bn;
       }
-    }
-    const uint32_t n_own = spec_total - from;
-    if (lane == 0) {
-      G.seg_dst[slot0 + k] = off + f;
-      G.seg_from[slot0 + k] = from;
-      G.seg_n[slot0 + k] = n_own;
-    }
-    // block cut (write_block_symbol zd.ml:1118-1123): the step that holds source byte blk_start + 65534 --
-    // the first one that ends behind it -- closes the block
-    while (exit_k - blk_start > (uint32_t)MAX_BLOCK_SRC_LEN) {
-      const uint32_t T = blk_start + (uint32_t)MAX_BLOCK_SRC_LEN;
-      // the last visited position <= T; it lies in this segment (behind its end the tiles still hold the next
-      // segment's own path, and the step that leaves this segment started inside it)
-      const uint32_t Ts = T < seg_end ? T : seg_end - 1u;
-      uint32_t Bt = Ts & ~63u;
-      unsigned long long w = vis[Bt >> 6] & (~0ull >> (63u - (Ts & 63u)));
-      while (w == 0ull) { Bt -= PARSE_TILE; w = vis[Bt >> 6]; }  // (the step started in an earlier tile: at most 9 back)
-      const int c = 63 - __builtin_clzll(w);
-      const Tile t = eval_tile(Bt, 0, true, vis[Bt >> 6]);
-      const bool again = k != 0 && Bt >= (e & ~63u) && Bt < again_end;
-      const uint32_t tile0 = again ? off + tile_sym0[Bt >> 6] : off + f - from + tile_sym0[Bt >> 6];
-      const uint32_t p = Bt + (uint32_t)lane;
-      const uint32_t rel = p - blk_start, first = tile0 + t.first_rel;
-      uint32_t cutpos, symidx;
-      if (t.br == 0) { cutpos = p; symidx = first; }
-      else if (rel + t.lits > (uint32_t)MAX_BLOCK_SRC_LEN) { const uint32_t i = (uint32_t)MAX_BLOCK_SRC_LEN - rel; cutpos = p + i; symidx = first + i; }
-      else { cutpos = p + t.lits; symidx = first + t.lits; }
-      cutpos = (uint32_t)__builtin_amdgcn_readlane((int)cutpos, c);
-      symidx = (uint32_t)__builtin_amdgcn_readlane((int)symidx, c);
-      if (lane == 0) {
-        BlockDesc b;
-        b.src_start = blk_start; b.src_len = cutpos - blk_start;
-        b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
-        blocks[nblk] = b;
+      const uint32_t f = a.f, from = a.from, exit_k = a.exit, again_end = a.again_end;
+      const uint32_t n_own = spec_total - from;
+      if ((uint32_t)lane == i) {
+        out_dst = off + f; out_from = from; out_n = n_own;
+        out_fix_dst = off; out_fix_n = in_buffer ? f : 0u;
       }
-      nblk++;
-      blk_start = cutpos;
-      blk_sym_start = symidx;
+      // block cut (write_block_symbol zd.ml:1118-1123): the step that holds source byte blk_start + 65534 --
+      // the first one that ends behind it -- closes the block
+      while (exit_k - blk_start > (uint32_t)MAX_BLOCK_SRC_LEN) {
+        const uint32_t T = blk_start + (uint32_t)MAX_BLOCK_SRC_LEN;
+        // the last visited position <= T; it lies in this segment (the step that leaves this segment started
+        // inside it).  A tile's marks: the true path's where the tile was parsed again, else the segment's own.
+        auto again_tile = [&](uint32_t Bt) -> bool { return k != 0 && Bt >= (e & ~63u) && Bt < again_end; };
+        auto marks = [&](uint32_t Bt) -> unsigned long long { return again_tile(Bt) ? P.vis2[Bt >> 6] : P.own_vis[Bt >> 6]; };
+        const uint32_t Ts = T < seg_end ? T : seg_end - 1u;
+        uint32_t Bt = Ts & ~63u;
+        unsigned long long w = marks(Bt) & (~0ull >> (63u - (Ts & 63u)));
+        while (w == 0ull) { Bt -= PARSE_TILE; w = marks(Bt); }  // (the step started in an earlier tile: at most 9 back)
+        const int c = 63 - __builtin_clzll(w);
+        const ParseTile t = parse_eval_tile(P, Bt, 0, true, marks(Bt));
+        const uint32_t tile0 = again_tile(Bt) ? off + P.sym02[Bt >> 6] : off + f - from + P.own_sym0[Bt >> 6];
+        const uint32_t p = Bt + (uint32_t)lane;
+        const uint32_t rel = p - blk_start, first = tile0 + t.first_rel;
+        uint32_t cutpos, symidx;
+        if (t.br == 0) { cutpos = p; symidx = first; }
+        else if (rel + t.lits > (uint32_t)MAX_BLOCK_SRC_LEN) { const uint32_t j = (uint32_t)MAX_BLOCK_SRC_LEN - rel; cutpos = p + j; symidx = first + j; }
+        else { cutpos = p + t.lits; symidx = first + t.lits; }
+        cutpos = (uint32_t)__builtin_amdgcn_readlane((int)cutpos, c);
+        symidx = (uint32_t)__builtin_amdgcn_readlane((int)symidx, c);
+        if (lane == 0) {
+          BlockDesc b;
+          b.src_start = blk_start; b.src_len = cutpos - blk_start;
+          b.sym_start = blk_sym_start; b.n_syms = symidx - blk_sym_start;
+          blocks[nblk] = b;
+        }
+        nblk++;
+        blk_start = cutpos;
+        blk_sym_start = symidx;
+      }
+      off += f + n_own;
+      exit_prev = exit_k;
+      spec_exit_prev = spec_exit;
     }
-    off += f + n_own;
-    exit_prev = exit_k;
+    if (c0 + (uint32_t)lane < nseg) {
+      const size_t slot = slot0 + c0 + (uint32_t)lane;
+      G.seg_dst[slot] = out_dst; G.seg_from[slot] = out_from; G.seg_n[slot] = out_n;
+      G.fix_dst[slot] = out_fix_dst; G.fix_n[slot] = out_fix_n;
+    }
   }
   if (lane == 0) {
     BlockDesc b;  // the final block, always present (zd.ml:1216)
@@ -1201,9 +1313,16 @@ __global__ __launch_bounds__(64) void lz_parse_gather_kernel(const StreamDesc *_
   const uint64_t len = descs[stream].src_len;
   if (len > MAX_STREAM_LEN || len < (uint64_t)MIN_MATCH_LEN || (uint64_t)seg * G.seg_positions >= len) return;
   const size_t slot = (size_t)stream * G.segs_per_stream + seg;
+  uint32_t *syms = S.syms + S.pos_base[stream];
+  {  // the symbols lz_parse_meet_kernel parsed again, if the stitch took them
+    const uint32_t n = G.fix_n[slot];
+    const uint32_t *from = G.meet_syms + slot * MEET_CAP;
+    uint32_t *to = syms + G.fix_dst[slot];
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) to[i] = from[i];
+  }
   const uint32_t n = G.seg_n[slot];
   const uint32_t *from = G.spec_syms + slot * G.seg_syms + G.seg_from[slot];
-  uint32_t *to = S.syms + S.pos_base[stream] + G.seg_dst[slot];
+  uint32_t *to = syms + G.seg_dst[slot];
   for (uint32_t i = threadIdx.x; i < n; i += 64u) to[i] = from[i];
 }
 
@@ -2154,7 +2273,8 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   const size_t sps = (max_src_len + segp - 1) / segp;
   bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 4096 && sps >= 8);  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 16 384 x 64 KiB: 15.6 -> 17.4)
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
-  const size_t csegs = (max_src_len + CHAIN_SEG - 1) / CHAIN_SEG;  // lz_chain: workgroups of the longest stream
+  const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 1024 ? CHAIN_SEG_MIN : CHAIN_SEG_MAX;
+  const size_t csegs = (max_src_len + chain_seg - 1) / chain_seg;  // lz_chain: workgroups of the longest stream
   if (segmented && (n * sps > 0x7FFFFFFFull || n * bps > 0x7FFFFFFFull)) segmented = false;
   ParseSegs segs{};
   EmitPlan *plans = nullptr;
@@ -2162,8 +2282,8 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     const size_t n_slots = n * sps, tiles = (size_t)(S.cap_positions / 64) + 4;
     const size_t plan_bytes = align_up((size_t)S.cap_blocks * sizeof(EmitPlan), 256);
     const size_t seg_syms = segp + PARSE_SEG_SLACK;
-    const size_t bytes = plan_bytes + align_up(n_slots * seg_syms * 4, 256) + align_up(tiles * 8, 256) +
-                         align_up(tiles * 4, 256) + 5 * align_up(n_slots * 4, 256);
+    const size_t bytes = plan_bytes + align_up(n_slots * seg_syms * 4, 256) + 2 * align_up(tiles * 8, 256) +
+                         2 * align_up(tiles * 4, 256) + 11 * align_up(n_slots * 4, 256) + align_up(n_slots * MEET_CAP * 4, 256);
     if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) return hipErrorOutOfMemory;
     uint8_t *q = (uint8_t *)ctx->parse_scratch.p;
     plans = (EmitPlan *)q; q += plan_bytes;
@@ -2174,7 +2294,16 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     segs.seg_total = (uint32_t *)q; q += align_up(n_slots * 4, 256);
     segs.seg_dst = (uint32_t *)q; q += align_up(n_slots * 4, 256);
     segs.seg_from = (uint32_t *)q; q += align_up(n_slots * 4, 256);
-    segs.seg_n = (uint32_t *)q;
+    segs.seg_n = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.meet_f = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.meet_from = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.meet_exit = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.meet_end = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.fix_dst = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.fix_n = (uint32_t *)q; q += align_up(n_slots * 4, 256);
+    segs.vis2 = (unsigned long long *)q; q += align_up(tiles * 8, 256);
+    segs.sym02 = (uint32_t *)q; q += align_up(tiles * 4, 256);
+    segs.meet_syms = (uint32_t *)q;
     segs.segs_per_stream = (uint32_t)sps;
     segs.seg_positions = (uint32_t)segp; segs.seg_syms = (uint32_t)seg_syms;
     const hipError_t me = hipMemsetAsync(segs.vis, 0, tiles * 8, ctx->cur);
@@ -2187,7 +2316,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     const StreamDesc *dd = d_descs + lo;
     if (segmented && csegs > 1 && m <= 128)  // (the run-up is a quarter more work: only while workgroups are what is missing)
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_segments_kernel, dim3((unsigned)(m * csegs)), dim3(CHAIN_THREADS), 0, d_src, dd,
-                Q, (uint32_t)csegs);
+                Q, (uint32_t)csegs, (uint32_t)chain_seg);
     else
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
     if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
@@ -2201,7 +2330,11 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
       const size_t o = lo * sps;  // the slice's segment slots
       G.spec_syms += o * G.seg_syms;
       G.seg_exit += o; G.seg_total += o; G.seg_dst += o; G.seg_from += o; G.seg_n += o;
+      G.meet_syms += o * MEET_CAP;
+      G.meet_f += o; G.meet_from += o; G.meet_exit += o; G.meet_end += o; G.fix_dst += o; G.fix_n += o;
       ZD_LAUNCH(ctx, "lz_parse_spec", lz_parse_spec_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, d_src, dd, Q,
+                good_match, G);
+      ZD_LAUNCH(ctx, "lz_parse_meet", lz_parse_meet_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, d_src, dd, Q,
                 good_match, G);
       ZD_LAUNCH(ctx, "lz_parse_stitch", lz_parse_stitch_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q,
                 good_match, G);
