@@ -2265,10 +2265,11 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // whenever a stream has more than one segment (tests).
   static const long segs_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEGMENTS"); return e ? atol(e) : -1L; }();
   static const long segp_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEG"); return e ? atol(e) : 0L; }();  // positions per segment (tuning)
-  // segment size: the stitch's serial time per stream is segments x ~2 us, the parallel part's a segment's tiles x ~0.3 us
-  // (one stream alone, 4-bit symbols, whole deflate, ms at 4096 / 8192 / 16384 / 32768 / 65536 positions: 1 MiB 1.52 / 1.35 /
-  // 1.39 / 1.63 / 2.15, 16 MiB 11.8 / 8.0 / 6.3 / 5.6 / 5.7)
-  size_t segp = max_src_len <= ((size_t)256 << 10) ? 4096 : max_src_len <= ((size_t)2 << 20) ? 8192 : max_src_len <= ((size_t)8 << 20) ? 16384 : 32768;
+  // segment size: the stitch's serial time per stream is segments x ~0.25 us, the parallel part's a segment's tiles x ~0.3 us
+  // (one stream alone, 4-bit symbols, whole deflate, ms at 4096 / 8192 / 16384 / 32768 / 65536 positions: 1 MiB 0.91 / 1.04 /
+  // 1.09 / 1.38 / 1.94, 16 MiB 2.18 / 1.89 / 1.87 / 2.10 / 2.57 -- since lz_parse_meet_kernel the stitch's turn per
+  // segment is a quarter of a microsecond)
+  size_t segp = max_src_len <= ((size_t)4 << 20) ? 4096 : max_src_len <= ((size_t)32 << 20) ? 8192 : 16384;
   if (segp_env >= (long)PARSE_SEG_MIN && segp_env % 64 == 0 && segp_env <= (1L << 20)) segp = (size_t)segp_env;
   const size_t sps = (max_src_len + segp - 1) / segp;
   bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 4096 && sps >= 8);  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 16 384 x 64 KiB: 15.6 -> 17.4)
