@@ -1047,21 +1047,43 @@ __device__ __forceinline__ ParseTile parse_eval_tile(const ParseStream &P, uint3
 
 // A segment parsed again from its true entry e (seg_start <= e < seg_end) until the path meets the segment's own --
 // a common position in a tile -- or the segment ends.  Symbols to out[0 .. f), the path's marks to vis2 / sym02.
+// A path that leaves segment k without having met goes on into k + 1 and so on, up to segment k_limit - 1: a long run
+// of equal steps crosses segments 64 steps at a time instead of being cut at every boundary.
 struct ParseAgain {
+  uint32_t k_end;      // the segment the path met in, or was stopped at the end of
   uint32_t f;          // symbols parsed again
-  uint32_t from;       // the segment's own symbols from this one on follow them
-  uint32_t exit;       // where the segment is left
+  uint32_t from;       // segment k_end's own symbols from this one on follow them (segments before it: none do)
+  uint32_t exit;       // where segment k_end is left
   uint32_t again_end;  // tiles in [tile of e, again_end) were parsed again (their marks are vis2 / sym02)
   bool ok;             // false: out[] was too small (cap) -- nothing of the above holds
 };
-__device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t seg_end, uint32_t e, uint32_t spec_total,
-                                                  uint32_t spec_exit, uint32_t *__restrict__ out, uint32_t cap) {
+__device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t seg_positions, const uint32_t *seg_total,
+                                                  const uint32_t *seg_exit, uint32_t k, uint32_t k_limit, uint32_t e,
+                                                  uint32_t *__restrict__ out, uint32_t cap) {
   const int lane = P.lane;
+  auto end_of = [&](uint32_t j) -> uint32_t {
+    const uint64_t x = (uint64_t)(j + 1) * seg_positions;
+    return x < P.len ? (uint32_t)x : P.len;
+  };
+  const uint32_t ext_end = end_of(k_limit - 1);  // nothing behind this is touched
+  uint32_t j = k, seg_end = end_of(k);
   ParseAgain r;
-  r.f = 0; r.from = spec_total; r.exit = e; r.again_end = seg_end; r.ok = true;
+  r.k_end = k; r.f = 0; r.from = 0; r.exit = e; r.again_end = seg_end; r.ok = true;
   uint32_t f = 0;
   uint32_t B = e & ~63u, entry = e;
   uint32_t rest = 0;  // tiles until a run of equal steps is tried again
+  // the path is at tile Bx, behind segment j's end: on into the next segment, or the end (true: stop here)
+  auto leave = [&](uint32_t Bx) -> bool {
+    while (Bx >= seg_end) {
+      if (j + 1 >= k_limit || seg_end >= P.len) {
+        r.k_end = j; r.again_end = Bx; r.from = seg_total[j]; r.exit = entry;
+        return true;
+      }
+      j++;
+      seg_end = end_of(j);
+    }
+    return false;
+  };
   for (;;) {
     if (cap - f < 64u + 576u) { r.ok = false; return r; }  // (a tile's steps make at most a symbol per position they cover)
     const ParseTile t = parse_eval_tile(P, B, entry, false, 0ull);
@@ -1084,14 +1106,15 @@ __device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t
     // a given one)
     if (Bn > B + PARSE_TILE) {
       const uint32_t tz = B + PARSE_TILE * (1u + (uint32_t)lane);
-      if (tz < Bn && tz < seg_end) P.vis2[tz >> 6] = 0ull;
+      if (tz < Bn && tz < ext_end) P.vis2[tz >> 6] = 0ull;
     }
-    if (met || Bn >= seg_end) {
-      r.again_end = Bn;
-      r.from = (met && Bn < seg_end) ? P.own_sym0[Bn >> 6] : spec_total;  // (the segment's own parse went on with tile Bn too)
-      r.exit = met ? spec_exit : entry;
+    if (met) {
+      r.k_end = j; r.again_end = Bn;
+      r.from = Bn < seg_end ? P.own_sym0[Bn >> 6] : seg_total[j];  // (the segment's own parse went on with tile Bn too)
+      r.exit = seg_exit[j];
       break;
     }
+    if (leave(Bn)) break;
     // One long step through the tile and no meeting: a run of one byte, or a short period -- the data on which
     // this path and the segment's own stay out of phase to the segment's end.  Then the next steps are probably
     // the same: every lane takes the position i steps on and works out ITS step (lz_macro_position); the lanes
@@ -1101,7 +1124,7 @@ __device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t
     if (rest != 0) rest--;
     else if (__builtin_popcountll(t.vm) == 1 && stride >= (uint32_t)PARSE_TILE) {
       const uint64_t ahead = (uint64_t)lane * stride;
-      const bool in = ahead < (uint64_t)(seg_end - entry);
+      const bool in = ahead < (uint64_t)(ext_end - entry);
       const uint32_t p = in ? entry + (uint32_t)ahead : entry;
       const uint64_t *match = P.match;
       const MacroStep m = lz_macro_position(p, P.len, P.good_match, [&](uint32_t j) -> uint64_t { return match[j]; });
@@ -1121,16 +1144,13 @@ __device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t
           // the path's marks for the block cut: this step's tile holds it alone, the tiles it jumps over nothing
           P.vis2[p >> 6] = 1ull << (p & 63u);
           P.sym02[p >> 6] = f + first_rel;
-          for (uint32_t tz = (p & ~63u) + PARSE_TILE; tz < ((p + stride) & ~63u) && tz < seg_end; tz += PARSE_TILE) P.vis2[tz >> 6] = 0ull;
+          for (uint32_t tz = (p & ~63u) + PARSE_TILE; tz < ((p + stride) & ~63u) && tz < ext_end; tz += PARSE_TILE) P.vis2[tz >> 6] = 0ull;
         }
         f += made;
-        entry += lead * stride;  // (< seg_end + stride: lane lead - 1 was inside)
+        entry += lead * stride;  // (< ext_end + stride: lane lead - 1 was inside)
         if (entry > P.len) entry = P.len;
         const uint32_t Bs = entry & ~63u;
-        if (Bs >= seg_end) {
-          r.again_end = Bs; r.from = spec_total; r.exit = entry;
-          break;
-        }
+        if (leave(Bs)) break;
         B = Bs;
         continue;
       }
@@ -1164,12 +1184,13 @@ __global__ __launch_bounds__(64) void lz_parse_meet_kernel(const uint8_t *__rest
   const uint32_t seg_start = k * G.seg_positions;
   const uint32_t seg_end = len - seg_start > G.seg_positions ? seg_start + G.seg_positions : len;
   const uint32_t e = G.seg_exit[slot - 1];
-  const uint32_t spec_total = G.seg_total[slot], spec_exit = G.seg_exit[slot];
+  const uint32_t spec_total = G.seg_total[slot];
   ParseAgain a;
   if (e >= seg_end) {  // (a step over a short last segment)
-    a.f = 0; a.from = spec_total; a.exit = e; a.again_end = seg_end; a.ok = true;
+    a.k_end = k; a.f = 0; a.from = spec_total; a.exit = e; a.again_end = seg_end; a.ok = true;
   } else {
-    a = parse_again(P, seg_end, e, spec_total, spec_exit, G.meet_syms + slot * MEET_CAP, MEET_CAP);
+    a = parse_again(P, G.seg_positions, G.seg_total + (slot - k), G.seg_exit + (slot - k), k, k + 1, e,
+                    G.meet_syms + slot * MEET_CAP, MEET_CAP);
   }
   if (P.lane == 0) {
     G.meet_f[slot] = a.ok ? a.f : 0xFFFFFFFFu;
@@ -1228,26 +1249,35 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
     uint32_t out_dst = 0, out_from = 0, out_n = 0, out_fix_dst = 0, out_fix_n = 0;  // my segment's verdict, stored after the turn
     const uint32_t turn = nseg - c0 < 64u ? nseg - c0 : 64u;
     for (uint32_t i = 0; i < turn; i++) {
-      const uint32_t k = c0 + i;
-      auto of_lane = [&](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)i); };
-      const uint32_t seg_start = k * PARSE_SEG;
-      const uint32_t seg_end = len - seg_start > PARSE_SEG ? seg_start + PARSE_SEG : len;
-      const uint32_t spec_total = of_lane(my_total), spec_exit = of_lane(my_exit);
+      uint32_t k = c0 + i;
+      auto of_lane = [&](uint32_t v, uint32_t l) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); };
+      uint32_t spec_total = of_lane(my_total, i), spec_exit = of_lane(my_exit, i);
       const uint32_t e = exit_prev;
       ParseAgain a;
-      a.f = 0; a.from = 0; a.exit = spec_exit; a.again_end = seg_start; a.ok = true;  // segment 0: its own parse is the true one
+      a.k_end = k; a.f = 0; a.from = 0; a.exit = spec_exit; a.ok = true;  // segment 0: its own parse is the true one
+      a.again_end = k * PARSE_SEG;
       bool in_buffer = false;  // the symbols parsed again are in the segment's meet buffer (else at syms[off ..))
       if (k != 0) {
-        const uint32_t mf = of_lane(my_mf);
+        const uint32_t mf = of_lane(my_mf, i);
+        const uint32_t seg_end_k = len - k * PARSE_SEG > PARSE_SEG ? (k + 1) * PARSE_SEG : len;
         if (e == spec_exit_prev && mf != 0xFFFFFFFFu) {  // as lz_parse_meet_kernel assumed
-          a.f = mf; a.from = of_lane(my_mfrom); a.exit = of_lane(my_mexit); a.again_end = of_lane(my_mend);
+          a.f = mf; a.from = of_lane(my_mfrom, i); a.exit = of_lane(my_mexit, i); a.again_end = of_lane(my_mend, i);
           in_buffer = true;
-        } else if (e >= seg_end) {  // (a step over a short last segment)
-          a.from = spec_total; a.exit = e; a.again_end = seg_end;
-        } else {
-          a = parse_again(P, seg_end, e, spec_total, spec_exit, syms + off, 0xFFFFFFFFu);
+        } else if (e >= seg_end_k) {  // (a step over a short last segment)
+          a.from = spec_total; a.exit = e; a.again_end = seg_end_k;
+        } else {  // from the true entry, through the turn's segments if need be
+          a = parse_again(P, PARSE_SEG, G.seg_total + slot0, G.seg_exit + slot0, k, c0 + turn, e, syms + off, 0xFFFFFFFFu);
+          if (a.k_end != k) {  // the segments the path went through without meeting: nothing of their own is used
+            const uint32_t i2 = a.k_end - c0;
+            if ((uint32_t)lane >= i && (uint32_t)lane < i2) { out_dst = off; out_from = my_total; out_n = 0; out_fix_dst = off; out_fix_n = 0; }
+            i = i2;
+            k = a.k_end;
+            spec_total = of_lane(my_total, i);
+            spec_exit = of_lane(my_exit, i);
+          }
         }
       }
+      const uint32_t seg_end = len - k * PARSE_SEG > PARSE_SEG ? (k + 1) * PARSE_SEG : len;
       const uint32_t f = a.f, from = a.from, exit_k = a.exit, again_end = a.again_end;
       const uint32_t n_own = spec_total - from;
       if ((uint32_t)lane == i) {
@@ -1642,13 +1672,22 @@ __device__ __forceinline__ int wave_choose(const BlockCoder &c, uint32_t block_s
 // The blocks of a stream coded by a wave each (deflate_plan_kernel / deflate_scan_kernel / deflate_pack_kernel /
 // deflate_seal_kernel below): what they leave for each other, one record per block at the block's slot.
 constexpr uint32_t EMIT_SKIP = 0xFFu;  // kind of every block of a stream whose output does not fit
+constexpr uint32_t EMIT_PART = 8192;   // symbols a pack wave takes
+constexpr uint32_t EMIT_PARTS = 8;     // parts of a block at most (65534 symbols: all literals)
+static_assert(EMIT_PART * EMIT_PARTS >= (uint32_t)MAX_BLOCK_SRC_LEN, "a block's symbols fit its parts");
+// (split: a wave per part -- worth its per-wave set-up only while a call has few blocks; else a wave per block)
+__host__ __device__ inline uint32_t emit_parts_of(bool split, uint32_t kind, uint32_t n_syms) {
+  return !split || kind == 0 || n_syms == 0 ? 1u : (n_syms + EMIT_PART - 1) / EMIT_PART;
+}
 struct EmitPlan {
   uint64_t flen;          // plan: bits of the block as a fixed block,
   uint64_t dyn_sym_bits;  //   and of its symbols under its own dynamic code
   uint64_t dlen, dbits;   // codelen: the reference's estimate of the block as a dynamic block, and its bits
   uint64_t bit_start, bit_end;  // scan: the block's bits in the stream's output
   uint32_t kind;          // scan: 0 stored, 1 fixed, 2 dynamic, EMIT_SKIP
-  uint32_t tail;          // pack: the bits behind the block's last whole byte
+  uint32_t part_tail[EMIT_PARTS];  // pack: the bits behind a part's last whole byte
+  uint64_t part_bits[EMIT_PARTS];  // bits: of the part's symbols under the block's code (a coded block is packed by a wave
+                                   //   per EMIT_PART symbols: part 0 with the header in front, the last one with the end-of-block symbol)
   int32_t codelen_syms_len, hlit, hdist;  // plan
   int32_t hclen;          // codelen
   uint32_t n_chunks;      // plan (Adler-32): the block's chunks, first = len mod 5552 (possibly empty), then 5552 each
@@ -1661,14 +1700,15 @@ struct EmitPlan {
 
 // MODE 0: a wave codes a whole stream, block after block.  MODE 1 (plan): a wave takes ONE block as far as its
 // bits do not depend on the blocks before it -- histogram, the codes of its symbols, its code-length symbols, the
-// fixed and dynamic sizes, its Adler-32 chunk sums.  MODE 2 (pack): a wave writes one block where the scan put it.
+// fixed and dynamic sizes, its Adler-32 chunk sums.  MODE 2 (pack): a wave writes one PART of a block where the scan
+// and the parts before it put it.  MODE 3 (bits): a wave adds up the bits of a part's symbols under the block's code.
 template <int MODE>
 __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ src_arena,
                                                   uint8_t *__restrict__ dst_arena,
                                                   const StreamDesc *__restrict__ descs,
                                                   StreamResult *__restrict__ results,
                                                   DeflateScratch S, int crc_op, uint32_t stream, uint32_t only_block,
-                                                  EmitPlan *__restrict__ plans) {
+                                                  EmitPlan *__restrict__ plans, uint32_t part = 0, bool split = false) {
   __shared__ uint32_t lit_freq[288], dist_freq[32], codelen_freq[32];
   __shared__ uint32_t dyn_lit[288], dyn_dist[32], dyn_codelen[32], fix_lit[288], fix_dist[32];
   __shared__ uint32_t codelen_syms[320], heap[580];
@@ -1688,7 +1728,11 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
   const BlockDesc *blocks = S.blocks + S.blk_base[stream];
   const uint32_t *syms = S.syms + S.pos_base[stream];
   EmitPlan *plan = MODE != 0 ? plans + S.blk_base[stream] + only_block : nullptr;
-  if (MODE == 2 && plan->kind == EMIT_SKIP) return;
+  if (MODE >= 2) {
+    const uint32_t k = plan->kind;
+    if (k == EMIT_SKIP || part >= emit_parts_of(split, k, blocks[only_block].n_syms)) return;
+    if (MODE == 3 && k == 0) return;
+  }
 
   BlockCoder c;
   c.lit_freq = lit_freq; c.dist_freq = dist_freq; c.codelen_freq = codelen_freq;
@@ -1719,9 +1763,14 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
   const uint64_t ph_begin = __builtin_readcyclecounter();
 #endif
 
-  if (MODE == 2) {  // where the scan put the block; the bits of the block before it come from the seal
-    bo.out_pos = (uint32_t)(plan->bit_start >> 3);
-    bo.acc_bits = (int)(plan->bit_start & 7u);
+  if (MODE == 2) {  // where the scan put the block, and the parts before this one its first bit; the bits before come from the seal
+    uint64_t at = plan->bit_start;
+    if (part != 0) {
+      at += plan->kind == 2 ? plan->dbits - plan->dyn_sym_bits : 3u;  // type bits and header
+      for (uint32_t i = 0; i < part; i++) at += plan->part_bits[i];
+    }
+    bo.out_pos = (uint32_t)(at >> 3);
+    bo.acc_bits = (int)(at & 7u);
   }
   const uint32_t b_first = MODE == 0 ? 0u : only_block, b_end = MODE == 0 ? nblk : only_block + 1u;
   for (uint32_t b = b_first; b < b_end && status == ST_OK; b++) {
@@ -1746,7 +1795,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     }
     int kind = 0;
     uint64_t block_bits = 0;
-    if (MODE != 2) {
+    if (MODE < 2) {
 
 #ifdef ZD_EMIT_PHASES
     const uint64_t ph0 = __builtin_readcyclecounter();
@@ -1824,7 +1873,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     ph_hist += ph1 - ph0;
     ph_code += ph2 - ph1;
 #endif
-    } else {  // MODE 2: the plan's codes
+    } else {  // MODE 2, 3: the plan's codes
       kind = (int)plan->kind;
       if (kind == 2) {
         for (int i = lane; i < 288; i += 64) dyn_lit[i] = plan->dyn_lit[i];
@@ -1894,6 +1943,10 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     // then EOB.  Symbol loads are unconditional (clamped); what an item is gets decided
     // when it is used, a turn after its load was issued.
     const uint32_t last_sym = bd.n_syms ? bd.n_syms - 1u : 0u;
+    // MODE 2: this part's items -- the type bits and the header go with part 0, the end-of-block symbol with the last
+    const uint32_t n_parts = MODE == 2 ? emit_parts_of(split, (uint32_t)kind, bd.n_syms) : 1u;
+    const uint32_t item_lo = (MODE == 2 && part != 0) ? 1u + n_hdr + part * EMIT_PART : 0u;
+    const uint32_t item_hi = (MODE == 2 && part + 1 != n_parts) ? 1u + n_hdr + (part + 1u) * EMIT_PART : n_items;
     auto fetch = [&](uint32_t idx) -> uint32_t {
       const uint32_t k = idx > n_hdr ? idx - 1u - n_hdr : 0u;
       return syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
@@ -1907,7 +1960,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
         const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
         value[u] = 0;
         nbits[u] = 0;
-        if (idx < n_items) {
+        if (idx < item_hi) {
           if (idx == 0) {
             value[u] = (final ? 1u : 0u) | ((uint32_t)kind << 1);
             nbits[u] = 3;
@@ -1936,24 +1989,40 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
       }
       pack_tiles(bo, stage, value, nbits, lane);
     };
+    if (MODE == 3) {  // the bits of the part's symbols (not the end-of-block symbol)
+      const uint32_t s_lo = part * EMIT_PART, s_hi = bd.n_syms - s_lo > EMIT_PART ? s_lo + EMIT_PART : bd.n_syms;
+      uint64_t acc = 0;
+      for (uint32_t k = s_lo + (uint32_t)lane; k < s_hi; k += 64u) {
+        const uint32_t sr = syms[bd.sym_start + k];
+        const uint32_t dist = sr >> 9, len = sr & 0x1FF;
+        if (dist == 0) acc += hl[len] & 0x1F;
+        else {
+          const int dsym = dist_to_sym((int)dist);
+          acc += (len_item[len] & 0x1F) + (hd[dsym] & 0x1F) + (dist_info[dsym] & 0x1F);
+        }
+      }
+      acc = wave_sum64(acc);
+      if (lane == 0) plan->part_bits[part] = acc;
+      return;
+    }
     // (two sets of registers that swap roles by name, as in the histogram loop)
     uint32_t sref_a[PACK_TILES], sref_b[PACK_TILES];
 #pragma unroll
-    for (int u = 0; u < PACK_TILES; u++) sref_a[u] = fetch((uint32_t)(64 * u + lane));
-    for (uint32_t base = 0; base < n_items; base += 2u * 64u * PACK_TILES) {
+    for (int u = 0; u < PACK_TILES; u++) sref_a[u] = fetch(item_lo + (uint32_t)(64 * u + lane));
+    for (uint32_t base = item_lo; base < item_hi; base += 2u * 64u * PACK_TILES) {
 #pragma unroll
       for (int u = 0; u < PACK_TILES; u++) sref_b[u] = fetch(base + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
       pack_turn(base, sref_a);
       const uint32_t base2 = base + 64u * PACK_TILES;
-      if (base2 >= n_items) break;  // uniform
+      if (base2 >= item_hi) break;  // uniform
 #pragma unroll
       for (int u = 0; u < PACK_TILES; u++) sref_a[u] = fetch(base2 + 64u * (uint32_t)(PACK_TILES + u) + (uint32_t)lane);
       pack_turn(base2, sref_b);
     }
   }
 
-  if (MODE == 2) {  // what the block leaves of its last byte: the seal puts it there
-    if (lane == 0) plan->tail = bo.acc;
+  if (MODE == 2) {  // what the part leaves of its last byte: the seal puts it there
+    if (lane == 0) plan->part_tail[part] = bo.acc;
     return;
   }
   if (status == ST_OK && bo.acc_bits > 0) {  // flush zd.ml:856-858
@@ -2001,12 +2070,24 @@ __global__ __launch_bounds__(64, 4) void deflate_plan_kernel(const uint8_t *__re
                        blockIdx.x % blocks_per_stream, plans);
 }
 
+// (grids of a wave per part of a block: slot = (stream * blocks_per_stream + block) * parts_per_block + part;
+// parts_per_block is EMIT_PARTS or, for a wave per block, 1)
+__global__ __launch_bounds__(64, 4) void deflate_bits_kernel(const uint8_t *__restrict__ src_arena,
+                                                          const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                          int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
+  const uint32_t blk = blockIdx.x / EMIT_PARTS;
+  deflate_emit_wave<3>(src_arena, nullptr, descs, nullptr, S, crc_op, blk / blocks_per_stream, blk % blocks_per_stream,
+                       plans, blockIdx.x % EMIT_PARTS, true);
+}
+
 __global__ __launch_bounds__(64, 4) void deflate_pack_kernel(const uint8_t *__restrict__ src_arena,
                                                           uint8_t *__restrict__ dst_arena,
                                                           const StreamDesc *__restrict__ descs, DeflateScratch S,
-                                                          int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans) {
-  deflate_emit_wave<2>(src_arena, dst_arena, descs, nullptr, S, crc_op, blockIdx.x / blocks_per_stream,
-                       blockIdx.x % blocks_per_stream, plans);
+                                                          int crc_op, uint32_t blocks_per_stream, EmitPlan *__restrict__ plans,
+                                                          uint32_t parts_per_block) {
+  const uint32_t blk = blockIdx.x / parts_per_block;
+  deflate_emit_wave<2>(src_arena, dst_arena, descs, nullptr, S, crc_op, blk / blocks_per_stream, blk % blocks_per_stream,
+                       plans, blockIdx.x % parts_per_block, parts_per_block != 1);
 }
 
 // the counts of the code-length symbols as block b's code sees them: its own and those of every block before (Q1)
@@ -2140,19 +2221,34 @@ __global__ __launch_bounds__(64) void deflate_scan_kernel(const StreamDesc *__re
 __global__ __launch_bounds__(256) void deflate_seal_kernel(uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs, DeflateScratch S,
                                                            uint32_t n_streams, uint32_t blocks_per_stream,
-                                                           const EmitPlan *__restrict__ plans) {
+                                                           const EmitPlan *__restrict__ plans, uint32_t parts_per_block) {
+  const bool split = parts_per_block != 1;
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t stream = (uint32_t)(i / blocks_per_stream), b = (uint32_t)(i % blocks_per_stream);
+  const uint32_t part = (uint32_t)(i % parts_per_block);
+  const uint64_t ib = i / parts_per_block;
+  const uint32_t stream = (uint32_t)(ib / blocks_per_stream), b = (uint32_t)(ib % blocks_per_stream);
   if (stream >= n_streams || S.error[0]) return;
   const StreamDesc sd = descs[stream];
   if (sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) return;
   const uint32_t nblk = S.n_blocks[stream];
   if (b >= nblk) return;
   const EmitPlan *p = plans + S.blk_base[stream] + b;
+  const BlockDesc *blocks = S.blocks + S.blk_base[stream];
   if (p->kind == EMIT_SKIP) return;
+  const uint32_t n_parts = emit_parts_of(split, p->kind, blocks[b].n_syms);
+  if (part >= n_parts) return;
   uint8_t *dst = dst_arena + sd.dst_off;
-  if (b != 0 && (p->bit_start & 7u)) dst[p->bit_start >> 3] |= (uint8_t)p[-1].tail;
-  if (b + 1 == nblk && (p->bit_end & 7u)) dst[p->bit_end >> 3] = (uint8_t)p->tail;  // flush zd.ml:856-858
+  // the part's first bit (deflate_emit_wave<2>), and the bits the part before it left of that byte
+  uint64_t at = p->bit_start;
+  if (part != 0) {
+    at += p->kind == 2 ? p->dbits - p->dyn_sym_bits : 3u;
+    for (uint32_t j = 0; j < part; j++) at += p->part_bits[j];
+  }
+  if ((at & 7u) && (b != 0 || part != 0)) {
+    const uint32_t before = part != 0 ? p->part_tail[part - 1] : p[-1].part_tail[emit_parts_of(split, p[-1].kind, blocks[b - 1].n_syms) - 1];
+    dst[at >> 3] |= (uint8_t)before;
+  }
+  if (b + 1 == nblk && part + 1 == n_parts && (p->bit_end & 7u)) dst[p->bit_end >> 3] = (uint8_t)p->part_tail[part];  // flush zd.ml:856-858
 }
 
 // ---------------------------------------------------------------------------------
@@ -2276,7 +2372,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
   const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 1024 ? CHAIN_SEG_MIN : CHAIN_SEG_MAX;
   const size_t csegs = (max_src_len + chain_seg - 1) / chain_seg;  // lz_chain: workgroups of the longest stream
-  if (segmented && (n * sps > 0x7FFFFFFFull || n * bps > 0x7FFFFFFFull)) segmented = false;
+  if (segmented && (n * sps > 0x7FFFFFFFull || n * bps * EMIT_PARTS > 0x7FFFFFFFull)) segmented = false;
   ParseSegs segs{};
   EmitPlan *plans = nullptr;
   if (segmented) {
@@ -2351,10 +2447,15 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
                 (uint32_t)bps, plans);
       ZD_LAUNCH(ctx, "deflate_scan", deflate_scan_kernel, dim3((unsigned)m), dim3(64), 0, dd, d_results + lo, Q, crc_op,
                 plans);
-      ZD_LAUNCH(ctx, "deflate_pack", deflate_pack_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, d_dst, dd, Q,
-                crc_op, (uint32_t)bps, plans);
-      ZD_LAUNCH(ctx, "deflate_seal", deflate_seal_kernel, dim3((unsigned)((m * bps + 255) / 256)), dim3(256), 0, d_dst,
-                dd, Q, (uint32_t)m, (uint32_t)bps, (const EmitPlan *)plans);
+      // few blocks in the call: a coded block's symbols by a wave per EMIT_PART of them
+      const size_t ppb = m * bps <= 2048 ? EMIT_PARTS : 1;
+      if (ppb != 1)
+        ZD_LAUNCH(ctx, "deflate_bits", deflate_bits_kernel, dim3((unsigned)(m * bps * EMIT_PARTS)), dim3(64), 0, d_src, dd, Q,
+                  crc_op, (uint32_t)bps, plans);
+      ZD_LAUNCH(ctx, "deflate_pack", deflate_pack_kernel, dim3((unsigned)(m * bps * ppb)), dim3(64), 0, d_src, d_dst,
+                dd, Q, crc_op, (uint32_t)bps, plans, (uint32_t)ppb);
+      ZD_LAUNCH(ctx, "deflate_seal", deflate_seal_kernel, dim3((unsigned)((m * bps * ppb + 255) / 256)), dim3(256), 0,
+                d_dst, dd, Q, (uint32_t)m, (uint32_t)bps, (const EmitPlan *)plans, (uint32_t)ppb);
     } else {
       ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
                 d_results + lo, Q, crc_op);
