@@ -129,8 +129,8 @@ def launch_workers(n, argv):
 
 DEFLATE_KERNELS = ("deflate_offsets", "lz_chain", "lz_match", "lz_parse", "deflate_emit", "deflate_stored",
                    # few long streams (at most 4096 of 32 KiB and more): the parse by segments, the blocks by a wave each
-                   "lz_parse_spec", "lz_parse_stitch", "lz_parse_gather", "deflate_plan", "deflate_counts", "deflate_codelen",
-                   "deflate_scan", "deflate_pack", "deflate_seal")
+                   "lz_parse_spec", "lz_parse_meet", "lz_parse_stitch", "lz_parse_gather", "deflate_plan", "deflate_counts",
+                   "deflate_codelen", "deflate_scan", "deflate_bits", "deflate_pack", "deflate_seal")
 
 
 def algorithmic_bytes(kernel, N, C):
