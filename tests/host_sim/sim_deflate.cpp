@@ -121,8 +121,8 @@ static uint32_t parse_segments_model(const uint8_t *s, uint32_t len, const uint3
   auto adv = [&](uint32_t p) { return brefs[p] ? macro_advance(steps[p]) : 1u; };
   auto step_of = [&](uint32_t p) { MacroStep m; m.bref = brefs[p]; m.step = steps[p]; return m; };
   const uint32_t nseg = (len + SEG - 1) / SEG, ntiles = len / 64 + 2;
-  std::vector<uint64_t> vis(ntiles, 0);
-  std::vector<uint32_t> tsym0(ntiles, 0), sexit(nseg + 1, 0), stotal(nseg + 1, 0);
+  std::vector<uint64_t> vis(ntiles, 0), vis2(ntiles, 0xA5A5A5A5A5A5A5A5ull);  // (vis2: stale marks wherever nothing wrote)
+  std::vector<uint32_t> tsym0(ntiles, 0), tsym2(ntiles, 0xDEADu), sexit(nseg + 1, 0), stotal(nseg + 1, 0);
   std::vector<std::vector<uint32_t>> spec(nseg + 1);
   for (uint32_t k = 0; k < nseg; k++) {
     const uint32_t lim = (k + 1) * SEG < len ? (k + 1) * SEG : len;
@@ -140,12 +140,23 @@ static uint32_t parse_segments_model(const uint8_t *s, uint32_t len, const uint3
   }
   uint32_t off = 0, exit_prev = 0, blk_start = 0, blk_sym_start = 0, nblk = 0;
   for (uint32_t k = 0; k < nseg; k++) {
-    const uint32_t seg_start = k * SEG, seg_end = (k + 1) * SEG < len ? (k + 1) * SEG : len;
+    const uint32_t seg_start = k * SEG;
+    uint32_t seg_end = (k + 1) * SEG < len ? (k + 1) * SEG : len;
     const uint32_t e = exit_prev;
     uint32_t f = 0, from = 0, exit_k = sexit[k], again_end = seg_start;
     if (k != 0 && e >= seg_end) { from = stotal[k]; exit_k = e; again_end = seg_end; }
     else if (k != 0) {
       uint32_t B = e & ~63u, entry = e, rest = 0;
+      // a path that leaves the segment without having met goes on into the next one (parse_again's `leave`); true: the end
+      auto leave = [&](uint32_t Bx) -> bool {
+        while (Bx >= seg_end) {
+          if (k + 1 >= nseg || seg_end >= len) { again_end = Bx; from = stotal[k]; exit_k = entry; return true; }
+          k++;
+          seg_end = (k + 1) * SEG < len ? (k + 1) * SEG : len;
+        }
+        return false;
+      };
+      const uint32_t ext_end = len;
       for (;;) {
         const uint64_t own = vis[B >> 6];
         uint64_t vm = 0;
@@ -158,36 +169,37 @@ static uint32_t parse_segments_model(const uint8_t *s, uint32_t len, const uint3
           p += adv(p);
         }
         const uint32_t node_pos = B + (uint32_t)__builtin_ctzll(vm | (1ull << 63));
-        vis[B >> 6] = vm; tsym0[B >> 6] = f0;
+        vis2[B >> 6] = vm; tsym2[B >> 6] = f0;
         entry = p < len ? p : len;
         const uint32_t Be = entry & ~63u, Bn = Be > B + 64 ? Be : B + 64;
         const bool met = (vm & own) != 0;
-        for (uint32_t tz = B + 64; tz < Bn && tz < seg_end; tz += 64) vis[tz >> 6] = 0;
-        if (met || Bn >= seg_end) {
+        for (uint32_t tz = B + 64; tz < Bn && tz < ext_end; tz += 64) vis2[tz >> 6] = 0;
+        if (met) {
           again_end = Bn;
-          from = (met && Bn < seg_end) ? tsym0[Bn >> 6] : stotal[k];
-          exit_k = met ? sexit[k] : entry;
+          from = Bn < seg_end ? tsym0[Bn >> 6] : stotal[k];
+          exit_k = sexit[k];
           break;
         }
+        if (leave(Bn)) break;
         const uint32_t stride = entry - node_pos;
         if (rest != 0) rest--;
         else if (__builtin_popcountll(vm) == 1 && stride >= 64) {
           uint32_t lead = 0;
-          while (lead < 64 && (uint64_t)lead * stride < (uint64_t)(seg_end - entry) && adv(entry + lead * stride) == stride) lead++;
+          while (lead < 64 && (uint64_t)lead * stride < (uint64_t)(ext_end - entry) && adv(entry + lead * stride) == stride) lead++;
           if (lead == 0) rest = 8;
           else {
             for (uint32_t i = 0; i < lead; i++) {
               const uint32_t q = entry + i * stride;
               lz_emit_position(s, q, step_of(q), syms + off, f);
-              vis[q >> 6] = 1ull << (q & 63);
-              tsym0[q >> 6] = f;
-              for (uint32_t tz = (q & ~63u) + 64; tz < ((q + stride) & ~63u) && tz < seg_end; tz += 64) vis[tz >> 6] = 0;
+              vis2[q >> 6] = 1ull << (q & 63);
+              tsym2[q >> 6] = f;
+              for (uint32_t tz = (q & ~63u) + 64; tz < ((q + stride) & ~63u) && tz < ext_end; tz += 64) vis2[tz >> 6] = 0;
               f += macro_sym_count(step_of(q));
             }
             entry += lead * stride;
             if (entry > len) entry = len;
             const uint32_t Bs = entry & ~63u;
-            if (Bs >= seg_end) { again_end = Bs; from = stotal[k]; exit_k = entry; break; }
+            if (leave(Bs)) break;
             B = Bs;
             continue;
           }
@@ -201,13 +213,14 @@ static uint32_t parse_segments_model(const uint8_t *s, uint32_t len, const uint3
       const uint32_t T = blk_start + MAX_BLOCK_SRC_LEN;
       const uint32_t Ts = T < seg_end ? T : seg_end - 1;
       uint32_t Bt = Ts & ~63u;
-      uint64_t w = vis[Bt >> 6] & (~0ull >> (63 - (Ts & 63)));
-      while (w == 0) { Bt -= 64; w = vis[Bt >> 6]; }
+      auto again_tile = [&](uint32_t b) { return k != 0 && b >= (e & ~63u) && b < again_end; };
+      auto marks = [&](uint32_t b) { return again_tile(b) ? vis2[b >> 6] : vis[b >> 6]; };
+      uint64_t w = marks(Bt) & (~0ull >> (63 - (Ts & 63)));
+      while (w == 0) { Bt -= 64; w = marks(Bt); }
       const uint32_t c = 63 - (uint32_t)__builtin_clzll(w);
-      const bool again = k != 0 && Bt >= (e & ~63u) && Bt < again_end;
-      uint32_t first = again ? off + tsym0[Bt >> 6] : off + f - from + tsym0[Bt >> 6];
+      uint32_t first = again_tile(Bt) ? off + tsym2[Bt >> 6] : off + f - from + tsym0[Bt >> 6];
       for (uint32_t t = 0; t < c; t++)
-        if ((vis[Bt >> 6] >> t) & 1) first += macro_sym_count(step_of(Bt + t));
+        if ((marks(Bt) >> t) & 1) first += macro_sym_count(step_of(Bt + t));
       const uint32_t p = Bt + c, rel = p - blk_start;
       const uint32_t br = brefs[p], lits = br ? macro_lits(steps[p]) : 0;
       uint32_t cutpos, symidx;
