@@ -53,3 +53,21 @@ def test_randomized_parity_under_overrides(env):
                        env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-600:]
     assert r.returncode == 0 and "FUZZ ok" in tail, tail
+
+
+@pytest.mark.parametrize("seg", ["default", "8192", "32768"])
+def test_long_mixed_streams_bounded(seg):
+    """tools/fuzz_long.py, a few seeds: long streams of mixed content (text, symbols, random bytes, runs of one byte,
+    short periods with and without defects) through the many-wave deflate forms at several segment sizes, bytes and
+    checksums against the oracle."""
+    import subprocess
+    import sys
+
+    day = datetime.date.today().timetuple().tm_yday
+    e = dict(os.environ)
+    if seg != "default":
+        e["ZIPC_HIP_PARSE_SEG"] = seg
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_long.py"), str(9000 + 10 * day), "8"],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    tail = r.stdout.decode()[-600:]
+    assert r.returncode == 0 and "FUZZ ok" in tail, tail
