@@ -2368,7 +2368,9 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   size_t segp = max_src_len <= ((size_t)4 << 20) ? 4096 : max_src_len <= ((size_t)32 << 20) ? 8192 : 16384;
   if (segp_env >= (long)PARSE_SEG_MIN && segp_env % 64 == 0 && segp_env <= (1L << 20)) segp = (size_t)segp_env;
   const size_t sps = (max_src_len + segp - 1) / segp;
-  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (n <= 4096 && sps >= 8);  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 16 384 x 64 KiB: 15.6 -> 17.4)
+  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 64 KiB streams, 256 / 1024 / 2048 / 4096 / 16 384 of them:
+  // 1.77 -> 0.73, 2.38 -> 1.67, 3.16 -> 2.85, 4.78 -> 5.11, 15.6 -> 17.4 ms)
+  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (sps >= 8 && (n <= 2048 || (n <= 4096 && max_src_len >= ((size_t)512 << 10))));
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
   const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 1024 ? CHAIN_SEG_MIN : CHAIN_SEG_MAX;
   const size_t csegs = (max_src_len + chain_seg - 1) / chain_seg;  // lz_chain: workgroups of the longest stream
