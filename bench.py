@@ -128,7 +128,7 @@ def launch_workers(n, argv):
 # ---- pieces of the JSON line -------------------------------------------------------------------------
 
 DEFLATE_KERNELS = ("deflate_offsets", "lz_chain", "lz_match", "lz_parse", "deflate_emit", "deflate_stored",
-                   # few long streams (at most 4096 of 32 KiB and more): the parse by segments, the blocks by a wave each
+                   # few long streams (at most 2048 of 32 KiB and more, 4096 of 512 KiB and more): the parse by segments, the blocks by a wave each
                    "lz_parse_spec", "lz_parse_meet", "lz_parse_stitch", "lz_parse_gather", "deflate_plan", "deflate_counts",
                    "deflate_codelen", "deflate_scan", "deflate_bits", "deflate_pack", "deflate_seal")
 
