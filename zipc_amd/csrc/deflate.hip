@@ -218,9 +218,9 @@ __device__ __forceinline__ void lds_barrier() {
 // a function of the 32 KiB before the position and nothing else.  So a long stream's links can be made by
 // several workgroups (SEG): each takes seg_positions of them, starts with an empty table at the sweep boundary at
 // least 32768 before its first one, and stores the links of its own positions only.
-// (seg_positions: a multiple of the sweep period; 64 Ki while that leaves the chip workgroups to spare -- half
-// again the work for twice the workgroups -- else 128 Ki)
-constexpr uint32_t CHAIN_SEG_MIN = 4 * SWEEP_PERIOD, CHAIN_SEG_MAX = 8 * SWEEP_PERIOD;
+// (seg_positions: a multiple of the sweep period; 32 or 64 Ki while that leaves the chip workgroups to spare -- twice
+// or half again the work for four times or twice the workgroups -- else 128 Ki)
+constexpr uint32_t CHAIN_SEG_MIN = 2 * SWEEP_PERIOD, CHAIN_SEG_MAX = 8 * SWEEP_PERIOD;
 template <bool SEG>
 __device__ __forceinline__ void lz_chain_workgroup(const uint8_t *__restrict__ src_arena,
                                                    const StreamDesc *__restrict__ descs,
@@ -2372,7 +2372,8 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // 1.77 -> 0.73, 2.38 -> 1.67, 3.16 -> 2.85, 4.78 -> 5.11, 15.6 -> 17.4 ms)
   bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (sps >= 8 && (n <= 2048 || (n <= 4096 && max_src_len >= ((size_t)512 << 10))));
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
-  const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 1024 ? CHAIN_SEG_MIN : CHAIN_SEG_MAX;
+  const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 512 ? CHAIN_SEG_MIN
+                           : n * ((max_src_len + 2 * CHAIN_SEG_MIN - 1) / (2 * CHAIN_SEG_MIN)) <= 1024 ? 2 * CHAIN_SEG_MIN : CHAIN_SEG_MAX;
   const size_t csegs = (max_src_len + chain_seg - 1) / chain_seg;  // lz_chain: workgroups of the longest stream
   if (segmented && (n * sps > 0x7FFFFFFFull || n * bps * EMIT_PARTS > 0x7FFFFFFFull)) segmented = false;
   ParseSegs segs{};
