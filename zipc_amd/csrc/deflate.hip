@@ -1361,7 +1361,9 @@ __global__ __launch_bounds__(64) void lz_parse_gather_kernel(const StreamDesc *_
 // symbols) are taken 64 at a time: each lane turns one item into (value, nbits),
 // an inclusive wave scan gives its bit offset, lanes OR their bits into the LDS
 // staging row, and the completed bytes are flushed with coalesced stores.
-constexpr int PACK_TILES = 2;  // tiles of 64 items packed between two flushes of the staging row
+// (measured, same box, emit on C2 / text with 1 / 2 / 3 / 4 / 6 / 8 tiles: 3.05 / 2.61 / 2.41 / 2.38 / 2.31 / 2.56 and 1.70 / 1.57 / 1.55 / 1.51 /
+// 1.49 / 1.70 ms: fewer flushes per item, until the staging row costs the wave its place on the CU)
+constexpr int PACK_TILES = 6;  // tiles of 64 items packed between two flushes of the staging row
 constexpr int STAGE_WORDS = (7 + PACK_TILES * 64 * 48 + 31) / 32 + 7;  // 7 carried bits + 48 bits per item
 
 // The emit kernel runs one wave per workgroup: LDS operations of one wave execute
