@@ -39,7 +39,10 @@ def test_randomized_parity_bounded(gpu_ctx, oracle):
     {"ZIPC_HIP_MATCH_FORM": "2", "ZIPC_HIP_MATCH_TILES_PER_GROUP": "3", "ZIPC_HIP_SLICES": "2", "ZIPC_HIP_SLICE_MIN": "1"},
     {"ZIPC_HIP_PARSE_SEGMENTS": "1"},                               # lz_parse by a wave per segment whenever a stream has two
     {"ZIPC_HIP_PARSE_SEGMENTS": "1", "ZIPC_HIP_SLICES": "2", "ZIPC_HIP_SLICE_MIN": "1"},
-], ids=["scan-walk", "first-walk", "slices", "scan-walk+groups+slices", "parse-segments", "parse-segments+slices"])
+    {"ZIPC_HIP_DEFLATE_GROUP_BYTES": "300000"},                     # a batch in groups of a few streams through one scratch (batches beyond 8 GiB)
+    {"ZIPC_HIP_DEFLATE_GROUP_BYTES": "500000", "ZIPC_HIP_PARSE_SEGMENTS": "1"},
+], ids=["scan-walk", "first-walk", "slices", "scan-walk+groups+slices", "parse-segments", "parse-segments+slices",
+        "batch-groups", "batch-groups+parse-segments"])
 def test_randomized_parity_under_overrides(env):
     """The same loop in a process of its own under the library's overrides (read once per process), so that
     the paths a 120-stream batch would not reach by itself are compared with the oracle too."""
