@@ -1604,14 +1604,33 @@ __device__ __forceinline__ void wave_make_dynamic_syms(BlockCoder &c, uint32_t *
   // compute_codelen_syms zd.ml:989-1030 (in place: the encoding never expands)
   // (one lane: the scan is serial, and 64 lanes bumping the same counter were 64 stores to one address)
   const int len_max = litlen_count + dist_count - 1;
+  // where the lengths are not zero, as one bit each (a ballot per 64): the end of a run of zeros -- up to 138 of
+  // them, and most of a sparse alphabet's array -- is then the next set bit, not a read per entry
+  constexpr int LC = 5;
+  static_assert(LITLEN_SYM_MAX + 1 + DIST_SYM_MAX + 1 <= LC * 64, "the lengths fit the masks");
+  unsigned long long NZ[LC];
+#pragma unroll
+  for (int cc = 0; cc < LC; cc++) {
+    const int idx = cc * 64 + lane;
+    NZ[cc] = __builtin_amdgcn_ballot_w64(idx > len_max || l[idx] != 0);  // (behind the array: a run ends there)
+  }
+  auto zeros_end = [&](int from) -> int {  // the first entry at or behind `from` that is not zero
+    int r = LC * 64;
+#pragma unroll
+    for (int cc = LC - 1; cc >= 0; cc--) {
+      const int c0 = from >> 6, b0 = from & 63;
+      const unsigned long long m = cc == c0 ? (NZ[cc] >> b0) << b0 : cc > c0 ? NZ[cc] : 0ull;
+      if (m) r = cc * 64 + __builtin_ctzll(m);
+    }
+    return r;
+  };
   int k = 0, i = 0;
   if (lane == 0) {
 #pragma unroll 1
   while (i <= len_max) {
     if (l[i] == 0) {
-      const int mx = len_max < i + 138 - 1 ? len_max : i + 138 - 1;
-      int j = i + 1;
-      while (j <= mx && l[j] == 0) j++;
+      const int ze = zeros_end(i + 1);
+      const int j = ze < i + 138 ? ze : i + 138;
       const int zcount = j - i;
       if (zcount < 3) { l[k] = 0; c.codelen_freq[0]++; i = i + 1; }
       else if (zcount <= 10) { l[k] = ((uint32_t)(zcount - 3) << 8) | 17; c.codelen_freq[17]++; i = j; }
