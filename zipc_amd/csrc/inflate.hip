@@ -227,6 +227,78 @@ __device__ __forceinline__ void wave_tables(InflateLane &d, const LaneLds &L, in
   }
 }
 
+// Phase PH_HDR_LENGTHS by the wave: the code lengths of a dynamic header (read_code_lengths zd.ml:638-669;
+// setup_dynamic_lengths, inflate_lane.h, is the serial form -- one lane, a symbol per turn of three dependent LDS
+// reads: 6.6 % of a stream of the benchmark's symbols, 8.8 % on text).  Like the wide turn: lane i decodes the
+// code-length symbol that would start i bits ahead, the symbols that do start are the chain from lane 0 (pointer
+// doubling), and then everything the serial loop carries from symbol to symbol is a scan over the chain -- where a
+// symbol's lengths go (sum of the repeats before it), how many bits were used before it, and the length a
+// "repeat the previous" symbol repeats (the nearest earlier symbol that has a length of its own).  Every check of
+// the serial loop is made for every symbol that is needed (those that start below the header's count), in the
+// same terms; any of them failing is the same ST_CORRUPTED.  Returns 0: waits for input, -1: corrupt, 1: done.
+__device__ __forceinline__ int wave_dynamic_lengths(InflateLane &d, const LaneLds &L, int lane) {
+  const uint32_t total = (uint32_t)(d.hdr_hlit + d.hdr_hdist);
+  const uint32_t lane4 = (uint32_t)lane * 4u;
+  for (;;) {
+    uint32_t num = (uint32_t)d.hdr_num;
+    if (num >= total) break;
+    if (!d.input_ready(4)) return 0;  // 64 + 14 bits from a position inside a word
+    const uint32_t left = d.bits_left();
+    const uint32_t prev = num > 0 ? (uint32_t)L.u16(LDS_LENGTHS, (int)num - 1) : 0u;
+    const uint32_t p = d.boff + (uint32_t)lane, w = d.in_word + (p >> 5);
+    const uint32_t w0 = L.slot((int)(w & (RING_WORDS - 1))), w1 = L.slot((int)((w + 1u) & (RING_WORDS - 1)));
+    const uint32_t x = funnel32(w1, w0, p & 31u);
+    const uint32_t e = L.u16(LDS_DIST_TBL, (int)(x & ((1u << DIST_TBITS) - 1)));
+    const uint32_t len = e & 15u, sym = e >> 4;
+    const bool no_code = len == 0u || (int)sym > d.hdr_cl_max;  // zd.ml:649
+    const uint32_t extra = sym < 16u ? 0u : sym == 16u ? 2u : sym == 17u ? 3u : 7u;
+    const uint32_t used = no_code ? 64u : len + extra;
+    const uint32_t v = (x >> len) & ((1u << extra) - 1u);
+    const uint32_t repeat = sym < 16u ? 1u : sym == 16u ? 3u + v : (sym == 17u ? 3u : 11u) + v;
+    // the chain of symbol starts from lane 0 (a symbol that ends behind the 64 bits, or is no code, ends it)
+    uint32_t J[7];
+    J[0] = (uint32_t)lane + used < 64u ? ((uint32_t)lane + used) * 4u : lane4;
+#pragma unroll
+    for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+    uint32_t at = 0;
+#pragma unroll
+    for (int k = 6; k >= 0; k--) {
+      const uint32_t y = lane_value(at, J[k]);
+      if (y <= lane4) at = y;
+    }
+    const bool on = at == lane4;
+    // where my lengths go, what was used before me
+    const uint32_t rep = on && !no_code ? repeat : 0u, rincl = wave_scan_incl(rep);
+    const uint32_t start = num + rincl - rep;
+    const uint32_t bits = on && !no_code ? used : 0u, bincl = wave_scan_incl(bits);
+    const bool needed = on && start < total;  // the serial loop would get to this symbol
+    const bool err = needed && (no_code || used > left - (bincl - bits) ||  // (no wrap: an earlier symbol that used more than was left has failed)
+                                (sym == 16u && start == 0u) ||                // zd.ml:653
+                                repeat > total - start);                      // zd.ml:659 (may span litlen / dist)
+    // (a symbol behind a failing one sees a `left` that may have wrapped: it does not matter, the call fails)
+    if (__builtin_amdgcn_ballot_w64(err)) return -1;
+    // the length a symbol fills in: its own, 0, or that of the nearest earlier symbol with one of its own
+    const unsigned long long has_own = __builtin_amdgcn_ballot_w64(needed && sym != 16u);
+    const uint32_t own = sym < 16u ? sym : 0u;
+    const unsigned long long before = has_own & ((1ull << lane) - 1ull);
+    const uint32_t from_lane = before ? 63u - (uint32_t)__builtin_clzll(before) : 0u;
+    const uint32_t theirs = lane_value(from_lane * 4u, own);
+    const uint32_t fill = sym != 16u ? own : before ? theirs : prev;
+    if (needed)
+      for (uint32_t r = 0; r < repeat; r++) L.u16(LDS_LENGTHS, (int)(start + r)) = (uint16_t)fill;
+    // the bits of the needed symbols, the lengths they made
+    const unsigned long long nm = __builtin_amdgcn_ballot_w64(needed);
+    const int last = 63 - __builtin_clzll(nm);  // (lane 0 is always needed here: num < total)
+    const uint32_t used_all = (uint32_t)__builtin_amdgcn_readlane((int)bincl, last);
+    const uint32_t made = (uint32_t)__builtin_amdgcn_readlane((int)rincl, last);
+    d.advance(used_all);
+    d.hdr_num = (int32_t)(num + made);
+    wv::sync();  // the lengths written are read by other lanes (the next turn's `prev`, the tables)
+  }
+  if (L.u16(LDS_LENGTHS, 256) == 0) return -1;  // zd.ml:662
+  return 1;  // the two decoders (zd.ml:663-666) are built in phase PH_TABLES
+}
+
 // A match that could not be queued (overlapping, long, or reading a hole) copied by the
 // whole wave.  Buf.recopy's bytewise overlapped copy (zd.ml:63-75) produces the periodic
 // extension of the last dist bytes, so output byte i is src[i mod dist]: no byte depends
@@ -503,7 +575,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     // ---- decode
     int plain_run = 0;
     for (int turn = 0; turn < ROUND_TURNS;) {
-      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS) {
+      if (d.phase == PH_HDR_LENGTHS) {
+        turn++;
+        ZD_PH_START();
+        const int r = wave_dynamic_lengths(d, L, lane);  // (wave-uniform: every lane keeps the same state)
+        if (r == 0) break;  // waits for input
+        if (r < 0) d.fail(ST_CORRUPTED);
+        else { d.hdr_fixed = 0; d.phase = PH_TABLES; }
+        ZD_PH(ph_hdr);
+      } else if (d.phase == PH_HEADER) {
         turn++;
         ZD_PH_START();
         bool ok = true;
