@@ -28,7 +28,7 @@ elif os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts 
 else:
     src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
 descs = batch.uniform_layout(n, L, batch.deflate_bound(L))
-comp = torch.zeros(n * int(descs["dst_off"][1]) + 256, dtype=torch.uint8, device=dev)
+comp = torch.zeros(n * (int(descs["dst_off"][1]) if n > 1 else batch.deflate_bound(L)) + 256, dtype=torch.uint8, device=dev)
 out = torch.zeros(n * L + 256, dtype=torch.uint8, device=dev)
 d_descs = batch.to_device(descs, dev); d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
 batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, 2, 0)
