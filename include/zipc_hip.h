@@ -109,6 +109,10 @@ void *zipc_hip_stream(zipc_hip_ctx *ctx);
 int zipc_hip_synchronize(zipc_hip_ctx *ctx);
 /* text of the last HIP runtime error seen by this context ("" if none) */
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx);
+/* how the last inflate of ONE stream ran: the number of blocks it was decoded by, a wave per block (inflate.hip),
+ * or 0 when the stream's one wave decoded it (short streams, streams that are not a chain of dynamic blocks,
+ * anything that reports an error).  For tests and measurements; the results are the same either way. */
+unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx);
 /* the reference's message for a status (format strings kept verbatim) */
 const char *zipc_hip_strerror(int status);
 

@@ -6,8 +6,10 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+#include <vector>
 #include "../../zipc_amd/csrc/inflate_lane.h"
 #include "../../zipc_amd/csrc/inflate_span.h"
+#include "../../zipc_amd/csrc/inflate_find.h"
 
 using namespace zd;
 
@@ -138,7 +140,7 @@ struct SpanCall {
 static void span_lane(int lane, void *arg) {
   SpanCall &c = *(SpanCall *)arg;
   static uint16_t idx[SPAN_IDX_ENTRIES];  // the kernel's per-stream slot of global scratch
-  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, lane);
+  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, nullptr, lane);
 }
 extern "C" { uint64_t sim_span_stats[8]; }  // spans run, symbols' bits committed, output bytes committed, per return code
 static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending) {
@@ -164,6 +166,29 @@ static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint
   return c.ret[0];
 }
 
+// where the blocks of the last sim_inflate started (bit, BTYPE): the finder below must find the dynamic ones
+static std::vector<uint64_t> sim_block_bits;
+static std::vector<int> sim_block_types;
+extern "C" uint64_t sim_inflate_block_starts(uint64_t *bits, int *types, uint64_t cap) {
+  for (uint64_t i = 0; i < sim_block_bits.size() && i < cap; i++) { bits[i] = sim_block_bits[i]; types[i] = sim_block_types[i]; }
+  return sim_block_bits.size();
+}
+// inflate_find.h over every bit offset of a stream: the candidates, as inflate.hip's two kernels list them
+extern "C" uint64_t sim_find_candidates(const uint8_t *src, uint64_t src_len, uint64_t *cand, uint64_t cap, uint64_t *n_first) {
+  uint64_t n = 0, nf = 0;
+  const uint64_t total_bits = src_len * 8u;
+  if (cap) cand[n++] = 0;
+  for (uint64_t p = 1; p < total_bits; p++) {
+    if (!find_header_test(find_bits(src, src_len, p), find_bits(src, src_len, p + 64u), total_bits - p)) continue;
+    nf++;
+    if (!find_lengths_test(src, src_len, p)) continue;
+    if (n < cap) cand[n] = p;
+    n++;
+  }
+  *n_first = nf;
+  return n;
+}
+
 extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, uint64_t dst_cap,
                            int has_limit, uint64_t limit, int crc_op, uint64_t *out_len,
                            uint32_t *checksum, int budget) {
@@ -184,11 +209,19 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   const bool span = span_env != nullptr;
   const bool span_desc = span && span_env[0] == 'd';
   refill(d, L, src);
+  sim_block_bits.clear();
+  sim_block_types.clear();
   for (;;) {
     // decode phase: the kernel's round
     for (int turn = 0; turn < budget; turn++) {
       if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS || d.phase == PH_HDR_CODELEN) {
+        const bool at_header = d.phase == PH_HEADER;
+        const uint64_t hbit = (uint64_t)d.in_word * 32u + d.boff;
         if (!lane_header_step(d, L, src)) break;
+        if (at_header) {
+          sim_block_bits.push_back(hbit);
+          sim_block_types.push_back((int)((find_bits(src, src_len, hbit) >> 1) & 3u));
+        }
         if (d.phase == PH_TABLES) lane_finish_tables(d, L);
         if (d.phase == PH_SYMBOLS && !d.fixed_lazy) {
           uint32_t shortest = 15;

@@ -605,3 +605,66 @@ def test_deflate_start_offset_is_the_requested_range(gpu_ctx, oracle):
         adler, z = Z.zlib_compress(data, level="default", start=start, len=n).get_ok()
         assert zlib.decompress(z) == data[start:start + n]  # (text and 4-bit bytes: the two Adler-32s agree)
         assert adler == zlib.adler32(data[start:start + n])
+
+
+def _one_stream_sources(n):
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "SURVEY.md"), "rb").read() + open(os.path.join(root, "BASELINE.md"), "rb").read()
+    rng = np.random.default_rng(21)
+    yield "text", (text * (n // len(text) + 1))[:n]
+    yield "symbols", (rng.integers(0, 16, n, dtype=np.uint8) * 17).astype(np.uint8).tobytes()
+    yield "records", (rng.integers(0, 1 << 14, n // 4 + 1, dtype=np.uint32) * np.uint32(0x10001)).tobytes()[:n]
+
+
+def _raw_zlib(data, level, flush_every=0):
+    c = zlib.compressobj(level, zlib.DEFLATED, -15)
+    if not flush_every:
+        return c.compress(data) + c.flush()
+    out = b""  # (a full flush ends the block and puts an empty stored block behind it: stored blocks inside the chain)
+    for i in range(0, len(data), flush_every):
+        out += c.compress(data[i:i + flush_every]) + c.flush(zlib.Z_FULL_FLUSH)
+    return out + c.flush()
+
+
+def test_one_stream_inflates_by_a_wave_per_block(gpu_ctx, oracle):
+    """ONE stream per call -- the shape of the reference's inflate (zipc_deflate.mli:79-97) -- long enough to be
+    decoded by a wave per block (inflate.hip: find, dry, chain, token, resolve): streams of the reference's encoder
+    (dynamic blocks, a fixed block at the end) and of zlib (other block sizes; with full flushes: empty stored
+    blocks in the chain), bytes and CRC-32 equal to the source's, and the path really taken."""
+    from zipc_amd import zipc_deflate as Z
+
+    n = 1200000
+    for name, data in _one_stream_sources(n):
+        streams = [("oracle-2", oracle.deflate(data, level=2)[1]), ("zlib-1", _raw_zlib(data, 1)), ("zlib-6", _raw_zlib(data, 6)),
+                   ("zlib-9-flushes", _raw_zlib(data, 9, 200000))]
+        for enc, raw in streams:
+            got, crc = Z.inflate_and_crc_32(raw, decompressed_size=n).get_ok()
+            assert gpu_ctx.last_inflate_blocks() >= 6, (name, enc, gpu_ctx.last_inflate_blocks())
+            assert got == data and crc == zlib.crc32(data), (name, enc)
+            # no size given: the first tries are too small (the stream's one wave says so), the last one fits
+            assert Z.inflate(raw).get_ok() == data, (name, enc)
+
+
+def test_one_stream_by_blocks_leaves_errors_to_the_streams_wave(gpu_ctx, oracle):
+    """what the block path must not decide: damaged streams, cut streams, sizes that do not fit -- status and
+    message of the oracle, whatever the blocks before the damage were decoded by"""
+    from zipc_amd import zipc_deflate as Z
+
+    n = 600000
+    rnd = random.Random(8)
+    for name, data in _one_stream_sources(n):
+        raw = _raw_zlib(data, 6)
+        cases = [("cut", raw[:len(raw) * 2 // 3], n), ("one byte short", raw[:-1], n), ("limit one short", raw, n - 1),
+                 ("limit far short", raw, n // 2), ("garbage behind", raw + bytes(rnd.randrange(256) for _ in range(999)), n)]
+        for k in range(6):
+            at = rnd.randrange(len(raw) // 8, len(raw))
+            cases.append(("flipped bit at %d" % at, raw[:at] + bytes([raw[at] ^ (1 << rnd.randrange(8))]) + raw[at + 1:], n))
+        for what, s, lim in cases:
+            st0, d0, c0 = oracle.inflate(s, decompressed_size=lim, crc_op=oracle.CRC_CRC32)
+            r = Z.inflate_and_crc_32(s, decompressed_size=lim)
+            assert r.is_ok() == (st0 == 0), (name, what)
+            if st0 == 0:
+                assert r.get_ok() == (d0, c0), (name, what)
+            else:
+                assert r.error == oracle.MESSAGES[st0], (name, what)

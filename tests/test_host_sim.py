@@ -367,3 +367,43 @@ def test_huffman_two_queues_equal_the_heap(sim):
         a = np.zeros(n, np.uint32)
         b = np.zeros(n, np.uint32)
         assert sim.sim_huff_lengths(f.ctypes.data, max_sym, max_len, a.ctypes.data, b.ctypes.data) == 0, (it, fr)
+
+
+def _find_sources():
+    import os
+    import zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = (open(os.path.join(root, "SURVEY.md"), "rb").read() + open(os.path.join(root, "BASELINE.md"), "rb").read() * 40)[:150000]
+    assert len(text) == 150000
+    rnd = random.Random(11)
+    symbols = bytes(rnd.randrange(16) * 17 for _ in range(150000))
+    records = b"".join(bytes([rnd.randrange(256), rnd.randrange(64)]) * 2 for _ in range(40000))
+    for name, data in (("text", text), ("symbols", symbols), ("records", records)):
+        yield name, data, zlib
+
+
+def test_block_header_search_finds_every_dynamic_block(sim, oracle):
+    """inflate_find.h (the search of inflate.hip's one-stream path) over every bit offset of streams of the
+    reference's encoder (the oracle) and of zlib: every block with a dynamic header is found where the inflate model
+    says it starts, and next to nothing else passes."""
+    sim.sim_find_candidates.restype = C.c_uint64
+    sim.sim_inflate_block_starts.restype = C.c_uint64
+    for name, data, zlib in _find_sources():
+        streams = [("oracle-%d" % lv, oracle.deflate(data, level=lv)[1]) for lv in (1, 2)]
+        for lv in (1, 6):
+            c = zlib.compressobj(lv, zlib.DEFLATED, -15)
+            streams.append(("zlib-%d" % lv, c.compress(data) + c.flush()))
+        for enc, raw in streams:
+            st, d, _ = sim_inflate(sim, raw, len(data), limit=len(data))
+            assert st == 0 and d == data, (name, enc)
+            bits, types = (C.c_uint64 * 4096)(), (C.c_int * 4096)()
+            nb = sim.sim_inflate_block_starts(bits, types, 4096)
+            starts = {int(bits[i]) for i in range(nb) if types[i] == 2}
+            assert nb >= 2 and len(starts) >= 1, (name, enc, nb)
+            cand, nf = (C.c_uint64 * 65536)(), C.c_uint64()
+            nc = sim.sim_find_candidates(raw, len(raw), cand, 65536, C.byref(nf))
+            found = {int(cand[i]) for i in range(nc)}
+            assert 0 in found
+            assert starts <= found, (name, enc, sorted(starts - found))
+            assert len(found - starts - {0}) <= 1, (name, enc, sorted(found - starts))
+            assert nf.value < len(raw) // 32  # what the first test lets through to the second

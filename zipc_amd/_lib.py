@@ -58,6 +58,7 @@ SYMBOLS = [
     ("zipc_hip_stream", _P, [_P]),
     ("zipc_hip_synchronize", C.c_int, [_P]),
     ("zipc_hip_last_error", C.c_char_p, [_P]),
+    ("zipc_hip_last_inflate_blocks", C.c_uint, [_P]),
     ("zipc_hip_strerror", C.c_char_p, [C.c_int]),
     ("zipc_hip_set_profiling", C.c_int, [_P, C.c_int]),
     ("zipc_hip_set_adler_rfc1950", C.c_int, [_P, C.c_int]),
@@ -141,6 +142,10 @@ class Context:
         """the zlib forms and checksum_device of this context compute RFC 1950's Adler-32 (what zlib
         computes) instead of the reference's signed-remainder value (include/zipc_hip.h)"""
         self.check(lib().zipc_hip_set_adler_rfc1950(self._h, int(on)))
+
+    def last_inflate_blocks(self) -> int:
+        """blocks the last one-stream inflate was decoded by, a wave each (0: by the stream's one wave)"""
+        return int(lib().zipc_hip_last_inflate_blocks(self._h))
 
     def set_profiling(self, on: bool):
         self.check(lib().zipc_hip_set_profiling(self._h, int(on)))

@@ -330,6 +330,8 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch); free_buf(ctx->parse_scratch);
   free_buf(ctx->inflate_scratch);
+  free_buf(ctx->blocks_scratch);
+  free_buf(ctx->tok_scratch);
   free_buf(ctx->stored_list);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
@@ -352,6 +354,7 @@ int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
 }
 
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx) { return ctx ? ctx->last_inflate_blocks : 0u; }
 
 int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled) {
   if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
@@ -511,6 +514,99 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
   return ZIPC_HIP_OK;
 }
 
+// One stream of at least BLOCKS_MIN_SRC bytes by a wave per block (inflate.hip: find, dry, chain, token, resolve).
+// *handled: the stream went that way (result and, if asked for, CRC-32 are in d_results); else it is left to
+// inflate_batch_kernel -- a stream that is not a chain of dynamic blocks behind its first block, anything the dry
+// run or the chain did not like: the one-wave kernel owns the reference's messages.  Reads a
+// few words back between its steps: it SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0 turns it off.
+constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
+constexpr uint32_t BLOCKS_CAND_CAP = 65536;
+static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                             zipc_hip_stream_result *d_results, int crc_op, bool *handled) {
+  *handled = false;
+  ctx->last_inflate_blocks = 0;
+  static const bool enabled = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS"); return !(e && e[0] == '0'); }();
+  if (!enabled || (crc_op != ZIPC_HIP_CRC_NOP && crc_op != ZIPC_HIP_CRC_CRC32)) return ZIPC_HIP_OK;
+  StreamDesc sd;
+  HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (sd.src_len < BLOCKS_MIN_SRC || sd.src_len > BLOCKS_MAX_SRC || sd.dst_cap < 8 || sd.dst_cap > MAX_STREAM_LEN) return ZIPC_HIP_OK;
+  const uint32_t first_cap = (uint32_t)(sd.src_len / 8 + 4096);
+  uint32_t cand_cap = (uint32_t)(sd.src_len / 512 + 64);
+  if (cand_cap > BLOCKS_CAND_CAP) cand_cap = BLOCKS_CAND_CAP;
+  const uint32_t chain_cap = 2 * cand_cap;  // (blocks whose header cannot be looked for -- fixed, stored -- join the chain)
+  // scratch: counts | first | cand | sorted | ends | chain | chain_end | span index
+  size_t off = 0;
+  auto carve = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+  const size_t o_counts = carve(sizeof(FindCounts)), o_first = carve((size_t)first_cap * 4), o_cand = carve((size_t)cand_cap * 4),
+               o_sorted = carve((size_t)cand_cap * sizeof(BlockStart)), o_ends = carve((size_t)cand_cap * sizeof(BlockEnd)),
+               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd)),
+               o_span = carve((size_t)chain_cap * INFLATE_SCRATCH_PER_STREAM);
+  HIP_TRY(ctx, ctx->ensure(ctx->blocks_scratch, off));
+  uint8_t *base = (uint8_t *)ctx->blocks_scratch.p;
+  FindCounts *d_counts = (FindCounts *)(base + o_counts);
+  uint32_t *d_first = (uint32_t *)(base + o_first), *d_cand = (uint32_t *)(base + o_cand);
+  BlockStart *d_sorted = (BlockStart *)(base + o_sorted), *d_chain = (BlockStart *)(base + o_chain);
+  BlockEnd *d_ends = (BlockEnd *)(base + o_ends), *d_chain_end = (BlockEnd *)(base + o_chain_end);
+  uint16_t *d_span = (uint16_t *)(base + o_span);
+  const uint8_t *src = (const uint8_t *)d_src_arena;
+  uint8_t *dst = (uint8_t *)d_dst_arena;
+  const StreamDesc *dd = (const StreamDesc *)d_descs;
+
+  HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, sizeof(FindCounts), ctx->stream));
+  ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel, dim3((unsigned)((sd.src_len + 255) / 256)), dim3(256), 0, src, dd,
+            d_first, first_cap, d_counts);
+  ZD_LAUNCH(ctx, "inflate_find_lengths", inflate_find_lengths_kernel, dim3((first_cap + 63u) / 64u), dim3(64), 0, src, dd,
+            (const uint32_t *)d_first, first_cap, d_cand, cand_cap, d_counts);
+  FindCounts fc;
+  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  static const int stage = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS_STAGE"); return e ? atoi(e) : 99; }();  // (debugging: stop behind a step)
+  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
+  if (stage < 2) return ZIPC_HIP_OK;
+  if (fc.n_cand < 2 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;  // (one block: nothing to gain)
+  const uint32_t n = fc.n_cand;
+  ZD_LAUNCH(ctx, "inflate_sort_candidates", inflate_sort_candidates_kernel, dim3((n + 255u) / 256u), dim3(256), 0,
+            (const uint32_t *)d_cand, n, d_sorted);
+  if (stage < 3) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return ZIPC_HIP_OK; }
+  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const BlockStart *)d_sorted,
+            d_ends, n, d_span);
+  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockStart *)d_sorted,
+            (const BlockEnd *)d_ends, n, d_chain, d_chain_end, chain_cap, d_span, d_counts);
+  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len);
+  if (stage < 4) return ZIPC_HIP_OK;
+  if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;
+  const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
+  if (out_len == 0) return ZIPC_HIP_OK;
+  HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 4));
+  uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
+  const unsigned out_grid = (out_len + 255u) / 256u;
+  ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
+  ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(nb), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
+            (const BlockEnd *)d_chain_end, nb, d_span, d_tok, d_counts);
+  if (stage < 5) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return ZIPC_HIP_OK; }
+  for (int r = 0; r < RESOLVE_ROUNDS; r++)
+    ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len, d_counts, r);
+  ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
+  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[RESOLVE_ROUNDS - 1]);
+  if (fc.token_bad != 0 || fc.more[RESOLVE_ROUNDS - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
+  StreamResult res;
+  res.status = ZIPC_HIP_OK; res.checksum = 0; res.out_len = out_len;
+  HIP_TRY(ctx, hipMemcpyAsync(d_results, &res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (res leaves the stack)
+  ctx->last_inflate_blocks = nb;
+  if (crc_op == ZIPC_HIP_CRC_CRC32) {
+    const int st = crc32_pass(ctx, dst, RANGE_INFLATE_OUT, dd, (StreamResult *)d_results, 1, 0, 0, (size_t)out_len, nullptr);
+    if (st) return st;
+  }
+  *handled = true;
+  return ZIPC_HIP_OK;
+}
+
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
                            size_t n_streams, size_t max_dst_cap, int crc_op) {
@@ -520,6 +616,11 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_streams == 1 && max_dst_cap > MAX_STREAM_LEN)
     return inflate_huge_stream(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op);
+  if (n_streams == 1 && max_dst_cap >= BLOCKS_MIN_SRC) {
+    bool handled = false;
+    const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op, &handled);
+    if (by != ZIPC_HIP_OK || handled) return by;
+  }
   // one wave per stream (ZIPC_HIP_SLICES > 1: in slices on queues of their own, the CRC pass of one slice
   // beside the inflate kernel of the next; measured, not the default: deflate.hip)
   HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));

@@ -40,6 +40,7 @@
 // not exec-mask arithmetic.  LDS: 10072 B per stream (inflate_lane.h has the map): 16 streams per CU.
 #include "inflate_lane.h"
 #include "inflate_span.h"
+#include "inflate_find.h"
 #include "kernels.h"
 #include "wave_ops.h"
 
@@ -404,8 +405,8 @@ __device__ __forceinline__ uint32_t match_run(InflateLane &d, const LaneLds &L, 
 // LEVELS: the path has at most 63 / (shortest code of the block) symbols, so
 // 2^LEVELS - 1 hops of doubling are enough (InflateLane::levels).
 // PLENTY: the input does not end within the turn's reach, no lane can run out of bits.
-template <int LEVELS, bool PLENTY>
-__device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane) {
+template <int LEVELS, bool PLENTY, int MODE>
+__device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, uint32_t *__restrict__ tok, int lane) {
   typedef unsigned long long mask_t;  // one bit per lane; the predicates of the turn are kept as masks
   // the symbol that would start at my offset
   const uint32_t p = d.boff + (uint32_t)lane;
@@ -466,8 +467,10 @@ __device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, 
   const uint32_t h0 = d.hole_min;
   const uint32_t h1 = h0 < first_match_dst ? h0 : first_match_dst;  // also what queued destinations are relative to
   const uint32_t hole = mrank == 0 ? h0 : h1;  // the turn's first match only sees the queued copies
-  const uint32_t bad_match = over(sp.dist, dstp) | over(mrank + 1u, qfree) | over(dstp - h1, QUEUE_REL_MAX) |
-                             over(src_end, hole);
+  // (IM_DRY / IM_TOKEN copy nothing: no queue, no holes)
+  const uint32_t bad_match = MODE != IM_REAL ? over(sp.dist, dstp)
+                                             : over(sp.dist, dstp) | over(mrank + 1u, qfree) | over(dstp - h1, QUEUE_REL_MAX) |
+                                                   over(src_end, hole);
   const uint32_t bad = over(outoff + outlen, room) | (lane_in(match0_m) ? bad_match : 0u);
   const mask_t late_m = commit0_m & wave_mask(bad != 0u);
   // the path ends in a stop, or it runs into the sink (bit 63: the sink's own hop
@@ -476,18 +479,25 @@ __device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, 
   const uint32_t c = (uint32_t)__builtin_ctzll(cut_m);  // a lane on the path, or the sink
   const mask_t commit_m = commit0_m & ((1ull << c) - 1ull);
   const mask_t commit_match_m = commit_m & match_m;
-  if (lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
+  if (MODE != IM_DRY && lane_in(commit_m & lit_m)) dst[dstp] = (uint8_t)sp.lit;
   // every lane writes a queue word: the ones without a committed match into the spare slot
-  L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - h1, sp.dist, sp.length);
+  if (MODE == IM_REAL)
+    L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - h1, sp.dist, sp.length);
+  if (MODE == IM_TOKEN && lane_in(commit_match_m)) {
+    const uint32_t from = dstp - sp.dist;
+    for (uint32_t i = 0; i < sp.length; i++) tok[dstp + i] = from + i;
+  }
   // bytes produced: what precedes the cut lane.  Bits used: up to the cut lane, or
   // past it when the last symbol runs over the sink.
   d.out_pos += (uint32_t)__builtin_amdgcn_readlane((int)outoff, (int)c);
   const uint32_t end_c = lane_in(commit_m) ? end : 0u;
   const uint32_t end_last = (uint32_t)__builtin_amdgcn_readlane((int)end_c, (63 - __clzll((long long)commit_m)) & 63);
   const uint32_t consumed = c > end_last ? c : end_last;
-  const uint32_t fm_kept = fm_lane < c ? first_match_dst : INF;  // the first match, if it was committed
-  d.hole_min = d.hole_min < fm_kept ? d.hole_min : fm_kept;
-  d.q_count += (uint32_t)__popcll(commit_match_m);
+  if (MODE == IM_REAL) {
+    const uint32_t fm_kept = fm_lane < c ? first_match_dst : INF;  // the first match, if it was committed
+    d.hole_min = d.hole_min < fm_kept ? d.hole_min : fm_kept;
+    d.q_count += (uint32_t)__popcll(commit_match_m);
+  }
   d.advance(consumed);
   return c;
 }
@@ -495,8 +505,8 @@ __device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, 
 // Wide turns until one stops, the round's turns are used up or the staged input
 // runs low.  Only the position and the output/queue counters change in here; the
 // rest of the state stays put in its scalar registers.
-template <int LEVELS>
-__device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane,
+template <int LEVELS, int MODE>
+__device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, uint32_t *__restrict__ tok, int lane,
                                            int &turn) {
   // turns with input to spare (PLENTY) while the staged words reach, then the careful form
   const uint32_t total = d.total_words();
@@ -507,38 +517,59 @@ __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uin
     if (turn >= ROUND_TURNS) return false;
     if (d.in_word >= fast_below) break;
     turn++;
-    if (wide_turn<LEVELS, true>(d, L, dst, lane) < 63u) return true;
+    if (wide_turn<LEVELS, true, MODE>(d, L, dst, tok, lane) < 63u) return true;
   }
   for (;;) {
     if (turn >= ROUND_TURNS) return false;
     if (!d.input_ready(TURN_WORDS)) return false;
     turn++;
-    if (wide_turn<LEVELS, false>(d, L, dst, lane) < 63u) return true;
+    if (wide_turn<LEVELS, false, MODE>(d, L, dst, tok, lane) < 63u) return true;
   }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
-                                                           uint8_t *__restrict__ dst_arena,
-                                                           const StreamDesc *__restrict__ descs,
-                                                           StreamResult *__restrict__ results,
-                                                           uint32_t n_streams, uint16_t *__restrict__ span_scratch, int crc_op) {
-  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+// A match handed to the wave, by MODE: its bytes (wave_copy_match), nothing, or where its bytes come from
+template <int MODE>
+__device__ __forceinline__ void wave_match(uint8_t *dst, uint32_t *__restrict__ tok, uint32_t pos, uint32_t dist, uint32_t len, int lane,
+                                           uint8_t *pattern) {
+  if (MODE == IM_REAL) wave_copy_match(dst, pos, dist, len, lane, pattern);
+  else if (MODE == IM_TOKEN)
+    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) tok[pos + i] = pos - dist + i;
+}
+
+// A block of ONE stream decoded by a wave of its own (IM_DRY, IM_TOKEN): where it starts in the stream's input and
+// in its output.  IM_DRY knows neither the output position nor what lies before it: it counts from BLOCK_DRY_BASE,
+// where every distance is allowed, and reports the block's size and end; IM_TOKEN is given the real position and so
+// makes the reference's check of a distance against it (zd.ml:614).
+constexpr uint32_t BLOCK_DRY_BASE = 32768;
+
+// The stream's wave: MODE IM_REAL is the whole stream (inflate_batch_kernel); the other two stop at the end of the
+// block they were started on.
+// (returns, in every lane, what the block modes found of their block)
+template <int MODE>
+__device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                                 const StreamDesc &sd, const BlockStart at, StreamResult *__restrict__ result,
+                                                 uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op) {
   const int lane = threadIdx.x;
-  const uint32_t stream = blockIdx.x;
-  if (stream >= n_streams) return;
-  const bool crc_adler = crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC;
+  const bool crc_adler = MODE == IM_REAL && (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC);
   const bool adler_rfc = crc_op == CRC_ADLER32_RFC;
-  const bool writer = lane == 0;
+  const bool writer = lane == 0 && MODE != IM_DRY;  // (the lane that stores a literal decoded alone)
 
   LaneLds L;
   L.at(lds_raw);  // (the input ring first: its reads encode their offsets)
-  uint16_t *span_idx = span_scratch + (size_t)stream * SPAN_IDX_ENTRIES;
 
   Arenas A;
   A.src = src_arena;
   A.dst = dst_arena;
   InflateLane d;
-  lane_init(d, descs[stream]);
+  lane_init(d, sd);
+  if (MODE != IM_REAL && d.status == ST_OK) {
+    d.in_word = (uint32_t)(at.bit >> 5);
+    d.boff = (uint32_t)at.bit & 31u;
+    d.ring_wr = d.in_word;
+    d.out_pos = MODE == IM_DRY ? BLOCK_DRY_BASE : at.out_pos;
+    d.blk_out_start = d.out_pos;
+    if (MODE == IM_DRY) d.hard_cap = d.limit = d.cap_min = (uint32_t)MAX_STREAM_LEN;
+  }
   uint8_t *dst = dst_arena + d.dst_off;
   const uint8_t *src = src_arena + d.src_off;
 
@@ -587,7 +618,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         turn++;
         ZD_PH_START();
         bool ok = true;
-        if (writer) ok = lane_header_step(d, L, src_arena);
+        if (lane == 0) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
         if (!uni((uint32_t)ok)) break;  // waits for input
         ZD_PH(ph_hdr);
@@ -607,14 +638,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {  // a fixed block's first symbols, straight from the code
         turn++;
         ZD_PH_START();
-        const int r = lane_one_symbol_fixed(d, L, A, writer);
+        const int r = lane_one_symbol_fixed(d, L, A, writer, MODE == IM_REAL);
         uniformize(d);
         const int ru = uni(r);
         ZD_PH(ph_plain);
-        if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); }
+        if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); if (MODE != IM_REAL) d.phase = PH_DONE; }
         else if (ru == SYM_STOP) {
           if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
-            wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
+            wave_match<MODE>(dst, tok, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
             lane_after_match(d);
           } else break;
         }
@@ -625,9 +656,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           const uint32_t out_before = d.out_pos;
           ZD_PH_START();
 #ifdef ZD_INFLATE_PHASES
-          const int sr = span_decode(d, L, src, dst, span_idx, lane, span_ph);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, lane, span_ph);
 #else
-          const int sr = span_decode(d, L, src, dst, span_idx, lane);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, lane);
 #endif
           if (sr != SPAN_NONE) {
             uniformize(d);
@@ -653,25 +684,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         if (plain_run > 0) { plain_run--; turn++; }
         else {
           const uint32_t before = d.out_pos;
-          if (d.levels == 4) stopped = wide_turns<4>(d, L, dst, lane, turn);
-          else if (d.levels == 5) stopped = wide_turns<5>(d, L, dst, lane, turn);
-          else stopped = wide_turns<6>(d, L, dst, lane, turn);
+          if (d.levels == 4) stopped = wide_turns<4, MODE>(d, L, dst, tok, lane, turn);
+          else if (d.levels == 5) stopped = wide_turns<5, MODE>(d, L, dst, tok, lane, turn);
+          else stopped = wide_turns<6, MODE>(d, L, dst, tok, lane, turn);
           if (stopped && d.out_pos == before) plain_run = 6;
         }
         ZD_PH(ph_wide);
         if (stopped) {
           const uint32_t pos_before = d.in_word * 32u + d.boff;
-          const int r = lane_one_symbol(d, L, A, writer);
+          const int r = lane_one_symbol(d, L, A, writer, MODE == IM_REAL);
           uniformize(d);
           const int ru = uni(r);
           ZD_PH(ph_plain);
-          if (ru == SYM_EOB) lane_end_of_block(d, crc_adler);
+          if (ru == SYM_EOB) { lane_end_of_block(d, crc_adler); if (MODE != IM_REAL) d.phase = PH_DONE; }
           else if (ru == SYM_STOP) {
             // a match that cannot be queued (long, or overlapping its own output) and nothing queued
             // before it: the wave copies it here and now instead of going round through the services
             if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
               d.req_len = match_run(d, L, lane, d.in_word * 32u + d.boff - pos_before);
-              wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
+              wave_match<MODE>(dst, tok, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
               lane_after_match(d);
               continue;
             }
@@ -693,11 +724,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       d.hole_min = 0xFFFFFFFFu;
     }
     if (d.phase == PH_REQ_MATCH) {
-      wave_copy_match(dst, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
+      wave_match<MODE>(dst, tok, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
       lane_after_match(d);
     } else if (d.phase == PH_REQ_COPY) {
-      wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
+      if (MODE != IM_DRY) wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
       lane_after_copy(d, crc_adler);
+      if (MODE != IM_REAL) d.phase = PH_DONE;
     }
     if (d.phase == PH_REQ_ADLER) {
       // the block's bytes were stored by other lanes of this wave: make them visible
@@ -708,6 +740,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     if (d.phase == PH_DONE && d.q_count == 0) break;
   }
 
+  BlockEnd e;
+  e.status = d.status;
+  e.final_block = (uint32_t)d.final_block;
+  e.end_bit = (uint64_t)d.in_word * 32u + d.boff;
+  e.out_len = d.out_pos - (MODE == IM_DRY ? BLOCK_DRY_BASE : at.out_pos);
+  e.pad = 0;
+  if (MODE != IM_REAL) return e;
   if (writer) {
     StreamResult r;
     r.status = d.status;
@@ -721,8 +760,203 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     r.out_len = (ph_wide >> 6) | ((ph_plain >> 6) << 32);
     for (int i = 0; i < 8; i++) ((uint64_t *)dst)[i] = span_ph[i];  // over the stream's first output bytes (dst slots are 256-byte aligned)
 #endif
-    results[stream] = r;
+    *result = r;
   }
+  return e;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
+                                                           uint8_t *__restrict__ dst_arena,
+                                                           const StreamDesc *__restrict__ descs,
+                                                           StreamResult *__restrict__ results,
+                                                           uint32_t n_streams, uint16_t *__restrict__ span_scratch, int crc_op) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const uint32_t stream = blockIdx.x;
+  if (stream >= n_streams) return;
+  BlockStart at;
+  at.bit = 0; at.out_pos = 0; at.pad = 0;
+  inflate_wave<IM_REAL>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
+                        span_scratch + (size_t)stream * SPAN_IDX_ENTRIES, nullptr, crc_op);
+}
+
+
+// ---------------------------------------------------------------------------------
+// ONE stream by a wave per BLOCK -- the shape of the reference's own functions (inflate zd.ml:711-724 takes one
+// stream), where the kernel above has one wave to give.  A block's symbols can be walked without anything that lies
+// before it, and where its bytes come from can be written down without knowing them:
+//
+//   find    every bit offset of the input is tried as the header of a dynamic block (zd.ml:638-669: the block type,
+//           the three counts in range, a code-length code that is complete, then the code lengths read with it: a
+//           literal/length code that is complete and has an end-of-block symbol, a distance code that is complete,
+//           single or empty).  A block's real header passes; of random bits about one offset in 2^30 does.
+//           (inflate_find_headers_kernel: a thread per input byte, 8 offsets; inflate_find_lengths_kernel: a thread
+//           per offset that got as far as the code-length code.)  Bit 0 is a block's start whatever its type.
+//   dry     a wave per candidate runs the stream's wave (IM_DRY) over that one block: every check but the distance
+//           against the output position, nothing stored: the block's end bit, size, status.
+//   chain   from bit 0 on, a block must end where a candidate starts, until a final block: the blocks' output
+//           positions.  Anything else -- a fixed or stored block behind the first, an error, output beyond the
+//           limit -- and the stream is left to inflate_batch_kernel, which owns every message of the reference.
+//   token   a wave per block of the chain runs the stream's wave again (IM_TOKEN) at the block's real output
+//           position: literals (and stored bytes) are stored, every byte of a match gets, in tok[], the position
+//           it is a copy of (a position that holds a literal is a copy of itself).
+//   resolve tok[i] <- tok[tok[i]] until every byte points at a literal (pointer jumping: rounds ~ log of the longest
+//           chain of copies, whatever blocks it crosses), then out[i] = out[tok[i]].
+
+__global__ __launch_bounds__(256) void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena,
+                                                                  const StreamDesc *__restrict__ descs, uint32_t *__restrict__ first,
+                                                                  uint32_t first_cap, FindCounts *__restrict__ counts) {
+  const StreamDesc sd = descs[0];
+  const uint8_t *s = src_arena + sd.src_off;
+  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  if (t >= sd.src_len) return;
+  const uint64_t total_bits = sd.src_len * 8u;
+  const uint64_t a = find_bits(s, sd.src_len, t * 8u), b = find_bits(s, sd.src_len, t * 8u + 64u);
+#pragma unroll 1
+  for (uint32_t off = 0; off < 8u; off++) {
+    if (t == 0 && off == 0) continue;  // (bit 0 is a candidate anyway)
+    if (!find_header_test(off ? (a >> off) | (b << (64u - off)) : a, b >> off, total_bits - (t * 8u + off))) continue;
+    const uint32_t at = atomicAdd(&counts->n_first, 1u);
+    if (at < first_cap) first[at] = (uint32_t)(t * 8u + off);
+  }
+}
+
+// the code lengths behind a header that passed: a thread per offset
+__global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_arena,
+                                                                 const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ first,
+                                                                 uint32_t first_cap, uint32_t *__restrict__ cand, uint32_t cand_cap,
+                                                                 FindCounts *__restrict__ counts) {
+  const StreamDesc sd = descs[0];
+  const uint8_t *s = src_arena + sd.src_off;
+  const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+  uint32_t n_first = counts->n_first;
+  if (n_first > first_cap) n_first = first_cap;
+  if (i == 0) {  // bit 0
+    const uint32_t at = atomicAdd(&counts->n_cand, 1u);
+    if (at < cand_cap) cand[at] = 0;
+  }
+  if (i >= n_first) return;
+  const uint32_t start = first[i];
+  if (!find_lengths_test(s, sd.src_len, start)) return;
+  const uint32_t at = atomicAdd(&counts->n_cand, 1u);
+  if (at < cand_cap) cand[at] = start;
+}
+
+// the candidates in stream order: each finds its rank (they are few, and all different)
+__global__ __launch_bounds__(256) void inflate_sort_candidates_kernel(const uint32_t *__restrict__ cand, uint32_t n,
+                                                                     BlockStart *__restrict__ sorted) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mine = cand[i];
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < n; j++) r += cand[j] < mine ? 1u : 0u;
+  BlockStart b;
+  b.bit = mine; b.out_pos = 0; b.pad = 0;
+  sorted[r] = b;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_dry_kernel(
+    const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+    const BlockStart *__restrict__ starts, BlockEnd *__restrict__ ends, uint32_t n, uint16_t *__restrict__ span_scratch) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const uint32_t b = blockIdx.x;
+  if (b >= n) return;
+  const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], starts[b], nullptr,
+                                          span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP);
+  if (threadIdx.x == 0) ends[b] = e;
+}
+
+// The chain of blocks from bit 0, by one wave.  chain[k]: block k's header bit and output position; chain_end[k]:
+// what the dry run said of it (the token run must agree).  A block that ends where no candidate starts is followed
+// by a block whose header could not be looked for -- a fixed or a stored one (the reference's encoder ends nearly
+// every stream with a fixed block of a few bytes): this wave makes its dry run here and now, and goes on.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_chain_kernel(
+    const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+    const BlockStart *__restrict__ starts, const BlockEnd *__restrict__ ends, uint32_t n, BlockStart *__restrict__ chain,
+    BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const StreamDesc sd = descs[0];
+  const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
+  uint64_t out = 0, bit = 0;
+  uint32_t j = 0, k = 0, walked = 0;  // candidates below j start before `bit`
+  bool ok = n != 0 && starts[0].bit == 0;
+  while (ok) {
+    while (j < n && starts[j].bit < bit) j++;
+    BlockEnd e;
+    if (j < n && starts[j].bit == bit) e = ends[j];
+    else {
+      BlockStart at;
+      at.bit = bit; at.out_pos = 0; at.pad = 0;
+      walked++;
+      e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, sd, at, nullptr, span_scratch, nullptr, CRC_NOP);
+    }
+    if (e.status != ST_OK || out + e.out_len > room || out + e.out_len > MAX_STREAM_LEN || k >= chain_cap) { ok = false; break; }
+    if (threadIdx.x == 0) {
+      BlockStart b;
+      b.bit = bit; b.out_pos = (uint32_t)out; b.pad = 0;
+      chain[k] = b;
+      chain_end[k] = e;
+    }
+    k++;
+    out += e.out_len;
+    if (e.final_block) break;
+    if (e.end_bit <= bit) { ok = false; break; }  // (cannot be: a block has a header)
+    bit = e.end_bit;
+  }
+  if (threadIdx.x == 0) {
+    counts->chain_ok = ok ? 1u : 0u;
+    counts->n_blocks = k;
+    counts->out_len = out;
+    counts->n_walked = walked;
+  }
+}
+
+__global__ __launch_bounds__(256) void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i < n) tok[i] = i;
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_token_kernel(
+    const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+    const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end, uint32_t n,
+    uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok, FindCounts *__restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const uint32_t b = blockIdx.x;
+  if (b >= n) return;
+  const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[0], chain[b], nullptr,
+                                              span_scratch + (size_t)b * SPAN_IDX_ENTRIES, tok, CRC_NOP);
+  if (threadIdx.x == 0) {
+    const BlockEnd want = chain_end[b];
+    if (got.status != ST_OK || got.end_bit != want.end_bit || got.out_len != want.out_len) atomicAdd(&counts->token_bad, 1u);
+  }
+}
+
+// One round of pointer jumping, up to RESOLVE_HOPS hops a thread: a pointer only ever moves to an earlier byte of
+// the same chain of copies, so reading one that another thread has already moved is as good.  more[round] counts
+// threads that did not arrive; a round whose predecessor left none returns at once (the rounds are all launched).
+constexpr int RESOLVE_HOPS = 8;
+__global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts,
+                                                             int round) {
+  if (round > 0 && counts->more[round - 1] == 0u) return;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  bool open = false;
+  if (i < n) {
+    uint32_t j = tok[i];
+    if (j != i) {
+      uint32_t j2 = tok[j];
+      for (int h = 1; h < RESOLVE_HOPS && j2 != j; h++) { j = j2; j2 = tok[j]; }
+      open = j2 != j;
+      tok[i] = j2;
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(open) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&counts->more[round], 1u);
+}
+__global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+                                                            const uint32_t *__restrict__ tok, uint32_t n) {
+  uint8_t *o = dst_arena + descs[0].dst_off;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t j = tok[i];
+  if (j != i) o[i] = o[j];
 }
 
 

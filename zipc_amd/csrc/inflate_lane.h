@@ -575,10 +575,15 @@ ZD_HD bool lane_block_header(InflateLane &d, const LaneLds &L, const uint8_t *__
 }
 
 enum : int { SYM_OK = 0, SYM_EOB = 1, SYM_STOP = 2 };
+// What a wave does with the bytes (inflate.hip): IM_REAL the stream's output; IM_DRY nothing -- one block's symbols
+// are walked for its end and its size; IM_TOKEN literals are stored and a match leaves, per byte, the position it
+// copies (one stream's blocks side by side: the copies are resolved once all of them are known).
+enum : int { IM_REAL = 0, IM_DRY = 1, IM_TOKEN = 2 };
 
 // A decoded match (its bits in c): the reference's checks, then Buf.recopy zd.ml:615 -- queued, or
 // handed to the wave
-ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const BitCursor &c, uint32_t length, uint32_t dist) {
+ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const BitCursor &c, uint32_t length, uint32_t dist,
+                            bool may_queue = true) {
   if (dist > d.out_pos) { d.fail(ST_CORRUPTED); return SYM_STOP; }  // zd.ml:614
   if ((uint64_t)d.out_pos + length > d.cap_min) { d.overflow((uint64_t)d.out_pos + length); return SYM_STOP; }
   d.advance((uint32_t)c.used);
@@ -587,7 +592,7 @@ ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const
   const bool hazard = src_pos + length > d.hole_min;
   const uint32_t qbase = d.hole_min < d.out_pos ? d.hole_min : d.out_pos;  // hole_min once this one is queued
   const bool in_reach = d.out_pos - qbase <= QUEUE_REL_MAX;
-  if (length <= DEFER_MAX_LEN && dist >= length && dist >= DEFER_MIN_DIST && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
+  if (may_queue && length <= DEFER_MAX_LEN && dist >= length && dist >= DEFER_MIN_DIST && !hazard && in_reach && d.q_count < (uint32_t)QUEUE_ENTRIES) {
     d.hole_min = qbase;
     if (writer) L.queue((int)d.q_count) = queue_pack(d.out_pos - d.hole_min, dist, length);
     d.q_count++;
@@ -602,7 +607,7 @@ ZD_HD int lane_match_commit(InflateLane &d, const LaneLds &L, bool writer, const
 
 // Exactly one symbol of read_block_symbols (zd.ml:593-616), decoded the plain
 // way.  SYM_STOP: failed, parked on a request, or waiting for input.
-ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer) {
+ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer, bool may_queue = true) {
   uint8_t *dst = A.dst + d.dst_off;
   if (!d.input_ready(3)) return SYM_STOP;
   BitCursor c = cursor_at(d, L);
@@ -642,7 +647,7 @@ ZD_HD int lane_one_symbol(InflateLane &d, const LaneLds &L, const Arenas &A, boo
     if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
     dist = vbase + v;
   }
-  return lane_match_commit(d, L, writer, c, length, dist);
+  return lane_match_commit(d, L, writer, c, length, dist, may_queue);
 }
 
 // read_symbol on the FIXED codes (fixed_litlen_decoder / fixed_dist_decoder zd.ml:334-349) without
@@ -664,7 +669,7 @@ ZD_HD int fixed_litlen_symbol(BitCursor &c) {
   return (int)(144u + bitrev(x & 511u, 9) - 0x190u);
 }
 // lane_one_symbol for a fixed block whose tables are not built
-ZD_HD int lane_one_symbol_fixed(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer) {
+ZD_HD int lane_one_symbol_fixed(InflateLane &d, const LaneLds &L, const Arenas &A, bool writer, bool may_queue = true) {
   uint8_t *dst = A.dst + d.dst_off;
   if (!d.input_ready(3)) return SYM_STOP;
   BitCursor c = cursor_at(d, L);
@@ -690,7 +695,7 @@ ZD_HD int lane_one_symbol_fixed(InflateLane &d, const LaneLds &L, const Arenas &
   dist_sym_value(dsym, vbase, vextra);
   v = 0;
   if (vextra != 0 && !c.take((int)vextra, v)) { d.fail(ST_CORRUPTED); return SYM_STOP; }
-  return lane_match_commit(d, L, writer, c, length, vbase + v);
+  return lane_match_commit(d, L, writer, c, length, vbase + v, may_queue);
 }
 
 // One header action: false = must wait for input.

@@ -482,7 +482,11 @@ ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, u
 #else
 #define ZD_SPAN_PH(i) do {} while (0)
 #endif
-ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, int lane
+// MODE (inflate_lane.h IM_*): IM_DRY walks and checks the symbols and moves the position, touching neither `dst` nor a
+// tile; IM_TOKEN stores the literals and, for every byte of a match, the output position it is a copy of in tok[]
+// (inflate.hip: one stream by a wave per block).
+template <int MODE = IM_REAL>
+ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, uint32_t *tok, int lane
 #ifdef ZD_INFLATE_PHASES
                       , uint64_t *span_ph
 #endif
@@ -721,7 +725,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       if (!wv::any(p < stop_p)) break;
 #pragma unroll
       for (int u = 0; u < SPAN_FLY; u++) {
-        span_land(tile, f_meta[u], f_a[u], f_b[u]);
+        if (MODE == IM_REAL) span_land(tile, f_meta[u], f_a[u], f_b[u]);
         const bool act = p < stop_p;
 #ifdef SPAN_TRACE
         if (lane == 0) span_trace_steps[2]++;
@@ -737,29 +741,39 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         stop_p = bad ? 0u : stop_p;
         err = bad ? 1u : err;
         const bool is_match = good && !s.is_lit;
-        const bool fly = is_match && s.outlen - 4u <= 4u && s.val >= o2;
-        if (good && s.is_lit) {
+        const bool fly = MODE == IM_REAL && is_match && s.outlen - 4u <= 4u && s.val >= o2;
+        if (MODE != IM_DRY && good && s.is_lit) {
           tile[o] = (uint8_t)s.val;
           if (s.outlen == 2u) tile[o + 1u] = (uint8_t)s.val2;
         }
-        const uint32_t goff = fly ? out_pos + o - s.val : 0u;  // (the output has 8 bytes: checked above)
-        f_a[u] = load_u32_le(dst + goff);
-        f_b[u] = load_u32_le(dst + (goff + (fly ? s.outlen - 4u : 0u)));
-        f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
-        nh += is_match && !fly ? 1u : 0u;
-        if (is_match && !fly) {
-          store_u16_le(tile + o, (uint16_t)(s.val - 1u));
-          tile[o + 2u] = (uint8_t)(s.outlen - 3u);
-          span_bits_set(mbits, o, s.outlen);
-          if (s.val >= o2 && s.outlen <= SPAN_LONG) has_far = 1;  // (a hole the pass over far sources is for)
+        if (MODE == IM_REAL) {
+          const uint32_t goff = fly ? out_pos + o - s.val : 0u;  // (the output has 8 bytes: checked above)
+          f_a[u] = load_u32_le(dst + goff);
+          f_b[u] = load_u32_le(dst + (goff + (fly ? s.outlen - 4u : 0u)));
+          f_meta[u] = fly ? (o + 1u) | (s.outlen << 16) : 0u;
+          nh += is_match && !fly ? 1u : 0u;
+          if (is_match && !fly) {
+            store_u16_le(tile + o, (uint16_t)(s.val - 1u));
+            tile[o + 2u] = (uint8_t)(s.outlen - 3u);
+            span_bits_set(mbits, o, s.outlen);
+            if (s.val >= o2 && s.outlen <= SPAN_LONG) has_far = 1;  // (a hole the pass over far sources is for)
+          }
+        } else if (MODE == IM_TOKEN) {
+          if (is_match) {  // (recorded like a hole: a tile that is refused below must leave nothing behind)
+            store_u16_le(tile + o, (uint16_t)(s.val - 1u));
+            tile[o + 2u] = (uint8_t)(s.outlen - 3u);
+            span_bits_set(mbits, o, s.outlen);
+          }
         }
         o = good ? o2 : o;
         p += good ? s.tot : 0u;
         span_advance(R, E, p);
       }
     }
+    if (MODE == IM_REAL) {
 #pragma unroll
-    for (int u = 0; u < SPAN_FLY; u++) span_land(tile, f_meta[u], f_a[u], f_b[u]);
+      for (int u = 0; u < SPAN_FLY; u++) span_land(tile, f_meta[u], f_a[u], f_b[u]);
+    }
     // both phases must have walked the same symbols
     if (mine && err == 0u) {
       if (o != o_end) err = 1;
@@ -772,6 +786,22 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     }
     wv::sync();
     ZD_SPAN_PH(3);
+    if (MODE == IM_TOKEN) {  // the tile stands: where the bytes of its matches come from (every lane walks its own)
+      uint32_t cursor = mine ? o0 : 0u;
+      const uint32_t range_end = mine ? o_end : 0u;
+      for (;;) {
+        const uint32_t dp = span_bits_first(mbits, cursor, range_end);
+        const bool open = dp != 0xFFFFFFFFu;
+        if (!wv::any(open)) break;
+        if (open) {
+          const uint32_t rec = span_rec(tile, dp);
+          const uint32_t dist = (rec & 0x7FFFu) + 1u, len = (rec >> 16) + 3u;
+          const uint32_t at = out_pos + dp, from = at - dist;
+          for (uint32_t i = 0; i < len; i++) tok[at + i] = from + i;
+          cursor = dp + len;
+        }
+      }
+    }
 
     // The other holes.  They are listed first (tile positions, in stream order: every lane walks its
     // own, their places in the list from a scan of the counts the decode loop kept), so that the
@@ -978,8 +1008,8 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       }
     }
     ZD_SPAN_PH(5);
-    // the tile leaves
-    for (uint32_t i = ulane * 16u; i < tile_len; i += 1024u) {
+    // the tile leaves (IM_TOKEN: the bytes of its matches are whatever the tile held; tok[] says what they are)
+    for (uint32_t i = ulane * 16u; MODE != IM_DRY && i < tile_len; i += 1024u) {
       if (i + 16u <= tile_len) {
         const uint32_t *t = (const uint32_t *)(tile + i);
         wv::Quad q;

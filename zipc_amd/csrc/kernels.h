@@ -14,6 +14,52 @@ __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      StreamResult *__restrict__ results, uint32_t n_streams,
                                      uint16_t *__restrict__ span_scratch, int crc_op);
 
+// one stream by a wave per block (inflate.hip has the description; api.hip inflate_by_blocks the order of the launches)
+struct BlockStart {
+  uint64_t bit;       // of the block's header in the stream's input
+  uint32_t out_pos;   // of its first byte in the stream's output (the token run)
+  uint32_t pad;
+};
+struct BlockEnd {
+  uint32_t status, final_block;
+  uint64_t end_bit;   // of the first bit behind the block (a stored block: behind its bytes)
+  uint32_t out_len, pad;
+};
+constexpr int RESOLVE_ROUNDS = 12;  // 8 hops a round: pointers of 8^r copies after round r
+struct FindCounts {
+  uint32_t n_first;   // offsets that passed the header test (may exceed the list: those are lost)
+  uint32_t n_cand;    // candidates (likewise)
+  uint32_t chain_ok;  // inflate_chain_kernel: 1 = the blocks chain up to a final one and fit
+  uint32_t n_blocks;
+  uint64_t out_len;
+  uint32_t token_bad; // inflate_blocks_token_kernel: blocks that did not end as the dry run said
+  uint32_t more[RESOLVE_ROUNDS];  // inflate_resolve_kernel: threads round r left short of a literal
+  uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that were not among the candidates
+};
+__global__ void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                            uint32_t *__restrict__ first, uint32_t first_cap, FindCounts *__restrict__ counts);
+__global__ void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
+                                            const uint32_t *__restrict__ first, uint32_t first_cap, uint32_t *__restrict__ cand,
+                                            uint32_t cand_cap, FindCounts *__restrict__ counts);
+__global__ void inflate_sort_candidates_kernel(const uint32_t *__restrict__ cand, uint32_t n, BlockStart *__restrict__ sorted);
+__global__ void inflate_blocks_dry_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                          const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ starts,
+                                          BlockEnd *__restrict__ ends, uint32_t n, uint16_t *__restrict__ span_scratch);
+__global__ void inflate_chain_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                     const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ starts,
+                                     const BlockEnd *__restrict__ ends, uint32_t n, BlockStart *__restrict__ chain,
+                                     BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch,
+                                     FindCounts *__restrict__ counts);
+__global__ void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n);
+__global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                            const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ chain,
+                                            const BlockEnd *__restrict__ chain_end, uint32_t n,
+                                            uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
+                                            FindCounts *__restrict__ counts);
+__global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round);
+__global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+                                      const uint32_t *__restrict__ tok, uint32_t n);
+
 // a huge stream of equal stored blocks (inflate.hip, api.hip)
 struct StoredChain {
   uint32_t len0;        // LEN of the first block (0: the stream does not start with a stored block)
