@@ -520,12 +520,15 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
 // run or the chain did not like: the one-wave kernel owns the reference's messages.  Reads a
 // few words back between its steps: it SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0 turns it off.
 constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
-constexpr uint32_t BLOCKS_CAND_CAP = 65536;
+constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
+constexpr uint64_t EXPLORE_STRIDE = 8192;  // bytes of input between two explorers
 static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
                              zipc_hip_stream_result *d_results, int crc_op, bool *handled) {
   *handled = false;
   ctx->last_inflate_blocks = 0;
   static const bool enabled = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS"); return !(e && e[0] == '0'); }();
+  static const bool trace = getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE") != nullptr;
+  static const bool explore = [] { const char *e = getenv("ZIPC_HIP_INFLATE_EXPLORE"); return !(e && e[0] == '0'); }();
   if (!enabled || (crc_op != ZIPC_HIP_CRC_NOP && crc_op != ZIPC_HIP_CRC_CRC32)) return ZIPC_HIP_OK;
   StreamDesc sd;
   HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
@@ -534,24 +537,29 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   const uint32_t first_cap = (uint32_t)(sd.src_len / 8 + 4096);
   uint32_t cand_cap = (uint32_t)(sd.src_len / 512 + 64);
   if (cand_cap > BLOCKS_CAND_CAP) cand_cap = BLOCKS_CAND_CAP;
-  const uint32_t chain_cap = 2 * cand_cap;  // (blocks whose header cannot be looked for -- fixed, stored -- join the chain)
-  // scratch: counts | first | cand | sorted | ends | chain | chain_end | span index
+  // explorers (blocks without a findable header): one every EXPLORE_STRIDE bytes at most, 4 blocks listed each on average
+  const uint32_t max_explorers = (uint32_t)(sd.src_len / EXPLORE_STRIDE + 1);
+  uint64_t rec_cap64 = (uint64_t)cand_cap + 4ull * max_explorers;
+  if (rec_cap64 > BLOCKS_REC_CAP) rec_cap64 = BLOCKS_REC_CAP;
+  const uint32_t rec_cap = (uint32_t)rec_cap64, chain_cap = rec_cap;
+  // scratch: counts | first | cand | recs | sorted | chain | chain_end
   size_t off = 0;
   auto carve = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   const size_t o_counts = carve(sizeof(FindCounts)), o_first = carve((size_t)first_cap * 4), o_cand = carve((size_t)cand_cap * 4),
-               o_sorted = carve((size_t)cand_cap * sizeof(BlockStart)), o_ends = carve((size_t)cand_cap * sizeof(BlockEnd)),
-               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd)),
-               o_span = carve((size_t)chain_cap * INFLATE_SCRATCH_PER_STREAM);
+               o_recs = carve((size_t)rec_cap * sizeof(BlockRec)), o_sorted = carve((size_t)rec_cap * sizeof(BlockRec)),
+               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd));
   HIP_TRY(ctx, ctx->ensure(ctx->blocks_scratch, off));
   uint8_t *base = (uint8_t *)ctx->blocks_scratch.p;
   FindCounts *d_counts = (FindCounts *)(base + o_counts);
   uint32_t *d_first = (uint32_t *)(base + o_first), *d_cand = (uint32_t *)(base + o_cand);
-  BlockStart *d_sorted = (BlockStart *)(base + o_sorted), *d_chain = (BlockStart *)(base + o_chain);
-  BlockEnd *d_ends = (BlockEnd *)(base + o_ends), *d_chain_end = (BlockEnd *)(base + o_chain_end);
-  uint16_t *d_span = (uint16_t *)(base + o_span);
+  BlockRec *d_recs = (BlockRec *)(base + o_recs), *d_sorted = (BlockRec *)(base + o_sorted);
+  BlockStart *d_chain = (BlockStart *)(base + o_chain);
+  BlockEnd *d_chain_end = (BlockEnd *)(base + o_chain_end);
   const uint8_t *src = (const uint8_t *)d_src_arena;
   uint8_t *dst = (uint8_t *)d_dst_arena;
   const StreamDesc *dd = (const StreamDesc *)d_descs;
+  // (the span decoder's index, a slot per wave: grown before the launch that needs it)
+  auto span_scratch = [ctx](size_t waves) { return ctx->ensure(ctx->inflate_scratch, waves * INFLATE_SCRATCH_PER_STREAM); };
 
   HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, sizeof(FindCounts), ctx->stream));
   ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel, dim3((unsigned)((sd.src_len + 255) / 256)), dim3(256), 0, src, dd,
@@ -561,38 +569,52 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   FindCounts fc;
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  static const int stage = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS_STAGE"); return e ? atoi(e) : 99; }();  // (debugging: stop behind a step)
-  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
-  if (stage < 2) return ZIPC_HIP_OK;
-  if (fc.n_cand < 2 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;  // (one block: nothing to gain)
+  if (trace) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
+  if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
   const uint32_t n = fc.n_cand;
-  ZD_LAUNCH(ctx, "inflate_sort_candidates", inflate_sort_candidates_kernel, dim3((n + 255u) / 256u), dim3(256), 0,
-            (const uint32_t *)d_cand, n, d_sorted);
-  if (stage < 3) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return ZIPC_HIP_OK; }
-  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const BlockStart *)d_sorted,
-            d_ends, n, d_span);
-  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockStart *)d_sorted,
-            (const BlockEnd *)d_ends, n, d_chain, d_chain_end, chain_cap, d_span, d_counts);
+  HIP_TRY(ctx, span_scratch(n));
+  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, n,
+            (uint16_t *)ctx->inflate_scratch.p, d_counts);
+  ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
+            (const FindCounts *)d_counts, rec_cap, d_sorted);
+  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, rec_cap, d_chain,
+            d_chain_end, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, explore ? 0 : 1);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len);
-  if (stage < 4) return ZIPC_HIP_OK;
-  if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;
+  if (trace) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu miss %lld\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len, (long long)fc.miss_bit);
+  if (!fc.chain_ok && fc.miss_bit != ~0ull) {
+    // the chain came to a block nobody listed: explorers from there on, then the chain again (which now walks what
+    // is still missing itself)
+    const uint64_t bits_left = sd.src_len * 8u - fc.miss_bit;
+    uint64_t ne = (bits_left + EXPLORE_STRIDE * 8u - 1) / (EXPLORE_STRIDE * 8u);
+    if (ne > max_explorers) ne = max_explorers;
+    HIP_TRY(ctx, span_scratch(ne));
+    ZD_LAUNCH(ctx, "inflate_explore", inflate_explore_kernel, dim3((unsigned)ne), dim3(64), 0, src, dst, dd, (const FindCounts *)d_counts,
+              (uint32_t)(EXPLORE_STRIDE * 8u), (uint32_t)ne, d_recs, rec_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
+    ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((rec_cap + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
+              (const FindCounts *)d_counts, rec_cap, d_sorted);
+    ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, rec_cap, d_chain,
+              d_chain_end, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 1);
+    HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace) fprintf(stderr, "inflate_by_blocks: %llu explorers, %u blocks listed; chain ok %u blocks %u (walked %u) out %llu\n", (unsigned long long)ne, fc.n_recs, fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len);
+  }
+  if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;  // (one block: nothing to gain)
   const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
   if (out_len == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 4));
+  HIP_TRY(ctx, span_scratch(nb));
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
   ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
   ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(nb), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
-            (const BlockEnd *)d_chain_end, nb, d_span, d_tok, d_counts);
-  if (stage < 5) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); return ZIPC_HIP_OK; }
+            (const BlockEnd *)d_chain_end, nb, (uint16_t *)ctx->inflate_scratch.p, d_tok, d_counts);
   for (int r = 0; r < RESOLVE_ROUNDS; r++)
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len, d_counts, r);
   ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE")) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[RESOLVE_ROUNDS - 1]);
+  if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[RESOLVE_ROUNDS - 1]);
   if (fc.token_bad != 0 || fc.more[RESOLVE_ROUNDS - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
   StreamResult res;
   res.status = ZIPC_HIP_OK; res.checksum = 0; res.out_len = out_len;

@@ -545,10 +545,21 @@ constexpr uint32_t BLOCK_DRY_BASE = 32768;
 // The stream's wave: MODE IM_REAL is the whole stream (inflate_batch_kernel); the other two stop at the end of the
 // block they were started on.
 // (returns, in every lane, what the block modes found of their block)
-template <int MODE>
+// MULTI (with IM_DRY): an explorer (inflate_explore_kernel) -- the wave goes on from block to block and lists every
+// block it walked from header to end in X.recs, until one of them started at or behind X.stop_bit; with
+// X.inside_fixed it starts on what is taken for a symbol of a FIXED block (whose header lies somewhere before).
+struct Explore {
+  BlockRec *recs;
+  uint32_t *n_recs;
+  uint32_t cap, max_recs, inside_fixed;
+  uint64_t stop_bit;
+};
+constexpr uint64_t NO_BIT = ~0ull;
+template <int MODE, bool MULTI = false>
 __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                                  const StreamDesc &sd, const BlockStart at, StreamResult *__restrict__ result,
-                                                 uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op) {
+                                                 uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op,
+                                                 const Explore X = Explore()) {
   const int lane = threadIdx.x;
   const bool crc_adler = MODE == IM_REAL && (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC);
   const bool adler_rfc = crc_op == CRC_ADLER32_RFC;
@@ -569,7 +580,37 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
     d.out_pos = MODE == IM_DRY ? BLOCK_DRY_BASE : at.out_pos;
     d.blk_out_start = d.out_pos;
     if (MODE == IM_DRY) d.hard_cap = d.limit = d.cap_min = (uint32_t)MAX_STREAM_LEN;
+    if (MULTI && X.inside_fixed) {  // as behind a fixed block's header (lane_block_header), tables to be built
+      d.hdr_fixed = 1;
+      d.phase = PH_TABLES;
+    }
   }
+  // the explorer's current block: its header's bit (NO_BIT: it was not seen), blocks listed so far
+  uint64_t blk_hdr_bit = MULTI && X.inside_fixed ? NO_BIT : at.bit;
+  uint32_t n_listed = 0;
+  // a block has ended (the phase says what the stream's wave would do next): the block modes stop here, or go on
+  auto block_done = [&]() {
+    if (MODE == IM_REAL || d.status != ST_OK) return;
+    if (!MULTI) { d.phase = PH_DONE; return; }
+    const uint64_t end_bit = (uint64_t)d.in_word * 32u + d.boff;
+    if (blk_hdr_bit != NO_BIT) {
+      if (lane == 0) {
+        const uint32_t k = atomicAdd(X.n_recs, 1u);
+        if (k < X.cap) {
+          BlockRec r;
+          r.bit = blk_hdr_bit;
+          r.e.status = ST_OK; r.e.final_block = (uint32_t)d.final_block; r.e.end_bit = end_bit;
+          r.e.out_len = d.out_pos - BLOCK_DRY_BASE; r.e.pad = 0;
+          X.recs[k] = r;
+        }
+      }
+      n_listed++;
+    }
+    if (d.final_block || (blk_hdr_bit != NO_BIT && blk_hdr_bit >= X.stop_bit) || n_listed >= X.max_recs) { d.phase = PH_DONE; return; }
+    blk_hdr_bit = end_bit;
+    d.out_pos = BLOCK_DRY_BASE;
+    d.blk_out_start = BLOCK_DRY_BASE;
+  };
   uint8_t *dst = dst_arena + d.dst_off;
   const uint8_t *src = src_arena + d.src_off;
 
@@ -642,7 +683,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         uniformize(d);
         const int ru = uni(r);
         ZD_PH(ph_plain);
-        if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); if (MODE != IM_REAL) d.phase = PH_DONE; }
+        if (ru == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, crc_adler); block_done(); }
         else if (ru == SYM_STOP) {
           if (d.phase == PH_REQ_MATCH && d.q_count == 0) {
             wave_match<MODE>(dst, tok, d.out_pos, d.req_dist, d.req_len, lane, L.x + LDS_SPAN_TILE_BYTE);
@@ -696,7 +737,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
           uniformize(d);
           const int ru = uni(r);
           ZD_PH(ph_plain);
-          if (ru == SYM_EOB) { lane_end_of_block(d, crc_adler); if (MODE != IM_REAL) d.phase = PH_DONE; }
+          if (ru == SYM_EOB) { lane_end_of_block(d, crc_adler); block_done(); }
           else if (ru == SYM_STOP) {
             // a match that cannot be queued (long, or overlapping its own output) and nothing queued
             // before it: the wave copies it here and now instead of going round through the services
@@ -729,7 +770,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
     } else if (d.phase == PH_REQ_COPY) {
       if (MODE != IM_DRY) wave_copy(dst + d.out_pos, src + d.req_src, d.req_len, lane);
       lane_after_copy(d, crc_adler);
-      if (MODE != IM_REAL) d.phase = PH_DONE;
+      block_done();
     }
     if (d.phase == PH_REQ_ADLER) {
       // the block's bytes were stored by other lanes of this wave: make them visible
@@ -841,48 +882,87 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
   if (at < cand_cap) cand[at] = start;
 }
 
-// the candidates in stream order: each finds its rank (they are few, and all different)
-__global__ __launch_bounds__(256) void inflate_sort_candidates_kernel(const uint32_t *__restrict__ cand, uint32_t n,
-                                                                     BlockStart *__restrict__ sorted) {
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint32_t mine = cand[i];
-  uint32_t r = 0;
-  for (uint32_t j = 0; j < n; j++) r += cand[j] < mine ? 1u : 0u;
-  BlockStart b;
-  b.bit = mine; b.out_pos = 0; b.pad = 0;
-  sorted[r] = b;
-}
-
+// A dry run per candidate: recs[b] = the candidate's bit and what became of its block
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_dry_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockStart *__restrict__ starts, BlockEnd *__restrict__ ends, uint32_t n, uint16_t *__restrict__ span_scratch) {
+    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, uint32_t n, uint16_t *__restrict__ span_scratch,
+    FindCounts *__restrict__ counts) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
-  const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], starts[b], nullptr,
+  BlockStart at;
+  at.bit = cand[b]; at.out_pos = 0; at.pad = 0;
+  const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr,
                                           span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP);
-  if (threadIdx.x == 0) ends[b] = e;
+  if (threadIdx.x == 0) {
+    BlockRec r;
+    r.bit = at.bit; r.e = e;
+    recs[b] = r;
+    if (b == 0) counts->n_recs = n;
+  }
+}
+
+// Blocks whose headers cannot be looked for: FIXED ones (the reference's encoder, whose estimate of a dynamic
+// block's size grows from block to block, ends up coding nearly every block of a long stream that way)
+// and stored ones.  From the first bit the chain could not go on from, an explorer every `stride` bits: the first
+// starts on that block's header; the others take their bit for the start of a symbol of a fixed block -- they all
+// have the one code -- and as two walks of one Huffman stream fall into step within a few symbols, what such a wave
+// walks is soon the real sequence: the end of its block, the next header, and block after block from there, each
+// listed with its bit, end and size until one started behind the next explorer's first bit.  What an explorer lists
+// before its walk was real are blocks that no chain leads to.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_explore_kernel(
+    const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+    const FindCounts *__restrict__ from, uint32_t stride_bits, uint32_t n, BlockRec *__restrict__ recs, uint32_t rec_cap,
+    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const uint32_t b = blockIdx.x;
+  if (b >= n) return;
+  BlockStart at;
+  at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.pad = 0;
+  if (at.bit + 64u > descs[0].src_len * 8u) return;
+  Explore X;
+  X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16; X.inside_fixed = b != 0;
+  X.stop_bit = at.bit + stride_bits;
+  inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
+                             nullptr, CRC_NOP, X);
+}
+
+// the listed blocks in stream order: each finds its rank (they are few; the same block may be listed more than once)
+__global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts,
+                                                                 uint32_t rec_cap, BlockRec *__restrict__ sorted) {
+  const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t mine = recs[i].bit;
+  uint32_t r = 0;
+  for (uint32_t j = 0; j < n; j++) {
+    const uint64_t b = recs[j].bit;
+    r += b < mine || (b == mine && j < i) ? 1u : 0u;
+  }
+  sorted[r] = recs[i];
 }
 
 // The chain of blocks from bit 0, by one wave.  chain[k]: block k's header bit and output position; chain_end[k]:
-// what the dry run said of it (the token run must agree).  A block that ends where no candidate starts is followed
-// by a block whose header could not be looked for -- a fixed or a stored one (the reference's encoder ends nearly
-// every stream with a fixed block of a few bytes): this wave makes its dry run here and now, and goes on.
+// what the dry run said of it (the token run must agree).  A block that ends where no listed block starts:
+// walk == 0 -- the chain stops and says where (miss_bit: the explorers start there); walk != 0 -- this wave makes
+// that block's dry run here and now, and goes on.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_chain_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockStart *__restrict__ starts, const BlockEnd *__restrict__ ends, uint32_t n, BlockStart *__restrict__ chain,
-    BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+    const BlockRec *__restrict__ sorted, uint32_t rec_cap, BlockStart *__restrict__ chain,
+    BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts,
+    int walk) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const StreamDesc sd = descs[0];
+  const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
-  uint64_t out = 0, bit = 0;
-  uint32_t j = 0, k = 0, walked = 0;  // candidates below j start before `bit`
-  bool ok = n != 0 && starts[0].bit == 0;
+  uint64_t out = 0, bit = 0, miss = NO_BIT;
+  uint32_t j = 0, k = 0, walked = 0;  // listed blocks below j start before `bit`
+  bool ok = n != 0 && sorted[0].bit == 0;
   while (ok) {
-    while (j < n && starts[j].bit < bit) j++;
+    while (j < n && sorted[j].bit < bit) j++;
     BlockEnd e;
-    if (j < n && starts[j].bit == bit) e = ends[j];
+    if (j < n && sorted[j].bit == bit) e = sorted[j].e;
+    else if (!walk) { ok = false; miss = bit; break; }
     else {
       BlockStart at;
       at.bit = bit; at.out_pos = 0; at.pad = 0;
@@ -907,6 +987,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     counts->n_blocks = k;
     counts->out_len = out;
     counts->n_walked = walked;
+    counts->miss_bit = miss;
   }
 }
 

@@ -25,6 +25,7 @@ struct BlockEnd {
   uint64_t end_bit;   // of the first bit behind the block (a stored block: behind its bytes)
   uint32_t out_len, pad;
 };
+struct BlockRec { uint64_t bit; BlockEnd e; };  // a block that was walked from its header's bit to its end
 constexpr int RESOLVE_ROUNDS = 12;  // 8 hops a round: pointers of 8^r copies after round r
 struct FindCounts {
   uint32_t n_first;   // offsets that passed the header test (may exceed the list: those are lost)
@@ -34,22 +35,30 @@ struct FindCounts {
   uint64_t out_len;
   uint32_t token_bad; // inflate_blocks_token_kernel: blocks that did not end as the dry run said
   uint32_t more[RESOLVE_ROUNDS];  // inflate_resolve_kernel: threads round r left short of a literal
-  uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that were not among the candidates
+  uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that it had to walk itself
+  uint32_t n_recs;    // blocks listed: the candidates' (inflate_blocks_dry_kernel), then the explorers' (may exceed the list)
+  uint32_t pad;
+  uint64_t miss_bit;  // inflate_chain_kernel without walking: where the chain could not go on (~0: nowhere)
 };
 __global__ void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
                                             uint32_t *__restrict__ first, uint32_t first_cap, FindCounts *__restrict__ counts);
 __global__ void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
                                             const uint32_t *__restrict__ first, uint32_t first_cap, uint32_t *__restrict__ cand,
                                             uint32_t cand_cap, FindCounts *__restrict__ counts);
-__global__ void inflate_sort_candidates_kernel(const uint32_t *__restrict__ cand, uint32_t n, BlockStart *__restrict__ sorted);
 __global__ void inflate_blocks_dry_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                          const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ starts,
-                                          BlockEnd *__restrict__ ends, uint32_t n, uint16_t *__restrict__ span_scratch);
+                                          const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ cand,
+                                          BlockRec *__restrict__ recs, uint32_t n, uint16_t *__restrict__ span_scratch,
+                                          FindCounts *__restrict__ counts);
+__global__ void inflate_explore_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                       const StreamDesc *__restrict__ descs, const FindCounts *__restrict__ from, uint32_t stride_bits,
+                                       uint32_t n, BlockRec *__restrict__ recs, uint32_t rec_cap, uint16_t *__restrict__ span_scratch,
+                                       FindCounts *__restrict__ counts);
+__global__ void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts, uint32_t rec_cap,
+                                           BlockRec *__restrict__ sorted);
 __global__ void inflate_chain_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                     const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ starts,
-                                     const BlockEnd *__restrict__ ends, uint32_t n, BlockStart *__restrict__ chain,
-                                     BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch,
-                                     FindCounts *__restrict__ counts);
+                                     const StreamDesc *__restrict__ descs, const BlockRec *__restrict__ sorted, uint32_t rec_cap,
+                                     BlockStart *__restrict__ chain, BlockEnd *__restrict__ chain_end, uint32_t chain_cap,
+                                     uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk);
 __global__ void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n);
 __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                             const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ chain,
