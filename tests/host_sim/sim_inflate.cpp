@@ -174,6 +174,8 @@ extern "C" uint64_t sim_inflate_block_starts(uint64_t *bits, int *types, uint64_
   return sim_block_bits.size();
 }
 // inflate_find.h over every bit offset of a stream: the candidates, as inflate.hip's two kernels list them
+static uint32_t sim_find_max_syms = 0xFFFFFFFFu;
+extern "C" void sim_find_set_max_syms(uint32_t n) { sim_find_max_syms = n; }
 extern "C" uint64_t sim_find_candidates(const uint8_t *src, uint64_t src_len, uint64_t *cand, uint64_t cap, uint64_t *n_first) {
   uint64_t n = 0, nf = 0;
   const uint64_t total_bits = src_len * 8u;
@@ -181,7 +183,7 @@ extern "C" uint64_t sim_find_candidates(const uint8_t *src, uint64_t src_len, ui
   for (uint64_t p = 1; p < total_bits; p++) {
     if (!find_header_test(find_bits(src, src_len, p), find_bits(src, src_len, p + 64u), total_bits - p)) continue;
     nf++;
-    if (!find_lengths_test(src, src_len, p)) continue;
+    if (!find_lengths_test(src, src_len, p, sim_find_max_syms)) continue;
     if (n < cap) cand[n] = p;
     n++;
   }

@@ -562,7 +562,7 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   auto span_scratch = [ctx](size_t waves) { return ctx->ensure(ctx->inflate_scratch, waves * INFLATE_SCRATCH_PER_STREAM); };
 
   HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, sizeof(FindCounts), ctx->stream));
-  ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel, dim3((unsigned)((sd.src_len + 255) / 256)), dim3(256), 0, src, dd,
+  ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel, dim3((unsigned)((sd.src_len + 1023) / 1024)), dim3(256), 0, src, dd,
             d_first, first_cap, d_counts);
   ZD_LAUNCH(ctx, "inflate_find_lengths", inflate_find_lengths_kernel, dim3((first_cap + 63u) / 64u), dim3(64), 0, src, dd,
             (const uint32_t *)d_first, first_cap, d_cand, cand_cap, d_counts);
@@ -602,15 +602,18 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;  // (one block: nothing to gain)
   const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
   if (out_len == 0) return ZIPC_HIP_OK;
-  HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 4));
+  HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 12));  // tok[], and two lists of bytes still to resolve
   HIP_TRY(ctx, span_scratch(nb));
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
   ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
   ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(nb), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
             (const BlockEnd *)d_chain_end, nb, (uint16_t *)ctx->inflate_scratch.p, d_tok, d_counts);
-  for (int r = 0; r < RESOLVE_ROUNDS; r++)
-    ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len, d_counts, r);
+  for (int r = 0; r < RESOLVE_ROUNDS; r++) {
+    uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
+    ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,
+              out_len, d_counts, r, (const uint32_t *)list_in, list_out);
+  }
   ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

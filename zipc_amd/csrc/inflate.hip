@@ -843,22 +843,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 //   resolve tok[i] <- tok[tok[i]] until every byte points at a literal (pointer jumping: rounds ~ log of the longest
 //           chain of copies, whatever blocks it crosses), then out[i] = out[tok[i]].
 
+// (a thread per 4 bytes = 32 offsets; what passes is gathered per workgroup -- 1 KiB of input, about 8 offsets -- so the
+// list's counter sees one atomic per workgroup, not one per offset: 110 000 on one address took a millisecond)
+constexpr uint32_t FIND_WG_LIST = 512;
 __global__ __launch_bounds__(256) void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena,
                                                                   const StreamDesc *__restrict__ descs, uint32_t *__restrict__ first,
                                                                   uint32_t first_cap, FindCounts *__restrict__ counts) {
+  __shared__ uint32_t l_n, l_base, l_list[FIND_WG_LIST];
   const StreamDesc sd = descs[0];
   const uint8_t *s = src_arena + sd.src_off;
-  const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-  if (t >= sd.src_len) return;
-  const uint64_t total_bits = sd.src_len * 8u;
-  const uint64_t a = find_bits(s, sd.src_len, t * 8u), b = find_bits(s, sd.src_len, t * 8u + 64u);
+  const uint64_t t = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;  // first byte
+  if (threadIdx.x == 0) l_n = 0;
+  __syncthreads();
+  if (t < sd.src_len) {
+    const uint64_t total_bits = sd.src_len * 8u;
+    const uint64_t a = find_bits(s, sd.src_len, t * 8u), b = find_bits(s, sd.src_len, t * 8u + 64u);
 #pragma unroll 1
-  for (uint32_t off = 0; off < 8u; off++) {
-    if (t == 0 && off == 0) continue;  // (bit 0 is a candidate anyway)
-    if (!find_header_test(off ? (a >> off) | (b << (64u - off)) : a, b >> off, total_bits - (t * 8u + off))) continue;
-    const uint32_t at = atomicAdd(&counts->n_first, 1u);
-    if (at < first_cap) first[at] = (uint32_t)(t * 8u + off);
+    for (uint32_t off = 0; off < 32u; off++) {
+      const uint64_t bit = t * 8u + off;
+      if (bit == 0 || bit >= total_bits) continue;  // (bit 0 is a candidate anyway)
+      if (!find_header_test(off ? (a >> off) | (b << (64u - off)) : a, b >> off, total_bits - bit)) continue;
+      const uint32_t k = atomicAdd(&l_n, 1u);
+      if (k < FIND_WG_LIST) l_list[k] = (uint32_t)bit;
+    }
   }
+  __syncthreads();
+  const uint32_t n = l_n < FIND_WG_LIST ? l_n : FIND_WG_LIST;
+  if (n == 0) return;
+  if (threadIdx.x == 0) l_base = atomicAdd(&counts->n_first, n);
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < n; k += 256u)
+    if (l_base + k < first_cap) first[l_base + k] = l_list[k];
 }
 
 // the code lengths behind a header that passed: a thread per offset
@@ -1011,16 +1026,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
-// One round of pointer jumping, up to RESOLVE_HOPS hops a thread: a pointer only ever moves to an earlier byte of
-// the same chain of copies, so reading one that another thread has already moved is as good.  more[round] counts
-// threads that did not arrive; a round whose predecessor left none returns at once (the rounds are all launched).
+// Pointer jumping, up to RESOLVE_HOPS hops a thread and round: a pointer only ever moves to an earlier byte of the
+// same chain of copies, so reading one that another thread has already moved is as good.  Round 0 looks at every
+// byte; a thread that did not arrive at a literal lists its byte (more[round] counts them), and the rounds behind
+// look at the listed bytes only (all rounds are launched; one whose list is empty returns at once).
 constexpr int RESOLVE_HOPS = 8;
-__global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts,
-                                                             int round) {
-  if (round > 0 && counts->more[round - 1] == 0u) return;
-  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void resolve_one(uint32_t *__restrict__ tok, uint32_t i, bool have, uint32_t *__restrict__ list_out,
+                                            uint32_t *__restrict__ count_out) {
   bool open = false;
-  if (i < n) {
+  if (have) {
     uint32_t j = tok[i];
     if (j != i) {
       uint32_t j2 = tok[j];
@@ -1029,7 +1043,27 @@ __global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restri
       tok[i] = j2;
     }
   }
-  if (__builtin_amdgcn_ballot_w64(open) != 0ull && (threadIdx.x & 63u) == 0u) atomicAdd(&counts->more[round], 1u);
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(open);
+  if (m != 0ull) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(count_out, (uint32_t)__builtin_popcountll(m));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(m));
+    if (open) list_out[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+  }
+}
+__global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts,
+                                                             int round, const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out) {
+  if (round == 0) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    resolve_one(tok, i, i < n, list_out, &counts->more[0]);
+    return;
+  }
+  const uint32_t n_in = counts->more[round - 1];
+  for (uint32_t t0 = blockIdx.x * 256u; t0 < n_in; t0 += gridDim.x * 256u) {  // (wave-uniform trip count)
+    const uint32_t t = t0 + threadIdx.x;
+    resolve_one(tok, t < n_in ? list_in[t] : 0u, t < n_in, list_out, &counts->more[round]);
+  }
 }
 __global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                                             const uint32_t *__restrict__ tok, uint32_t n) {

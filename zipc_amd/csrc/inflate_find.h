@@ -44,7 +44,9 @@ ZD_HD bool find_header_test(uint64_t x, uint64_t x_hi, uint64_t left) {
 // The code lengths behind a header that passed find_header_test at bit `start`: read with the code-length code,
 // they must make a literal/length code that is complete (or a single one-bit code) and has the end-of-block symbol
 // (zd.ml:662), and a distance code that is complete, a single one-bit code, or empty.
-ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64_t start) {
+// max_syms: code-length symbols read at most; a header that has passed so many is let through untested beyond (the
+// dry run reads it again anyway).
+ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64_t start, uint32_t max_syms = 0xFFFFFFFFu) {
   const uint64_t total_bits = len * 8u;
   uint64_t pos = start;
   uint64_t x = find_bits(s, len, pos);
@@ -76,7 +78,9 @@ ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64
   uint32_t kraft_lit = 0, n_lit = 0, kraft_dist = 0, n_dist = 0;
   bool has_eob = false;
   uint32_t have = 0;  // bits of x not used yet (a symbol is 14 at most)
+  uint32_t n_syms = 0;
   while (num < total) {
+    if (n_syms++ >= max_syms) return true;
     if (have < 14u) { x = find_bits(s, len, pos); have = 64; }
     // read_symbol zd.ml:584-591: the code bit by bit, most significant first
     uint32_t code = 0, firstc = 0, index = 0, sym = 0xFFFFFFFFu, used = 0;

@@ -34,7 +34,7 @@ struct FindCounts {
   uint32_t n_blocks;
   uint64_t out_len;
   uint32_t token_bad; // inflate_blocks_token_kernel: blocks that did not end as the dry run said
-  uint32_t more[RESOLVE_ROUNDS];  // inflate_resolve_kernel: threads round r left short of a literal
+  uint32_t more[RESOLVE_ROUNDS];  // inflate_resolve_kernel: bytes round r left short of a literal
   uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that it had to walk itself
   uint32_t n_recs;    // blocks listed: the candidates' (inflate_blocks_dry_kernel), then the explorers' (may exceed the list)
   uint32_t pad;
@@ -65,7 +65,8 @@ __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_aren
                                             const BlockEnd *__restrict__ chain_end, uint32_t n,
                                             uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
                                             FindCounts *__restrict__ counts);
-__global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round);
+__global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
+                                       const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out);
 __global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                       const uint32_t *__restrict__ tok, uint32_t n);
 
