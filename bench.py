@@ -549,7 +549,8 @@ def extra_legs(ctx, dev, n, L):
             gd, gi = device_round_trip(ctx, dev, src, 1, ML, 1 if bits == 0 else 2, reps=3)
             one[name] = {"deflate_ms": ML / GIB / gd * 1e3, "inflate_ms": ML / GIB / gi * 1e3}
         one["is"] = "ONE stream per call, device-resident: `Fast on 1 MiB of zeros (BASELINE C1's input), `Default on the C2 symbols; " \
-                    "deflate of a long stream runs as segments and blocks on many waves, inflate as one wave"
+                    "deflate of a long stream runs as segments and blocks on many waves, inflate as a wave per block (block starts " \
+                    "searched for; copies resolved by pointer jumping) -- zeros are one block: the stream's one wave"
         out["one_stream_ms"] = one
     except Exception as e:
         out["one_stream_ms"] = {"error": repr(e)}

@@ -134,6 +134,7 @@ inline uint32_t uni(uint32_t v) { return readlane(v, 0); }
 inline void sync() { rendezvous(OP_SYNC, 0); }
 inline void fence_global() { rendezvous(OP_SYNC, 0); }
 inline void lds_or(uint32_t *p, uint32_t v) { *p |= v; }
+inline uint32_t load_coherent(const uint32_t *p) { return *p; }
 inline void lds_and(uint32_t *p, uint32_t v) { *p &= v; }
 
 struct Quad { uint32_t x, y, z, w; };

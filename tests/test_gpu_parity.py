@@ -668,3 +668,29 @@ def test_one_stream_by_blocks_leaves_errors_to_the_streams_wave(gpu_ctx, oracle)
                 assert r.get_ok() == (d0, c0), (name, what)
             else:
                 assert r.error == oracle.MESSAGES[st0], (name, what)
+
+
+def test_one_stream_by_blocks_every_kind_of_block(gpu_ctx, oracle):
+    """the block path over streams of every make zlib has: fixed blocks only (nothing to search for: explorers),
+    stored only, Huffman-only and run-length strategies, small blocks by the thousand (memLevel 1), full flushes --
+    bytes and CRC-32 of the source whichever way a stream ends up being decoded, and the block path taken where its
+    blocks can be found"""
+    from zipc_amd import zipc_deflate as Z
+
+    n = 700000
+    for name, data in _one_stream_sources(n):
+        makes = [("fixed", dict(level=6, strategy=zlib.Z_FIXED), True), ("stored", dict(level=0), False),
+                 ("huffman-only", dict(level=6, strategy=zlib.Z_HUFFMAN_ONLY), True), ("rle", dict(level=6, strategy=zlib.Z_RLE), True),
+                 ("filtered", dict(level=9, strategy=zlib.Z_FILTERED), True), ("memlevel-1", dict(level=6, memLevel=1), False),
+                 ("memlevel-3", dict(level=1, memLevel=3), False)]
+        for make, kw, by_blocks in makes:
+            c = zlib.compressobj(kw.get("level", 6), zlib.DEFLATED, -15, kw.get("memLevel", 8), kw.get("strategy", zlib.Z_DEFAULT_STRATEGY))
+            raw = b"".join(c.compress(data[i:i + 150000]) + c.flush(zlib.Z_FULL_FLUSH if make == "rle" else zlib.Z_NO_FLUSH)
+                           for i in range(0, n, 150000)) + c.flush()
+            got, crc = Z.inflate_and_crc_32(raw, decompressed_size=n).get_ok()
+            assert got == data and crc == zlib.crc32(data), (name, make)
+            if by_blocks:
+                assert gpu_ctx.last_inflate_blocks() >= 4, (name, make, gpu_ctx.last_inflate_blocks())
+            st0, d0, _ = oracle.inflate(raw[:len(raw) // 2], decompressed_size=n)
+            r = Z.inflate(raw[:len(raw) // 2], decompressed_size=n)
+            assert (not r.is_ok()) and st0 != 0 and r.error == oracle.MESSAGES[st0], (name, make)

@@ -606,9 +606,13 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   HIP_TRY(ctx, span_scratch(nb));
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
+  // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and
+  // save the resolve rounds of a long stream more: measured at 1 MiB and 16 MiB)
+  static const int follow_env = [] { const char *e = getenv("ZIPC_HIP_INFLATE_FOLLOW"); return e ? atoi(e) : -1; }();
+  const int follow = follow_env >= 0 ? follow_env : out_len >= (4u << 20);
   ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
   ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(nb), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
-            (const BlockEnd *)d_chain_end, nb, (uint16_t *)ctx->inflate_scratch.p, d_tok, d_counts);
+            (const BlockEnd *)d_chain_end, nb, (uint16_t *)ctx->inflate_scratch.p, d_tok, d_counts, follow);
   for (int r = 0; r < RESOLVE_ROUNDS; r++) {
     uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,

@@ -483,9 +483,14 @@ __device__ __forceinline__ uint32_t wide_turn(InflateLane &d, const LaneLds &L, 
   // every lane writes a queue word: the ones without a committed match into the spare slot
   if (MODE == IM_REAL)
     L.queue(lane_in(commit_match_m) ? (int)(d.q_count + mrank) : QUEUE_ENTRIES) = queue_pack(dstp - h1, sp.dist, sp.length);
-  if (MODE == IM_TOKEN && lane_in(commit_match_m)) {
+  if (MODE == IM_TOKEN && lane_in(commit_match_m)) {  // (length <= 16 <= distance)
     const uint32_t from = dstp - sp.dist;
-    for (uint32_t i = 0; i < sp.length; i++) tok[dstp + i] = from + i;
+    uint32_t v[DEFER_MAX_LEN];
+#pragma unroll
+    for (uint32_t i = 0; i < DEFER_MAX_LEN; i++) v[i] = wv::load_coherent(tok + (from + (i < sp.length ? i : 0u)));
+#pragma unroll
+    for (uint32_t i = 0; i < DEFER_MAX_LEN; i++)
+      if (i < sp.length) tok[dstp + i] = v[i];
   }
   // bytes produced: what precedes the cut lane.  Bits used: up to the cut lane, or
   // past it when the last symbol runs over the sink.
@@ -532,8 +537,10 @@ template <int MODE>
 __device__ __forceinline__ void wave_match(uint8_t *dst, uint32_t *__restrict__ tok, uint32_t pos, uint32_t dist, uint32_t len, int lane,
                                            uint8_t *pattern) {
   if (MODE == IM_REAL) wave_copy_match(dst, pos, dist, len, lane, pattern);
-  else if (MODE == IM_TOKEN)
-    for (uint32_t i = (uint32_t)lane; i < len; i += 64u) tok[pos + i] = pos - dist + i;
+  else if (MODE == IM_TOKEN) {  // (what the source bytes are copies of, where that is known already: inflate_span.h)
+    for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
+      tok[pos + i] = wv::load_coherent(tok + (pos - dist + (dist < len ? i % dist : i)));
+  }
 }
 
 // A block of ONE stream decoded by a wave of its own (IM_DRY, IM_TOKEN): where it starts in the stream's input and
@@ -559,7 +566,7 @@ template <int MODE, bool MULTI = false>
 __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                                  const StreamDesc &sd, const BlockStart at, StreamResult *__restrict__ result,
                                                  uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op,
-                                                 const Explore X = Explore()) {
+                                                 const Explore X = Explore(), uint16_t *srcpos = nullptr) {
   const int lane = threadIdx.x;
   const bool crc_adler = MODE == IM_REAL && (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC);
   const bool adler_rfc = crc_op == CRC_ADLER32_RFC;
@@ -697,9 +704,9 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
           const uint32_t out_before = d.out_pos;
           ZD_PH_START();
 #ifdef ZD_INFLATE_PHASES
-          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, lane, span_ph);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, lane, span_ph);
 #else
-          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, lane);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, lane);
 #endif
           if (sr != SPAN_NONE) {
             uniformize(d);
@@ -1014,12 +1021,14 @@ __global__ __launch_bounds__(256) void inflate_tok_init_kernel(uint32_t *__restr
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_token_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
     const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end, uint32_t n,
-    uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok, FindCounts *__restrict__ counts) {
+    uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok, FindCounts *__restrict__ counts, int follow) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
+  __shared__ uint16_t srcpos[SPAN_TILE];
   const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[0], chain[b], nullptr,
-                                              span_scratch + (size_t)b * SPAN_IDX_ENTRIES, tok, CRC_NOP);
+                                              span_scratch + (size_t)b * SPAN_IDX_ENTRIES, tok, CRC_NOP, Explore(),
+                                              follow ? srcpos : nullptr);
   if (threadIdx.x == 0) {
     const BlockEnd want = chain_end[b];
     if (got.status != ST_OK || got.end_bit != want.end_bit || got.out_len != want.out_len) atomicAdd(&counts->token_bad, 1u);

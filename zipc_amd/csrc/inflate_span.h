@@ -484,9 +484,11 @@ ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, u
 #endif
 // MODE (inflate_lane.h IM_*): IM_DRY walks and checks the symbols and moves the position, touching neither `dst` nor a
 // tile; IM_TOKEN stores the literals and, for every byte of a match, the output position it is a copy of in tok[]
-// (inflate.hip: one stream by a wave per block).
+// (inflate.hip: one stream by a wave per block; srcpos: SPAN_TILE u16 of LDS, the tile's sources while they are
+// sorted out).
 template <int MODE = IM_REAL>
-ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, uint32_t *tok, int lane
+ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, uint32_t *tok,
+                      uint16_t *srcpos, int lane
 #ifdef ZD_INFLATE_PHASES
                       , uint64_t *span_ph
 #endif
@@ -786,7 +788,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     }
     wv::sync();
     ZD_SPAN_PH(3);
-    if (MODE == IM_TOKEN) {  // the tile stands: where the bytes of its matches come from (every lane walks its own)
+    if (MODE == IM_TOKEN && srcpos == nullptr) {  // the tile stands: where the bytes of its matches come from (every lane walks its own)
       uint32_t cursor = mine ? o0 : 0u;
       const uint32_t range_end = mine ? o_end : 0u;
       for (;;) {
@@ -799,6 +801,61 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           const uint32_t at = out_pos + dp, from = at - dist;
           for (uint32_t i = 0; i < len; i++) tok[at + i] = from + i;
           cursor = dp + len;
+        }
+      }
+    } else if (MODE == IM_TOKEN) {
+      // The same for a long stream, where the chains of copies get long (a phrase of a text is a copy of a copy of
+      // ... all the way to the stream's start) and every link costs the resolve rounds a pass: a source is written
+      // down as what IT is a copy of, as far as that is known.  srcpos[b] = the tile position byte b of a match
+      // copies + 32768 (a position before the tile is below 32768): every lane writes its own matches' (Buf.recopy
+      // zd.ml:63-75: byte i of a match is byte i mod dist of its source), one pass follows the chains inside the
+      // tile a step, and then the tile's bytes are swept 64 at a time -- a source before the tile is looked up in
+      // tok[]: this wave wrote it a while ago with ITS source looked up the same way.  (What another wave has not
+      // written yet reads as "a copy of itself", which is a valid if longer way to the same literal: nothing here
+      // has to be complete, inflate_resolve_kernel follows what is left.)
+      {
+        uint32_t cursor = mine ? o0 : 0u;
+        const uint32_t range_end = mine ? o_end : 0u;
+        for (;;) {
+          const uint32_t dp = span_bits_first(mbits, cursor, range_end);
+          const bool open = dp != 0xFFFFFFFFu;
+          if (!wv::any(open)) break;
+          if (open) {
+            const uint32_t rec = span_rec(tile, dp);
+            const uint32_t dist = (rec & 0x7FFFu) + 1u, len = (rec >> 16) + 3u;
+            const uint32_t from = dp + 32768u - dist;
+            uint32_t r = 0;
+            for (uint32_t i = 0; i < len; i++) {
+              srcpos[dp + i] = (uint16_t)(from + r);
+              r = r + 1u == dist ? 0u : r + 1u;
+            }
+            cursor = dp + len;
+          }
+        }
+      }
+      wv::sync();
+      // (mbits: a bit per tile byte, set for the bytes of matches; lane l sweeps bytes 64 k + l: bit l & 31 of word 2 k + (l >> 5))
+      const uint32_t my_bit = 1u << (ulane & 31u), my_word = ulane >> 5;
+      for (uint32_t b = ulane, w = my_word; b < tile_len; b += 64u, w += 2u) {
+        if (mbits[w] & my_bit) {
+          const uint32_t sp = srcpos[b];
+          if (sp >= 32768u && (mbits[(sp - 32768u) >> 5] >> (sp & 31u)) & 1u) srcpos[b] = srcpos[sp - 32768u];
+        }
+      }
+      wv::sync();
+      for (uint32_t b0 = 0; b0 < tile_len; b0 += 512u) {  // 8 loads in flight a lane
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+          const uint32_t b = b0 + u * 64u + ulane;
+          const bool m = b < tile_len && (mbits[(b0 >> 5) + 2u * u + my_word] & my_bit) != 0u;
+          const uint32_t sp = m ? (uint32_t)srcpos[b] : 32768u + b;
+          v[u] = sp >= 32768u ? out_pos + (sp - 32768u) : wv::load_coherent(tok + (out_pos - (32768u - sp)));
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8u; u++) {
+          const uint32_t b = b0 + u * 64u + ulane;
+          if (v[u] != out_pos + b) tok[out_pos + b] = v[u];
         }
       }
     }

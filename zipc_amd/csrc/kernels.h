@@ -64,7 +64,7 @@ __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_aren
                                             const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ chain,
                                             const BlockEnd *__restrict__ chain_end, uint32_t n,
                                             uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
-                                            FindCounts *__restrict__ counts);
+                                            FindCounts *__restrict__ counts, int follow);
 __global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
                                        const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out);
 __global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,

@@ -42,6 +42,10 @@ __device__ __forceinline__ void sync() {
 // global stores of this wave before, its global loads after
 __device__ __forceinline__ void fence_global() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); }
 __device__ __forceinline__ void lds_or(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+// a word other waves (or this one, a while ago) may have stored: not from this CU's vector cache
+__device__ __forceinline__ uint32_t load_coherent(const uint32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void lds_and(uint32_t *p, uint32_t v) { atomicAnd(p, v); }
 
 struct Quad { uint32_t x, y, z, w; };
