@@ -74,3 +74,22 @@ def test_long_mixed_streams_bounded(seg):
                        env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-600:]
     assert r.returncode == 0 and "FUZZ ok" in tail, tail
+
+
+def test_one_stream_inflate_by_blocks_bounded():
+    """tools/fuzz_inflate_blocks.py, a few dozen streams: sources of mixed content, the reference's encoder and zlib
+    with random levels, memory levels, strategies and flushes, some damaged, cut or given too small a limit, CRC-32 or
+    Adler-32 -- status, bytes and checksum against the oracle, and most of them decoded by a wave per block."""
+    import subprocess
+    import sys
+
+    day = datetime.date.today().timetuple().tm_yday
+    e = dict(os.environ)
+    e["TRIALS"] = "40"
+    e["SEED"] = str(500 + day)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_inflate_blocks.py")], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-800:]
+    assert r.returncode == 0 and "0 mismatches" in tail, tail
+    went = int(tail.split(" went by blocks")[0].split(", ")[-1])
+    assert went >= 15, tail

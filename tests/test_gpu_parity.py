@@ -642,6 +642,10 @@ def test_one_stream_inflates_by_a_wave_per_block(gpu_ctx, oracle):
             got, crc = Z.inflate_and_crc_32(raw, decompressed_size=n).get_ok()
             assert gpu_ctx.last_inflate_blocks() >= 6, (name, enc, gpu_ctx.last_inflate_blocks())
             assert got == data and crc == zlib.crc32(data), (name, enc)
+            # Adler-32: block by block, every block's bytes in 5552-byte chunks of their own (zd.ml:682-690)
+            got2, adler = Z.inflate_and_adler_32(raw, decompressed_size=n).get_ok()
+            assert gpu_ctx.last_inflate_blocks() >= 6, (name, enc)
+            assert got2 == data and adler == oracle.inflate(raw, decompressed_size=n, crc_op=oracle.CRC_ADLER32)[2], (name, enc)
             # no size given: the first tries are too small (the stream's one wave says so), the last one fits
             assert Z.inflate(raw).get_ok() == data, (name, enc)
 

@@ -514,7 +514,8 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
   return ZIPC_HIP_OK;
 }
 
-// One stream of at least BLOCKS_MIN_SRC bytes by a wave per block (inflate.hip: find, dry, chain, token, resolve).
+// One stream of at least BLOCKS_MIN_SRC bytes by a wave per block (inflate.hip: find, dry, explore, chain, token, resolve;
+// CRC-32 by the usual pass over the output, Adler-32 block by block as the reference updates it).
 // *handled: the stream went that way (result and, if asked for, CRC-32 are in d_results); else it is left to
 // inflate_batch_kernel -- a stream that is not a chain of dynamic blocks behind its first block, anything the dry
 // run or the chain did not like: the one-wave kernel owns the reference's messages.  Reads a
@@ -529,7 +530,8 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   static const bool enabled = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS"); return !(e && e[0] == '0'); }();
   static const bool trace = getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE") != nullptr;
   static const bool explore = [] { const char *e = getenv("ZIPC_HIP_INFLATE_EXPLORE"); return !(e && e[0] == '0'); }();
-  if (!enabled || (crc_op != ZIPC_HIP_CRC_NOP && crc_op != ZIPC_HIP_CRC_CRC32)) return ZIPC_HIP_OK;
+  if (!enabled) return ZIPC_HIP_OK;
+  const bool adler = crc_op == ZIPC_HIP_CRC_ADLER32 || crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950;
   StreamDesc sd;
   HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -628,6 +630,15 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   HIP_TRY(ctx, hipMemcpyAsync(d_results, &res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (res leaves the stack)
   ctx->last_inflate_blocks = nb;
+  if (adler) {  // block by block, every block's bytes in chunks of their own (inflate.hip)
+    if (fc.n_chunks) {
+      HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (size_t)fc.n_chunks * 12));
+      ZD_LAUNCH(ctx, "inflate_adler_chunks", inflate_adler_chunks_kernel, dim3(fc.n_chunks), dim3(64), 0, (const uint8_t *)dst, dd,
+                (const BlockStart *)d_chain, (const BlockEnd *)d_chain_end, nb, fc.n_chunks, (uint32_t *)ctx->adler_sums.p);
+    }
+    ZD_LAUNCH(ctx, "inflate_adler_fold", inflate_adler_fold_kernel, dim3(1), dim3(64), 0, (const uint32_t *)ctx->adler_sums.p, fc.n_chunks,
+              crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950 ? 1 : 0, (StreamResult *)d_results);
+  }
   if (crc_op == ZIPC_HIP_CRC_CRC32) {
     const int st = crc32_pass(ctx, dst, RANGE_INFLATE_OUT, dd, (StreamResult *)d_results, 1, 0, 0, (size_t)out_len, nullptr);
     if (st) return st;

@@ -822,7 +822,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
   BlockStart at;
-  at.bit = 0; at.out_pos = 0; at.pad = 0;
+  at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
                         span_scratch + (size_t)stream * SPAN_IDX_ENTRIES, nullptr, crc_op);
 }
@@ -913,7 +913,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
-  at.bit = cand[b]; at.out_pos = 0; at.pad = 0;
+  at.bit = cand[b]; at.out_pos = 0; at.chunk0 = 0;
   const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr,
                                           span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP);
   if (threadIdx.x == 0) {
@@ -940,7 +940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
-  at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.pad = 0;
+  at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.chunk0 = 0;
   if (at.bit + 64u > descs[0].src_len * 8u) return;
   Explore X;
   X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16; X.inside_fixed = b != 0;
@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
   uint64_t out = 0, bit = 0, miss = NO_BIT;
-  uint32_t j = 0, k = 0, walked = 0;  // listed blocks below j start before `bit`
+  uint32_t j = 0, k = 0, walked = 0, chunks = 0;  // listed blocks below j start before `bit`
   bool ok = n != 0 && sorted[0].bit == 0;
   while (ok) {
     while (j < n && sorted[j].bit < bit) j++;
@@ -987,19 +987,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     else if (!walk) { ok = false; miss = bit; break; }
     else {
       BlockStart at;
-      at.bit = bit; at.out_pos = 0; at.pad = 0;
+      at.bit = bit; at.out_pos = 0; at.chunk0 = 0;
       walked++;
       e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, sd, at, nullptr, span_scratch, nullptr, CRC_NOP);
     }
     if (e.status != ST_OK || out + e.out_len > room || out + e.out_len > MAX_STREAM_LEN || k >= chain_cap) { ok = false; break; }
     if (threadIdx.x == 0) {
       BlockStart b;
-      b.bit = bit; b.out_pos = (uint32_t)out; b.pad = 0;
+      b.bit = bit; b.out_pos = (uint32_t)out; b.chunk0 = chunks;
       chain[k] = b;
       chain_end[k] = e;
     }
     k++;
     out += e.out_len;
+    if (e.out_len) chunks += 1u + e.out_len / ADLER_CHUNK;  // (Adler_32.string_update zd.ml:175-198: a first chunk of len mod 5552, maybe empty)
     if (e.final_block) break;
     if (e.end_bit <= bit) { ok = false; break; }  // (cannot be: a block has a header)
     bit = e.end_bit;
@@ -1010,6 +1011,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     counts->out_len = out;
     counts->n_walked = walked;
     counts->miss_bit = miss;
+    counts->n_chunks = chunks;
   }
 }
 
@@ -1073,6 +1075,49 @@ __global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restri
     const uint32_t t = t0 + threadIdx.x;
     resolve_one(tok, t < n_in ? list_in[t] : 0u, t < n_in, list_out, &counts->more[round]);
   }
+}
+// Adler-32 of a stream that went by blocks: the reference updates it block by block (inflated_block_crc zd.ml:682-690),
+// every block's bytes in chunks of their own grid (first len mod 5552, then 5552 each), and its signed remainder makes
+// the value depend on that grid.  A wave per chunk: its two sums (sums[3 c .. 3 c + 2] = S1, S2, length); then one
+// wave folds the chunks in stream order, 64 loaded at a time, with the reference's step.
+__global__ __launch_bounds__(64) void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+                                                                 const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end,
+                                                                 uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums) {
+  const uint32_t c = blockIdx.x;
+  if (c >= n_chunks) return;
+  uint32_t lo = 0, hi = n_blocks - 1u;  // the last block whose chunks start at or before c (and that has chunks)
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (chain[mid].chunk0 <= c) lo = mid;
+    else hi = mid - 1u;
+  }
+  // (blocks without output have no chunks and share their chunk0 with the block behind: step back to the one that has)
+  while (lo > 0u && chain_end[lo].out_len == 0u) lo--;
+  const BlockStart b = chain[lo];
+  const uint32_t n = chain_end[lo].out_len, j = c - b.chunk0, first = n % ADLER_CHUNK;
+  const uint32_t start = j == 0u ? 0u : first + (j - 1u) * ADLER_CHUNK, len = j == 0u ? first : ADLER_CHUNK;
+  uint32_t S1, S2;
+  wave_adler_chunk_sums(dst_arena + descs[0].dst_off + b.out_pos + start, len, (int)threadIdx.x, S1, S2);
+  // (bit 31 of the length: the block's last chunk -- the reference packs the value into one word between two blocks
+  // and unpacks it again, zd.ml:178,198, which is not the identity once a signed remainder has gone negative)
+  if (threadIdx.x == 0) { sums[3u * c] = S1; sums[3u * c + 1u] = S2; sums[3u * c + 2u] = len | (j == n / ADLER_CHUNK ? 0x80000000u : 0u); }
+}
+__global__ __launch_bounds__(64) void inflate_adler_fold_kernel(const uint32_t *__restrict__ sums, uint32_t n_chunks, int rfc,
+                                                               StreamResult *__restrict__ result) {
+  uint32_t s1, s2;
+  adler_unpack(1u, s1, s2);  // Adler_32.init zd.ml:173
+  for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
+    const uint32_t c = c0 + threadIdx.x;
+    const uint32_t S1 = c < n_chunks ? sums[3u * c] : 0u, S2 = c < n_chunks ? sums[3u * c + 1u] : 0u, len = c < n_chunks ? sums[3u * c + 2u] : 0u;
+    const uint32_t m = n_chunks - c0 < 64u ? n_chunks - c0 : 64u;
+    for (uint32_t l = 0; l < m; l++) {
+      const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)len, (int)l);
+      adler_chunk_step(s1, s2, ln & 0x7FFFFFFFu, (uint32_t)__builtin_amdgcn_readlane((int)S1, (int)l),
+                       (uint32_t)__builtin_amdgcn_readlane((int)S2, (int)l), rfc != 0);
+      if (ln >> 31) adler_unpack(adler_pack(s1, s2), s1, s2);
+    }
+  }
+  if (threadIdx.x == 0) result->checksum = adler_pack(s1, s2);
 }
 __global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                                             const uint32_t *__restrict__ tok, uint32_t n) {

@@ -18,7 +18,7 @@ __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
 struct BlockStart {
   uint64_t bit;       // of the block's header in the stream's input
   uint32_t out_pos;   // of its first byte in the stream's output (the token run)
-  uint32_t pad;
+  uint32_t chunk0;    // the chain: Adler-32 chunks of the blocks before
 };
 struct BlockEnd {
   uint32_t status, final_block;
@@ -37,7 +37,7 @@ struct FindCounts {
   uint32_t more[RESOLVE_ROUNDS];  // inflate_resolve_kernel: bytes round r left short of a literal
   uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that it had to walk itself
   uint32_t n_recs;    // blocks listed: the candidates' (inflate_blocks_dry_kernel), then the explorers' (may exceed the list)
-  uint32_t pad;
+  uint32_t n_chunks;  // inflate_chain_kernel: Adler-32 chunks of the chain's blocks (every block has its own grid, zd.ml:682-690)
   uint64_t miss_bit;  // inflate_chain_kernel without walking: where the chain could not go on (~0: nowhere)
 };
 __global__ void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
@@ -67,6 +67,11 @@ __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_aren
                                             FindCounts *__restrict__ counts, int follow);
 __global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
                                        const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out);
+__global__ void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
+                                            const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end,
+                                            uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums);
+__global__ void inflate_adler_fold_kernel(const uint32_t *__restrict__ sums, uint32_t n_chunks, int rfc,
+                                          StreamResult *__restrict__ result);
 __global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                       const uint32_t *__restrict__ tok, uint32_t n);
 
