@@ -138,3 +138,38 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
         assert int(ires[i].out_len) == len(want) and out.bytes(i, len(want)) == want == d, i
         assert int(ires[i].checksum) == crc, i
     assert int(ires[short].status) == 2  # "Expected decompression size exceeded"
+
+
+def test_a_few_long_members_inflate_by_blocks(gpu_ctx, oracle):
+    """zipc_hip_inflate_many with a handful of long members (an archive of a few big files): each goes by a wave per
+    block (api.hip zipc_hip_inflate_batch), the damaged one and the one over its limit through the stream's one wave
+    -- bytes, lengths, CRC-32 and statuses against the oracle, guard bytes intact"""
+    from zipc_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(3)
+    text = util.text(1_300_000, 4)
+    plain = [bytes(text), (rng.integers(0, 16, 1_500_000, dtype=np.uint8) * 17).astype(np.uint8).tobytes(),
+             (rng.integers(0, 1 << 14, 300_000, dtype=np.uint32) * np.uint32(0x10001)).tobytes(), bytes(text[::-1])]
+    comp = []
+    for i, d in enumerate(plain):
+        c = zlib.compressobj(6 if i % 2 else 1, zlib.DEFLATED, -15)
+        comp.append(c.compress(d) + c.flush())
+    c3 = bytearray(comp[3]); c3[len(c3) // 2] ^= 0x10; comp[3] = bytes(c3)  # damaged (or merely different: the oracle says)
+    limits = [len(d) for d in plain]
+    limits[2] -= 1
+    n = len(plain)
+    out = _Bufs(limits)
+    keep, cp, cl = _srcs(comp)
+    lim = (C.c_size_t * n)(*limits)
+    ires = (_lib.StreamResult * n)()
+    assert lib.zipc_hip_inflate_many(gpu_ctx.handle, n, cp, cl, lim, 1, out.ptrs, out.cap, ires) == 0
+    assert out.guards_intact()
+    for i in range(n):
+        st, want, crc = oracle.inflate(comp[i], decompressed_size=limits[i], crc_op=oracle.CRC_CRC32)
+        assert int(ires[i].status) == st, (i, st, int(ires[i].status))
+        if st == 0:
+            assert int(ires[i].out_len) == len(want) and out.bytes(i, len(want)) == want and int(ires[i].checksum) == crc, i
+        else:
+            assert int(ires[i].out_len) == 0, i
+    assert int(ires[0].status) == 0 and int(ires[1].status) == 0 and int(ires[2].status) == 2

@@ -647,6 +647,9 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   return ZIPC_HIP_OK;
 }
 
+static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op);
+
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
                            size_t n_streams, size_t max_dst_cap, int crc_op) {
@@ -660,7 +663,24 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
     bool handled = false;
     const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op, &handled);
     if (by != ZIPC_HIP_OK || handled) return by;
+  } else if (max_dst_cap <= MAX_STREAM_LEN && ((n_streams <= 4 && max_dst_cap >= (1u << 20)) || (n_streams <= 16 && max_dst_cap >= (8u << 20)))) {
+    // a few long streams (an archive of a few big members): one after the other by blocks -- about 2-8 ms each -- where
+    // their one waves, side by side, take 10-17 ms per MiB of the longest; a stream the block path leaves alone
+    // goes through the batch kernel as a batch of one
+    for (size_t i = 0; i < n_streams; i++) {
+      bool handled = false;
+      int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs + i, d_results + i, crc_op, &handled);
+      if (by == ZIPC_HIP_OK && !handled) by = inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, d_descs + i, d_results + i, 1, max_dst_cap, crc_op);
+      if (by != ZIPC_HIP_OK) return by;
+    }
+    return ZIPC_HIP_OK;
   }
+  return inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, max_dst_cap, crc_op);
+}
+
+// the batch kernel: one wave per stream
+static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op) {
   // one wave per stream (ZIPC_HIP_SLICES > 1: in slices on queues of their own, the CRC pass of one slice
   // beside the inflate kernel of the next; measured, not the default: deflate.hip)
   HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));
