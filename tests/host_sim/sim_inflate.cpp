@@ -140,7 +140,7 @@ struct SpanCall {
 static void span_lane(int lane, void *arg) {
   SpanCall &c = *(SpanCall *)arg;
   static uint16_t idx[SPAN_IDX_ENTRIES];  // the kernel's per-stream slot of global scratch
-  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, nullptr, nullptr, lane);
+  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, nullptr, nullptr, 0xFFFFFFFFu, nullptr, lane);
 }
 extern "C" { uint64_t sim_span_stats[8]; }  // spans run, symbols' bits committed, output bytes committed, per return code
 static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending) {

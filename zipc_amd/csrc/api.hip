@@ -544,12 +544,14 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   uint64_t rec_cap64 = (uint64_t)cand_cap + 4ull * max_explorers;
   if (rec_cap64 > BLOCKS_REC_CAP) rec_cap64 = BLOCKS_REC_CAP;
   const uint32_t rec_cap = (uint32_t)rec_cap64, chain_cap = rec_cap;
-  // scratch: counts | first | cand | recs | sorted | chain | chain_end
+  // scratch: counts | first | cand | recs | sorted | sorted_src | chain | chain_end | chain_iv | cks (listed blocks, then blocks the chain walked)
   size_t off = 0;
   auto carve = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
   const size_t o_counts = carve(sizeof(FindCounts)), o_first = carve((size_t)first_cap * 4), o_cand = carve((size_t)cand_cap * 4),
                o_recs = carve((size_t)rec_cap * sizeof(BlockRec)), o_sorted = carve((size_t)rec_cap * sizeof(BlockRec)),
-               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd));
+               o_sorted_src = carve((size_t)rec_cap * 4),
+               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd)),
+               o_chain_iv = carve((size_t)chain_cap * sizeof(ChainIv)), o_cks = carve(((size_t)rec_cap + chain_cap) * sizeof(BlockCk));
   HIP_TRY(ctx, ctx->ensure(ctx->blocks_scratch, off));
   uint8_t *base = (uint8_t *)ctx->blocks_scratch.p;
   FindCounts *d_counts = (FindCounts *)(base + o_counts);
@@ -557,6 +559,9 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   BlockRec *d_recs = (BlockRec *)(base + o_recs), *d_sorted = (BlockRec *)(base + o_sorted);
   BlockStart *d_chain = (BlockStart *)(base + o_chain);
   BlockEnd *d_chain_end = (BlockEnd *)(base + o_chain_end);
+  uint32_t *d_sorted_src = (uint32_t *)(base + o_sorted_src);
+  ChainIv *d_chain_iv = (ChainIv *)(base + o_chain_iv);
+  BlockCk *d_cks = (BlockCk *)(base + o_cks);
   const uint8_t *src = (const uint8_t *)d_src_arena;
   uint8_t *dst = (uint8_t *)d_dst_arena;
   const StreamDesc *dd = (const StreamDesc *)d_descs;
@@ -575,12 +580,12 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
   const uint32_t n = fc.n_cand;
   HIP_TRY(ctx, span_scratch(n));
-  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, n,
+  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, d_cks, n,
             (uint16_t *)ctx->inflate_scratch.p, d_counts);
   ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
-            (const FindCounts *)d_counts, rec_cap, d_sorted);
-  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, rec_cap, d_chain,
-            d_chain_end, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, explore ? 0 : 1);
+            (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
+  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
+            d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, explore ? 0 : 1);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (trace) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu miss %lld\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len, (long long)fc.miss_bit);
@@ -592,11 +597,11 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
     if (ne > max_explorers) ne = max_explorers;
     HIP_TRY(ctx, span_scratch(ne));
     ZD_LAUNCH(ctx, "inflate_explore", inflate_explore_kernel, dim3((unsigned)ne), dim3(64), 0, src, dst, dd, (const FindCounts *)d_counts,
-              (uint32_t)(EXPLORE_STRIDE * 8u), (uint32_t)ne, d_recs, rec_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
+              (uint32_t)(EXPLORE_STRIDE * 8u), (uint32_t)ne, d_recs, d_cks, rec_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
     ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((rec_cap + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
-              (const FindCounts *)d_counts, rec_cap, d_sorted);
-    ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, rec_cap, d_chain,
-              d_chain_end, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 1);
+              (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
+    ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
+              d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 1);
     HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (trace) fprintf(stderr, "inflate_by_blocks: %llu explorers, %u blocks listed; chain ok %u blocks %u (walked %u) out %llu\n", (unsigned long long)ne, fc.n_recs, fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len);
@@ -605,7 +610,8 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
   if (out_len == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 12));  // tok[], and two lists of bytes still to resolve
-  HIP_TRY(ctx, span_scratch(nb));
+  const uint32_t n_iv = fc.n_intervals;
+  HIP_TRY(ctx, span_scratch(n_iv));
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
   // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and
@@ -613,8 +619,9 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   static const int follow_env = [] { const char *e = getenv("ZIPC_HIP_INFLATE_FOLLOW"); return e ? atoi(e) : -1; }();
   const int follow = follow_env >= 0 ? follow_env : out_len >= (4u << 20);
   ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
-  ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(nb), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
-            (const BlockEnd *)d_chain_end, nb, (uint16_t *)ctx->inflate_scratch.p, d_tok, d_counts, follow);
+  ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(n_iv), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
+            (const BlockEnd *)d_chain_end, (const ChainIv *)d_chain_iv, (const BlockCk *)d_cks, nb, n_iv, (uint16_t *)ctx->inflate_scratch.p,
+            d_tok, d_counts, follow);
   for (int r = 0; r < RESOLVE_ROUNDS; r++) {
     uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,

@@ -560,13 +560,29 @@ struct Explore {
   uint32_t *n_recs;
   uint32_t cap, max_recs, inside_fixed;
   uint64_t stop_bit;
+  // every IM_DRY wave: where the checkpoints of the block being walked are gathered (2 * CK_MAX words of LDS) and,
+  // for an explorer, where the listed blocks' go
+  uint32_t *ck_lds;
+  BlockCk *cks;
+  // IM_TOKEN: the wave takes the block over at a checkpoint (resume: the block's tables are built from its header as
+  // ever, then the position jumps) and/or leaves it at the next (until_bit: it stops at the first convenient
+  // point at or behind that bit -- what it decodes beyond it, the next wave decodes too, to the same values)
+  uint32_t resume, resume_out;
+  uint64_t resume_bit, until_bit;
 };
+static_assert(CK_MAX == BLOCK_CK_MAX, "kernels.h");
 constexpr uint64_t NO_BIT = ~0ull;
+__device__ __forceinline__ Explore no_explore() {
+  Explore X;
+  X.recs = nullptr; X.n_recs = nullptr; X.cap = 0; X.max_recs = 0; X.inside_fixed = 0; X.stop_bit = 0;
+  X.ck_lds = nullptr; X.cks = nullptr; X.resume = 0; X.resume_out = 0; X.resume_bit = 0; X.until_bit = NO_BIT;
+  return X;
+}
 template <int MODE, bool MULTI = false>
 __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                                  const StreamDesc &sd, const BlockStart at, StreamResult *__restrict__ result,
                                                  uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op,
-                                                 const Explore X = Explore(), uint16_t *srcpos = nullptr) {
+                                                 const Explore X = no_explore(), uint16_t *srcpos = nullptr) {
   const int lane = threadIdx.x;
   const bool crc_adler = MODE == IM_REAL && (crc_op == CRC_ADLER32 || crc_op == CRC_ADLER32_RFC);
   const bool adler_rfc = crc_op == CRC_ADLER32_RFC;
@@ -595,6 +611,10 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   // the explorer's current block: its header's bit (NO_BIT: it was not seen), blocks listed so far
   uint64_t blk_hdr_bit = MULTI && X.inside_fixed ? NO_BIT : at.bit;
   uint32_t n_listed = 0;
+  SpanCk ck;
+  ck.lds = X.ck_lds; ck.n = 0; ck.last = 0; ck.hdr_bit = at.bit; ck.out_base = BLOCK_DRY_BASE;
+  bool resume_pending = MODE == IM_TOKEN && X.resume != 0u;
+  bool left_early = false;  // IM_TOKEN: the wave stopped at until_bit
   // a block has ended (the phase says what the stream's wave would do next): the block modes stop here, or go on
   auto block_done = [&]() {
     if (MODE == IM_REAL || d.status != ST_OK) return;
@@ -607,12 +627,17 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
           BlockRec r;
           r.bit = blk_hdr_bit;
           r.e.status = ST_OK; r.e.final_block = (uint32_t)d.final_block; r.e.end_bit = end_bit;
-          r.e.out_len = d.out_pos - BLOCK_DRY_BASE; r.e.pad = 0;
+          r.e.out_len = d.out_pos - BLOCK_DRY_BASE; r.e.pad = ck.n;
           X.recs[k] = r;
+          if (X.cks) {
+            X.cks[k].n = ck.n;
+            for (uint32_t i = 0; i < 2u * ck.n; i++) X.cks[k].e[i] = ck.lds[i];
+          }
         }
       }
       n_listed++;
     }
+    ck.n = 0; ck.last = 0; ck.hdr_bit = end_bit;
     if (d.final_block || (blk_hdr_bit != NO_BIT && blk_hdr_bit >= X.stop_bit) || n_listed >= X.max_recs) { d.phase = PH_DONE; return; }
     blk_hdr_bit = end_bit;
     d.out_pos = BLOCK_DRY_BASE;
@@ -679,10 +704,25 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
+          if (resume_pending) {  // the tables stand: on from the checkpoint
+            resume_pending = false;
+            d.in_word = (uint32_t)(X.resume_bit >> 5);
+            d.boff = (uint32_t)X.resume_bit & 31u;
+            d.ring_wr = d.in_word;
+            d.out_pos = X.resume_out;
+            break;  // (the input ring starts over)
+          }
         }
 #ifndef ZD_HDR_SPLIT
         ZD_PH(ph_hdr);
 #endif
+      } else if (d.phase == PH_SYMBOLS && d.fixed_lazy && resume_pending) {  // (a fixed block taken over at a checkpoint: its tables now)
+        d.fixed_lazy = 0;
+        d.phase = PH_TABLES;
+      } else if (MODE == IM_TOKEN && d.phase == PH_SYMBOLS && X.until_bit != NO_BIT && d.q_count == 0 &&
+                 (uint64_t)d.in_word * 32u + d.boff >= X.until_bit) {  // the next wave's part
+        d.phase = PH_DONE;
+        left_early = true;
       } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {  // a fixed block's first symbols, straight from the code
         turn++;
         ZD_PH_START();
@@ -702,11 +742,17 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         if (!d.span_off && d.in_word >= d.span_retry_word) {  // the block's symbols by regions, all lanes busy (inflate_span.h)
           if (d.q_count) break;  // queued copies first: the span reads its match sources from memory
           const uint32_t out_before = d.out_pos;
+          SpanCk *ckp = MODE == IM_DRY && ck.lds != nullptr && blk_hdr_bit != NO_BIT ? &ck : nullptr;
+          uint32_t bits_cap = 0xFFFFFFFFu;
+          if (MODE == IM_TOKEN && X.until_bit != NO_BIT) {
+            const uint64_t pos = (uint64_t)d.in_word * 32u + d.boff;
+            bits_cap = pos >= X.until_bit ? 0u : (uint32_t)(X.until_bit - pos) + 4096u;
+          }
           ZD_PH_START();
 #ifdef ZD_INFLATE_PHASES
-          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, lane, span_ph);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, bits_cap, ckp, lane, span_ph);
 #else
-          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, lane);
+          const int sr = span_decode<MODE>(d, L, src, dst, span_idx, tok, srcpos, bits_cap, ckp, lane);
 #endif
           if (sr != SPAN_NONE) {
             uniformize(d);
@@ -793,7 +839,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   e.final_block = (uint32_t)d.final_block;
   e.end_bit = (uint64_t)d.in_word * 32u + d.boff;
   e.out_len = d.out_pos - (MODE == IM_DRY ? BLOCK_DRY_BASE : at.out_pos);
-  e.pad = 0;
+  e.pad = MODE == IM_DRY ? ck.n : left_early ? 1u : 0u;
   if (MODE != IM_REAL) return e;
   if (writer) {
     StreamResult r;
@@ -907,19 +953,24 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
 // A dry run per candidate: recs[b] = the candidate's bit and what became of its block
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_dry_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, uint32_t n, uint16_t *__restrict__ span_scratch,
-    FindCounts *__restrict__ counts) {
+    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t n,
+    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  __shared__ uint32_t ck_lds[2 * CK_MAX];
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
   at.bit = cand[b]; at.out_pos = 0; at.chunk0 = 0;
+  Explore X = no_explore();
+  X.ck_lds = ck_lds;
   const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr,
-                                          span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP);
+                                          span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP, X);
   if (threadIdx.x == 0) {
     BlockRec r;
     r.bit = at.bit; r.e = e;
     recs[b] = r;
+    cks[b].n = e.pad;
+    for (uint32_t i = 0; i < 2u * e.pad; i++) cks[b].e[i] = ck_lds[i];
     if (b == 0) counts->n_recs = n;
   }
 }
@@ -934,24 +985,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // before its walk was real are blocks that no chain leads to.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_explore_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const FindCounts *__restrict__ from, uint32_t stride_bits, uint32_t n, BlockRec *__restrict__ recs, uint32_t rec_cap,
-    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+    const FindCounts *__restrict__ from, uint32_t stride_bits, uint32_t n, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks,
+    uint32_t rec_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  __shared__ uint32_t ck_lds[2 * CK_MAX];
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
   at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.chunk0 = 0;
   if (at.bit + 64u > descs[0].src_len * 8u) return;
-  Explore X;
+  Explore X = no_explore();
   X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16; X.inside_fixed = b != 0;
   X.stop_bit = at.bit + stride_bits;
+  X.ck_lds = ck_lds; X.cks = cks;
   inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
                              nullptr, CRC_NOP, X);
 }
 
 // the listed blocks in stream order: each finds its rank (they are few; the same block may be listed more than once)
 __global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts,
-                                                                 uint32_t rec_cap, BlockRec *__restrict__ sorted) {
+                                                                 uint32_t rec_cap, BlockRec *__restrict__ sorted,
+                                                                 uint32_t *__restrict__ sorted_src) {
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -962,6 +1016,7 @@ __global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec
     r += b < mine || (b == mine && j < i) ? 1u : 0u;
   }
   sorted[r] = recs[i];
+  sorted_src[r] = i;
 }
 
 // The chain of blocks from bit 0, by one wave.  chain[k]: block k's header bit and output position; chain_end[k]:
@@ -970,26 +1025,36 @@ __global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec
 // that block's dry run here and now, and goes on.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_chain_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockRec *__restrict__ sorted, uint32_t rec_cap, BlockStart *__restrict__ chain,
-    BlockEnd *__restrict__ chain_end, uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts,
-    int walk) {
+    const BlockRec *__restrict__ sorted, const uint32_t *__restrict__ sorted_src, uint32_t rec_cap, BlockStart *__restrict__ chain,
+    BlockEnd *__restrict__ chain_end, ChainIv *__restrict__ chain_iv, BlockCk *__restrict__ cks, uint32_t chain_cap,
+    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  __shared__ uint32_t ck_lds[2 * CK_MAX];
   const StreamDesc sd = descs[0];
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
   uint64_t out = 0, bit = 0, miss = NO_BIT;
-  uint32_t j = 0, k = 0, walked = 0, chunks = 0;  // listed blocks below j start before `bit`
+  uint32_t j = 0, k = 0, walked = 0, chunks = 0, intervals = 0;  // listed blocks below j start before `bit`
   bool ok = n != 0 && sorted[0].bit == 0;
   while (ok) {
     while (j < n && sorted[j].bit < bit) j++;
     BlockEnd e;
-    if (j < n && sorted[j].bit == bit) e = sorted[j].e;
+    uint32_t ck_at;  // the block's checkpoints: the listed block's, or (a block walked here) slot rec_cap + k
+    if (j < n && sorted[j].bit == bit) { e = sorted[j].e; ck_at = sorted_src[j]; }
     else if (!walk) { ok = false; miss = bit; break; }
     else {
+      if (k >= chain_cap) { ok = false; break; }
       BlockStart at;
       at.bit = bit; at.out_pos = 0; at.chunk0 = 0;
       walked++;
-      e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, sd, at, nullptr, span_scratch, nullptr, CRC_NOP);
+      Explore X = no_explore();
+      X.ck_lds = ck_lds;
+      e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, sd, at, nullptr, span_scratch, nullptr, CRC_NOP, X);
+      ck_at = rec_cap + k;
+      if (threadIdx.x == 0) {
+        cks[ck_at].n = e.pad;
+        for (uint32_t i = 0; i < 2u * e.pad; i++) cks[ck_at].e[i] = ck_lds[i];
+      }
     }
     if (e.status != ST_OK || out + e.out_len > room || out + e.out_len > MAX_STREAM_LEN || k >= chain_cap) { ok = false; break; }
     if (threadIdx.x == 0) {
@@ -997,7 +1062,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       b.bit = bit; b.out_pos = (uint32_t)out; b.chunk0 = chunks;
       chain[k] = b;
       chain_end[k] = e;
+      ChainIv iv;
+      iv.first = intervals; iv.ck = ck_at;
+      chain_iv[k] = iv;
     }
+    intervals += 1u + e.pad;
     k++;
     out += e.out_len;
     if (e.out_len) chunks += 1u + e.out_len / ADLER_CHUNK;  // (Adler_32.string_update zd.ml:175-198: a first chunk of len mod 5552, maybe empty)
@@ -1012,6 +1081,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     counts->n_walked = walked;
     counts->miss_bit = miss;
     counts->n_chunks = chunks;
+    counts->n_intervals = intervals;
   }
 }
 
@@ -1020,20 +1090,45 @@ __global__ __launch_bounds__(256) void inflate_tok_init_kernel(uint32_t *__restr
   if (i < n) tok[i] = i;
 }
 
+// The token run: a wave per INTERVAL of the chain's blocks -- a block from its header to its first checkpoint, from
+// checkpoint to checkpoint, from the last one to the block's end (the dry run took one every 6 KiB of input or so, at
+// starts of the span decoder's tiles: bit and output position on the real sequence).  A wave that starts at a
+// checkpoint builds the block's tables from the header first.  The last wave of a block must end where and with as
+// many bytes as the dry run did; the others leave at or behind the next checkpoint (what they decode behind it the
+// next wave decodes too: the same literals, and for a match byte a source on the same chain of copies).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_token_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end, uint32_t n,
+    const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end, const ChainIv *__restrict__ chain_iv,
+    const BlockCk *__restrict__ cks, uint32_t n_blocks, uint32_t n,
     uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok, FindCounts *__restrict__ counts, int follow) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
-  const uint32_t b = blockIdx.x;
-  if (b >= n) return;
   __shared__ uint16_t srcpos[SPAN_TILE];
-  const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[0], chain[b], nullptr,
-                                              span_scratch + (size_t)b * SPAN_IDX_ENTRIES, tok, CRC_NOP, Explore(),
-                                              follow ? srcpos : nullptr);
+  const uint32_t w = blockIdx.x;
+  if (w >= n) return;
+  uint32_t lo = 0, hi = n_blocks - 1u;  // the last block whose first interval is at or before w
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi + 1u) >> 1;
+    if (chain_iv[mid].first <= w) lo = mid;
+    else hi = mid - 1u;
+  }
+  const ChainIv iv = chain_iv[lo];
+  const BlockStart blk = chain[lo];
+  const BlockCk *ck = cks + iv.ck;
+  const uint32_t j = w - iv.first, n_ck = ck->n;
+  Explore X = no_explore();
+  if (j > 0u) {
+    X.resume = 1;
+    X.resume_bit = blk.bit + ck->e[2u * (j - 1u)];
+    X.resume_out = blk.out_pos + ck->e[2u * (j - 1u) + 1u];
+  }
+  if (j < n_ck) X.until_bit = blk.bit + ck->e[2u * j];
+  const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[0], blk, nullptr,
+                                              span_scratch + (size_t)w * SPAN_IDX_ENTRIES, tok, CRC_NOP, X, follow ? srcpos : nullptr);
   if (threadIdx.x == 0) {
-    const BlockEnd want = chain_end[b];
-    if (got.status != ST_OK || got.end_bit != want.end_bit || got.out_len != want.out_len) atomicAdd(&counts->token_bad, 1u);
+    const BlockEnd want = chain_end[lo];
+    const bool good = got.status == ST_OK && (j < n_ck ? got.pad == 1u && got.end_bit >= X.until_bit
+                                                        : got.pad == 0u && got.end_bit == want.end_bit && got.out_len == want.out_len);
+    if (!good) atomicAdd(&counts->token_bad, 1u);
   }
 }
 

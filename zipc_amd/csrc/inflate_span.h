@@ -486,9 +486,19 @@ ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, u
 // tile; IM_TOKEN stores the literals and, for every byte of a match, the output position it is a copy of in tok[]
 // (inflate.hip: one stream by a wave per block; srcpos: SPAN_TILE u16 of LDS, the tile's sources while they are
 // sorted out).
+// bits_cap: a span walks no further than this many bits (a wave that takes a block over from a checkpoint on and only
+// up to the next one: inflate.hip).  ck (IM_DRY): checkpoints of the block -- bit and output position of a tile's start,
+// both known to be on the real sequence, every CK_GAP_BITS of input or so.
+constexpr uint32_t CK_MAX = 15, CK_GAP_BITS = 49152;
+struct SpanCk {
+  uint32_t *lds;      // 2 * CK_MAX words: bit (from the block's header bit), output byte (from the block's first)
+  uint32_t n, last;   // checkpoints taken, the last one's bit
+  uint64_t hdr_bit;   // the block's header bit
+  uint32_t out_base;  // the block's first output position
+};
 template <int MODE = IM_REAL>
 ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_stream, uint8_t *dst, uint16_t *idx, uint32_t *tok,
-                      uint16_t *srcpos, int lane
+                      uint16_t *srcpos, uint32_t bits_cap, SpanCk *ck, int lane
 #ifdef ZD_INFLATE_PHASES
                       , uint64_t *span_ph
 #endif
@@ -501,7 +511,8 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   const uint32_t full_words = src_len >> 2;
   if (full_words < in_word + SPAN_TAIL_WORDS + 2u) return SPAN_NONE;
   const uint32_t max_word = full_words - in_word;
-  const uint32_t usable = (max_word - SPAN_TAIL_WORDS) * 32u - base;  // bits a span may walk
+  uint32_t usable = (max_word - SPAN_TAIL_WORDS) * 32u - base;  // bits a span may walk
+  if (usable > bits_cap) usable = bits_cap;
   uint32_t est = usable;
   const uint32_t prev_bits = wv::uni(d.prev_block_bits);
   if (prev_bits != 0u) {
@@ -694,6 +705,14 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
       break;
     }
     const uint32_t tile_len = wv::readlane(incl, n - 1u);
+    if (MODE == IM_DRY && ck != nullptr) {  // (the tile's start is where the tile before was checked to end, or the span's first bit)
+      const uint64_t rel = (uint64_t)in_word * 32u + tile_start_p - ck->hdr_bit;
+      if (ck->n < CK_MAX && rel >= (uint64_t)ck->last + CK_GAP_BITS && rel < 0xFFFFFFFFull) {
+        if (ulane == 0u) { ck->lds[2u * ck->n] = (uint32_t)rel; ck->lds[2u * ck->n + 1u] = out_pos - ck->out_base; }
+        ck->n++;
+        ck->last = (uint32_t)rel;
+      }
+    }
     const bool mine = ulane < n;
     const uint32_t o0 = incl - eod, o_end = incl;
     uint32_t o = o0;

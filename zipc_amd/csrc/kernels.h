@@ -25,7 +25,11 @@ struct BlockEnd {
   uint64_t end_bit;   // of the first bit behind the block (a stored block: behind its bytes)
   uint32_t out_len, pad;
 };
-struct BlockRec { uint64_t bit; BlockEnd e; };  // a block that was walked from its header's bit to its end
+struct BlockRec { uint64_t bit; BlockEnd e; };  // a block that was walked from its header's bit to its end (e.pad: its checkpoints)
+// checkpoints of a block's dry run (inflate_span.h SpanCk): bit from the header's bit, output byte from the block's first
+constexpr uint32_t BLOCK_CK_MAX = 15;
+struct BlockCk { uint32_t n; uint32_t e[2 * BLOCK_CK_MAX]; uint32_t pad; };
+struct ChainIv { uint32_t first, ck; };  // a chain block's first interval (the token run: a wave per interval), its BlockCk
 constexpr int RESOLVE_ROUNDS = 12;  // 8 hops a round: pointers of 8^r copies after round r
 struct FindCounts {
   uint32_t n_first;   // offsets that passed the header test (may exceed the list: those are lost)
@@ -38,6 +42,7 @@ struct FindCounts {
   uint32_t n_walked;  // inflate_chain_kernel: blocks of the chain that it had to walk itself
   uint32_t n_recs;    // blocks listed: the candidates' (inflate_blocks_dry_kernel), then the explorers' (may exceed the list)
   uint32_t n_chunks;  // inflate_chain_kernel: Adler-32 chunks of the chain's blocks (every block has its own grid, zd.ml:682-690)
+  uint32_t n_intervals, pad2;  // inflate_chain_kernel: intervals of the chain's blocks (a block and its checkpoints)
   uint64_t miss_bit;  // inflate_chain_kernel without walking: where the chain could not go on (~0: nowhere)
 };
 __global__ void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
@@ -47,22 +52,24 @@ __global__ void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_aren
                                             uint32_t cand_cap, FindCounts *__restrict__ counts);
 __global__ void inflate_blocks_dry_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                           const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ cand,
-                                          BlockRec *__restrict__ recs, uint32_t n, uint16_t *__restrict__ span_scratch,
-                                          FindCounts *__restrict__ counts);
+                                          BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t n,
+                                          uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts);
 __global__ void inflate_explore_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                        const StreamDesc *__restrict__ descs, const FindCounts *__restrict__ from, uint32_t stride_bits,
-                                       uint32_t n, BlockRec *__restrict__ recs, uint32_t rec_cap, uint16_t *__restrict__ span_scratch,
-                                       FindCounts *__restrict__ counts);
+                                       uint32_t n, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t rec_cap,
+                                       uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts);
 __global__ void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts, uint32_t rec_cap,
-                                           BlockRec *__restrict__ sorted);
+                                           BlockRec *__restrict__ sorted, uint32_t *__restrict__ sorted_src);
 __global__ void inflate_chain_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                     const StreamDesc *__restrict__ descs, const BlockRec *__restrict__ sorted, uint32_t rec_cap,
-                                     BlockStart *__restrict__ chain, BlockEnd *__restrict__ chain_end, uint32_t chain_cap,
-                                     uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk);
+                                     const StreamDesc *__restrict__ descs, const BlockRec *__restrict__ sorted,
+                                     const uint32_t *__restrict__ sorted_src, uint32_t rec_cap, BlockStart *__restrict__ chain,
+                                     BlockEnd *__restrict__ chain_end, ChainIv *__restrict__ chain_iv, BlockCk *__restrict__ cks,
+                                     uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk);
 __global__ void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n);
 __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                             const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ chain,
-                                            const BlockEnd *__restrict__ chain_end, uint32_t n,
+                                            const BlockEnd *__restrict__ chain_end, const ChainIv *__restrict__ chain_iv,
+                                            const BlockCk *__restrict__ cks, uint32_t n_blocks, uint32_t n,
                                             uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
                                             FindCounts *__restrict__ counts, int follow);
 __global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
