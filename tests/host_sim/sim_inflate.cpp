@@ -183,7 +183,8 @@ extern "C" uint64_t sim_find_candidates(const uint8_t *src, uint64_t src_len, ui
   for (uint64_t p = 1; p < total_bits; p++) {
     if (!find_header_test(find_bits(src, src_len, p), find_bits(src, src_len, p + 64u), total_bits - p)) continue;
     nf++;
-    if (!find_lengths_test(src, src_len, p, sim_find_max_syms)) continue;
+    uint8_t tbl[128];
+    if (!find_lengths_test(src, src_len, p, tbl, 1u, sim_find_max_syms)) continue;
     if (n < cap) cand[n] = p;
     n++;
   }

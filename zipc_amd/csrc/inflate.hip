@@ -934,6 +934,7 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
                                                                  const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ first,
                                                                  uint32_t first_cap, uint32_t *__restrict__ cand, uint32_t cand_cap,
                                                                  FindCounts *__restrict__ counts) {
+  __shared__ uint8_t find_tbl[128 * 64];  // (a column per thread: entry e of thread t at e * 64 + t)
   const StreamDesc sd = descs[0];
   const uint8_t *s = src_arena + sd.src_off;
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
@@ -945,7 +946,7 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
   }
   if (i >= n_first) return;
   const uint32_t start = first[i];
-  if (!find_lengths_test(s, sd.src_len, start)) return;
+  if (!find_lengths_test(s, sd.src_len, start, find_tbl + threadIdx.x, 64u)) return;
   const uint32_t at = atomicAdd(&counts->n_cand, 1u);
   if (at < cand_cap) cand[at] = start;
 }
@@ -1105,7 +1106,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ uint16_t srcpos[SPAN_TILE];
   const uint32_t w = blockIdx.x;
   if (w >= n) return;
-  uint32_t lo = 0, hi = n_blocks - 1u;  // the last block whose first interval is at or before w
+  // (follow: a long stream, where a wave writes down what its sources are copies of -- inflate_span.h -- and that
+  // works best when ONE wave takes a block from start to end: a wave per block, n = n_blocks)
+  uint32_t lo = follow ? w : 0u, hi = follow ? w : n_blocks - 1u;  // the last block whose first interval is at or before w
   while (lo < hi) {
     const uint32_t mid = (lo + hi + 1u) >> 1;
     if (chain_iv[mid].first <= w) lo = mid;
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const ChainIv iv = chain_iv[lo];
   const BlockStart blk = chain[lo];
   const BlockCk *ck = cks + iv.ck;
-  const uint32_t j = w - iv.first, n_ck = ck->n;
+  const uint32_t j = follow ? 0u : w - iv.first, n_ck = follow ? 0u : ck->n;
   Explore X = no_explore();
   if (j > 0u) {
     X.resume = 1;

@@ -46,7 +46,10 @@ ZD_HD bool find_header_test(uint64_t x, uint64_t x_hi, uint64_t left) {
 // (zd.ml:662), and a distance code that is complete, a single one-bit code, or empty.
 // max_syms: code-length symbols read at most; a header that has passed so many is let through untested beyond (the
 // dry run reads it again anyway).
-ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64_t start, uint32_t max_syms = 0xFFFFFFFFu) {
+// tbl: 128 bytes of the caller's (entry i at tbl[i * stride]: the kernel gives every thread a column of LDS) for the
+// code-length code's look-up table -- a symbol is then one read, not a walk of the code bit by bit.
+ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64_t start, uint8_t *tbl, uint32_t stride,
+                             uint32_t max_syms = 0xFFFFFFFFu) {
   const uint64_t total_bits = len * 8u;
   uint64_t pos = start;
   uint64_t x = find_bits(s, len, pos);
@@ -62,17 +65,24 @@ ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64
     if (l) cnt += 1ull << (5u * (uint32_t)l);
   }
   pos += 3u * hclen;
-  uint64_t sorted_lo = 0, sorted_hi = 0;  // 19 symbols of 5 bits: 12 in the first word
+  // the table: entry = symbol | length << 5 at every 7-bit index whose low `length` bits are the symbol's code as it
+  // comes in the stream (read_symbol zd.ml:584-591 takes a code most significant bit first: the index is the code
+  // reversed); codes are handed out in the order (length, symbol).  0: no code (an incomplete code's gap).
+  for (uint32_t i = 0; i < 128u; i++) tbl[i * stride] = 0;
   {
-    uint32_t n = 0;
-    for (uint32_t l = 1; l <= 7u; l++)
+    uint32_t code = 0;
+    for (uint32_t l = 1; l <= 7u; l++) {
       for (uint32_t sym = 0; sym < 19u; sym++)
         if (((len_of >> (3u * sym)) & 7u) == l) {
-          if (n < 12u) sorted_lo |= (uint64_t)sym << (5u * n);
-          else sorted_hi |= (uint64_t)sym << (5u * (n - 12u));
-          n++;
+          uint32_t r = 0;
+          for (uint32_t b = 0; b < l; b++) r |= ((code >> b) & 1u) << (l - 1u - b);
+          for (uint32_t i = r; i < 128u; i += 1u << l) tbl[i * stride] = (uint8_t)(sym | (l << 5));
+          code++;
         }
+      code <<= 1;
+    }
   }
+  (void)cnt;
   const uint32_t total = hlit + hdist;
   uint32_t num = 0, prev = 0;
   uint32_t kraft_lit = 0, n_lit = 0, kraft_dist = 0, n_dist = 0;
@@ -82,22 +92,10 @@ ZD_HD bool find_lengths_test(const uint8_t *__restrict__ s, uint64_t len, uint64
   while (num < total) {
     if (n_syms++ >= max_syms) return true;
     if (have < 14u) { x = find_bits(s, len, pos); have = 64; }
-    // read_symbol zd.ml:584-591: the code bit by bit, most significant first
-    uint32_t code = 0, firstc = 0, index = 0, sym = 0xFFFFFFFFu, used = 0;
-    for (uint32_t l = 1; l <= 7u; l++) {
-      code |= (uint32_t)(x >> (l - 1u)) & 1u;
-      const uint32_t c = (uint32_t)(cnt >> (5u * l)) & 31u;
-      if (code - firstc < c) {
-        const uint32_t k = index + (code - firstc);
-        sym = (uint32_t)(k < 12u ? sorted_lo >> (5u * k) : sorted_hi >> (5u * (k - 12u))) & 31u;
-        used = l;
-        break;
-      }
-      index += c;
-      firstc = (firstc + c) << 1;
-      code <<= 1;
-    }
-    if (sym == 0xFFFFFFFFu) return false;
+    const uint32_t ent = tbl[((uint32_t)x & 127u) * stride];
+    if (ent == 0u) return false;
+    const uint32_t sym = ent & 31u;
+    uint32_t used = ent >> 5;
     uint32_t len, rep;
     if (sym < 16u) { len = sym; rep = 1; }
     else if (sym == 16u) {
