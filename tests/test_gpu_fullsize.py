@@ -458,6 +458,20 @@ def test_one_long_stream_deflates_on_many_waves_bytes_equal_oracle(gpu_ctx, orac
     batch.inflate_batch(gpu_ctx, comp, out, d_id, d_ires, 1, n, 1)
     ires = batch.results_from_device(d_ires)
     assert int(ires["status"][0]) == 0 and int(ires["checksum"][0]) == k0 and torch.equal(out[:n], src)
+    # ... by a wave per block (inflate.hip): ~650 blocks, most of them fixed ones that only the explorers find
+    assert gpu_ctx.last_inflate_blocks() >= 500, gpu_ctx.last_inflate_blocks()
+    # the same bytes as zlib codes them (other blocks, other matches), with the reference's Adler-32 this time
+    c = zlib.compressobj(1, zlib.DEFLATED, -15)
+    zraw = c.compress(plain) + c.flush()
+    d_z = torch.cat([torch.from_numpy(np.frombuffer(zraw, np.uint8).copy()).to(dev), torch.zeros(256, dtype=torch.uint8, device=dev)])
+    zdesc = batch.uniform_layout(1, len(zraw), n)
+    out.fill_(0x5A)
+    batch.inflate_batch(gpu_ctx, d_z, out, batch.to_device(zdesc, dev), d_ires, 1, n, 2)
+    ires = batch.results_from_device(d_ires)
+    assert int(ires["status"][0]) == 0 and int(ires["out_len"][0]) == n and torch.equal(out[:n], src)
+    st0, d0, a0 = oracle.inflate(zraw, decompressed_size=n, crc_op=oracle.CRC_ADLER32)  # (block by block: not adler32(plain))
+    assert st0 == 0 and int(ires["checksum"][0]) == a0 and bool((out[n:] == 0x5A).all())
+    assert gpu_ctx.last_inflate_blocks() >= 500, gpu_ctx.last_inflate_blocks()
 
 
 def test_real_text_at_16384_streams(gpu_ctx, oracle):

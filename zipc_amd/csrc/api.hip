@@ -609,7 +609,10 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;  // (one block: nothing to gain)
   const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
   if (out_len == 0) return ZIPC_HIP_OK;
-  HIP_TRY(ctx, ctx->ensure(ctx->tok_scratch, (size_t)out_len * 12));  // tok[], and two lists of bytes still to resolve
+  if (ctx->ensure(ctx->tok_scratch, (size_t)out_len * 12) != hipSuccess) {  // tok[], and two lists of bytes still to resolve
+    (void)hipGetLastError();  // (no room for a word per byte and the lists: the stream's one wave needs none)
+    return ZIPC_HIP_OK;
+  }
 
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
