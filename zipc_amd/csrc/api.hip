@@ -616,11 +616,12 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
 
   uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
   const unsigned out_grid = (out_len + 255u) / 256u;
-  // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and
-  // save the resolve rounds of a long stream more: measured at 1 MiB and 16 MiB)
+  // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and a
+  // wave per block instead of one per interval, and save the resolve rounds of a long stream more: with 256 hops a
+  // round, 64 MiB of text 6.3-10.8 -> 5.7-6.5 ms, 16 MiB 2.7-4.4 <- 3.3-4.2)
   static const int follow_env = [] { const char *e = getenv("ZIPC_HIP_INFLATE_FOLLOW"); return e ? atoi(e) : -1; }();
   // (... and nothing on data with few matches: 16 MiB of records that deflate to 0.85, resolve 0.13 ms either way)
-  const int follow = follow_env >= 0 ? follow_env : out_len >= (4u << 20) && (uint64_t)out_len * 2u >= sd.src_len * 3u;
+  const int follow = follow_env >= 0 ? follow_env : out_len >= (32u << 20) && (uint64_t)out_len * 2u >= sd.src_len * 3u;
   // the token run: a wave per interval of a block (its checkpoints), or -- follow -- a wave per block
   const uint32_t n_iv = follow ? nb : fc.n_intervals;
   HIP_TRY(ctx, span_scratch(n_iv));
@@ -628,10 +629,14 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(n_iv), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
             (const BlockEnd *)d_chain_end, (const ChainIv *)d_chain_iv, (const BlockCk *)d_cks, nb, n_iv, (uint16_t *)ctx->inflate_scratch.p,
             d_tok, d_counts, follow);
+  // (hops a thread follows in a round: 8 left most bytes of a text for the next round -- 16 MiB: three rounds over nearly
+  // everything, 3.4 ms; 64 and more let nearly every byte arrive in the first: 0.28 ms)
+  static const int hops0 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS0"); return e ? atoi(e) : 256; }();
+  static const int hops1 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS1"); return e ? atoi(e) : 256; }();
   for (int r = 0; r < RESOLVE_ROUNDS; r++) {
     uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,
-              out_len, d_counts, r, (const uint32_t *)list_in, list_out);
+              out_len, d_counts, r, (const uint32_t *)list_in, list_out, r == 0 ? hops0 : hops1);
   }
   ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));

@@ -1035,13 +1035,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
   uint64_t out = 0, bit = 0, miss = NO_BIT;
-  uint32_t j = 0, k = 0, walked = 0, chunks = 0, intervals = 0;  // listed blocks below j start before `bit`
+  uint32_t k = 0, walked = 0, chunks = 0, intervals = 0;
+  // the listed blocks, 64 at a time in the lanes' registers (a step of the chain is then a ballot and a few
+  // readlanes, not three loads one after the other): lane l holds block wj + l
+  uint32_t wj = 0;
+  uint64_t wbit = NO_BIT;
+  BlockEnd we;
+  uint32_t wsrc = 0;
+  auto window = [&](uint32_t base) {
+    wj = base;
+    const uint32_t i = base + threadIdx.x;
+    wbit = NO_BIT;
+    we.status = 0; we.final_block = 0; we.end_bit = 0; we.out_len = 0; we.pad = 0;
+    wsrc = 0;
+    if (i < n) { wbit = sorted[i].bit; we = sorted[i].e; wsrc = sorted_src[i]; }
+  };
+  window(0);
   bool ok = n != 0 && sorted[0].bit == 0;
   while (ok) {
-    while (j < n && sorted[j].bit < bit) j++;
+    unsigned long long hit;
+    for (;;) {  // the window that can hold `bit`
+      hit = __builtin_amdgcn_ballot_w64(wbit == bit);
+      if (hit != 0ull || wj + 64u >= n || __builtin_amdgcn_ballot_w64(wbit != NO_BIT && wbit > bit) != 0ull) break;
+      window(wj + 64u);
+    }
     BlockEnd e;
     uint32_t ck_at;  // the block's checkpoints: the listed block's, or (a block walked here) slot rec_cap + k
-    if (j < n && sorted[j].bit == bit) { e = sorted[j].e; ck_at = sorted_src[j]; }
+    if (hit != 0ull) {
+      const int l = __builtin_ctzll(hit);
+      e.status = (uint32_t)__builtin_amdgcn_readlane((int)we.status, l);
+      e.final_block = (uint32_t)__builtin_amdgcn_readlane((int)we.final_block, l);
+      e.end_bit = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(we.end_bit >> 32), l) << 32) |
+                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)we.end_bit, l);
+      e.out_len = (uint32_t)__builtin_amdgcn_readlane((int)we.out_len, l);
+      e.pad = (uint32_t)__builtin_amdgcn_readlane((int)we.pad, l);
+      ck_at = (uint32_t)__builtin_amdgcn_readlane((int)wsrc, l);
+    }
     else if (!walk) { ok = false; miss = bit; break; }
     else {
       if (k >= chain_cap) { ok = false; break; }
@@ -1129,25 +1158,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                                               span_scratch + (size_t)w * SPAN_IDX_ENTRIES, tok, CRC_NOP, X, follow ? srcpos : nullptr);
   if (threadIdx.x == 0) {
     const BlockEnd want = chain_end[lo];
-    const bool good = got.status == ST_OK && (j < n_ck ? got.pad == 1u && got.end_bit >= X.until_bit
-                                                        : got.pad == 0u && got.end_bit == want.end_bit && got.out_len == want.out_len);
+    // (a wave that was to leave at a checkpoint close to the block's end may have reached that end instead)
+    const bool at_end = got.pad == 0u && got.end_bit == want.end_bit && got.out_len == want.out_len;
+    const bool good = got.status == ST_OK && (at_end || (j < n_ck && got.pad == 1u && got.end_bit >= X.until_bit));
     if (!good) atomicAdd(&counts->token_bad, 1u);
   }
 }
 
-// Pointer jumping, up to RESOLVE_HOPS hops a thread and round: a pointer only ever moves to an earlier byte of the
+// Pointer jumping, up to `hops` hops a thread and round (api.hip: 256): a pointer only ever moves to an earlier byte of the
 // same chain of copies, so reading one that another thread has already moved is as good.  Round 0 looks at every
 // byte; a thread that did not arrive at a literal lists its byte (more[round] counts them), and the rounds behind
 // look at the listed bytes only (all rounds are launched; one whose list is empty returns at once).
-constexpr int RESOLVE_HOPS = 8;
+
 __device__ __forceinline__ void resolve_one(uint32_t *__restrict__ tok, uint32_t i, bool have, uint32_t *__restrict__ list_out,
-                                            uint32_t *__restrict__ count_out) {
+                                            uint32_t *__restrict__ count_out, int hops) {
   bool open = false;
   if (have) {
     uint32_t j = tok[i];
     if (j != i) {
       uint32_t j2 = tok[j];
-      for (int h = 1; h < RESOLVE_HOPS && j2 != j; h++) { j = j2; j2 = tok[j]; }
+      for (int h = 1; h < hops && j2 != j; h++) { j = j2; j2 = tok[j]; }
       open = j2 != j;
       tok[i] = j2;
     }
@@ -1162,16 +1192,17 @@ __device__ __forceinline__ void resolve_one(uint32_t *__restrict__ tok, uint32_t
   }
 }
 __global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts,
-                                                             int round, const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out) {
+                                                             int round, const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out,
+                                                             int hops) {
   if (round == 0) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    resolve_one(tok, i, i < n, list_out, &counts->more[0]);
+    resolve_one(tok, i, i < n, list_out, &counts->more[0], hops);
     return;
   }
   const uint32_t n_in = counts->more[round - 1];
   for (uint32_t t0 = blockIdx.x * 256u; t0 < n_in; t0 += gridDim.x * 256u) {  // (wave-uniform trip count)
     const uint32_t t = t0 + threadIdx.x;
-    resolve_one(tok, t < n_in ? list_in[t] : 0u, t < n_in, list_out, &counts->more[round]);
+    resolve_one(tok, t < n_in ? list_in[t] : 0u, t < n_in, list_out, &counts->more[round], hops);
   }
 }
 // Adler-32 of a stream that went by blocks: the reference updates it block by block (inflated_block_crc zd.ml:682-690),

@@ -30,7 +30,7 @@ struct BlockRec { uint64_t bit; BlockEnd e; };  // a block that was walked from 
 constexpr uint32_t BLOCK_CK_MAX = 15;
 struct BlockCk { uint32_t n; uint32_t e[2 * BLOCK_CK_MAX]; uint32_t pad; };
 struct ChainIv { uint32_t first, ck; };  // a chain block's first interval (the token run: a wave per interval), its BlockCk
-constexpr int RESOLVE_ROUNDS = 12;  // 8 hops a round: pointers of 8^r copies after round r
+constexpr int RESOLVE_ROUNDS = 12;  // (h hops a round: pointers of h^r copies after round r)
 struct FindCounts {
   uint32_t n_first;   // offsets that passed the header test (may exceed the list: those are lost)
   uint32_t n_cand;    // candidates (likewise)
@@ -73,7 +73,7 @@ __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_aren
                                             uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
                                             FindCounts *__restrict__ counts, int follow);
 __global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
-                                       const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out);
+                                       const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out, int hops);
 __global__ void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                             const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end,
                                             uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums);
