@@ -181,7 +181,11 @@ extern "C" uint64_t sim_find_candidates(const uint8_t *src, uint64_t src_len, ui
   const uint64_t total_bits = src_len * 8u;
   if (cap) cand[n++] = 0;
   for (uint64_t p = 1; p < total_bits; p++) {
-    if (!find_header_test(find_bits(src, src_len, p), find_bits(src, src_len, p + 64u), total_bits - p)) continue;
+    // (the kernel looks only at the offsets find_header_mask32 lets through: it must let through whatever passes)
+    const bool in_mask = (find_header_mask32(find_bits(src, src_len, p & ~31ull)) >> (p & 31u)) & 1u;
+    const bool passes = find_header_test(find_bits(src, src_len, p), find_bits(src, src_len, p + 64u), total_bits - p);
+    if (passes && !in_mask) { fprintf(stderr, "find_header_mask32 misses offset %llu\n", (unsigned long long)p); abort(); }
+    if (!passes) continue;
     nf++;
     uint8_t tbl[128];
     if (!find_lengths_test(src, src_len, p, tbl, 1u, sim_find_max_syms)) continue;

@@ -912,7 +912,8 @@ __global__ __launch_bounds__(256) void inflate_find_headers_kernel(const uint8_t
     const uint64_t total_bits = sd.src_len * 8u;
     const uint64_t a = find_bits(s, sd.src_len, t * 8u), b = find_bits(s, sd.src_len, t * 8u + 64u);
 #pragma unroll 1
-    for (uint32_t off = 0; off < 32u; off++) {
+    for (uint32_t m = find_header_mask32(a); m != 0u; m &= m - 1u) {
+      const uint32_t off = (uint32_t)__builtin_ctz(m);
       const uint64_t bit = t * 8u + off;
       if (bit == 0 || bit >= total_bits) continue;  // (bit 0 is a candidate anyway)
       if (!find_header_test(off ? (a >> off) | (b << (64u - off)) : a, b >> off, total_bits - bit)) continue;
