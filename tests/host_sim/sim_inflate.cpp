@@ -136,19 +136,26 @@ struct SpanCall {
   const LaneLds *L;
   const uint8_t *src;
   uint8_t *dst;
+  // the token form (inflate.hip IM_TOKEN): tok[] instead of copies; srcpos: the tile's sources (following), or null
+  uint32_t *tok;
+  uint16_t *srcpos;
+  uint32_t bits_cap;
 };
 static void span_lane(int lane, void *arg) {
   SpanCall &c = *(SpanCall *)arg;
   static uint16_t idx[SPAN_IDX_ENTRIES];  // the kernel's per-stream slot of global scratch
-  c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, nullptr, nullptr, 0xFFFFFFFFu, nullptr, lane);
+  if (c.tok) c.ret[lane] = span_decode<IM_TOKEN>(c.d[lane], *c.L, c.src, c.dst, idx, c.tok, c.srcpos, c.bits_cap, nullptr, lane);
+  else c.ret[lane] = span_decode(c.d[lane], *c.L, c.src, c.dst, idx, nullptr, nullptr, 0xFFFFFFFFu, nullptr, lane);
 }
 extern "C" { uint64_t sim_span_stats[8]; }  // spans run, symbols' bits committed, output bytes committed, per return code
-static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending) {
+static int span_model(InflateLane &d, const LaneLds &L, const uint8_t *src, uint8_t *dst, bool descending,
+                      uint32_t *tok = nullptr, uint16_t *srcpos = nullptr, uint32_t bits_cap = 0xFFFFFFFFu) {
   static wv::Emu emu;
   static SpanCall c;
   emu.descending = descending;
   for (int i = 0; i < 64; i++) c.d[i] = d;
   c.L = &L; c.src = src; c.dst = dst;
+  c.tok = tok; c.srcpos = srcpos; c.bits_cap = bits_cap;
   emu.run(span_lane, &c);
   for (int i = 1; i < 64; i++) {
     if (c.ret[i] != c.ret[0] || memcmp(&c.d[i], &c.d[0], sizeof(InflateLane)) != 0) {
@@ -314,6 +321,95 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
   }
   *out_len = d.status == ST_OK ? d.out_pos : 0;
   *checksum = crc_adler ? d.adler : 0;
+  return (int)d.status;
+}
+
+// The token form of a stream's decode, as inflate.hip's IM_TOKEN wave makes it of a block: the span decoder stores
+// literals and writes down, for every byte of a match, the output position it copies (tok[]; with `follow`, what
+// THAT position copies, as far as it is written: inflate_span.h); matches decoded one by one are written down here the
+// way wave_match does.  Then the copies are resolved -- in stream order a byte's source is final when its turn comes
+// -- and the result must be the stream's plain decode.  cut_every: spans are cut short like those of a wave that
+// leaves a block at a checkpoint (bits_cap), every so many bits.
+extern "C" int sim_inflate_token(const uint8_t *src, uint64_t src_len, uint8_t *dst, uint64_t dst_cap, int follow, int descending,
+                                 uint32_t cut_every, uint64_t *out_len) {
+  static __attribute__((aligned(16))) uint8_t block[LDS_BYTES_PER_LANE];
+  static uint16_t srcpos[SPAN_TILE];
+  LaneLds L;
+  L.at(block);
+  StreamDesc s;
+  memset(&s, 0, sizeof s);
+  s.src_len = src_len; s.dst_cap = dst_cap; s.limit = dst_cap; s.flags = STREAM_HAS_LIMIT;
+  Arenas A;
+  A.src = src; A.dst = dst;
+  InflateLane d;
+  lane_init(d, s);
+  std::vector<uint32_t> tok(dst_cap + 1);
+  for (uint64_t i = 0; i <= dst_cap; i++) tok[i] = (uint32_t)i;
+  auto token_match = [&](uint32_t pos, uint32_t dist, uint32_t len) {
+    for (uint32_t i = 0; i < len; i++) tok[pos + i] = follow ? tok[pos - dist + (dist < len ? i % dist : i)] : pos - dist + i;
+  };
+  refill(d, L, src);
+  for (;;) {
+    for (int turn = 0; turn < 512; turn++) {
+      if (d.phase == PH_HEADER || d.phase == PH_HDR_LENGTHS || d.phase == PH_HDR_CODELEN) {
+        if (!lane_header_step(d, L, src)) break;
+        if (d.phase == PH_TABLES) lane_finish_tables(d, L);
+        if (d.phase == PH_SYMBOLS && !d.fixed_lazy)
+          for (int lane = 0; lane < 64; lane++) build_wide_tables(d, L, lane);
+      } else if (d.phase == PH_TABLES) {
+        lane_finish_tables(d, L);
+        if (d.phase == PH_SYMBOLS)
+          for (int lane = 0; lane < 64; lane++) build_wide_tables(d, L, lane);
+      } else if (d.phase == PH_SYMBOLS && d.fixed_lazy) {
+        const int rr = lane_one_symbol_fixed(d, L, A, true, false);
+        if (rr == SYM_EOB) { d.fixed_lazy = 0; lane_end_of_block(d, false); }
+        else if (rr == SYM_STOP) {
+          if (d.phase != PH_REQ_MATCH) break;
+          token_match(d.out_pos, d.req_dist, d.req_len);
+          lane_after_match(d);
+        }
+        if (d.phase == PH_SYMBOLS && d.fixed_lazy && --d.fixed_lazy == 0) d.phase = PH_TABLES;
+      } else if (d.phase == PH_SYMBOLS) {
+        if (!d.span_off && d.in_word >= d.span_retry_word) {
+          const uint32_t out_before = d.out_pos;
+          const int sr = span_model(d, L, src, dst, descending != 0, tok.data(), follow ? srcpos : nullptr, cut_every ? cut_every : 0xFFFFFFFFu);
+          if (sr != SPAN_NONE) {
+            d.span_off = sr == SPAN_OFF;
+            if (sr == SPAN_LATER) {
+              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
+              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
+            } else {
+              d.span_fails = 0;
+            }
+            break;
+          }
+          if (!cut_every) d.span_off = 1;  // (a span cut short is tried again behind a few plain symbols)
+          else d.span_retry_word = d.in_word + 2u;
+        }
+        const int rr = lane_one_symbol(d, L, A, true, false);
+        if (rr == SYM_EOB) lane_end_of_block(d, false);
+        else if (rr == SYM_STOP) {
+          if (d.phase != PH_REQ_MATCH) break;
+          token_match(d.out_pos, d.req_dist, d.req_len);
+          lane_after_match(d);
+        }
+      } else {
+        break;
+      }
+    }
+    if (d.phase == PH_REQ_COPY) {
+      memcpy(dst + d.out_pos, src + d.req_src, d.req_len);
+      lane_after_copy(d, false);
+    }
+    if (d.phase == PH_DONE) break;
+    refill(d, L, src);
+  }
+  if (d.status == ST_OK)
+    for (uint32_t i = 0; i < d.out_pos; i++) {
+      if (tok[i] > i) return -1;  // (a source lies before its copy)
+      if (tok[i] != i) dst[i] = dst[tok[i]];
+    }
+  *out_len = d.status == ST_OK ? d.out_pos : 0;
   return (int)d.status;
 }
 

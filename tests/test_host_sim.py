@@ -407,3 +407,28 @@ def test_block_header_search_finds_every_dynamic_block(sim, oracle):
             assert starts <= found, (name, enc, sorted(starts - found))
             assert len(found - starts - {0}) <= 1, (name, enc, sorted(found - starts))
             assert nf.value < len(raw) // 32  # what the first test lets through to the second
+
+
+def test_inflate_token_form_resolves_to_the_plain_decode(sim, oracle):
+    """inflate.hip's IM_TOKEN form of the span decoder on the emulated wave (literals stored, a match's bytes written
+    down as the positions they copy -- directly, or "following": what those positions copy -- tiles that are refused
+    leave nothing behind), spans cut short like those of a wave that leaves at a checkpoint; the copies resolved
+    afterwards must give the stream's bytes."""
+    import zlib
+    rnd = random.Random(5)
+    datas = []
+    for name, data, _ in _find_sources():
+        datas.append((name, data[:90000]))
+    datas.append(("runs", b"".join(bytes([rnd.randrange(256)]) * rnd.randrange(1, 700) + bytes(rnd.randrange(256) for _ in range(rnd.randrange(40)))
+                                   for _ in range(300))))
+    for name, data in datas:
+        streams = [("oracle-2", oracle.deflate(data, level=2)[1])]
+        for lv, stg in ((6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED)):
+            c = zlib.compressobj(lv, zlib.DEFLATED, -15, 8, stg)
+            streams.append(("zlib-%d-%d" % (lv, stg), c.compress(data) + c.flush()))
+        for enc, raw in streams:
+            for follow, desc, cut in ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 20000), (1, 0, 9000)):
+                dst = C.create_string_buffer(len(data) + 64)
+                ol = C.c_uint64()
+                st = sim.sim_inflate_token(raw, len(raw), dst, len(data), follow, desc, cut, C.byref(ol))
+                assert st == 0 and ol.value == len(data) and dst.raw[:len(data)] == data, (name, enc, follow, desc, cut)
