@@ -536,6 +536,11 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (sd.src_len < BLOCKS_MIN_SRC || sd.src_len > BLOCKS_MAX_SRC || sd.dst_cap < 8 || sd.dst_cap > MAX_STREAM_LEN) return ZIPC_HIP_OK;
+  // Runs (zeros, short periods: output beyond 64 x the input) are not for this path: a word of tok[] per byte of a
+  // run costs more than the run (16 MiB of zeros as zlib codes them, 4 blocks: token run 10-11 ms, the one wave
+  // 3.4-6.9), and where the reference's encoder has coded them with the fixed code, the explorers' walks never fall
+  // into step with a bit stream that has a period (64 MiB: the chain walks nearly every block itself, 65 ms).
+  if (sd.dst_cap / 64 > sd.src_len) return ZIPC_HIP_OK;
   const uint32_t first_cap = (uint32_t)(sd.src_len / 8 + 4096);
   uint32_t cand_cap = (uint32_t)(sd.src_len / 512 + 64);
   if (cand_cap > BLOCKS_CAND_CAP) cand_cap = BLOCKS_CAND_CAP;
