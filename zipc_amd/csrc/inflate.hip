@@ -538,8 +538,13 @@ __device__ __forceinline__ void wave_match(uint8_t *dst, uint32_t *__restrict__ 
                                            uint8_t *pattern) {
   if (MODE == IM_REAL) wave_copy_match(dst, pos, dist, len, lane, pattern);
   else if (MODE == IM_TOKEN) {  // (what the source bytes are copies of, where that is known already: inflate_span.h)
-    for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
-      tok[pos + i] = wv::load_coherent(tok + (pos - dist + (dist < len ? i % dist : i)));
+    if (dist < len && 64u % dist == 0u) {  // (a run whose period divides the wave: a lane's bytes all copy one source)
+      const uint32_t v = wv::load_coherent(tok + (pos - dist + (uint32_t)lane % dist));
+      for (uint32_t i = (uint32_t)lane; i < len; i += 64u) tok[pos + i] = v;
+    } else {
+      for (uint32_t i = (uint32_t)lane; i < len; i += 64u)
+        tok[pos + i] = wv::load_coherent(tok + (pos - dist + (dist < len ? i % dist : i)));
+    }
   }
 }
 
