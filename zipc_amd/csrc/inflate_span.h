@@ -489,7 +489,7 @@ ZD_WV void span_fill_by_wave(uint8_t *tile, const uint8_t *gbase, uint32_t dp, u
 // bits_cap: a span walks no further than this many bits (a wave that takes a block over from a checkpoint on and only
 // up to the next one: inflate.hip).  ck (IM_DRY): checkpoints of the block -- bit and output position of a tile's start,
 // both known to be on the real sequence, every CK_GAP_BITS of input or so.
-constexpr uint32_t CK_MAX = 15, CK_GAP_BITS = 49152;
+constexpr uint32_t CK_MAX = 31, CK_GAP_BITS = 24576;
 struct SpanCk {
   uint32_t *lds;      // 2 * CK_MAX words: bit (from the block's header bit), output byte (from the block's first)
   uint32_t n, last;   // checkpoints taken, the last one's bit

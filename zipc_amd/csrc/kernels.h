@@ -27,7 +27,7 @@ struct BlockEnd {
 };
 struct BlockRec { uint64_t bit; BlockEnd e; };  // a block that was walked from its header's bit to its end (e.pad: its checkpoints)
 // checkpoints of a block's dry run (inflate_span.h SpanCk): bit from the header's bit, output byte from the block's first
-constexpr uint32_t BLOCK_CK_MAX = 15;
+constexpr uint32_t BLOCK_CK_MAX = 31;
 struct BlockCk { uint32_t n; uint32_t e[2 * BLOCK_CK_MAX]; uint32_t pad; };
 struct ChainIv { uint32_t first, ck; };  // a chain block's first interval (the token run: a wave per interval), its BlockCk
 constexpr int RESOLVE_ROUNDS = 12;  // (h hops a round: pointers of h^r copies after round r)
