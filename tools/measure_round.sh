@@ -31,6 +31,7 @@ ZIPC_HIP_PARSE_SEGMENTS=0 ZIPC_HIP_INFLATE_BLOCKS=0 python3 tools/bench_single.p
 # inflate of one stream by a wave per block: streams of the reference's encoder and of zlib, 1 MiB and 16 MiB, and by its one wave
 python3 tools/exp_inflate_blocks.py > "$OUT/inflate_blocks.jsonl" 2> /dev/null
 LEN=16777216 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks.jsonl" 2> /dev/null
+LEN=67108864 REPS=3 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks.jsonl" 2> /dev/null
 ZIPC_HIP_INFLATE_BLOCKS=0 python3 tools/exp_inflate_blocks.py > "$OUT/inflate_blocks_one_wave.jsonl" 2> /dev/null
 ZIPC_HIP_INFLATE_BLOCKS=0 LEN=16777216 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks_one_wave.jsonl" 2> /dev/null
 python3 "$B" --config c4 --steps 3 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"

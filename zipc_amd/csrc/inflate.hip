@@ -574,6 +574,9 @@ struct Explore {
   // point at or behind that bit -- what it decodes beyond it, the next wave decodes too, to the same values)
   uint32_t resume, resume_out;
   uint64_t resume_bit, until_bit;
+  // what the block's symbols are likely to take in bits (0: no idea): sizes the span decoder's regions like the
+  // block before does for a stream's wave (prev_block_bits)
+  uint32_t est_bits;
 };
 static_assert(CK_MAX == BLOCK_CK_MAX, "kernels.h");
 constexpr uint64_t NO_BIT = ~0ull;
@@ -581,6 +584,7 @@ __device__ __forceinline__ Explore no_explore() {
   Explore X;
   X.recs = nullptr; X.n_recs = nullptr; X.cap = 0; X.max_recs = 0; X.inside_fixed = 0; X.stop_bit = 0;
   X.ck_lds = nullptr; X.cks = nullptr; X.resume = 0; X.resume_out = 0; X.resume_bit = 0; X.until_bit = NO_BIT;
+  X.est_bits = 0;
   return X;
 }
 template <int MODE, bool MULTI = false>
@@ -608,6 +612,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
     d.out_pos = MODE == IM_DRY ? BLOCK_DRY_BASE : at.out_pos;
     d.blk_out_start = d.out_pos;
     if (MODE == IM_DRY) d.hard_cap = d.limit = d.cap_min = (uint32_t)MAX_STREAM_LEN;
+    d.prev_block_bits = X.est_bits;
     if (MULTI && X.inside_fixed) {  // as behind a fixed block's header (lane_block_header), tables to be built
       d.hdr_fixed = 1;
       d.phase = PH_TABLES;
@@ -970,6 +975,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   at.bit = cand[b]; at.out_pos = 0; at.chunk0 = 0;
   Explore X = no_explore();
   X.ck_lds = ck_lds;
+  {  // the block probably ends where the next candidate starts (the candidates are few: a pass over them)
+    uint32_t next = 0xFFFFFFFFu;
+    for (uint32_t i = threadIdx.x; i < n; i += 64u) {
+      const uint32_t c = cand[i];
+      if (c > (uint32_t)at.bit && c < next) next = c;
+    }
+    next = wave_min(next);
+    if (next != 0xFFFFFFFFu && next - (uint32_t)at.bit < (1u << 22)) X.est_bits = next - (uint32_t)at.bit;
+  }
   const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr,
                                           span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP, X);
   if (threadIdx.x == 0) {
