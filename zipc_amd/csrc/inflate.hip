@@ -975,7 +975,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   at.bit = cand[b]; at.out_pos = 0; at.chunk0 = 0;
   Explore X = no_explore();
   X.ck_lds = ck_lds;
-  {  // the block probably ends where the next candidate starts (the candidates are few: a pass over them)
+  if (n <= 8192u) {  // the block probably ends where the next candidate starts (the candidates are few: a pass over them)
     uint32_t next = 0xFFFFFFFFu;
     for (uint32_t i = threadIdx.x; i < n; i += 64u) {
       const uint32_t c = cand[i];
