@@ -579,20 +579,26 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   ZD_LAUNCH(ctx, "inflate_find_lengths", inflate_find_lengths_kernel, dim3((first_cap + 63u) / 64u), dim3(64), 0, src, dd,
             (const uint32_t *)d_first, first_cap, d_cand, cand_cap, d_counts);
   FindCounts fc;
-  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (trace) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
-  if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
-  const uint32_t n = fc.n_cand;
+  // (how many candidates there are: the host asks when the list is long -- a wave each is launched -- and lets the
+  // kernels read it themselves when it is short: a round trip less for streams of a few MiB)
+  uint32_t n = cand_cap;
+  if (cand_cap > 8192u) {
+    HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (trace) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
+    if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
+    n = fc.n_cand;
+  }
   HIP_TRY(ctx, span_scratch(n));
-  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, d_cks, n,
-            (uint16_t *)ctx->inflate_scratch.p, d_counts);
+  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, d_cks,
+            cand_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
   ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
             (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
   ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
             d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, explore ? 0 : 1);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
   if (trace) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu miss %lld\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len, (long long)fc.miss_bit);
   if (!fc.chain_ok && fc.miss_bit != ~0ull) {
     // the chain came to a block nobody listed: explorers from there on, then the chain again (which now walks what
@@ -648,10 +654,7 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[RESOLVE_ROUNDS - 1]);
   if (fc.token_bad != 0 || fc.more[RESOLVE_ROUNDS - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
-  StreamResult res;
-  res.status = ZIPC_HIP_OK; res.checksum = 0; res.out_len = out_len;
-  HIP_TRY(ctx, hipMemcpyAsync(d_results, &res, sizeof res, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (res leaves the stack)
+  ZD_LAUNCH(ctx, "inflate_blocks_result", inflate_blocks_result_kernel, dim3(1), dim3(1), 0, (StreamResult *)d_results, (uint64_t)out_len);
   ctx->last_inflate_blocks = nb;
   if (adler) {  // block by block, every block's bytes in chunks of their own (inflate.hip)
     if (fc.n_chunks) {

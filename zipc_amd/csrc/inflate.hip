@@ -965,11 +965,12 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
 // A dry run per candidate: recs[b] = the candidate's bit and what became of its block
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_dry_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t n,
+    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t cand_cap,
     uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint32_t ck_lds[2 * CK_MAX];
   const uint32_t b = blockIdx.x;
+  const uint32_t n = counts->n_cand <= cand_cap ? counts->n_cand : 0u;  // (more candidates than the list holds: the call gives up)
   if (b >= n) return;
   BlockStart at;
   at.bit = cand[b]; at.out_pos = 0; at.chunk0 = 0;
@@ -1267,6 +1268,12 @@ __global__ __launch_bounds__(64) void inflate_adler_fold_kernel(const uint32_t *
     }
   }
   if (threadIdx.x == 0) result->checksum = adler_pack(s1, s2);
+}
+// the stream's result, written where the caller reads it (no copy from the host, no wait for one)
+__global__ void inflate_blocks_result_kernel(StreamResult *__restrict__ result, uint64_t out_len) {
+  StreamResult r;
+  r.status = ST_OK; r.checksum = 0; r.out_len = out_len;
+  *result = r;
 }
 __global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                                             const uint32_t *__restrict__ tok, uint32_t n) {

@@ -52,7 +52,7 @@ __global__ void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_aren
                                             uint32_t cand_cap, FindCounts *__restrict__ counts);
 __global__ void inflate_blocks_dry_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                           const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ cand,
-                                          BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t n,
+                                          BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t cand_cap,
                                           uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts);
 __global__ void inflate_explore_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                        const StreamDesc *__restrict__ descs, const FindCounts *__restrict__ from, uint32_t stride_bits,
@@ -79,6 +79,7 @@ __global__ void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_aren
                                             uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums);
 __global__ void inflate_adler_fold_kernel(const uint32_t *__restrict__ sums, uint32_t n_chunks, int rfc,
                                           StreamResult *__restrict__ result);
+__global__ void inflate_blocks_result_kernel(StreamResult *__restrict__ result, uint64_t out_len);
 __global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                       const uint32_t *__restrict__ tok, uint32_t n);
 
