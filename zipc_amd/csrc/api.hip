@@ -522,7 +522,7 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
 // few words back between its steps: it SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0 turns it off.
 constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
 constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
-constexpr uint64_t EXPLORE_STRIDE = 8192;  // bytes of input between two explorers
+static const uint64_t EXPLORE_STRIDE = [] { const char *e = getenv("ZIPC_HIP_EXPLORE_STRIDE"); return e ? (uint64_t)atoi(e) : 8192ull; }();  // bytes of input between two explorers
 static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
                              zipc_hip_stream_result *d_results, int crc_op, bool *handled) {
   *handled = false;
