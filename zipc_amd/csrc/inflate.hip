@@ -625,6 +625,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   ck.lds = X.ck_lds; ck.n = 0; ck.last = 0; ck.hdr_bit = at.bit; ck.out_base = BLOCK_DRY_BASE;
   bool resume_pending = MODE == IM_TOKEN && X.resume != 0u;
   bool left_early = false;  // IM_TOKEN: the wave stopped at until_bit
+  bool fixed_tables = false;  // MULTI: the tables in LDS are the fixed codes'
   // a block has ended (the phase says what the stream's wave would do next): the block modes stop here, or go on
   auto block_done = [&]() {
     if (MODE == IM_REAL || d.status != ST_OK) return;
@@ -707,6 +708,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         ZD_PH(ph_hdr);
       } else if (d.phase == PH_TABLES || d.phase == PH_HDR_CODELEN) {  // (PH_TABLES: a dynamic header's lengths are read, or a fixed block went on beyond its table-free symbols)
         ZD_PH_START();
+        if (MULTI) fixed_tables = d.phase == PH_TABLES && d.hdr_fixed != 0;  // (a dynamic header's codes go where the fixed ones stood)
         wave_tables(d, L, lane);
 #ifdef ZD_HDR_SPLIT  // (experiment: the tables booked as "wide turns", the wide tables as "services+rest")
         ZD_PH(ph_wide);
@@ -726,6 +728,11 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
 #ifndef ZD_HDR_SPLIT
         ZD_PH(ph_hdr);
 #endif
+      } else if (MULTI && d.phase == PH_SYMBOLS && d.fixed_lazy && fixed_tables) {
+        // (an explorer walks fixed block after fixed block: the tables of the one before are this one's -- nothing
+        // but a dynamic header's wave_tables writes where they stand -- instead of 48 symbols decoded one by one and
+        // 15 us of building them again)
+        d.fixed_lazy = 0;
       } else if (d.phase == PH_SYMBOLS && d.fixed_lazy && resume_pending) {  // (a fixed block taken over at a checkpoint: its tables now)
         d.fixed_lazy = 0;
         d.phase = PH_TABLES;
