@@ -229,7 +229,7 @@ typedef struct zipc_hip_stream_result_s {
  * max_dst_cap above ZIPC_HIP_MAX_STREAM_LEN (a stream of stored blocks beyond 4 GiB, below), and a call with one to
  * four streams of a MiB and more (up to 16 of 8 MiB and more; one stream: 96 KiB of input and more), which are decoded
  * by a wave per BLOCK -- block starts searched for, the blocks walked side by side, copies resolved afterwards: a MiB in
- * 1.3-2.0 ms instead of 10-30 -- read a few words back between their steps and so synchronise the stream themselves.
+ * 1.2-1.9 ms instead of 10-30 -- read a few words back between their steps and so synchronise the stream themselves.
  * Results, messages and limits are the same whichever way a stream is decoded (zipc_hip_last_inflate_blocks tells;
  * ZIPC_HIP_INFLATE_BLOCKS=0 in the environment keeps every stream on its one wave). */
 /* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream

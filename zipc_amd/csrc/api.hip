@@ -644,7 +644,8 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   // everything, 3.4 ms; 64 and more let nearly every byte arrive in the first: 0.28 ms)
   static const int hops0 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS0"); return e ? atoi(e) : 256; }();
   static const int hops1 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS1"); return e ? atoi(e) : 256; }();
-  for (int r = 0; r < RESOLVE_ROUNDS; r++) {
+  const int rounds = hops0 >= 16 && hops1 >= 16 ? 6 : RESOLVE_ROUNDS;  // (16^6 links: more than a stream has bytes)
+  for (int r = 0; r < rounds; r++) {
     uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,
               out_len, d_counts, r, (const uint32_t *)list_in, list_out, r == 0 ? hops0 : hops1);
@@ -652,8 +653,8 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[RESOLVE_ROUNDS - 1]);
-  if (fc.token_bad != 0 || fc.more[RESOLVE_ROUNDS - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
+  if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[rounds - 1]);
+  if (fc.token_bad != 0 || fc.more[rounds - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
   ZD_LAUNCH(ctx, "inflate_blocks_result", inflate_blocks_result_kernel, dim3(1), dim3(1), 0, (StreamResult *)d_results, (uint64_t)out_len);
   ctx->last_inflate_blocks = nb;
   if (adler) {  // block by block, every block's bytes in chunks of their own (inflate.hip)
