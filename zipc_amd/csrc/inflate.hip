@@ -38,6 +38,11 @@
 // The stream state is wave-uniform; it is pinned to scalar registers with
 // readfirstlane so that the control flow around the turns is scalar branches,
 // not exec-mask arithmetic.  LDS: 10072 B per stream (inflate_lane.h has the map): 16 streams per CU.
+//
+// ONE long stream handed over alone gets a wave per BLOCK instead (further down: "ONE stream by a wave per BLOCK"):
+// the same wave code in two more modes -- IM_DRY walks a block for its end and size, IM_TOKEN stores its literals
+// and writes down what its matches copy -- around a search for block headers, a chain of the blocks and pointer
+// jumping over the copies.
 #include "inflate_lane.h"
 #include "inflate_span.h"
 #include "inflate_find.h"
