@@ -724,9 +724,14 @@ static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, vo
     if (k > 1) ctx->use_slice_stream(i);
     const StreamDesc *dd = (const StreamDesc *)d_descs + lo;
     StreamResult *dr = (StreamResult *)d_results + lo;
-    ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
-              (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
-              (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
+    if (n_streams <= 256)  // (a few streams: the form that shares the tables of blocks with one and the same header, inflate.hip)
+      ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_few_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
+                (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
+                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
+    else
+      ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
+                (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
+                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
     if (hipGetLastError() != hipSuccess) { ctx->last_error = "inflate_batch launch failed"; st = ZIPC_HIP_ERR_HIP; break; }
     if (crc_op == ZIPC_HIP_CRC_CRC32)
       st = crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, dd, dr, hi - lo, 0, 0, max_dst_cap, nullptr,

@@ -537,6 +537,20 @@ __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uin
   }
 }
 
+// Are the n bits from bit a on the n bits from bit b on (b < a, all inside the input)?  32 bits a lane.
+__device__ __forceinline__ bool same_bits(const uint8_t *__restrict__ src, uint32_t src_len, uint64_t a, uint64_t b, uint32_t n, int lane) {
+  bool differ = false;
+  for (uint32_t o = (uint32_t)lane * 32u; o < n; o += 2048u) {
+    const uint64_t pa = a + o, pb = b + o;
+    if ((pa >> 5) * 4u + 8u > src_len) { differ = true; break; }  // (two whole words are read: not at the input's very end)
+    const uint32_t wa = funnel32(load_u32_le(src + (pa >> 5) * 4u + 4u), load_u32_le(src + (pa >> 5) * 4u), (uint32_t)pa & 31u);
+    const uint32_t wb = funnel32(load_u32_le(src + (pb >> 5) * 4u + 4u), load_u32_le(src + (pb >> 5) * 4u), (uint32_t)pb & 31u);
+    const uint32_t left = n - o;
+    differ |= ((wa ^ wb) & (left >= 32u ? 0xFFFFFFFFu : (1u << left) - 1u)) != 0u;
+  }
+  return __builtin_amdgcn_ballot_w64(differ) == 0ull;
+}
+
 // A match handed to the wave, by MODE: its bytes (wave_copy_match), nothing, or where its bytes come from
 template <int MODE>
 __device__ __forceinline__ void wave_match(uint8_t *dst, uint32_t *__restrict__ tok, uint32_t pos, uint32_t dist, uint32_t len, int lane,
@@ -592,7 +606,7 @@ __device__ __forceinline__ Explore no_explore() {
   X.est_bits = 0;
   return X;
 }
-template <int MODE, bool MULTI = false>
+template <int MODE, bool MULTI = false, bool REUSE = false>
 __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
                                                  const StreamDesc &sd, const BlockStart at, StreamResult *__restrict__ result,
                                                  uint16_t *__restrict__ span_idx, uint32_t *__restrict__ tok, int crc_op,
@@ -631,6 +645,13 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   bool resume_pending = MODE == IM_TOKEN && X.resume != 0u;
   bool left_early = false;  // IM_TOKEN: the wave stopped at until_bit
   bool fixed_tables = false;  // MULTI: the tables in LDS are the fixed codes'
+  // REUSE (inflate_batch_few_kernel: calls of a few streams): the last dynamic header read -- where it stood and how
+  // long it was (0: none whose tables still stand).  A block behind a short block with the very same header bits (a
+  // run: 1 MiB of zeros is 16 such blocks of 254 matches, their 15 us of code lengths and tables each half the
+  // stream's time) goes on with the tables there are.  Not in the kernel of the large batches: three words of state
+  // more in its main loop cost it 1.5 %.
+  uint64_t hdr_at = 0, prev_hdr_at = 0;
+  uint32_t prev_hdr_bits = 0;
   // a block has ended (the phase says what the stream's wave would do next): the block modes stop here, or go on
   auto block_done = [&]() {
     if (MODE == IM_REAL || d.status != ST_OK) return;
@@ -706,6 +727,19 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
       } else if (d.phase == PH_HEADER) {
         turn++;
         ZD_PH_START();
+        if (REUSE) {
+          hdr_at = (uint64_t)d.in_word * 32u + d.boff;
+          if (prev_hdr_bits != 0u && d.prev_block_bits < 16384u && prev_hdr_bits <= d.bits_left() &&
+              same_bits(src, d.src_len, hdr_at, prev_hdr_at, prev_hdr_bits, lane)) {  // (the first bit, "final", is one of them)
+            d.advance(prev_hdr_bits);
+            d.blk_out_start = d.out_pos;
+            lane_begin_symbols(d);  // (final_block 0, the codes, their tables, levels: the block before's)
+            prev_hdr_at = hdr_at;
+            ZD_PH(ph_hdr);
+            continue;
+          }
+          prev_hdr_bits = 0;
+        }
         bool ok = true;
         if (lane == 0) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
@@ -721,6 +755,11 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
+          if (REUSE && !d.hdr_fixed && !d.final_block) {  // (a dynamic header's tables stand: its bits are hdr_at .. here)
+            prev_hdr_at = hdr_at;
+            const uint64_t len = (uint64_t)d.in_word * 32u + d.boff - hdr_at;
+            prev_hdr_bits = len < 8192u ? (uint32_t)len : 0u;
+          }
           if (resume_pending) {  // the tables stand: on from the checkpoint
             resume_pending = false;
             d.in_word = (uint32_t)(X.resume_bit >> 5);
@@ -893,6 +932,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
                         span_scratch + (size_t)stream * SPAN_IDX_ENTRIES, nullptr, crc_op);
+}
+// the same for calls of a few streams (api.hip: up to 256), where a wave has more to itself than its share of a full
+// GPU and a stream of runs -- blocks of a few hundred matches with one and the same header -- is not lost in a batch:
+// REUSE (inflate_wave)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_batch_few_kernel(const uint8_t *__restrict__ src_arena,
+                                                           uint8_t *__restrict__ dst_arena,
+                                                           const StreamDesc *__restrict__ descs,
+                                                           StreamResult *__restrict__ results,
+                                                           uint32_t n_streams, uint16_t *__restrict__ span_scratch, int crc_op) {
+  __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
+  const uint32_t stream = blockIdx.x;
+  if (stream >= n_streams) return;
+  BlockStart at;
+  at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
+  inflate_wave<IM_REAL, false, true>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
+                                     span_scratch + (size_t)stream * SPAN_IDX_ENTRIES, nullptr, crc_op);
 }
 
 

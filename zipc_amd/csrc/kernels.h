@@ -14,6 +14,9 @@ __global__ void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                      StreamResult *__restrict__ results, uint32_t n_streams,
                                      uint16_t *__restrict__ span_scratch, int crc_op);
 
+__global__ void inflate_batch_few_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
+                                         const StreamDesc *__restrict__ descs, StreamResult *__restrict__ results, uint32_t n_streams,
+                                         uint16_t *__restrict__ span_scratch, int crc_op);
 // one stream by a wave per block (inflate.hip has the description; api.hip inflate_by_blocks the order of the launches)
 struct BlockStart {
   uint64_t bit;       // of the block's header in the stream's input
