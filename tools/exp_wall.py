@@ -30,15 +30,17 @@ def make_src(data, n, L, dev):
         chunks = corpus.chunks(L)
         host = np.frombuffer(b"".join(chunks[i % len(chunks)] for i in range(n)), np.uint8).copy()
         return torch.from_numpy(host).to(dev), (lambda j: chunks[j % len(chunks)])
+    if data == "c1":  # BASELINE C1: one stream, 1 MiB of zeros
+        return torch.zeros(n * L, dtype=torch.uint8, device=dev), (lambda j: bytes(L))
     cfg, bits = (4, 3) if data == "c4" else (2, int(os.environ.get("BITS", "4")))
     return synth.batch_bytes_torch(cfg, 0, n, L, bits, dev), (lambda j: synth.stream_bytes_np(cfg, j, L, bits).tobytes())
 
 
 def main():
     data = os.environ.get("DATA", "c2")
-    L = (1 << 20) if data == "c4" else 65536
-    n = int(os.environ.get("N_STREAMS", "2048" if data == "c4" else "16384"))
-    level = int(os.environ.get("LEVEL", "2"))
+    L = (1 << 20) if data in ("c4", "c1") else 65536
+    n = int(os.environ.get("N_STREAMS", "2048" if data == "c4" else "1" if data == "c1" else "16384"))
+    level = int(os.environ.get("LEVEL", "1" if data == "c1" else "2"))
     reps = int(os.environ.get("REPS", "5"))
     crc = int(os.environ.get("CRC_OP", "1"))
     dev = torch.device("cuda", 0)

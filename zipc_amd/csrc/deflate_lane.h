@@ -49,6 +49,32 @@ ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t 
   return i;
 }
 
+// ... in the LDS window (WORDS: s 4-byte aligned, may be over-read by 11 bytes): aligned words and a funnel shift, like
+// every other read of the window -- a misaligned 8-byte LDS read stalls the pipe for ~55 clocks (SQ_LDS_IDX_ACTIVE per
+// instruction on 1 MiB of zeros, where every position's one candidate is compared over 258 bytes)
+template <bool WORDS>
+ZD_HD uint32_t common_prefix_t(const uint8_t *s, uint32_t q, uint32_t p, uint32_t maxlen, uint32_t from) {
+  if (!WORDS) return common_prefix(s, q, p, maxlen, from);
+  uint32_t i = from;
+  // (the first 16 bytes as they come: on text most compares end there, and three aligned reads and two funnel shifts
+  // per 8 bytes cost it more than the odd stall -- lz_match 95.5 -> 101.3 ms with words from the first byte on)
+#ifndef ZD_PREFIX_PLAIN
+#define ZD_PREFIX_PLAIN 2
+#endif
+  for (int k = 0; k < ZD_PREFIX_PLAIN && i + 8 <= maxlen; k++) {
+    const uint64_t x = load_u64_le(s + q + i) ^ load_u64_le(s + p + i);
+    if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+    i += 8;
+  }
+  while (i + 8 <= maxlen) {
+    const uint64_t x = load_u64_words(s, q + i) ^ load_u64_words(s, p + i);
+    if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+    i += 8;
+  }
+  while (i < maxlen && s[q + i] == s[p + i]) i++;
+  return i;
+}
+
 // find_backref zd.ml:1176-1201 as a pure function of the position: walks the
 // hash chain of p (prev[] holds the distance to the previous position with the
 // same hash, 0 = none within 32768) and returns, packed like the reference's
@@ -230,7 +256,7 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
       const uint32_t toff = r.best_len - 7u;  // best_len < maxlen: these bytes lie inside both strings
       compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
     }
-    if (compare) l = common_prefix(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);  // (maxlen >= 8 here means x == 0: the first 8 agree)
+    if (compare) l = common_prefix_t<WORDS>(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);  // (maxlen >= 8 here means x == 0: the first 8 agree)
   }
   const uint32_t steps = r.steps + (walk ? 1u : 0u);
   const bool better = walk && l > r.best_len;
@@ -400,10 +426,10 @@ ZD_HD void scan_run_compare(ScanRun &r, const uint8_t *s, const uint16_t *prev, 
         compare = WORDS ? load_u64_words(s, q + toff) == load_u64_words(s, r.p + toff)
                         : load_u64_le(s + q + toff) == load_u64_le(s + r.p + toff);
       }
-      if (compare) l = common_prefix(s, q, r.p, r.maxlen, 8u);
+      if (compare) l = common_prefix_t<WORDS>(s, q, r.p, r.maxlen, 8u);
     }
   } else {
-    l = common_prefix(s, q, r.p, r.maxlen, 0u);
+    l = common_prefix_t<WORDS>(s, q, r.p, r.maxlen, 0u);
   }
   const bool better = l > r.best_len;
   r.best_len = better ? l : r.best_len;
