@@ -565,3 +565,52 @@ def test_corpus_every_chunk_against_the_oracle(gpu_ctx, oracle):
         ires = batch.results_from_device(d_ires)
         assert (ires["status"] == 0).all() and torch.equal(out[:n * L], src)
         assert (ires["checksum"] == res["checksum"]).all()
+
+
+def test_one_stream_of_48_mib_inflates_by_blocks_with_following(gpu_ctx, oracle):
+    """48 MiB of text and 4-bit symbols in ONE stream -- long enough for the form in which a block's wave writes down
+    what its sources are copies of (api.hip: from 32 MiB of output on, output at least 1.5 x the input) -- as zlib
+    codes it and as the reference's encoder does (most of its blocks fixed: explorers): the source's bytes, CRC-32."""
+    import zlib
+
+    import torch
+
+    import util
+    from zipc_amd import batch, synth
+
+    dev = torch.device("cuda", 0)
+    n = 48 << 20
+    text = util.text(4 << 20, 12)
+    parts = []
+    for k in range(8):
+        parts.append(text[(k * 37777) % (1 << 20):][:3 << 20])
+        parts.append(synth.stream_bytes_np(2, 50 + k, 3 << 20, 4).tobytes())
+    plain = b"".join(parts)[:n]
+    assert len(plain) == n
+    src = torch.from_numpy(np.frombuffer(plain, np.uint8).copy()).to(dev)
+    out = torch.zeros(n + 256, dtype=torch.uint8, device=dev)
+    d_ires = torch.zeros(16, dtype=torch.uint8, device=dev)
+    # zlib's coding
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    zraw = c.compress(plain) + c.flush()
+    assert n >= 1.5 * len(zraw)
+    d_z = torch.cat([torch.from_numpy(np.frombuffer(zraw, np.uint8).copy()).to(dev), torch.zeros(256, dtype=torch.uint8, device=dev)])
+    out.fill_(0x5A)
+    batch.inflate_batch(gpu_ctx, d_z, out, batch.to_device(batch.uniform_layout(1, len(zraw), n), dev), d_ires, 1, n, 1)
+    ires = batch.results_from_device(d_ires)
+    assert int(ires["status"][0]) == 0 and int(ires["out_len"][0]) == n and torch.equal(out[:n], src)
+    assert int(ires["checksum"][0]) == zlib.crc32(plain) and bool((out[n:] == 0x5A).all())
+    assert gpu_ctx.last_inflate_blocks() >= 300, gpu_ctx.last_inflate_blocks()
+    # the reference's encoder (this library's deflate: bytes checked against the oracle elsewhere)
+    cap = batch.deflate_bound(n)
+    descs = batch.uniform_layout(1, n, cap)
+    comp = torch.zeros(cap + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    batch.deflate_batch(gpu_ctx, src, comp, batch.to_device(descs, dev), d_res, 1, n, n, 2, 1)
+    res = batch.results_from_device(d_res)
+    assert int(res["status"][0]) == 0 and int(res["checksum"][0]) == zlib.crc32(plain)
+    out.fill_(0x5A)
+    batch.inflate_batch(gpu_ctx, comp, out, batch.to_device(batch.compact_descs(res, descs, n), dev), d_ires, 1, n, 1)
+    ires = batch.results_from_device(d_ires)
+    assert int(ires["status"][0]) == 0 and int(ires["out_len"][0]) == n and torch.equal(out[:n], src)
+    assert int(ires["checksum"][0]) == zlib.crc32(plain) and gpu_ctx.last_inflate_blocks() >= 700, gpu_ctx.last_inflate_blocks()
