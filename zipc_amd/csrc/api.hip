@@ -316,6 +316,7 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
       return ZIPC_HIP_ERR_HIP;
     }
   }
+  ctx->xchg_ordered = zd::xchg_order_probe(ctx);
   *out = ctx;
   return ZIPC_HIP_OK;
 }

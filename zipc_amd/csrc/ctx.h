@@ -22,6 +22,7 @@ struct zipc_hip_ctx {
   std::vector<hipEvent_t> side_done;
   hipEvent_t fork_ev = nullptr;
   bool profiling = false;
+  bool xchg_ordered = false;   // deflate.hip xchg_order_probe: one LDS exchange serves lanes on one address in ascending lane order
   bool adler_rfc1950 = false;  // zipc_hip_set_adler_rfc1950: the zlib forms and checksum_device use RFC 1950's Adler-32
   std::string last_error;
   zd::CrcConsts crc_consts;
@@ -88,6 +89,8 @@ hipError_t crc32_segments_launch(zipc_hip_ctx *ctx, const uint8_t *base, int mod
 hipError_t crc32_finish_launch(zipc_hip_ctx *ctx, int mode, const StreamDesc *d_descs, StreamResult *d_results,
                                size_t n_ranges, uint64_t single_len, size_t max_len, const uint32_t *partials,
                                uint32_t *d_single_out);
+// deflate.hip: the probe behind ctx->xchg_ordered
+bool xchg_order_probe(zipc_hip_ctx *ctx);
 // deflate.hip: bytes of scratch the pipeline needs, and the pipeline itself
 size_t deflate_scratch_bytes(size_t n_streams, size_t max_src_len, size_t total_src_len, int level);
 hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,

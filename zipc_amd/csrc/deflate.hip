@@ -32,39 +32,12 @@
 //                            lengths, scatter-OR into an LDS staging row, coalesced
 //                            flush of the completed bytes.
 //   deflate_stored_kernel    level `None (write_all_non_compressed zd.ml:1106-1116).
-#include "ctx.h"
-#include "deflate_lane.h"
-#include "wave_ops.h"
+#include <cstring>
+#include <type_traits>
+
+#include "deflate_pipeline.h"
 
 namespace zd {
-
-constexpr uint32_t POS_PAD = 256;            // scratch slack per stream, in positions
-constexpr uint32_t PARSE_PAD = 200;          // table entries behind the last position the parse may load (3 tiles of 64 + 3)
-static_assert(PARSE_PAD <= POS_PAD, "inside the stream's scratch");
-constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 - 258 source bytes
-
-// streams with an out-of-range length are rejected by every kernel and take no scratch
-__host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
-  if (src_len > MAX_STREAM_LEN) src_len = 0;
-  return ((src_len + 255) & ~255ull) + POS_PAD;
-}
-__host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
-  if (src_len > MAX_STREAM_LEN) src_len = 0;
-  return src_len / MIN_BLOCK_SRC + 2;
-}
-
-struct DeflateScratch {
-  uint64_t *pos_base;   // [n] first position slot of stream i
-  uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
-  uint32_t *n_blocks;   // [n]
-  uint32_t *error;      // [1] != 0: the batch does not fit what the caller declared (total_src_len too small,
-                        //     or a stream longer than max_src_len: the grids are sized from it)
-  uint16_t *prev;       // [P] chain links
-  uint64_t *match;      // [P] lz_match_position: best-of-K | best-of-K/4 << 32
-  uint32_t *syms;       // [P]
-  BlockDesc *blocks;    // [Bk]
-  uint64_t cap_positions, cap_blocks;
-};
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -107,7 +80,7 @@ size_t deflate_scratch_bytes(size_t n_all, size_t max_src_len, size_t total_all,
   uint64_t P, Bk;
   scratch_caps(n, total_src_len, P, Bk);
   size_t b = 0;
-  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
+  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) * 2 + 256;
   if (level != LEVEL_NONE) {
     b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
@@ -123,7 +96,9 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.pos_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
+  s.punt = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
+  s.n_punt = s.error + 1;
   s.prev = nullptr; s.match = nullptr;
   s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
@@ -170,6 +145,7 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
       ap += vp; ab += vb;
     }
     S.error[0] = (ap > S.cap_positions || ab > S.cap_blocks || too_long) ? 1u : 0u;
+    S.n_punt[0] = 0;
   }
   __syncthreads();
   sp = part_p[t];
@@ -205,14 +181,6 @@ constexpr uint32_t SWEEP_MARK = 20000;
 constexpr int NEAR = 8;
 constexpr int PLAIN_TURNS = 4;  // peel turns before the neighbour short-cut is worth its LDS reads
 static_assert(SWEEP_PERIOD % CHAIN_ROUND == 0, "sweeps fall on round boundaries");
-
-// The threads of the chain kernel exchange data through LDS only, so its barriers
-// wait for the LDS counter alone: __syncthreads() would also wait (vmcnt) for the
-// next round's source words, which are requested a round ahead, and for the
-// round's stores of the links.
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-}
 
 // A link is the distance to the nearest earlier position with the same hash if that is within 32768, else 0:
 // a function of the 32 KiB before the position and nothing else.  So a long stream's links can be made by
@@ -394,6 +362,162 @@ __global__ __launch_bounds__(CHAIN_THREADS) void lz_chain_segments_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------
+// Hash-chain links by ORDERED LDS EXCHANGE (round 4).  insert_hash (zd.ml:1150-1152) is "prev[pos] <- head[hash];
+// head[hash] <- pos", position after position.  One ds_wrxchg_rtn_b32 does exactly that for 64 positions at once
+// IF the lanes that hit one address are served in ascending lane order -- which gfx950's LDS does (measured:
+// tools/probes/lds_xchg_order.hip, any mix of addresses, banks and EXEC masks; every context repeats the probe when it
+// is created, xchg_order_probe below, and keeps the peel kernel above where it fails) -- and a wave's LDS
+// operations execute in the order they were issued.  So ONE wave inserts a stream: lane = position, 64 consecutive
+// positions per exchange, the table 32 Ki words of 32 bits (positions as they are: no wrap, no sweeps; "none" is a
+// value 64 Ki below zero, so that its distance from any position is beyond the window).  No barrier, no peel, ~10
+// instructions per 64 positions where the peel kernel issues 67 + 60 -- and what bounds it is one wave's issue rate:
+// the table takes 128 of the CU's 160 KiB, so a CU works on one stream at a time.
+constexpr uint32_t XCHG_NONE = 0xFFFF0000u;  // p - XCHG_NONE = p + 65536 (p <= MAX_STREAM_LEN: no wrap) > MAX_MATCH_DIST
+static_assert(MAX_STREAM_LEN <= XCHG_NONE, "no position looks like the table's empty entry or wraps past it");
+// ONE wave's exchanges are ordered; to give a stream more than one wave, XCHG_WAVES waves take TURNS: turn t -- XCHG_U
+// rounds of 64 positions -- belongs to wave t mod XCHG_WAVES, which requests its source words and hashes them while the
+// others have their turns, waits until the word `turn_now` in LDS says t, issues its exchanges and hands over
+// (turn_now <- t + 1, behind its exchanges: a wave's LDS operations are executed in the order they were issued, and
+// the next wave issues its exchanges only after it has READ the new value), then works out its links and stores them.
+// The chain of hand-overs is what a stream takes: ~16 exchanges and one LDS round trip per 1024 positions.
+constexpr uint32_t XCHG_WAVES = 4;
+constexpr int XCHG_U = 16;                    // rounds of 64 positions per turn
+constexpr uint32_t XCHG_TURN = 64u * XCHG_U;  // positions per turn
+static_assert(MAX_MATCH_DIST % XCHG_TURN == 0 && SWEEP_PERIOD % XCHG_TURN == 0, "segments start on turn boundaries");
+
+template <bool SEG>
+__device__ __forceinline__ void lz_chain_xchg_workgroup(const uint8_t *__restrict__ src_arena,
+                                                        const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                        uint32_t stream, uint32_t seg, uint32_t seg_positions) {
+  __shared__ __attribute__((aligned(16))) uint32_t head[32768];
+  __shared__ uint32_t turn_now;
+  if (S.error[0]) return;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const StreamDesc sd = descs[stream];
+  if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
+  const uint32_t len = (uint32_t)sd.src_len;
+  const uint8_t *s = src_arena + sd.src_off;
+  uint16_t *prev = S.prev + S.pos_base[stream];
+  const uint32_t stream_max_pos = len - 4;
+  // SEG: links of [own_lo, own_hi]; the table is warmed up with the 32 Ki positions before (a link is the distance to
+  // the nearest earlier position with the same hash if within 32768, else 0: a function of those and nothing else)
+  const uint32_t own_lo = SEG ? seg * seg_positions : 0u;
+  if (SEG && own_lo > stream_max_pos) return;
+  const uint32_t max_pos = SEG ? (stream_max_pos - own_lo >= seg_positions ? own_lo + seg_positions - 1u : stream_max_pos) : stream_max_pos;
+  const uint32_t first = SEG ? (own_lo > (uint32_t)MAX_MATCH_DIST ? own_lo - (uint32_t)MAX_MATCH_DIST : 0u) : 0u;
+  const uint32_t t_first = first / XCHG_TURN, t_last = max_pos / XCHG_TURN;  // turns [t_first, t_last]
+  {
+    const u32x4 none = {XCHG_NONE, XCHG_NONE, XCHG_NONE, XCHG_NONE};
+    for (uint32_t i = tid * 4u; i < 32768u; i += 4u * 64u * XCHG_WAVES) *(u32x4 *)(head + i) = none;
+    if (tid == 0) turn_now = t_first;
+  }
+  __syncthreads();
+  auto load = [&](uint32_t t, uint32_t *wd) {  // (clamped, never predicated: the wait counts stay exact)
+    const uint32_t tc = t <= t_last ? t : t_last;
+#pragma unroll
+    for (int u = 0; u < XCHG_U; u++) {
+      const uint32_t p = tc * XCHG_TURN + 64u * (uint32_t)u + lane;  // (64 KiB of headroom below 2^32: no wrap)
+      wd[u] = load_u32_le(s + (p <= max_pos ? p : max_pos));
+    }
+  };
+  // my turn t: wait for it, all its exchanges one behind the other, hand over, then the links
+  auto insert = [&](uint32_t t, const uint32_t *wd, auto WHOLE) {
+    uint32_t old[XCHG_U], hb[XCHG_U];
+#pragma unroll
+    for (int u = 0; u < XCHG_U; u++) hb[u] = hash4(wd[u]);
+    while (__hip_atomic_load(&turn_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int u = 0; u < XCHG_U; u++) {
+      const uint32_t p = t * XCHG_TURN + 64u * (uint32_t)u + lane;
+      old[u] = XCHG_NONE;
+      if (decltype(WHOLE)::value || p <= max_pos)
+        old[u] = __hip_atomic_exchange(&head[hb[u]], p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    // (release: the exchanges above are complete before the next wave sees its turn)
+    if (lane == 0) __hip_atomic_store(&turn_now, t + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int u = 0; u < XCHG_U; u++) {
+      const uint32_t p = t * XCHG_TURN + 64u * (uint32_t)u + lane;
+      const uint32_t d = p - old[u];
+      if ((decltype(WHOLE)::value || p <= max_pos) && (!SEG || p >= own_lo)) prev[p] = (uint16_t)(d <= (uint32_t)MAX_MATCH_DIST ? d : 0u);
+    }
+  };
+  uint32_t wa[XCHG_U], wb[XCHG_U];
+  uint32_t t = t_first + w;
+  if (t > t_last) return;
+  load(t, wa);
+  for (;;) {  // (two sets of registers that swap roles by name: nothing waits for the words just requested)
+    load(t + XCHG_WAVES, wb);
+    if (t == t_last) { insert(t, wa, std::false_type{}); break; }
+    insert(t, wa, std::true_type{});
+    t += XCHG_WAVES;
+    if (t > t_last) break;
+    load(t + XCHG_WAVES, wa);
+    if (t == t_last) { insert(t, wb, std::false_type{}); break; }
+    insert(t, wb, std::true_type{});
+    t += XCHG_WAVES;
+    if (t > t_last) break;
+  }
+}
+
+__global__ __launch_bounds__(64 * XCHG_WAVES) void lz_chain_xchg_kernel(const uint8_t *__restrict__ src_arena,
+                                                                        const StreamDesc *__restrict__ descs, DeflateScratch S) {
+  lz_chain_xchg_workgroup<false>(src_arena, descs, S, blockIdx.x, 0, 0);
+}
+__global__ __launch_bounds__(64 * XCHG_WAVES) void lz_chain_xchg_segments_kernel(const uint8_t *__restrict__ src_arena,
+                                                                                 const StreamDesc *__restrict__ descs, DeflateScratch S,
+                                                                                 uint32_t segs_per_stream, uint32_t seg_positions) {
+  lz_chain_xchg_workgroup<true>(src_arena, descs, S, blockIdx.x / segs_per_stream, blockIdx.x % segs_per_stream, seg_positions);
+}
+
+// The probe every context runs once (api.hip zipc_hip_create): 256 exchanges of 64 lanes on a few addresses, under EXEC
+// masks, against the order the reference inserts in.  out[0] = mismatches.
+__global__ __launch_bounds__(64) void xchg_order_probe_kernel(uint32_t *__restrict__ out) {
+  __shared__ uint32_t head[64];
+  const uint32_t lane = threadIdx.x;
+  head[lane] = XCHG_NONE;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t bad = 0, x = 0x9E3779B1u * (lane + 1u);
+  for (uint32_t r = 0; r < 256u; r++) {
+    x = x * 1664525u + 1013904223u;
+    const uint32_t kind = r & 3u;
+    const uint32_t a = kind == 0 ? 5u : kind == 1 ? (lane & 1u) : kind == 2 ? ((x >> 13) & 7u) : ((x >> 9) & 63u);
+    const bool active = (r % 3u == 0) || ((x >> 20) & 1u);
+    // expected: the nearest lower ACTIVE lane with my address in this round, else the address's value before the round
+    uint32_t before = head[a];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t want = before;
+    for (uint32_t l = 0; l < 64u; l++) {
+      const uint32_t al = (uint32_t)__builtin_amdgcn_readlane((int)a, (int)l);
+      const bool actl = (__builtin_amdgcn_ballot_w64(active) >> l) & 1ull;
+      if (actl && al == a && l < lane) want = r * 64u + l;
+    }
+    uint32_t got = want;
+    if (active) got = __hip_atomic_exchange(&head[a], r * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    bad += got != want ? 1u : 0u;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  bad = wave_sum(bad);
+  if (lane == 0) out[0] = bad;
+}
+
+bool xchg_order_probe(zipc_hip_ctx *ctx) {
+  if (ctx->ensure(ctx->io_small, 256) != hipSuccess) return false;
+  uint32_t *d = (uint32_t *)ctx->io_small.p;
+  uint32_t h = 1;
+  if (hipMemcpyAsync(d, &h, 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return false;
+  hipLaunchKernelGGL(xchg_order_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
+  if (hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
+  return h == 0;
+}
+
+// ---------------------------------------------------------------------------------
 constexpr uint32_t MATCH_THREADS = 256;
 constexpr int MATCH_NP = 4;  // positions per lane, their chain walks interleaved
 constexpr uint32_t MATCH_TILE = MATCH_THREADS * MATCH_NP;
@@ -509,7 +633,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
                                                                          uint32_t tiles_per_group, int K, int Kq,
-                                                                         int form) {
+                                                                         int form, int punted_only) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
   __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
@@ -521,6 +645,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   if (threadIdx.x < 4) ph_acc[threadIdx.x] = 0;
 #endif
   if (S.error[0]) return;
+  if (punted_only && S.n_punt[0] == 0) return;  // behind lz_tile_kernel: only the streams it left (almost always none)
   // XCD-aware order as in lz_match_kernel: the groups of a stream re-read each
   // other's windows, so they go to one XCD's L2
   const uint32_t nb = gridDim.x;
@@ -530,6 +655,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint32_t stream = logical / groups_per_stream;
   const uint32_t group = logical % groups_per_stream;
   if (stream >= n_streams) return;  // grid is padded to a multiple of 8
+  if (punted_only && S.punt[stream] == 0) return;
   const StreamDesc sd = descs[stream];
   if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
@@ -964,7 +1090,8 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
                                                       const StreamDesc *__restrict__ descs,
-                                                      DeflateScratch S, int good_match) {
+                                                      DeflateScratch S, int good_match, int punted_only) {
+  if (punted_only && (S.n_punt[0] == 0 || S.punt[blockIdx.x] == 0)) return;  // behind lz_tile_kernel: only the streams it left
   lz_parse_wave<0>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
 }
 
@@ -2437,22 +2564,48 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     const hipError_t me = hipMemsetAsync(segs.vis, 0, tiles * 8, ctx->cur);
     if (me != hipSuccess) return me;
   }
+  // lz_chain: by ordered exchange where the context's probe passed (ZIPC_HIP_CHAIN=peel keeps the peel kernel: tests, A/B).
+  // A wave per stream leaves most of the chip idle while there are fewer streams than CUs: a long stream is then cut into
+  // segments of xseg positions, each warmed up with the 32 Ki positions before it (at most a third more work at 96 Ki).
+  static const int chain_env = [] { const char *e = getenv("ZIPC_HIP_CHAIN"); return e && !strcmp(e, "peel") ? 1 : 0; }();
+  const bool xchg_chain = ctx->xchg_ordered && chain_env == 0;
+  size_t xseg = 0, xsegs = 1;
+  if (xchg_chain && n < 1024 && max_src_len > ((size_t)192 << 10)) {
+    xseg = (size_t)96 << 10;
+    while (n * ((max_src_len + 2 * xseg - 1) / (2 * xseg)) >= 2048) xseg *= 2;  // twice the chip's CUs of waves is plenty
+    xsegs = (max_src_len + xseg - 1) / xseg;
+  }
+  static const long tile_env = [] { const char *e = getenv("ZIPC_HIP_TILE"); return e ? atol(e) : 1L; }();  // 0: never lz_tile_kernel (tests, A/B)
+  hipError_t slice_err = hipSuccess;
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;
     DeflateScratch Q = S;
-    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo;
+    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo; Q.punt += lo;
     const StreamDesc *dd = d_descs + lo;
-    if (segmented && csegs > 1 && m <= 128)  // (the run-up is a quarter more work: only while workgroups are what is missing)
+    if (xchg_chain) {  // one wave per stream (per segment of a long one while there are few): ordered LDS exchange
+      if (m * xsegs > m && m * xsegs <= 0x7FFFFFFFull)
+        ZD_LAUNCH(ctx, "lz_chain", lz_chain_xchg_segments_kernel, dim3((unsigned)(m * xsegs)), dim3(64 * XCHG_WAVES), 0, d_src, dd, Q,
+                  (uint32_t)xsegs, (uint32_t)xseg);
+      else
+        ZD_LAUNCH(ctx, "lz_chain", lz_chain_xchg_kernel, dim3((unsigned)m), dim3(64 * XCHG_WAVES), 0, d_src, dd, Q);
+    } else if (segmented && csegs > 1 && m <= 128)  // (the run-up is a quarter more work: only while workgroups are what is missing)
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_segments_kernel, dim3((unsigned)(m * csegs)), dim3(CHAIN_THREADS), 0, d_src, dd,
                 Q, (uint32_t)csegs, (uint32_t)chain_seg);
     else
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
+    // Many streams of more than a few KiB: search and parse in one kernel, a workgroup per stream (lz_tile.hip); the two
+    // kernels behind it then only take the streams it left to them (S.punt)
+    const bool tiled = tile_env != 0 && !segmented && max_src_len > MATCHW_SMALL && K >= 4;
+    if (tiled) {
+      const hipError_t te = launch_lz_tile(ctx, d_src, dd, Q, m, K, good_match);
+      if (te != hipSuccess) { slice_err = te; return; }
+    }
     if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
       ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((m * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
                 d_src, dd, Q, (uint32_t)m, (uint32_t)cps, K, K / 4);
     else
       ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((m * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env);
+                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env, tiled ? 1 : 0);
     if (segmented) {
       ParseSegs G = segs;
       const size_t o = lo * sps;  // the slice's segment slots
@@ -2468,7 +2621,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
                 good_match, G);
       ZD_LAUNCH(ctx, "lz_parse_gather", lz_parse_gather_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, dd, Q, G);
     } else {
-      ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
+      ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match, tiled ? 1 : 0);
     }
     if (segmented) {
       ZD_LAUNCH(ctx, "deflate_plan", deflate_plan_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, dd, Q, crc_op,
@@ -2510,6 +2663,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   } else {
     slice(0, n);
   }
+  if (e == hipSuccess) e = slice_err;
   if (e == hipSuccess) e = hipGetLastError();
   if (e == hipSuccess && crc_op == CRC_CRC32) {
     uint32_t *partials = (uint32_t *)ctx->crc_partials.p;

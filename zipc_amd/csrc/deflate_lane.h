@@ -235,9 +235,10 @@ ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t
 // instructions per update, a divergent `if` four to eight.  A run without a position goes through the
 // step like any other (it parks on a valid position and never walks); only the long compare and
 // the store of a finished position stay behind branches.
-template <bool WORDS>
-ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
-                          uint64_t *out) {
+// (sink(p, best, snap): where a finished position's two answers go)
+template <bool WORDS, typename Sink>
+ZD_HD bool match_run_step_to(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
+                             Sink sink) {
   const uint32_t qn = r.q - r.dn;
   const bool walk = r.alive != 0 && r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
   const uint32_t qc = walk ? qn : r.p;
@@ -273,9 +274,16 @@ ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, u
   const bool fin = r.alive != 0 && !more;
   if (fin) {
     const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : best);
-    out[r.p] = (uint64_t)best | ((uint64_t)snap << 32);
+    sink(r.p, best, snap);
   }
   return fin;
+}
+template <bool WORDS>
+ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
+                          uint64_t *out) {
+  return match_run_step_to<WORDS>(r, s, prev, K, Kq, [out](uint32_t p, uint32_t best, uint32_t snap) {
+    out[p] = (uint64_t)best | ((uint64_t)snap << 32);
+  });
 }
 // A lane's positions are first, first + step, first + 2 step, ... < pend.  Its NP run
 // slots draw from ONE cursor over them: a slot that finishes a position takes the

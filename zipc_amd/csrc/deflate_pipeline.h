@@ -1,0 +1,53 @@
+// deflate_pipeline.h -- what the kernels of the deflate pipeline share (deflate.hip, lz_tile.hip): the layout of the
+// context's scratch and the barrier that waits for LDS only.
+#pragma once
+
+#include "ctx.h"
+#include "deflate_lane.h"
+#include "wave_ops.h"
+
+namespace zd {
+
+constexpr uint32_t POS_PAD = 256;            // scratch slack per stream, in positions
+constexpr uint32_t PARSE_PAD = 200;          // table entries behind the last position the parse may load (3 tiles of 64 + 3)
+static_assert(PARSE_PAD <= POS_PAD, "inside the stream's scratch");
+constexpr uint32_t MIN_BLOCK_SRC = 65277;    // a non-final block holds > 65534 - 258 source bytes
+
+// streams with an out-of-range length are rejected by every kernel and take no scratch
+__host__ __device__ inline uint64_t padded_positions(uint64_t src_len) {
+  if (src_len > MAX_STREAM_LEN) src_len = 0;
+  return ((src_len + 255) & ~255ull) + POS_PAD;
+}
+__host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
+  if (src_len > MAX_STREAM_LEN) src_len = 0;
+  return src_len / MIN_BLOCK_SRC + 2;
+}
+
+struct DeflateScratch {
+  uint64_t *pos_base;   // [n] first position slot of stream i
+  uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
+  uint32_t *n_blocks;   // [n]
+  uint32_t *punt;       // [n] lz_tile_kernel: != 0, the stream's search and parse are left to lz_match_window_kernel + lz_parse_kernel
+  uint32_t *n_punt;     // [1] streams so left (zeroed by deflate_offsets_kernel)
+  uint32_t *error;      // [1] != 0: the batch does not fit what the caller declared (total_src_len too small,
+                        //     or a stream longer than max_src_len: the grids are sized from it)
+  uint16_t *prev;       // [P] chain links
+  uint64_t *match;      // [P] lz_match_position: best-of-K | best-of-K/4 << 32
+  uint32_t *syms;       // [P]
+  BlockDesc *blocks;    // [Bk]
+  uint64_t cap_positions, cap_blocks;
+};
+
+// The threads of a workgroup that exchange data through LDS only wait for the LDS counter alone:
+// __syncthreads() would also wait (vmcnt) for every global load and store the wave has in flight --
+// source words requested ahead, the stores of results.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// lz_tile.hip: the match search and the lazy parse of a batch of streams in one kernel (a workgroup per stream).
+// S.punt[i] != 0 afterwards: stream i is left to lz_match_window_kernel + lz_parse_kernel.
+hipError_t launch_lz_tile(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *d_descs, DeflateScratch S,
+                          size_t n, int K, int good_match);
+
+}  // namespace zd
