@@ -205,18 +205,70 @@ def issue_bound(kernel, launch_ms):
         return None
 
 
+_PIECES = {}
+
+
+def text_pieces(L):
+    if L not in _PIECES:
+        _PIECES[L] = _text_pieces(L)
+    return _PIECES[L]
+
+
+def _text_pieces(L):
+    """the reference's own texts (tests/golden/zip-docs.zip) as the four chunks of L bytes the text legs repeat"""
+    import zipfile
+
+    z = zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "zip-docs.zip"))
+    app = z.read("zip-docs/APPNOTE.TXT")
+    rfc = z.read("zip-docs/rfc1951.txt")
+    return [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+
+
+def leg_plain(source, j, stream_len):
+    """stream j of a leg, on the host: ("synth", config, bits) | ("text",) | ("corpus",) | ("zeros",)"""
+    if source[0] == "synth":
+        from zipc_amd import synth
+
+        return synth.stream_bytes_np(source[1], j, stream_len, source[2]).tobytes()
+    if source[0] == "text":
+        return text_pieces(stream_len)[j % 4]
+    if source[0] == "zeros":
+        return bytes(stream_len)
+    if ("corpus", stream_len) not in _PIECES:
+        from tools import corpus
+
+        _PIECES[("corpus", stream_len)] = corpus.chunks(stream_len)
+    chunks = _PIECES[("corpus", stream_len)]
+    return chunks[j % len(chunks)]
+
+
+# The legs bench.py reports beside the headline: what each is made of, so that the cpu_baseline process (the only place
+# the oracle runs) can time the SAME streams on the host and hand over what the oracle makes of a few of them.
+# name: (source, level, stream_len, sampled streams, do_inflate, 1-thread budget in seconds)
+LEGS = {
+    "c2_default": (("synth", 2, 4), 2, 65536, (0, 1, 16383), True, 12.0),
+    "text_default": (("text",), 2, 65536, (0, 1, 2, 3), True, 3.0),
+    "text_best": (("text",), 3, 65536, (0, 1, 2, 3), True, 4.0),
+    "c2_best": (("synth", 2, 4), 3, 65536, (0, 1), True, 1.5),
+    "corpus_default": (("corpus",), 2, 65536, (0, 1, 2), True, 2.0),
+    "corpus_best": (("corpus",), 3, 65536, (0, 1), True, 2.0),
+    "c4_default": (("synth", 4, 3), 2, 1 << 20, (0, 1), False, 3.0),
+    "one_c1_zeros_1mib": (("zeros",), 1, 1 << 20, (0,), True, 0.5),
+    "one_symbols_1mib": (("synth", 2, 4), 2, 1 << 20, (0,), True, 0.5),
+}
+
+
 def _cpu_worker(job):
     """one host thread of the cpu_baseline leg: streams j0, j0 + stride, ... until the deadline"""
-    config_id, bits, level, stream_len, j0, stride, budget_s, do_inflate = job
+    source, level, stream_len, j0, stride, budget_s, do_inflate = job
     import oracle
-    from zipc_amd import synth
 
     t_def = t_inf = 0.0
     n = 0
     j = j0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < budget_s and n < 65536:
-        plain = synth.stream_bytes_np(config_id, j, stream_len, bits).tobytes()
+        plain = leg_plain(source, j, stream_len)
         a = time.perf_counter()
         st, comp, _ = oracle.deflate(plain, level=level, crc_op=oracle.CRC_CRC32)
         b = time.perf_counter()
@@ -231,34 +283,68 @@ def _cpu_worker(job):
     return n, t_def, t_inf, time.perf_counter() - t0
 
 
-def cpu_baseline(config_id, bits, level, stream_len, do_inflate=True, budget_s=12.0):
-    """The oracle (C port of the reference algorithm) on this host on a bounded sample of the same
-    workload: 1 thread (like the reference), then every host thread, member-sharded."""
+def cpu_leg(name, all_threads=True):
+    """The oracle (C port of the reference algorithm) on this host on a bounded sample of one leg's workload: 1 thread
+    (like the reference), then every host thread, member-sharded."""
     import multiprocessing as mp
 
-    n, t_def, t_inf, _ = _cpu_worker((config_id, bits, level, stream_len, 0, 1, budget_s, do_inflate))
+    source, level, stream_len, _, do_inflate, budget_s = LEGS[name]
+    n, t_def, t_inf, _ = _cpu_worker((source, level, stream_len, 0, 1, budget_s, do_inflate))
     what = "deflate+inflate" if do_inflate else "deflate"
     line = {
         "value": n * stream_len / GIB / (t_def + t_inf),
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d streams x %d B of the same workload (%s, oracle/zd_oracle.c, gcc -O2)" % (n, stream_len, what),
+        "sample": "%d streams x %d B of the same workload (%s level %s, oracle/zd_oracle.c, gcc -O2)" % (n, stream_len, what, LEVELS[level]),
         "deflate_gib_s": n * stream_len / GIB / t_def,
     }
     if do_inflate:
         line["inflate_gib_s"] = n * stream_len / GIB / t_inf
+    if not all_threads:
+        return line
     threads = os.cpu_count() or 1
     try:
         with mp.get_context("fork").Pool(threads) as pool:
-            res = pool.map(_cpu_worker, [(config_id, bits, level, stream_len, k, threads, budget_s / 2, do_inflate)
-                                         for k in range(threads)])
+            res = pool.map(_cpu_worker, [(source, level, stream_len, k, threads, budget_s / 2, do_inflate) for k in range(threads)])
         total = sum(r[0] for r in res)
         wall = max(r[3] for r in res)
         line["nproc"] = {"value": total * stream_len / GIB / wall, "unit": "GiB/s", "cores": threads,
+                         "deflate_gib_s": total * stream_len / GIB / (sum(r[1] for r in res) / threads) if sum(r[1] for r in res) else None,
                          "sample": "%d streams, member-sharded over %d host threads" % (total, threads)}
     except Exception as e:  # a host that cannot fork: the 1-thread figure stands alone
         line["nproc"] = {"value": None, "error": repr(e)}
+    return line
+
+
+def cpu_samples():
+    """What the oracle makes of the sampled streams of every leg: sha256 of the compressed bytes and the CRC-32,
+    for the GPU process to hold its own output against (the oracle itself stays in this process)."""
+    import hashlib
+
+    import oracle
+
+    out = {}
+    for name, (source, level, stream_len, sampled, _, _) in LEGS.items():
+        d = {}
+        for j in sampled:
+            st, comp, crc = oracle.deflate(leg_plain(source, j, stream_len), level=level, crc_op=oracle.CRC_CRC32)
+            assert st == 0
+            d[str(j)] = [hashlib.sha256(comp).hexdigest()[:24], int(crc), len(comp)]
+        out[name] = d
+    return out
+
+
+def cpu_baseline(config):
+    """the cpu_baseline object of the JSON line (this process only: host threads, the oracle, no GPU)"""
+    if config == "c4":
+        line = cpu_leg("c4_default")
+        line["samples"] = {"c4_default": cpu_samples()["c4_default"]}
+        return line
+    line = cpu_leg("c2_default")
+    # the other legs the line reports GPU numbers for: a GPU-over-CPU ratio is context, not credit
+    line["legs"] = {k: cpu_leg(k) for k in ("text_default", "text_best", "c4_default")}
+    line["samples"] = cpu_samples()
     return line
 
 
@@ -274,11 +360,19 @@ def timed_steps(step, barrier, steps, warmup, world, dev):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    mine = elapsed / steps * 1e3
+    info = {"rccl_ranks": 1, "ms_per_step_by_rank": [mine]}
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    return elapsed
+        # every rank's own time, gathered on DEVICE tensors: the collective goes through RCCL (backend "nccl"), and the
+        # number of ranks that answered is what "rccl_ranks" reports
+        t = torch.tensor([mine, float(dist.get_rank())], dtype=torch.float64, device=dev)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        per = sorted((int(g[1].item()), float(g[0].item())) for g in got)
+        assert [r for r, _ in per] == list(range(world)), "a rank did not answer the all-gather"
+        info = {"rccl_ranks": len(per), "rccl_backend": dist.get_backend(), "ms_per_step_by_rank": [m for _, m in per]}
+        elapsed = max(m for _, m in per) * steps / 1e3
+    return elapsed, info
 
 
 def roofline_of(ctx, per_step_fn, psteps, N, C):
@@ -367,7 +461,7 @@ def _roofline_entry(dom, dom_ms, N, C, brief=False):
 
 # ---- C2 ----------------------------------------------------------------------------------------------
 
-def run_c2(args, rank, local_rank, world, dev):
+def run_c2(args, rank, local_rank, world, dev, cpu=None):
     import torch
     import torch.distributed as dist
 
@@ -403,6 +497,10 @@ def run_c2(args, rank, local_rank, world, dev):
     ires = batch.results_from_device(d_ires)
     assert (ires["status"] == 0).all() and torch.equal(out[:N], src), "round trip failed"
     assert (ires["checksum"] == res["checksum"]).all()
+    # a few of the timed streams byte for byte against what the oracle made of them in the cpu_baseline process
+    default_shape = (n, L, bits, args.level) == (16384, 65536, 4, 2) and rank == 0
+    same = sampled_equal(comp, descs, res, ((cpu or {}).get("samples") or {}).get("c2_default")) if default_shape else None
+    assert same is not False, "a sampled stream of the timed batch differs from the oracle's output"
 
     def step():
         batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1, sync=False)
@@ -415,7 +513,7 @@ def run_c2(args, rank, local_rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
+    elapsed, ranks = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
 
     psteps = max(1, min(args.steps, 3))
     t = {"def": 0.0, "inf": 0.0}
@@ -450,26 +548,33 @@ def run_c2(args, rank, local_rank, world, dev):
                         % (n, L, bits, LEVELS[args.level]),
             "streams_per_gpu": n, "stream_len": L, "level": args.level,
             "compressed_ratio": C / N, "parallelism": "member-shard x%d" % world,
+            "sampled_bytes_equal_oracle": same,
         },
+        **ranks,
         "roofline": roof,
         "deflate_gib_s": N / GIB * psteps / t["def"],
         "inflate_gib_s": N / GIB * psteps / t["inf"],
         "kernels_ms_per_step": per_step,
     }
     if world == 1 and not args.no_extra_legs:
-        line.update(extra_legs(ctx, dev, n, L))
+        line.update(extra_legs(ctx, dev, n, L, cpu))
     return line
 
 
-def extra_legs(ctx, dev, n, L):
-    """Untimed legs beside the headline (each bounded to a second or two of GPU time): the
-    PCIe-inclusive host forms on the same workload, the whole path on real text, and C4's shape."""
+def extra_legs(ctx, dev, n, L, cpu):
+    """Untimed legs beside the headline (each bounded to a second or two of GPU time): the PCIe-inclusive host forms on
+    the same workload, the whole path on real text, a corpus, level `Best, one stream per call, and C4's shape.  Every
+    device-resident leg carries its own parity sample (a few streams against the oracle's bytes, worked out in the
+    cpu_baseline process), its fraction of the HBM roofline and -- where the cpu_baseline process timed the same
+    streams -- the host's figures."""
     import numpy as np
     import torch
 
     import zipc_amd
     from zipc_amd import batch, synth
 
+    samples = (cpu or {}).get("samples") or {}
+    cpu_legs = (cpu or {}).get("legs") or {}
     out = {}
     try:  # e2e: pageable host buffers in, host buffers out (zipc_hip_{deflate,inflate}_many)
         import ctypes as C
@@ -502,28 +607,25 @@ def extra_legs(ctx, dev, n, L):
                             "is": "PCIe-inclusive host forms (zipc_hip_*_many) on %d of the streams, pageable host memory in and out, best of 3" % m}
     except Exception as e:
         out["e2e_gib_s"] = {"error": repr(e)}
+    pieces = None
     try:  # the reference's own texts (tests/golden/zip-docs.zip), 64 KiB chunks
-        import zipfile
-
-        z = zipfile.ZipFile(os.path.join(ROOT, "tests", "golden", "zip-docs.zip"))
-        app = z.read("zip-docs/APPNOTE.TXT")
-        rfc = z.read("zip-docs/rfc1951.txt")
-        pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+        pieces = text_pieces(L)
         m = min(n, 16384)
         src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(m)), np.uint8).copy()).to(dev)
-        gd, gi = device_round_trip(ctx, dev, src, m, L, 2)
-        out["text_gib_s"] = {"deflate": gd, "inflate": gi, "is": "%d x 64 KiB chunks of APPNOTE.TXT / rfc1951.txt, device-resident" % m}
+        leg = device_round_trip(ctx, dev, src, m, L, 2, expect=samples.get("text_default"))
+        leg["cpu_baseline"] = cpu_legs.get("text_default")
+        leg["is"] = "%d x 64 KiB chunks of APPNOTE.TXT / rfc1951.txt, level `Default, device-resident" % m
+        out["text_gib_s"] = leg
     except Exception as e:
         out["text_gib_s"] = {"error": repr(e)}
     try:  # level `Best, the seam's default (make_encoder ?(level = `Best), zd.ml:817): K = 4096 candidates per position
         m = min(n, 4096)
         src = synth.batch_bytes_torch(2, 0, m, L, 4, dev)
-        gd, gi = device_round_trip(ctx, dev, src, m, L, 3)
-        best = {"c2": {"deflate": gd, "inflate": gi, "streams": m}}
+        best = {"c2": device_round_trip(ctx, dev, src, m, L, 3, expect=samples.get("c2_best"))}
         m = min(n, 2048)
         src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(m)), np.uint8).copy()).to(dev)
-        gd, gi = device_round_trip(ctx, dev, src, m, L, 3, reps=1)
-        best["text"] = {"deflate": gd, "inflate": gi, "streams": m}
+        best["text"] = device_round_trip(ctx, dev, src, m, L, 3, reps=1, expect=samples.get("text_best"))
+        best["text"]["cpu_baseline"] = cpu_legs.get("text_best")
         best["is"] = "level `Best on the C2 symbols and on the text chunks, device-resident (the text walks ~300 candidates per position where `Default walks ~33)"
         out["best_gib_s"] = best
     except Exception as e:
@@ -535,9 +637,8 @@ def extra_legs(ctx, dev, n, L):
         k = len(chunks)
         m = min(n, 4096)
         src = torch.from_numpy(np.frombuffer(b"".join(chunks[i % k] for i in range(m)), np.uint8).copy()).to(dev)
-        gd, gi = device_round_trip(ctx, dev, src, m, L, 2)
-        gdb, gib = device_round_trip(ctx, dev, src[:2048 * L], min(m, 2048), L, 3, reps=1)
-        out["corpus_gib_s"] = {"default": {"deflate": gd, "inflate": gi}, "best": {"deflate": gdb, "inflate": gib},
+        out["corpus_gib_s"] = {"default": device_round_trip(ctx, dev, src, m, L, 2, expect=samples.get("corpus_default")),
+                               "best": device_round_trip(ctx, dev, src[:2048 * L], min(m, 2048), L, 3, reps=1, expect=samples.get("corpus_best")),
                                "is": "%d distinct 64 KiB chunks (APPNOTE.TXT, rfc1951.txt, this repository's sources, documents, fixtures "
                                      "and built libraries) repeated to %d streams (`Best: 2048), device-resident" % (k, m)}
     except Exception as e:
@@ -546,8 +647,9 @@ def extra_legs(ctx, dev, n, L):
         one = {}
         for name, ML, bits in (("c1_zeros_1mib", 1 << 20, 0), ("symbols_1mib", 1 << 20, 4), ("symbols_16mib", 16 << 20, 4)):
             src = torch.zeros(ML, dtype=torch.uint8, device=dev) if bits == 0 else synth.batch_bytes_torch(2, 0, 1, ML, bits, dev)
-            gd, gi = device_round_trip(ctx, dev, src, 1, ML, 1 if bits == 0 else 2, reps=3)
-            one[name] = {"deflate_ms": ML / GIB / gd * 1e3, "inflate_ms": ML / GIB / gi * 1e3}
+            leg = device_round_trip(ctx, dev, src, 1, ML, 1 if bits == 0 else 2, reps=3, expect=samples.get("one_" + name))
+            one[name] = {"deflate_ms": ML / GIB / leg["deflate"] * 1e3, "inflate_ms": ML / GIB / leg["inflate"] * 1e3,
+                         "sampled_bytes_equal_oracle": leg["sampled_bytes_equal_oracle"]}
         one["is"] = "ONE stream per call, device-resident: `Fast on 1 MiB of zeros (BASELINE C1's input), `Default on the C2 symbols; " \
                     "deflate of a long stream runs as segments and blocks on many waves, inflate as a wave per block (block starts " \
                     "searched for; copies resolved by pointer jumping) -- zeros are one block: the stream's one wave"
@@ -557,17 +659,40 @@ def extra_legs(ctx, dev, n, L):
     try:  # C4 shape on this GPU: 4096 members x 1 MiB of 3-bit symbols (a wave per member: half of them leaves the GPU half empty)
         m, ML = 4096, 1 << 20
         src = synth.batch_bytes_torch(4, 0, m, ML, 3, dev)
-        gd, gi = device_round_trip(ctx, dev, src, m, ML, 2)
-        out["c4_deflate_gib_s"] = gd
-        out["c4_inflate_gib_s"] = gi
+        leg = device_round_trip(ctx, dev, src, m, ML, 2, expect=samples.get("c4_default"))
+        leg["cpu_baseline"] = cpu_legs.get("c4_default")
+        out["c4_deflate_gib_s"] = leg["deflate"]
+        out["c4_inflate_gib_s"] = leg["inflate"]
+        out["c4_leg"] = leg
         out["c4_leg_is"] = "%d members x 1 MiB of 3-bit symbols on this GPU, device-resident (bench.py --config c4 runs all 8192)" % m
     except Exception as e:
         out["c4_deflate_gib_s"] = {"error": repr(e)}
     return out
 
 
-def device_round_trip(ctx, dev, src, n, L, level, reps=2):
-    """GiB/s (deflate, inflate) of n streams of L bytes held in `src`, device-resident, checked"""
+def sampled_equal(comp, descs, res, expect):
+    """Do the sampled streams' compressed bytes (device tensor comp, layout descs, results res) and CRC-32s equal what
+    the oracle made of them in the cpu_baseline process (expect: stream -> [sha256 prefix, crc, length])?  None: no
+    expectation at hand (--no-cpu-baseline, N > 1)."""
+    import hashlib
+
+    if not expect:
+        return None
+    ok = True
+    for j, (sha, crc, ln) in expect.items():
+        j = int(j)
+        if j >= len(res):
+            continue
+        o, k = int(descs["dst_off"][j]), int(res["out_len"][j])
+        got = comp[o:o + k].cpu().numpy().tobytes()
+        ok = ok and k == ln and int(res["checksum"][j]) == crc and hashlib.sha256(got).hexdigest()[:24] == sha
+    return ok
+
+
+def device_round_trip(ctx, dev, src, n, L, level, reps=2, expect=None):
+    """One leg: n streams of L bytes held in `src`, device-resident, deflate (CRC-32) then inflate, checked by the
+    round trip and -- a few sampled streams -- byte for byte against the oracle's output (expect).  Returns GiB/s and
+    the two directions against the HBM roofline on SURVEY 8(d)'s bytes (N + C each way)."""
     import torch
 
     from zipc_amd import batch
@@ -583,6 +708,8 @@ def device_round_trip(ctx, dev, src, n, L, level, reps=2):
     batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, 1)
     res = batch.results_from_device(d_res)
     assert (res["status"] == 0).all()
+    same = sampled_equal(comp, descs, res, expect)
+    assert same is not False, "a sampled stream differs from the oracle's output"
     d_id = batch.to_device(batch.compact_descs(res, descs, L), dev)
     batch.inflate_batch(ctx, comp, out, d_id, d_ires, n, L, 1)
     assert torch.equal(out[:n * L], src)
@@ -594,12 +721,17 @@ def device_round_trip(ctx, dev, src, n, L, level, reps=2):
         batch.inflate_batch(ctx, comp, out, d_id, d_ires, n, L, 1)
         td += b - a
         ti += time.perf_counter() - b
-    return n * L / GIB * reps / td, n * L / GIB * reps / ti
+    N, C = n * L, int(res["out_len"].sum())
+    gd, gi = N / GIB * reps / td, N / GIB * reps / ti
+    roof = {d: {"achieved": (N + C) / (t / reps) / 1e9, "frac": (N + C) / (t / reps) / 1e9 / HBM_PEAK_GBS}
+            for d, t in (("deflate", td), ("inflate", ti))}
+    return {"deflate": gd, "inflate": gi, "streams": n, "compressed_ratio": C / N, "sampled_bytes_equal_oracle": same,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes": N + C, **roof}}
 
 
 # ---- C4 ----------------------------------------------------------------------------------------------
 
-def run_c4(args, rank, local_rank, world, dev):
+def run_c4(args, rank, local_rank, world, dev, cpu=None):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -646,7 +778,7 @@ def run_c4(args, rank, local_rank, world, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
+    elapsed, ranks = timed_steps(step, barrier, args.steps, args.warmup, world, dev)
     res, records = state["res"], state["records"]
     assert (res["status"] == 0).all(), "deflate failed"
     assert len(records) == members
@@ -677,6 +809,7 @@ def run_c4(args, rank, local_rank, world, dev):
             "members": members, "member_len": L, "level": args.level, "compressed_ratio": C_all / (members * L),
             "parallelism": "member-shard x%d" % world, "members_per_rank": counts,
         },
+        **ranks,
         "roofline": roof,
         "kernels_ms_per_step": per_step,
         "archive_check": check,
@@ -720,6 +853,13 @@ def c4_check(ctx, dev, rank, world, parts, paths, records, comp, descs, L, bits,
             f.write(blob)
             f.flush()
             unzip_ok = subprocess.run(["unzip", "-tq", f.name], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode == 0
+    # Python's zipfile as the second independent reader (the only one where Info-ZIP is not installed): the names in the
+    # order Zipc writes them, every member inflated and CRC-checked
+    import io
+    import zipfile
+
+    with zipfile.ZipFile(io.BytesIO(blob)) as zf:
+        zipfile_ok = zf.namelist() == [q.decode() for q in paths] and zf.testzip() is None
     same = None
     if world > 1:
         # the archive one rank writes: rank 0 deflates every member itself, range by range through its own arenas
@@ -743,9 +883,9 @@ def c4_check(ctx, dev, rank, world, parts, paths, records, comp, descs, L, bits,
             del src, h
         blob1 = shard.assemble_archive(paths, recs1, parts1, [min(step, members - a0) for a0 in range(0, members, step)], L)
         same = hashlib.sha256(blob1).hexdigest() == digest and len(blob1) == len(blob)
-    ok = unzip_ok is not False and same is not False
-    assert ok, "C4 archive check failed: equal to the one-rank archive: %s, unzip -tq: %s" % (same, unzip_ok)
-    return {"members": members, "archive_bytes": len(blob), "sha256": digest, "unzip_tq_ok": unzip_ok,
+    ok = unzip_ok is not False and zipfile_ok and same is not False
+    assert ok, "C4 archive check failed: equal to the one-rank archive: %s, unzip -tq: %s, zipfile: %s" % (same, unzip_ok, zipfile_ok)
+    return {"members": members, "archive_bytes": len(blob), "sha256": digest, "unzip_tq_ok": unzip_ok, "zipfile_ok": zipfile_ok,
             "bytes_equal_one_rank_archive": same, "check_s": time.perf_counter() - t0,
             "is": "all members gathered to rank 0, laid out by zipc_amd/host, the whole file tested by Info-ZIP; "
                   "with N > 1 also compared with the archive rank 0 writes alone"}
@@ -766,10 +906,14 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.cpu_baseline_only:  # a process of its own: host threads only, nothing of the GPU in it
-        if args.config == "c4":
-            line = cpu_baseline(4, args.bits or 3, args.level, args.stream_len or (1 << 20), do_inflate=False, budget_s=8.0)
-        else:
-            line = cpu_baseline(2, args.bits or 4, args.level, args.stream_len or 65536)
+        if args.config == "c2" and (args.bits or 4) == 4 and args.level == 2 and (args.stream_len or 65536) == 65536:
+            line = cpu_baseline("c2")
+        elif args.config == "c4" and (args.bits or 3) == 3 and args.level == 2 and (args.stream_len or (1 << 20)) == (1 << 20):
+            line = cpu_baseline("c4")
+        else:  # a workload of the caller's own: its one leg, no samples
+            LEGS["custom"] = (("synth", 4 if args.config == "c4" else 2, args.bits or (3 if args.config == "c4" else 4)), args.level,
+                              args.stream_len or ((1 << 20) if args.config == "c4" else 65536), (), args.config != "c4", 8.0)
+            line = cpu_leg("custom")
         print(json.dumps(line))
         return 0
     sys.stderr.write("[bench] rank %d of %d (local rank %d), config %s\n" % (rank, world, local_rank, args.config))
@@ -798,7 +942,7 @@ def main(argv=None):
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    line = (run_c4 if args.config == "c4" else run_c2)(args, rank, local_rank, world, dev)
+    line = (run_c4 if args.config == "c4" else run_c2)(args, rank, local_rank, world, dev, cpu)
     if rank == 0:
         if cpu is not None:
             line["cpu_baseline"] = cpu

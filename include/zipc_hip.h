@@ -113,6 +113,11 @@ const char *zipc_hip_last_error(zipc_hip_ctx *ctx);
  * or 0 when the stream's one wave decoded it (short streams, streams that are not a chain of dynamic blocks,
  * anything that reports an error).  For tests and measurements; the results are the same either way. */
 unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx);
+/* 1 when this context builds hash chains by ordered LDS exchange (deflate.hip lz_chain_xchg_kernel): the probe run
+ * by zipc_hip_create found that one LDS exchange instruction serves the lanes that hit one address in ascending lane
+ * order, which is the order insert_hash (zipc_deflate.ml:1150-1152) inserts positions in.  0: the probe failed and the
+ * context keeps the kernel that orders them itself (same links either way).  For tests and measurements. */
+int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx);
 /* the reference's message for a status (format strings kept verbatim) */
 const char *zipc_hip_strerror(int status);
 

@@ -55,6 +55,29 @@ def test_gpus_must_agree_with_world_size():
 def test_cpu_baseline_leg_reports_one_thread_and_all_threads():
     import bench
 
-    line = bench.cpu_baseline(2, 4, 2, 65536, budget_s=1.0)
+    bench.LEGS["quick"] = (("synth", 2, 4), 2, 65536, (0, 1), True, 1.0)
+    line = bench.cpu_leg("quick")
     assert line["cores"] == 1 and line["kind"] == "port" and line["value"] > 0
     assert line["nproc"]["cores"] == (os.cpu_count() or 1) and line["nproc"]["value"] > line["value"] * 0.5
+
+
+def test_cpu_baseline_leg_hands_over_the_oracles_samples():
+    """the legs' parity samples: what the oracle makes of a few streams of every leg, worked out in the cpu_baseline
+    process (the only place bench.py runs the oracle) -- digest, CRC-32 and length per sampled stream"""
+    import hashlib
+
+    import bench
+    import oracle
+
+    keep = dict(bench.LEGS)
+    try:
+        for k in list(bench.LEGS):
+            if k not in ("text_default", "one_c1_zeros_1mib"):
+                del bench.LEGS[k]
+        s = bench.cpu_samples()
+    finally:
+        bench.LEGS.clear()
+        bench.LEGS.update(keep)
+    assert sorted(s) == ["one_c1_zeros_1mib", "text_default"] and sorted(s["text_default"]) == ["0", "1", "2", "3"]
+    st, comp, crc = oracle.deflate(bench.text_pieces(65536)[2], level=2, crc_op=oracle.CRC_CRC32)
+    assert s["text_default"]["2"] == [hashlib.sha256(comp).hexdigest()[:24], crc, len(comp)]

@@ -41,8 +41,14 @@ def test_randomized_parity_bounded(gpu_ctx, oracle):
     {"ZIPC_HIP_PARSE_SEGMENTS": "1", "ZIPC_HIP_SLICES": "2", "ZIPC_HIP_SLICE_MIN": "1"},
     {"ZIPC_HIP_DEFLATE_GROUP_BYTES": "300000"},                     # a batch in groups of a few streams through one scratch (batches beyond 8 GiB)
     {"ZIPC_HIP_DEFLATE_GROUP_BYTES": "500000", "ZIPC_HIP_PARSE_SEGMENTS": "1"},
+    {"ZIPC_HIP_CHAIN": "peel"},                                     # hash chains by the kernel that orders equal hashes itself (default: ordered LDS exchange)
+    {"ZIPC_HIP_CHAIN": "peel", "ZIPC_HIP_PARSE_SEGMENTS": "0"},
+    {"ZIPC_HIP_PARSE_SEGMENTS": "0"},                               # a wave per stream for parse and blocks (what 16 384 streams take)
+    {"ZIPC_HIP_TILE": "1", "ZIPC_HIP_PARSE_SEGMENTS": "0"},         # search and parse in one workgroup (lz_tile.hip)
+    {"ZIPC_HIP_TILE": "1", "ZIPC_HIP_TILE_PUNT": "1", "ZIPC_HIP_PARSE_SEGMENTS": "0"},  # ... every stream left to the kernels behind it
 ], ids=["scan-walk", "first-walk", "slices", "scan-walk+groups+slices", "parse-segments", "parse-segments+slices",
-        "batch-groups", "batch-groups+parse-segments"])
+        "batch-groups", "batch-groups+parse-segments", "chain-peel", "chain-peel+one-wave-forms", "one-wave-forms",
+        "tile-kernel", "tile-kernel-punts"])
 def test_randomized_parity_under_overrides(env):
     """The same loop in a process of its own under the library's overrides (read once per process), so that
     the paths a 120-stream batch would not reach by itself are compared with the oracle too."""
@@ -102,3 +108,9 @@ def test_one_stream_inflate_by_blocks_bounded(form):
     assert r.returncode == 0 and "0 mismatches" in tail, tail
     went = int(tail.split(" went by blocks")[0].split(", ")[-1])
     assert went >= (15 if form == "default" else 8), tail
+
+
+def test_chains_are_built_by_ordered_exchange(gpu_ctx):
+    """The context's probe (deflate.hip xchg_order_probe) passes on gfx950, so the suite's deflate tests run
+    lz_chain_xchg_kernel; the peel kernel is compared with the oracle by the overrides above."""
+    assert gpu_ctx.lds_exchange_ordered()

@@ -129,3 +129,26 @@ def test_random_hand_made_blocks(gpu_ctx, oracle):
     for i, (comp, plain) in enumerate(cases):
         st0, _, _ = oracle.inflate(comp, decompressed_size=lims[i])
         assert got[i][0] == st0 != 0, i
+
+
+def test_a_repeated_header_longer_than_what_stays_staged(gpu_ctx, oracle):
+    """Calls of up to 256 streams go on with the tables there are when a block repeats the header bits of the short
+    block before it (inflate.hip REUSE): the header's bits are compared in memory and skipped, so the position may
+    pass what the input ring holds -- with a header of a few hundred bits it does, and the ring must start over
+    there (round 3's kernel decoded stale slots).  Headers of several lengths, short and long blocks, batches of 1,
+    3, 64 and 256 streams, all three checksum modes."""
+    cases = []
+    for seed, (n_blocks, n_used, per_block) in enumerate([(6, 2, 40), (5, 20, 10), (9, 60, 3), (4, 100, 200), (12, 200, 1),
+                                                          (7, 255, 30), (3, 150, 1500), (20, 90, 7)]):
+        comp, plain = util.repeated_literal_blocks(1000 + seed, n_blocks, n_used, per_block)
+        assert zlib.decompress(comp, -15) == plain
+        cases.append((comp, plain))
+    for n in (1, 3, 64, 256):
+        srcs = [cases[i % len(cases)][0] for i in range(n)]
+        plains = [cases[i % len(cases)][1] for i in range(n)]
+        for crc_op in (0, 1, 2):
+            got = util.gpu_inflate_batch(gpu_ctx, srcs, [len(p) for p in plains], [True] * n, [len(p) for p in plains], crc_op)
+            for i in range(n):
+                st0, d0, c0 = oracle.inflate(srcs[i], decompressed_size=len(plains[i]), crc_op=crc_op)
+                assert st0 == 0 and d0 == plains[i]
+                assert got[i] == (0, plains[i], c0), (n, i, crc_op, got[i][0])

@@ -1,10 +1,11 @@
 """Member sharding (zipc_amd/shard.py): partition properties and the N > 1 record
-all-gather on CPU (gloo, world_size 2)."""
+all-gather on CPU (gloo, world_size 2 and 4)."""
 import os
 import socket
 import sys
 
 import numpy as np
+import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -48,13 +49,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_record_allgather_gloo_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_record_allgather_gloo(world):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in procs]
@@ -128,8 +130,9 @@ def _archive_worker(rank, world, port, members, L, q):
     dist.destroy_process_group()
 
 
-def test_archive_of_two_ranks_equals_the_archive_of_one():
-    """The N-rank archive is the 1-rank archive: members spread over 2 ranks (gloo), payloads gathered, laid out
+@pytest.mark.parametrize("world", [2, 4])
+def test_archive_of_n_ranks_equals_the_archive_of_one(world):
+    """The N-rank archive is the 1-rank archive: members spread over 2 and over 4 ranks (gloo), payloads gathered, laid out
     by the host layer -- against the same members laid out in one process, and read back by zipfile."""
     import io
     import zipfile
@@ -143,7 +146,7 @@ def test_archive_of_two_ranks_equals_the_archive_of_one():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_archive_worker, args=(r, 2, port, members, L, q)) for r in range(2)]
+    procs = [ctx.Process(target=_archive_worker, args=(r, world, port, members, L, q)) for r in range(world)]
     for p in procs:
         p.start()
     blob2 = q.get(timeout=180)

@@ -422,3 +422,55 @@ def random_fixed_block(seed, n_symbols, max_dist=300, max_len=20, lit_share=0.3)
             plain.append(plain[-d])
     w.code(0, 7)
     return w.bytes(), bytes(plain)
+
+
+def repeated_literal_blocks(seed, n_blocks, n_used, syms_per_block):
+    """A deflate stream of n_blocks + 1 dynamic blocks with the very SAME bits (but the last one's "final" bit): a
+    random complete code over n_used literals and the end-of-block symbol, syms_per_block random literals per block.
+    Returns (stream, plain).  (What inflate_batch_few_kernel's shortcut for a repeated header is tested with: the
+    header is a few hundred bits long, far more than stays staged behind an end of block.)"""
+    import random
+
+    r = random.Random(seed)
+    lits = sorted(r.sample(range(256), n_used))
+    ll = [0] * 286
+    for sym, l in zip(lits + [256], _random_code_lengths(r, n_used + 1, 15)):
+        ll[sym] = l
+    seq = ll[:257] + [1]  # HLIT = 257 codes, HDIST = 1 code: distance symbol 0 with length 1, never used
+    items, i = [], 0
+    while i < len(seq):
+        run = 1
+        while i + run < len(seq) and seq[i + run] == seq[i]:
+            run += 1
+        if seq[i] == 0 and run >= 3:
+            n = min(run, 138)
+            items.append((17, n - 3, 3) if n <= 10 else (18, n - 11, 7))
+            i += n
+        else:
+            items.append((seq[i], 0, 0))
+            i += 1
+    cl_used = sorted({it[0] for it in items})
+    cl = [0] * 19
+    for sym, l in zip(cl_used, _random_code_lengths(r, len(cl_used), 7)):
+        cl[sym] = l
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    hclen = max(4, max(i for i, s in enumerate(order) if cl[s]) + 1)
+    body = [r.choice(lits) for _ in range(syms_per_block)]
+
+    def block(w, final):
+        w.put(final, 1); w.put(2, 2); w.put(0, 5); w.put(0, 5); w.put(hclen - 4, 4)
+        for s_ in order[:hclen]:
+            w.put(cl[s_], 3)
+        clc = _canonical(cl)
+        for sym, extra, nb in items:
+            w.code(clc[sym], cl[sym]); w.put(extra, nb)
+        lc = _canonical(ll)
+        for s_ in body:
+            w.code(lc[s_], ll[s_])
+        w.code(lc[256], ll[256])
+
+    w = _Bits()
+    for _ in range(n_blocks):
+        block(w, 0)
+    block(w, 1)
+    return w.bytes(), bytes(body) * (n_blocks + 1)

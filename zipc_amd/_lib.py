@@ -59,6 +59,7 @@ SYMBOLS = [
     ("zipc_hip_synchronize", C.c_int, [_P]),
     ("zipc_hip_last_error", C.c_char_p, [_P]),
     ("zipc_hip_last_inflate_blocks", C.c_uint, [_P]),
+    ("zipc_hip_lds_exchange_ordered", C.c_int, [_P]),
     ("zipc_hip_strerror", C.c_char_p, [C.c_int]),
     ("zipc_hip_set_profiling", C.c_int, [_P, C.c_int]),
     ("zipc_hip_set_adler_rfc1950", C.c_int, [_P, C.c_int]),
@@ -146,6 +147,10 @@ class Context:
     def last_inflate_blocks(self) -> int:
         """blocks the last one-stream inflate was decoded by, a wave each (0: by the stream's one wave)"""
         return int(lib().zipc_hip_last_inflate_blocks(self._h))
+
+    def lds_exchange_ordered(self) -> bool:
+        """hash chains are built by ordered LDS exchange (the context's probe passed; include/zipc_hip.h)"""
+        return bool(lib().zipc_hip_lds_exchange_ordered(self._h))
 
     def set_profiling(self, on: bool):
         self.check(lib().zipc_hip_set_profiling(self._h, int(on)))

@@ -356,6 +356,7 @@ int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
 
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx) { return ctx ? ctx->last_inflate_blocks : 0u; }
+int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx) { return ctx && ctx->xchg_ordered ? 1 : 0; }
 
 int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled) {
   if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
@@ -655,6 +656,9 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[rounds - 1]);
+  // (12 bytes of scratch per output byte: what a long stream took goes back -- a context lives as long as its thread,
+  // and a 1 GiB member would pin 12 GiB per device; the stream is idle here, the gather has been waited for)
+  if (ctx->tok_scratch.cap > ((size_t)512 << 20)) free_buf(ctx->tok_scratch);
   if (fc.token_bad != 0 || fc.more[rounds - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
   ZD_LAUNCH(ctx, "inflate_blocks_result", inflate_blocks_result_kernel, dim3(1), dim3(1), 0, (StreamResult *)d_results, (uint64_t)out_len);
   ctx->last_inflate_blocks = nb;

@@ -379,9 +379,21 @@ static_assert(MAX_STREAM_LEN <= XCHG_NONE, "no position looks like the table's e
 // others have their turns, waits until the word `turn_now` in LDS says t, issues its exchanges and hands over
 // (turn_now <- t + 1, behind its exchanges: a wave's LDS operations are executed in the order they were issued, and
 // the next wave issues its exchanges only after it has READ the new value), then works out its links and stores them.
-// The chain of hand-overs is what a stream takes: ~16 exchanges and one LDS round trip per 1024 positions.
-constexpr uint32_t XCHG_WAVES = 4;
-constexpr int XCHG_U = 16;                    // rounds of 64 positions per turn
+// Measured (C2, ms per GiB; tools/ab_wall.sh on one box): 4 waves x 16 rounds 1.42-1.45; 8 waves 1.41; 2 waves 1.97;
+// turns of 8 / 32 rounds 1.83 / 1.41; polling without s_sleep 1.63; the hand-over NOT waiting for the exchanges' answers
+// 1.42 -- neither the hand-over nor a wave's own work is what a stream waits for: 1024 exchanges of 64 random addresses
+// take the LDS ~45 clocks each (text, where lanes of one exchange share addresses: 1.59).  One wave alone: 3.4.
+#ifndef ZD_XCHG_WAVES
+#define ZD_XCHG_WAVES 4
+#endif
+#ifndef ZD_XCHG_U
+#define ZD_XCHG_U 16
+#endif
+#ifndef ZD_XCHG_SLEEP
+#define ZD_XCHG_SLEEP 1
+#endif
+constexpr uint32_t XCHG_WAVES = ZD_XCHG_WAVES;
+constexpr int XCHG_U = ZD_XCHG_U;             // rounds of 64 positions per turn
 constexpr uint32_t XCHG_TURN = 64u * XCHG_U;  // positions per turn
 static_assert(MAX_MATCH_DIST % XCHG_TURN == 0 && SWEEP_PERIOD % XCHG_TURN == 0, "segments start on turn boundaries");
 
@@ -426,7 +438,11 @@ __device__ __forceinline__ void lz_chain_xchg_workgroup(const uint8_t *__restric
     uint32_t old[XCHG_U], hb[XCHG_U];
 #pragma unroll
     for (int u = 0; u < XCHG_U; u++) hb[u] = hash4(wd[u]);
-    while (__hip_atomic_load(&turn_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) __builtin_amdgcn_s_sleep(1);
+    while (__hip_atomic_load(&turn_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != t) {
+#if ZD_XCHG_SLEEP
+      __builtin_amdgcn_s_sleep(ZD_XCHG_SLEEP);
+#endif
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
     for (int u = 0; u < XCHG_U; u++) {
@@ -2393,17 +2409,36 @@ __global__ __launch_bounds__(256) void deflate_seal_kernel(uint8_t *__restrict__
   const uint32_t n_parts = emit_parts_of(split, p->kind, blocks[b].n_syms);
   if (part >= n_parts) return;
   uint8_t *dst = dst_arena + sd.dst_off;
-  // the part's first bit (deflate_emit_wave<2>), and the bits the part before it left of that byte
-  uint64_t at = p->bit_start;
-  if (part != 0) {
-    at += p->kind == 2 ? p->dbits - p->dyn_sym_bits : 3u;
-    for (uint32_t j = 0; j < part; j++) at += p->part_bits[j];
-  }
+  // A part's pack wave (deflate_emit_wave<2>) wrote the part's whole bytes and left the low bits of its first byte --
+  // the bits of what lies before it -- zero; what the part leaves of its last byte is part_tail.  ONE thread puts a
+  // shared byte together: the thread of the part that COMPLETES the byte ORs in the tails of what ends inside it.
+  // A part that lies wholly inside one byte (the last part of a split block: a symbol or two and the end-of-block
+  // symbol under short codes) completes nothing and writes nothing -- two threads ORing into one byte lost one of the
+  // two updates (round 3) -- its bits travel in the next part's `before`.
+  auto start_of = [&](const EmitPlan *q, uint32_t j) -> uint64_t {  // first bit of part j of q's block
+    uint64_t a = q->bit_start;
+    if (j != 0) {
+      a += q->kind == 2 ? q->dbits - q->dyn_sym_bits : 3u;  // type bits and header
+      for (uint32_t k = 0; k < j; k++) a += q->part_bits[k];
+    }
+    return a;
+  };
+  const uint64_t at = start_of(p, part);
+  const uint64_t end = part + 1 != n_parts ? start_of(p, part + 1) : p->bit_end;
+  const bool completes = (at >> 3) != (end >> 3);  // the part holds the last bit of its first byte
+  uint32_t before = 0;
   if ((at & 7u) && (b != 0 || part != 0)) {
-    const uint32_t before = part != 0 ? p->part_tail[part - 1] : p[-1].part_tail[emit_parts_of(split, p[-1].kind, blocks[b - 1].n_syms) - 1];
-    dst[at >> 3] |= (uint8_t)before;
+    // the part before me, and -- when that one lies wholly inside this byte -- the one before it (never a third: only
+    // the last part of a block can be that short, and a block's first part holds at least the 10 bits of an empty block)
+    const EmitPlan *q = part != 0 ? p : p - 1;
+    const uint32_t qj = part != 0 ? part - 1 : emit_parts_of(split, q->kind, blocks[b - 1].n_syms) - 1;
+    before = q->part_tail[qj];
+    const uint64_t qs = start_of(q, qj);
+    if ((qs >> 3) == (at >> 3) && (qs & 7u) && qj != 0) before |= q->part_tail[qj - 1];
+    if (completes) dst[at >> 3] |= (uint8_t)before;
   }
-  if (b + 1 == nblk && part + 1 == n_parts && (p->bit_end & 7u)) dst[p->bit_end >> 3] = (uint8_t)p->part_tail[part];  // flush zd.ml:856-858
+  if (b + 1 == nblk && part + 1 == n_parts && (p->bit_end & 7u))  // flush zd.ml:856-858
+    dst[p->bit_end >> 3] = (uint8_t)(p->part_tail[part] | (completes ? 0u : before));
 }
 
 // ---------------------------------------------------------------------------------
@@ -2575,7 +2610,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     while (n * ((max_src_len + 2 * xseg - 1) / (2 * xseg)) >= 2048) xseg *= 2;  // twice the chip's CUs of waves is plenty
     xsegs = (max_src_len + xseg - 1) / xseg;
   }
-  static const long tile_env = [] { const char *e = getenv("ZIPC_HIP_TILE"); return e ? atol(e) : 1L; }();  // 0: never lz_tile_kernel (tests, A/B)
+  static const long tile_env = [] { const char *e = getenv("ZIPC_HIP_TILE"); return e ? atol(e) : 0L; }();  // 1: lz_tile_kernel in place of lz_match + lz_parse (exact; slower on every shape measured: lz_tile.hip)
   hipError_t slice_err = hipSuccess;
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;

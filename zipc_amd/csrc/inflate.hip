@@ -736,6 +736,10 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
             lane_begin_symbols(d);  // (final_block 0, the codes, their tables, levels: the block before's)
             prev_hdr_at = hdr_at;
             ZD_PH(ph_hdr);
+            // The header's bits -- up to 8191 -- were compared in memory, not read through the ring: the position may
+            // now stand behind what is staged (input_ready's unsigned difference would wrap to "plenty" and the next
+            // turn decode stale slots).  The ring starts over at the position, as behind a checkpoint.
+            if (d.in_word + (uint32_t)TURN_WORDS > d.ring_wr) { d.ring_wr = d.in_word; break; }
             continue;
           }
           prev_hdr_bits = 0;
@@ -1462,7 +1466,9 @@ __global__ __launch_bounds__(64) void stored_walk_kernel(const uint8_t *__restri
     o += (uint64_t)m * guess;
     room -= (uint64_t)m * guess;
     if (stop == WALK_FINAL) break;
-    if (m < 64u) guess = 0xFFFFFFFFu;  // the run ended: the next header's own length
+    // (the guess stays: a step that listed one block because its guess was fresh or wrong has just LEARNED the length
+    // the next 64 headers are tried with -- round 3 dropped it again here and walked one header per step -- and a guess
+    // that no longer holds costs the one-block step in which lane 0 corrects it)
   }
   if (lane == 0) { walk->src_pos = p; walk->dst_pos = o; walk->room = room; walk->n_blocks = n; walk->stop = stop; }
 }
