@@ -32,8 +32,18 @@ let c_deflate =
     (ctx_t @-> ocaml_string @-> size_t @-> int @-> int @-> ocaml_bytes @-> size_t @->
      ptr size_t @-> ptr uint32_t @-> returning int)
 
+let c_zlib_decompress =
+  f "zipc_hip_zlib_decompress"
+    (ctx_t @-> ocaml_string @-> size_t @-> int @-> size_t @-> ocaml_bytes @-> size_t @->
+     ptr size_t @-> ptr uint32_t @-> ptr uint32_t @-> ptr uint32_t @-> returning int)
+let c_zlib_bound = f "zipc_hip_zlib_bound" (size_t @-> returning size_t)
+let c_zlib_compress =
+  f "zipc_hip_zlib_compress"
+    (ctx_t @-> ocaml_string @-> size_t @-> int @-> ocaml_bytes @-> size_t @->
+     ptr size_t @-> ptr uint32_t @-> returning int)
+
 (* status codes and enums of include/zipc_hip.h *)
-let ok = 0 and err_dst_too_small = 16
+let ok = 0 and err_zlib_method = 3 and err_checksum = 6 and err_dst_too_small = 16
 let crc_nop = 0 and crc_crc32 = 1 and crc_adler32 = 2
 
 (* ONE context for the whole program: a zipc_hip context owns one HIP stream and staging buffers
@@ -125,26 +135,33 @@ let inflate_and_adler_32 ?decompressed_size ?start ?len s =
 let inflate ?decompressed_size ?start ?len s =
   Result.map fst (inflate_and_crc ?decompressed_size ?start ?len s ~crc_op:crc_nop)
 
-(* zlib_decompress zipc_deflate.ml:720-740: the 6 bytes of container are parsed
-   here, the body goes through inflate_and_adler_32 *)
+(* zlib_decompress zipc_deflate.ml:720-740: the library's own entry point (header checks, body, trailer and the
+   Adler-32 comparison all behind zipc_hip_zlib_decompress); only the messages are put together here *)
 let zlib_decompress ?decompressed_size ?start ?len s =
   let s = range ?start ?len s in
-  let len = String.length s in
-  let err m = Error (None, m) in
-  if len < 6 then err "Corrupted data stream" else
-  let cmf = String.get_uint8 s 0 and flg = String.get_uint8 s 1 in
-  if (256 * cmf + flg) mod 31 <> 0 then err "Corrupted data stream" else
-  let cm = cmf land 0x0F in
-  if cm <> 8 then err (Printf.sprintf "Unknown compression method (%d)" cm) else
-  if cmf lsr 4 > 7 then err "Window size too large" else
-  if flg land 0x20 <> 0 then err "Preset dictionary unsupported" else
-  let expect = String.get_int32_be s (len - 4) in
-  match inflate_and_adler_32 ?decompressed_size s ~start:2 ~len:(len - 4) with
-  | Error e -> err e
-  | Ok (_, found) as r ->
-      match Adler_32.check ~expect ~found with
-      | Error e -> Error (Some (expect, found), e)
-      | Ok () -> r
+  let n = String.length s in
+  let has_limit, limit = match decompressed_size with None -> 0, 0 | Some d -> 1, d in
+  let rec go cap =
+    let dst = Bytes.create cap in
+    let out_len = allocate size_t Unsigned.Size_t.zero in
+    let adler = allocate uint32_t Unsigned.UInt32.zero in
+    let expect = allocate uint32_t Unsigned.UInt32.zero in
+    let found = allocate uint32_t Unsigned.UInt32.zero in
+    let st =
+      c_zlib_decompress (Lazy.force ctx) (ocaml_string_start s) (sz n) has_limit (sz limit)
+        (ocaml_bytes_start dst) (sz cap) out_len adler expect found
+    in
+    if st = err_dst_too_small && has_limit = 0 then go (2 * cap) else
+    if st = ok then Ok (Bytes.sub_string dst 0 (Unsigned.Size_t.to_int (!@ out_len)), u32 adler) else
+    if st = err_checksum then begin
+      let e = u32 expect and f = u32 found in
+      Error (Some (e, f), Printf.sprintf "Checksum mismatch, expected %lx found %lx)" e f)
+    end else
+    if st = err_zlib_method
+    then Error (None, Printf.sprintf "Unknown compression method (%d)" (String.get_uint8 s 0 land 0x0F))
+    else Error (None, c_strerror st)
+  in
+  go (if has_limit = 1 then limit else max (3 * n) 1024)
 
 type level = [ `None | `Fast | `Default | `Best ]
 
@@ -169,15 +186,17 @@ let crc_32_and_deflate ?level ?start ?len s = crc_and_deflate ?level ?start ?len
 let adler_32_and_deflate ?level ?start ?len s = crc_and_deflate ?level ?start ?len s ~crc_op:crc_adler32
 let deflate ?level ?start ?len s = Result.map snd (crc_and_deflate ?level ?start ?len s ~crc_op:crc_nop)
 
-(* zlib_compress zipc_deflate.ml:1262-1277 *)
+(* zlib_compress zipc_deflate.ml:1262-1277: header, body and trailer by zipc_hip_zlib_compress *)
 let zlib_compress ?(level = `Best) ?start ?len s =
-  match adler_32_and_deflate ~level ?start ?len s with
-  | Error _ as e -> e
-  | Ok (adler, body) ->
-      let cmf = (7 lsl 4) lor 8 in
-      let header = (cmf lsl 8) lor (level_code level lsl 6) in
-      let flg = (header + 31 - (header mod 31)) land 0xFF in
-      let b = Buffer.create (String.length body + 6) in
-      Buffer.add_uint8 b cmf; Buffer.add_uint8 b flg; Buffer.add_string b body;
-      Buffer.add_int32_be b adler;
-      Ok (adler, Buffer.contents b)
+  let s = range ?start ?len s in
+  let n = String.length s in
+  let cap = Unsigned.Size_t.to_int (c_zlib_bound (sz n)) in
+  let dst = Bytes.create cap in
+  let out_len = allocate size_t Unsigned.Size_t.zero in
+  let adler = allocate uint32_t Unsigned.UInt32.zero in
+  let st =
+    c_zlib_compress (Lazy.force ctx) (ocaml_string_start s) (sz n) (level_code level)
+      (ocaml_bytes_start dst) (sz cap) out_len adler
+  in
+  if st <> ok then Error (c_strerror st) else
+  Ok (u32 adler, Bytes.sub_string dst 0 (Unsigned.Size_t.to_int (!@ out_len)))

@@ -13,6 +13,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.h"
+#include "tuning.h"
 
 using namespace zd;
 
@@ -155,8 +156,7 @@ static void free_buf(zipc_hip_ctx::Buf &b) {
 // ZIPC_HIP_HOST_THREADS overrides the count (default: 8 or the core count, if lower).
 static size_t host_threads() {
   static const size_t nt = [] {
-    const char *e = getenv("ZIPC_HIP_HOST_THREADS");
-    long v = e ? atol(e) : 0;
+    long v = zd::tuning().host_threads;
     if (v < 1) {
       const unsigned hw = std::thread::hardware_concurrency();
       v = hw >= 8 ? 8 : (hw ? hw : 1);
@@ -169,8 +169,7 @@ static size_t host_threads() {
 // gather, H2D, kernels, D2H and scatter on its own, so those overlap (1 = one after the other)
 static size_t host_chunks() {
   static const size_t k = [] {
-    const char *e = getenv("ZIPC_HIP_HOST_CHUNKS");
-    long v = e ? atol(e) : 0;
+    long v = zd::tuning().host_chunks;
     if (v < 1) v = 3;  // profiles/r01_host_forms_sweep.txt: medians of 11 calls, 2 / 3 / 4 sub-batches:
                        // deflate 49 / 41.5 / 55 ms, inflate 45 / 38 / 36 ms (4 has the best single calls, unstable medians)
     return (size_t)(v > 64 ? 64 : v);
@@ -203,9 +202,37 @@ struct EventSet {
 };
 
 namespace zd {
+const Tuning &tuning() {
+  static const Tuning t = [] {
+    auto num = [](const char *name, long dflt) { const char *e = getenv(name); return e ? atol(e) : dflt; };
+    auto is = [](const char *name, const char *v) { const char *e = getenv(name); return e && !strcmp(e, v); };
+    Tuning x;
+    x.chain_peel = is("ZIPC_HIP_CHAIN", "peel");
+    x.tile = num("ZIPC_HIP_TILE", 0) != 0;
+    x.tile_punt = num("ZIPC_HIP_TILE_PUNT", 0) != 0;
+    x.parse_segments = num("ZIPC_HIP_PARSE_SEGMENTS", -1);
+    x.parse_seg = num("ZIPC_HIP_PARSE_SEG", 0);
+    x.match_tiles_per_group = num("ZIPC_HIP_MATCH_TILES_PER_GROUP", 0);
+    const long form = num("ZIPC_HIP_MATCH_FORM", 0);
+    x.match_form = form == 1 || form == 2 ? (int)form : 0;
+    const long long group = getenv("ZIPC_HIP_DEFLATE_GROUP_BYTES") ? atoll(getenv("ZIPC_HIP_DEFLATE_GROUP_BYTES")) : 0;
+    x.deflate_group_bytes = group > 0 ? (size_t)group : (size_t)8 << 30;
+    x.slices = num("ZIPC_HIP_SLICES", 0);
+    x.slice_min = num("ZIPC_HIP_SLICE_MIN", 0);
+    x.inflate_blocks = num("ZIPC_HIP_INFLATE_BLOCKS", 1) != 0;
+    x.inflate_follow = (int)num("ZIPC_HIP_INFLATE_FOLLOW", -1);
+    x.explore_stride = (uint64_t)num("ZIPC_HIP_EXPLORE_STRIDE", 8192);
+    x.resolve_hops0 = (int)num("ZIPC_HIP_RESOLVE_HOPS0", 256);
+    x.resolve_hops1 = (int)num("ZIPC_HIP_RESOLVE_HOPS1", 256);
+    x.checksum_fused = num("ZIPC_HIP_CHECKSUM_FUSED", 1) != 0;
+    x.host_threads = num("ZIPC_HIP_HOST_THREADS", 0);
+    x.host_chunks = num("ZIPC_HIP_HOST_CHUNKS", 0);
+    return x;
+  }();
+  return t;
+}
 size_t batch_slices(size_t n_streams) {
-  static const long env = [] { const char *e = getenv("ZIPC_HIP_SLICES"); return e ? atol(e) : 0L; }();
-  static const long env_min = [] { const char *e = getenv("ZIPC_HIP_SLICE_MIN"); return e ? atol(e) : 0L; }();  // tests
+  const long env = tuning().slices, env_min = tuning().slice_min;
   size_t k = env > 0 ? (size_t)env : 1;
   if (k > 8) k = 8;
   const size_t least = env_min > 0 ? (size_t)env_min : 2048;
@@ -524,15 +551,12 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
 // few words back between its steps: it SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0 turns it off.
 constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
 constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
-static const uint64_t EXPLORE_STRIDE = [] { const char *e = getenv("ZIPC_HIP_EXPLORE_STRIDE"); return e ? (uint64_t)atoi(e) : 8192ull; }();  // bytes of input between two explorers
 static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
                              zipc_hip_stream_result *d_results, int crc_op, bool *handled) {
   *handled = false;
   ctx->last_inflate_blocks = 0;
-  static const bool enabled = [] { const char *e = getenv("ZIPC_HIP_INFLATE_BLOCKS"); return !(e && e[0] == '0'); }();
-  static const bool trace = getenv("ZIPC_HIP_INFLATE_BLOCKS_TRACE") != nullptr;
-  static const bool explore = [] { const char *e = getenv("ZIPC_HIP_INFLATE_EXPLORE"); return !(e && e[0] == '0'); }();
-  if (!enabled) return ZIPC_HIP_OK;
+  const uint64_t EXPLORE_STRIDE = zd::tuning().explore_stride;  // bytes of input between two explorers
+  if (!zd::tuning().inflate_blocks) return ZIPC_HIP_OK;
   const bool adler = crc_op == ZIPC_HIP_CRC_ADLER32 || crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950;
   StreamDesc sd;
   HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
@@ -587,7 +611,6 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   if (cand_cap > 8192u) {
     HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (trace) fprintf(stderr, "inflate_by_blocks: src %llu first %u cand %u (cap %u)\n", (unsigned long long)sd.src_len, fc.n_first, fc.n_cand, cand_cap);
     if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
     n = fc.n_cand;
   }
@@ -597,11 +620,10 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
             (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
   ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
-            d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, explore ? 0 : 1);
+            d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 0);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
-  if (trace) fprintf(stderr, "inflate_by_blocks: chain ok %u blocks %u (walked %u) out %llu miss %lld\n", fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len, (long long)fc.miss_bit);
   if (!fc.chain_ok && fc.miss_bit != ~0ull) {
     // the chain came to a block nobody listed: explorers from there on, then the chain again (which now walks what
     // is still missing itself)
@@ -617,7 +639,6 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
               d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 1);
     HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (trace) fprintf(stderr, "inflate_by_blocks: %llu explorers, %u blocks listed; chain ok %u blocks %u (walked %u) out %llu\n", (unsigned long long)ne, fc.n_recs, fc.chain_ok, fc.n_blocks, fc.n_walked, (unsigned long long)fc.out_len);
   }
   if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;  // (one block: nothing to gain)
   const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
@@ -632,7 +653,7 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and a
   // wave per block instead of one per interval, and save the resolve rounds of a long stream more: with 256 hops a
   // round, 64 MiB of text 6.3-10.8 -> 5.7-6.5 ms, 16 MiB 2.7-4.4 <- 3.3-4.2)
-  static const int follow_env = [] { const char *e = getenv("ZIPC_HIP_INFLATE_FOLLOW"); return e ? atoi(e) : -1; }();
+  const int follow_env = zd::tuning().inflate_follow;
   // (... and nothing on data with few matches: 16 MiB of records that deflate to 0.85, resolve 0.13 ms either way)
   const int follow = follow_env >= 0 ? follow_env : out_len >= (32u << 20) && (uint64_t)out_len * 2u >= sd.src_len * 3u;
   // the token run: a wave per interval of a block (its checkpoints), or -- follow -- a wave per block
@@ -644,8 +665,7 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
             d_tok, d_counts, follow);
   // (hops a thread follows in a round: 8 left most bytes of a text for the next round -- 16 MiB: three rounds over nearly
   // everything, 3.4 ms; 64 and more let nearly every byte arrive in the first: 0.28 ms)
-  static const int hops0 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS0"); return e ? atoi(e) : 256; }();
-  static const int hops1 = [] { const char *e = getenv("ZIPC_HIP_RESOLVE_HOPS1"); return e ? atoi(e) : 256; }();
+  const int hops0 = zd::tuning().resolve_hops0, hops1 = zd::tuning().resolve_hops1;
   const int rounds = hops0 >= 16 && hops1 >= 16 ? 6 : RESOLVE_ROUNDS;  // (16^6 links: more than a stream has bytes)
   for (int r = 0; r < rounds; r++) {
     uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
@@ -655,7 +675,6 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
   ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
   HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (trace) fprintf(stderr, "inflate_by_blocks: token_bad %u more %u %u %u .. %u\n", fc.token_bad, fc.more[0], fc.more[1], fc.more[2], fc.more[rounds - 1]);
   // (12 bytes of scratch per output byte: what a long stream took goes back -- a context lives as long as its thread,
   // and a 1 GiB member would pin 12 GiB per device; the stream is idle here, the gather has been waited for)
   if (ctx->tok_scratch.cap > ((size_t)512 << 20)) free_buf(ctx->tok_scratch);
@@ -788,8 +807,8 @@ int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len, i
   // Both checksums: ONE pass over the bytes (crc32_adler_segments_kernel leaves the CRC partials and the
   // Adler chunk sums), then the two finishes -- on two queues for a large buffer.  ZIPC_HIP_CHECKSUM_FUSED=0
   // keeps the two passes of rounds 1-3 (CRC on a side queue from 64 MiB on) for comparison and for the tests.
-  static const bool fused_ok = [] { const char *e = getenv("ZIPC_HIP_CHECKSUM_FUSED"); return !e || atoi(e) != 0; }();
-  static const bool c3_two_queues = [] { const char *e = getenv("ZIPC_HIP_CHECKSUM_QUEUES"); return !e || atoi(e) != 1; }();
+  const bool fused_ok = zd::tuning().checksum_fused;
+  const bool c3_two_queues = true;
   const bool fused = want_crc32 && want_adler32 && len > 0 && fused_ok;
   const bool side = want_crc32 && want_adler32 && len >= (64u << 20) && c3_two_queues;
   if (side || fused)  // (before any fork: growing a buffer synchronises)
@@ -959,8 +978,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (crc_op < 0 || crc_op > 3 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  // ZIPC_HIP_HOST_TIMING=1: wall time of the call's three host phases on stderr
-  static const bool timing = getenv("ZIPC_HIP_HOST_TIMING") != nullptr;
+  constexpr bool timing = false;  // (true: wall time of the call's three host phases on stderr)
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();

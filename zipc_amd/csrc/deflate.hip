@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "deflate_pipeline.h"
+#include "tuning.h"
 
 namespace zd {
 
@@ -54,14 +55,7 @@ static void scratch_caps(size_t n, size_t total_src_len, uint64_t &P, uint64_t &
 // lz_parse and deflate_emit are one wave per stream, and 2048 streams leave 2 waves per SIMD where
 // 8192 leave 8 -- so the scratch is bounded, not halved.  ZIPC_HIP_DEFLATE_GROUP_BYTES overrides
 // the size (tests run with groups of a few streams).
-static size_t deflate_group_bytes() {
-  static const size_t v = [] {
-    const char *e = getenv("ZIPC_HIP_DEFLATE_GROUP_BYTES");
-    const long long x = e ? atoll(e) : 0;
-    return x > 0 ? (size_t)x : (size_t)8 << 30;
-  }();
-  return v;
-}
+static size_t deflate_group_bytes() { return tuning().deflate_group_bytes; }
 // streams per group, and the source bytes a group can hold at most
 static void deflate_grouping(size_t n, size_t max_src_len, size_t total_src_len, size_t &per_group, size_t &group_total) {
   per_group = n;
@@ -2541,16 +2535,16 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // workgroups (32 per CU: with 2048 a group of 2048 long streams had one workgroup per stream
   // and a long tail), so few long streams still spread over the chip
   // (ZIPC_HIP_MATCH_TILES_PER_GROUP, read once, overrides the rule: tuning and tests)
-  static const long tpg_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_TILES_PER_GROUP"); return e ? atol(e) : 0L; }();
-  static const int form_env = [] { const char *e = getenv("ZIPC_HIP_MATCH_FORM"); const long v = e ? atol(e) : 0L; return v == 1 || v == 2 ? (int)v : 0; }();
+  const long tpg_env = tuning().match_tiles_per_group;
+  const int form_env = tuning().match_form;
   size_t tpg = tpg_env > 0 ? (size_t)tpg_env : n * tps / 8192;
   tpg = tpg < 1 ? 1 : (tpg > tps ? tps : tpg);
   const size_t gps = (tps + tpg - 1) / tpg;
   // Few long streams: lz_parse by a wave per segment (lz_parse_spec_kernel) and the blocks coded by a wave each
   // (deflate_plan_kernel); many streams fill the chip with a wave each.  ZIPC_HIP_PARSE_SEGMENTS=0 never, =1
   // whenever a stream has more than one segment (tests).
-  static const long segs_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEGMENTS"); return e ? atol(e) : -1L; }();
-  static const long segp_env = [] { const char *e = getenv("ZIPC_HIP_PARSE_SEG"); return e ? atol(e) : 0L; }();  // positions per segment (tuning)
+  const long segs_env = tuning().parse_segments;
+  const long segp_env = tuning().parse_seg;  // positions per segment (tuning)
   // segment size: the stitch's serial time per stream is segments x ~0.25 us, the parallel part's a segment's tiles x ~0.3 us
   // (one stream alone, 4-bit symbols, whole deflate, ms at 4096 / 8192 / 16384 / 32768 / 65536 positions: 1 MiB 0.91 / 1.04 /
   // 1.09 / 1.38 / 1.94, 16 MiB 2.18 / 1.89 / 1.87 / 2.10 / 2.57 -- since lz_parse_meet_kernel the stitch's turn per
@@ -2602,15 +2596,14 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // lz_chain: by ordered exchange where the context's probe passed (ZIPC_HIP_CHAIN=peel keeps the peel kernel: tests, A/B).
   // A wave per stream leaves most of the chip idle while there are fewer streams than CUs: a long stream is then cut into
   // segments of xseg positions, each warmed up with the 32 Ki positions before it (at most a third more work at 96 Ki).
-  static const int chain_env = [] { const char *e = getenv("ZIPC_HIP_CHAIN"); return e && !strcmp(e, "peel") ? 1 : 0; }();
-  const bool xchg_chain = ctx->xchg_ordered && chain_env == 0;
+  const bool xchg_chain = ctx->xchg_ordered && !tuning().chain_peel;
   size_t xseg = 0, xsegs = 1;
   if (xchg_chain && n < 1024 && max_src_len > ((size_t)192 << 10)) {
     xseg = (size_t)96 << 10;
     while (n * ((max_src_len + 2 * xseg - 1) / (2 * xseg)) >= 2048) xseg *= 2;  // twice the chip's CUs of waves is plenty
     xsegs = (max_src_len + xseg - 1) / xseg;
   }
-  static const long tile_env = [] { const char *e = getenv("ZIPC_HIP_TILE"); return e ? atol(e) : 0L; }();  // 1: lz_tile_kernel in place of lz_match + lz_parse (exact; slower on every shape measured: lz_tile.hip)
+  const bool tile_env = tuning().tile;  // lz_tile_kernel in place of lz_match + lz_parse (exact; slower on every shape measured: lz_tile.hip)
   hipError_t slice_err = hipSuccess;
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;
@@ -2630,7 +2623,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
     // Many streams of more than a few KiB: search and parse in one kernel, a workgroup per stream (lz_tile.hip); the two
     // kernels behind it then only take the streams it left to them (S.punt)
-    const bool tiled = tile_env != 0 && !segmented && max_src_len > MATCHW_SMALL && K >= 4;
+    const bool tiled = tile_env && !segmented && max_src_len > MATCHW_SMALL && K >= 4;
     if (tiled) {
       const hipError_t te = launch_lz_tile(ctx, d_src, dd, Q, m, K, good_match);
       if (te != hipSuccess) { slice_err = te; return; }

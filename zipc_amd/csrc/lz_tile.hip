@@ -29,6 +29,7 @@
 #include <type_traits>
 
 #include "deflate_pipeline.h"
+#include "tuning.h"
 
 namespace zd {
 
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(TL_THREADS) void lz_tile_kernel(const uint8_t *__re
 
 hipError_t launch_lz_tile(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *d_descs, DeflateScratch S, size_t n,
                           int K, int good_match) {
-  static const int force_punt = [] { const char *e = getenv("ZIPC_HIP_TILE_PUNT"); return e ? atoi(e) : 0; }();  // tests: every stream is left to the old kernels
+  const int force_punt = tuning().tile_punt ? 1 : 0;  // tests: every stream is left to the kernels behind this one
   ZD_LAUNCH(ctx, "lz_tile", lz_tile_kernel, dim3((unsigned)n), dim3(TL_THREADS), 0, d_src, d_descs, S, K, K / 4, good_match,
             force_punt);
   return hipGetLastError();

@@ -1,0 +1,46 @@
+// tuning.h -- every switch the library reads from the environment, in ONE place.
+//
+// None of them changes a result: each either picks between two exact implementations of the same step (so that the
+// suite can compare BOTH with the oracle: tests/test_gpu_fuzz.py runs the randomized parity loop once per setting, in
+// a process of its own) or sizes something for an experiment (tools/).  They are read once per process, the first time
+// zd::tuning() is called; the defaults are what measured faster (DESIGN.md section 6 has the numbers).
+// Switches whose experiment lost and that nothing uses any more are gone: ZIPC_HIP_CHECKSUM_QUEUES (the two checksum
+// passes of a large buffer on one queue), ZIPC_HIP_INFLATE_EXPLORE, ZIPC_HIP_INFLATE_BLOCKS_TRACE, ZIPC_HIP_HOST_TIMING.
+#pragma once
+
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zd {
+
+struct Tuning {
+  // ---- deflate: which exact form of a step runs
+  bool chain_peel;             // ZIPC_HIP_CHAIN=peel     hash chains by the kernel that orders equal hashes itself (lz_chain_kernel)
+                               //                          instead of ordered LDS exchange (lz_chain_xchg_kernel, the default where the
+                               //                          context's probe passes)
+  bool tile;                   // ZIPC_HIP_TILE=1          search + parse in one workgroup (lz_tile.hip) instead of lz_match + lz_parse
+                               //                          (exact; slower on every shape measured, hence off)
+  bool tile_punt;              // ZIPC_HIP_TILE_PUNT=1     ... and every stream left to the two kernels behind it (tests the hand-over)
+  long parse_segments;         // ZIPC_HIP_PARSE_SEGMENTS  -1 (default): parse and blocks by many waves for few long streams; 0 never;
+                               //                          1 whenever a stream has two segments
+  long parse_seg;              // ZIPC_HIP_PARSE_SEG       positions per parse segment (default 0: by stream length, 4096-16384)
+  long match_tiles_per_group;  // ZIPC_HIP_MATCH_TILES_PER_GROUP  consecutive tiles per lz_match workgroup (default 0: by the grid)
+  int match_form;              // ZIPC_HIP_MATCH_FORM      0 (default): lz_match's walk chosen per tile; 1 / 2: always the first / second form
+  size_t deflate_group_bytes;  // ZIPC_HIP_DEFLATE_GROUP_BYTES  source bytes per pass through the scratch (default 8 GiB; tests: a few streams)
+  long slices, slice_min;      // ZIPC_HIP_SLICES, ZIPC_HIP_SLICE_MIN  a batch cut into slices on side queues (default 1: measured, lost
+                               //                          by -4 .. +3 %; kept because the tests run the queues' hand-over)
+  // ---- inflate of one long stream by blocks (api.hip inflate_by_blocks)
+  bool inflate_blocks;         // ZIPC_HIP_INFLATE_BLOCKS=0  the stream's one wave instead
+  int inflate_follow;          // ZIPC_HIP_INFLATE_FOLLOW  -1 (default): sources followed inside the token run from 32 MiB on; 0 / 1 never / always
+  uint64_t explore_stride;     // ZIPC_HIP_EXPLORE_STRIDE  input bytes between two explorers (default 8192)
+  int resolve_hops0, resolve_hops1;  // ZIPC_HIP_RESOLVE_HOPS0 / 1  links a thread follows in the first / a later resolve round (default 256)
+  // ---- checksums
+  bool checksum_fused;         // ZIPC_HIP_CHECKSUM_FUSED=0  both checksums of one buffer by two passes instead of one
+  // ---- host forms
+  long host_threads, host_chunks;  // ZIPC_HIP_HOST_THREADS / ZIPC_HIP_HOST_CHUNKS  staging threads and chunks of the many-stream host forms
+                               //                          (default 0: by the call's size)
+};
+
+const Tuning &tuning();  // api.hip
+
+}  // namespace zd
