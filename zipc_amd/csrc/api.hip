@@ -232,8 +232,11 @@ const Tuning &tuning() {
   return t;
 }
 size_t batch_slices(size_t n_streams) {
+  // Two slices by default (each of at least 2048 streams): since lz_chain is four waves per CU (round 4) the second
+  // slice's chain links are made beside the first one's parse and blocks -- C2 deflate 13.25 -> 12.67 ms, the step
+  // 16.97 -> 16.34; text the same either way; 3 / 4 / 6 slices lose 7 / 3 / 8 % (one box, tools/exp_wall.py).
   const long env = tuning().slices, env_min = tuning().slice_min;
-  size_t k = env > 0 ? (size_t)env : 1;
+  size_t k = env > 0 ? (size_t)env : 2;
   if (k > 8) k = 8;
   const size_t least = env_min > 0 ? (size_t)env_min : 2048;
   while (k > 1 && n_streams / k < least) k--;

@@ -2672,12 +2672,22 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
       ZD_LAUNCH(ctx, "deflate_emit", deflate_emit_kernel, dim3((unsigned)m), dim3(64), 0, d_src, d_dst, dd,
                 d_results + lo, Q, crc_op);
     }
+    // The CRC-32 pass over the slice's source (deflated_block_src_crc, zd.ml:1081-1086: exact across blocks for
+    // CRC-32) on the slice's own queue: its second half writes the checksums into the results the block coder wrote,
+    // and the pass -- a plain read of the source at memory speed -- runs beside the other slice's kernels, which wait
+    // for instruction issue and LDS, not for memory.
+    if (crc_op == CRC_CRC32 && slice_err == hipSuccess) {
+      uint32_t *partials = (uint32_t *)ctx->crc_partials.p + lo * crc32_segs(max_src_len);
+      hipError_t ce = crc32_segments_launch(ctx, d_src, RANGE_DEFLATE_SRC, dd, nullptr, m, 0, 0, max_src_len, partials);
+      if (ce == hipSuccess)
+        ce = crc32_finish_launch(ctx, RANGE_DEFLATE_SRC, dd, d_results + lo, m, 0, max_src_len, partials, nullptr);
+      if (ce != hipSuccess) slice_err = ce;
+    }
   };
   // ZIPC_HIP_SLICES > 1: the group goes out in slices on queues of their own (ctx.h).  Measured on the
   // three shapes of tools/exp_wall.py and NOT the default: the kernels are each near their issue bound and
-  // share the chip by workgroup, so slices change the time by -4 .. +3 % (2 slices) or lose (more).  The
-  // CRC-32 pass over the source (deflated_block_src_crc, zd.ml:1081-1086: exact across blocks for CRC-32)
-  // follows the pipeline: its second half writes the checksums into the results deflate_emit wrote.
+  // share the chip by workgroup, so slices changed the time by -4 .. +3 % (2 slices) or lost (more) -- until lz_chain
+  // became four waves per CU (round 4): two slices are the default now, api.hip batch_slices has the numbers.
   const size_t k = batch_slices(n);
   hipError_t e = hipSuccess;
   if (k > 1) {
@@ -2693,12 +2703,6 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   }
   if (e == hipSuccess) e = slice_err;
   if (e == hipSuccess) e = hipGetLastError();
-  if (e == hipSuccess && crc_op == CRC_CRC32) {
-    uint32_t *partials = (uint32_t *)ctx->crc_partials.p;
-    e = crc32_segments_launch(ctx, d_src, RANGE_DEFLATE_SRC, d_descs, nullptr, n, 0, 0, max_src_len, partials);
-    if (e == hipSuccess)
-      e = crc32_finish_launch(ctx, RANGE_DEFLATE_SRC, d_descs, d_results, n, 0, max_src_len, partials, nullptr);
-  }
   return e;
 }
 

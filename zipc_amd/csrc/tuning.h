@@ -27,8 +27,8 @@ struct Tuning {
   long match_tiles_per_group;  // ZIPC_HIP_MATCH_TILES_PER_GROUP  consecutive tiles per lz_match workgroup (default 0: by the grid)
   int match_form;              // ZIPC_HIP_MATCH_FORM      0 (default): lz_match's walk chosen per tile; 1 / 2: always the first / second form
   size_t deflate_group_bytes;  // ZIPC_HIP_DEFLATE_GROUP_BYTES  source bytes per pass through the scratch (default 8 GiB; tests: a few streams)
-  long slices, slice_min;      // ZIPC_HIP_SLICES, ZIPC_HIP_SLICE_MIN  a batch cut into slices on side queues (default 1: measured, lost
-                               //                          by -4 .. +3 %; kept because the tests run the queues' hand-over)
+  long slices, slice_min;      // ZIPC_HIP_SLICES, ZIPC_HIP_SLICE_MIN  a batch cut into slices on side queues (default 0: two slices of at
+                               //                          least 2048 streams each, api.hip batch_slices; tests force more and smaller ones)
   // ---- inflate of one long stream by blocks (api.hip inflate_by_blocks)
   bool inflate_blocks;         // ZIPC_HIP_INFLATE_BLOCKS=0  the stream's one wave instead
   int inflate_follow;          // ZIPC_HIP_INFLATE_FOLLOW  -1 (default): sources followed inside the token run from 32 MiB on; 0 / 1 never / always
