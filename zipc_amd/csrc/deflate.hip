@@ -828,16 +828,23 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
     j += take;
     chaining = take;
   };
-  // chains within the staged tiles (all but pathological ones): entries by shuffle
+  // chains within the staged tiles (all but pathological ones).  Every chaining lane looks at the same distance ahead,
+  // lane + ahead (< 128), so the two tiles' best-of-K words are SHIFTED down a lane per turn (v_mov_b32_dpp wave_shl:1:
+  // lane i takes lane i + 1's, lane 63 the next tile's lane 0 -- tools/probes/dpp_wave_shl.hip) where round 3 fetched
+  // them by two ds_bpermute a turn: no LDS operation and no address -- and no measurable difference (C2 lz_parse 2.90-2.93
+  // against 2.86-2.97 ms beside the other slice's kernels): the shuffles' round trips are not what a tile waits for.
+  uint32_t sh_cur = cur_lo, sh_nxt = nxt_lo;  // after k turns: the words of positions p + k (this tile's lanes), p + 64 + k
   for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining != 0); ahead++) {
-    // every chaining lane looks at the same distance ahead: lane + ahead (< 128)
     const uint32_t off = (uint32_t)lane + ahead;
     const uint32_t addr = (off & 63u) * 4u;
     const bool in_cur = off < 64u;
     // best-of-K of position j; best-of-K/4 only if a pending match is that long
-    // (all lanes take part in every shuffle: a lane is also somebody's source)
-    const uint32_t a_lo = lane_value(addr, cur_lo), b_lo = lane_value(addr, nxt_lo);
-    const uint32_t mj_lo = in_cur ? a_lo : b_lo;
+    {
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)sh_nxt, 0);
+      sh_cur = (uint32_t)__builtin_amdgcn_update_dpp((int)n0, (int)sh_cur, 0x130, 0xf, 0xf, false);
+      sh_nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh_nxt, 0x130, 0xf, 0xf, false);
+    }
+    const uint32_t mj_lo = sh_cur;
     uint32_t mj_hi = 0;
     const uint32_t want_hi = (chaining != 0 && (pend & 0x1FF) >= (uint32_t)good_match) ? 1u : 0u;
     if (__builtin_amdgcn_ballot_w64(want_hi != 0)) {
