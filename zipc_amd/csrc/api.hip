@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <deque>
 #include <thread>
 #include <vector>
 #include "ctx.h"
@@ -363,6 +364,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->inflate_scratch);
   free_buf(ctx->blocks_scratch);
   free_buf(ctx->tok_scratch);
+  free_buf(ctx->descs_marked);
   free_buf(ctx->stored_list);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
@@ -546,158 +548,277 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
   return ZIPC_HIP_OK;
 }
 
-// One stream of at least BLOCKS_MIN_SRC bytes by a wave per block (inflate.hip: find, dry, explore, chain, token, resolve;
-// CRC-32 by the usual pass over the output, Adler-32 block by block as the reference updates it).
-// *handled: the stream went that way (result and, if asked for, CRC-32 are in d_results); else it is left to
-// inflate_batch_kernel -- a stream that is not a chain of dynamic blocks behind its first block, anything the dry
-// run or the chain did not like: the one-wave kernel owns the reference's messages.  Reads a
-// few words back between its steps: it SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0 turns it off.
+// Streams of at least BLOCKS_MIN_SRC bytes by a wave per block (inflate.hip: find, dry, explore, chain, token, resolve;
+// Adler-32 block by block as the reference updates it; CRC-32 is the caller's pass over the output).  The streams of
+// a call go through every step side by side -- the kernels' grids have them as their second dimension -- and the
+// host reads the counts of all of them back at once between the steps (three or four times a group, not per stream).
+// handled[i]: stream i went that way (its result is in d_results); else it is left to inflate_batch_kernel -- a stream
+// that is not a chain of dynamic blocks behind its first block, anything the dry run or the chain did not like: the
+// one-wave kernel owns the reference's messages.  It SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0
+// turns it off.
 constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
 constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
-static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
-                             zipc_hip_stream_result *d_results, int crc_op, bool *handled) {
-  *handled = false;
-  ctx->last_inflate_blocks = 0;
+constexpr size_t BLOCKS_BATCH_MIN_DST = 1u << 20, BLOCKS_MAX_STREAMS = 4096;
+// tok[] and the two lists: 12 bytes of scratch per output byte.  Streams share a group while their capacities fit
+// this much of it (a stream that needs more has a group to itself, and its scratch goes back afterwards)
+constexpr size_t BLOCKS_TOK_BUDGET = (size_t)1 << 30;
+
+static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *dst, const StreamDesc *dd, StreamResult *d_results,
+                                const StreamDesc *sds, const uint32_t *streams, size_t nj, int crc_op, uint8_t *handled) {
   const uint64_t EXPLORE_STRIDE = zd::tuning().explore_stride;  // bytes of input between two explorers
-  if (!zd::tuning().inflate_blocks) return ZIPC_HIP_OK;
   const bool adler = crc_op == ZIPC_HIP_CRC_ADLER32 || crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950;
-  StreamDesc sd;
-  HIP_TRY(ctx, hipMemcpyAsync(&sd, d_descs, sizeof sd, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (sd.src_len < BLOCKS_MIN_SRC || sd.src_len > BLOCKS_MAX_SRC || sd.dst_cap < 8 || sd.dst_cap > MAX_STREAM_LEN) return ZIPC_HIP_OK;
-  // Runs (zeros, short periods: output beyond 64 x the input) are not for this path: a word of tok[] per byte of a
-  // run costs more than the run (16 MiB of zeros as zlib codes them, 4 blocks: token run 10-11 ms, the one wave
-  // 3.4-6.9), and where the reference's encoder has coded them with the fixed code, the explorers' walks never fall
-  // into step with a bit stream that has a period (64 MiB: the chain walks nearly every block itself, 65 ms).
-  if (sd.dst_cap / 64 > sd.src_len) return ZIPC_HIP_OK;
-  const uint32_t first_cap = (uint32_t)(sd.src_len / 8 + 4096);
-  uint32_t cand_cap = (uint32_t)(sd.src_len / 512 + 64);
-  if (cand_cap > BLOCKS_CAND_CAP) cand_cap = BLOCKS_CAND_CAP;
-  // explorers (blocks without a findable header): one every EXPLORE_STRIDE bytes at most, 4 blocks listed each on average
-  const uint32_t max_explorers = (uint32_t)(sd.src_len / EXPLORE_STRIDE + 1);
-  uint64_t rec_cap64 = (uint64_t)cand_cap + 4ull * max_explorers;
-  if (rec_cap64 > BLOCKS_REC_CAP) rec_cap64 = BLOCKS_REC_CAP;
-  const uint32_t rec_cap = (uint32_t)rec_cap64, chain_cap = rec_cap;
-  // scratch: counts | first | cand | recs | sorted | sorted_src | chain | chain_end | chain_iv | cks (listed blocks, then blocks the chain walked)
+  std::vector<BlocksJob> jobs(nj);
+  std::vector<uint32_t> max_explorers(nj);
+  // scratch: counts of every stream | the launches' job lists | per stream: first | cand | recs | sorted | sorted_src |
+  // chain | chain_end | chain_iv | cks (listed blocks, then blocks the chain walked)
   size_t off = 0;
   auto carve = [&off](size_t bytes) { const size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-  const size_t o_counts = carve(sizeof(FindCounts)), o_first = carve((size_t)first_cap * 4), o_cand = carve((size_t)cand_cap * 4),
-               o_recs = carve((size_t)rec_cap * sizeof(BlockRec)), o_sorted = carve((size_t)rec_cap * sizeof(BlockRec)),
-               o_sorted_src = carve((size_t)rec_cap * 4),
-               o_chain = carve((size_t)chain_cap * sizeof(BlockStart)), o_chain_end = carve((size_t)chain_cap * sizeof(BlockEnd)),
-               o_chain_iv = carve((size_t)chain_cap * sizeof(ChainIv)), o_cks = carve(((size_t)rec_cap + chain_cap) * sizeof(BlockCk));
-  HIP_TRY(ctx, ctx->ensure(ctx->blocks_scratch, off));
-  uint8_t *base = (uint8_t *)ctx->blocks_scratch.p;
-  FindCounts *d_counts = (FindCounts *)(base + o_counts);
-  uint32_t *d_first = (uint32_t *)(base + o_first), *d_cand = (uint32_t *)(base + o_cand);
-  BlockRec *d_recs = (BlockRec *)(base + o_recs), *d_sorted = (BlockRec *)(base + o_sorted);
-  BlockStart *d_chain = (BlockStart *)(base + o_chain);
-  BlockEnd *d_chain_end = (BlockEnd *)(base + o_chain_end);
-  uint32_t *d_sorted_src = (uint32_t *)(base + o_sorted_src);
-  ChainIv *d_chain_iv = (ChainIv *)(base + o_chain_iv);
-  BlockCk *d_cks = (BlockCk *)(base + o_cks);
-  const uint8_t *src = (const uint8_t *)d_src_arena;
-  uint8_t *dst = (uint8_t *)d_dst_arena;
-  const StreamDesc *dd = (const StreamDesc *)d_descs;
-  // (the span decoder's index, a slot per wave: grown before the launch that needs it)
-  auto span_scratch = [ctx](size_t waves) { return ctx->ensure(ctx->inflate_scratch, waves * INFLATE_SCRATCH_PER_STREAM); };
-
-  HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, sizeof(FindCounts), ctx->stream));
-  ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel, dim3((unsigned)((sd.src_len + 1023) / 1024)), dim3(256), 0, src, dd,
-            d_first, first_cap, d_counts);
-  ZD_LAUNCH(ctx, "inflate_find_lengths", inflate_find_lengths_kernel, dim3((first_cap + 63u) / 64u), dim3(64), 0, src, dd,
-            (const uint32_t *)d_first, first_cap, d_cand, cand_cap, d_counts);
-  FindCounts fc;
-  // (how many candidates there are: the host asks when the list is long -- a wave each is launched -- and lets the
-  // kernels read it themselves when it is short: a round trip less for streams of a few MiB)
-  uint32_t n = cand_cap;
-  if (cand_cap > 8192u) {
-    HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
-    n = fc.n_cand;
+  const size_t o_counts = carve(nj * sizeof(FindCounts)), o_jobs = carve(nj * sizeof(BlocksJob));
+  struct Lists { size_t first, cand, recs, sorted, sorted_src, chain, chain_end, chain_iv, cks; };
+  std::vector<Lists> at(nj);
+  for (size_t j = 0; j < nj; j++) {
+    const StreamDesc &sd = sds[streams[j]];
+    BlocksJob &J = jobs[j];
+    memset(&J, 0, sizeof J);
+    J.stream = streams[j];
+    J.first_cap = (uint32_t)(sd.src_len / 8 + 4096);
+    J.cand_cap = (uint32_t)(sd.src_len / 512 + 64);
+    if (J.cand_cap > BLOCKS_CAND_CAP) J.cand_cap = BLOCKS_CAND_CAP;
+    // explorers (blocks without a findable header): one every EXPLORE_STRIDE bytes at most, 4 blocks listed each on average
+    max_explorers[j] = (uint32_t)(sd.src_len / EXPLORE_STRIDE + 1);
+    uint64_t rec_cap64 = (uint64_t)J.cand_cap + 4ull * max_explorers[j];
+    if (rec_cap64 > BLOCKS_REC_CAP) rec_cap64 = BLOCKS_REC_CAP;
+    J.rec_cap = J.chain_cap = (uint32_t)rec_cap64;
+    Lists &L = at[j];
+    L.first = carve((size_t)J.first_cap * 4); L.cand = carve((size_t)J.cand_cap * 4);
+    L.recs = carve((size_t)J.rec_cap * sizeof(BlockRec)); L.sorted = carve((size_t)J.rec_cap * sizeof(BlockRec));
+    L.sorted_src = carve((size_t)J.rec_cap * 4);
+    L.chain = carve((size_t)J.chain_cap * sizeof(BlockStart)); L.chain_end = carve((size_t)J.chain_cap * sizeof(BlockEnd));
+    L.chain_iv = carve((size_t)J.chain_cap * sizeof(ChainIv)); L.cks = carve(((size_t)J.rec_cap + J.chain_cap) * sizeof(BlockCk));
   }
-  HIP_TRY(ctx, span_scratch(n));
-  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(n), dim3(64), 0, src, dst, dd, (const uint32_t *)d_cand, d_recs, d_cks,
-            cand_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
-  ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((n + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
-            (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
-  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
-            d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 0);
-  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  if (fc.n_cand == 0 || fc.n_cand > cand_cap) return ZIPC_HIP_OK;
-  if (!fc.chain_ok && fc.miss_bit != ~0ull) {
-    // the chain came to a block nobody listed: explorers from there on, then the chain again (which now walks what
-    // is still missing itself)
-    const uint64_t bits_left = sd.src_len * 8u - fc.miss_bit;
-    uint64_t ne = (bits_left + EXPLORE_STRIDE * 8u - 1) / (EXPLORE_STRIDE * 8u);
-    if (ne > max_explorers) ne = max_explorers;
-    HIP_TRY(ctx, span_scratch(ne));
-    ZD_LAUNCH(ctx, "inflate_explore", inflate_explore_kernel, dim3((unsigned)ne), dim3(64), 0, src, dst, dd, (const FindCounts *)d_counts,
-              (uint32_t)(EXPLORE_STRIDE * 8u), (uint32_t)ne, d_recs, d_cks, rec_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts);
-    ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((rec_cap + 255u) / 256u), dim3(256), 0, (const BlockRec *)d_recs,
-              (const FindCounts *)d_counts, rec_cap, d_sorted, d_sorted_src);
-    ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1), dim3(64), 0, src, dst, dd, (const BlockRec *)d_sorted, (const uint32_t *)d_sorted_src, rec_cap, d_chain,
-              d_chain_end, d_chain_iv, d_cks, chain_cap, (uint16_t *)ctx->inflate_scratch.p, d_counts, 1);
-    HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  if (!fc.chain_ok || fc.n_blocks < 2) return ZIPC_HIP_OK;  // (one block: nothing to gain)
-  const uint32_t out_len = (uint32_t)fc.out_len, nb = fc.n_blocks;
-  if (out_len == 0) return ZIPC_HIP_OK;
-  if (ctx->ensure(ctx->tok_scratch, (size_t)out_len * 12) != hipSuccess) {  // tok[], and two lists of bytes still to resolve
-    (void)hipGetLastError();  // (no room for a word per byte and the lists: the stream's one wave needs none)
+  if (ctx->ensure(ctx->blocks_scratch, off) != hipSuccess) {
+    (void)hipGetLastError();  // (no room for the lists: the streams' one waves need none)
     return ZIPC_HIP_OK;
   }
+  uint8_t *base = (uint8_t *)ctx->blocks_scratch.p;
+  FindCounts *d_counts = (FindCounts *)(base + o_counts);
+  BlocksJob *d_jobs = (BlocksJob *)(base + o_jobs);
+  for (size_t j = 0; j < nj; j++) {
+    BlocksJob &J = jobs[j];
+    const Lists &L = at[j];
+    J.counts = d_counts + j;
+    J.first = (uint32_t *)(base + L.first); J.cand = (uint32_t *)(base + L.cand);
+    J.recs = (BlockRec *)(base + L.recs); J.sorted = (BlockRec *)(base + L.sorted);
+    J.sorted_src = (uint32_t *)(base + L.sorted_src);
+    J.chain = (BlockStart *)(base + L.chain); J.chain_end = (BlockEnd *)(base + L.chain_end);
+    J.chain_iv = (ChainIv *)(base + L.chain_iv); J.cks = (BlockCk *)(base + L.cks);
+  }
+  std::vector<FindCounts> fc(nj);
+  auto read_counts = [&]() -> hipError_t {
+    const hipError_t e = hipMemcpyAsync(fc.data(), d_counts, nj * sizeof(FindCounts), hipMemcpyDeviceToHost, ctx->stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(ctx->stream);
+  };
+  // a launch's streams: the jobs still on their way, as the kernels index them by blockIdx.y (the lists handed to
+  // the copies stay until the group is through)
+  std::deque<std::vector<BlocksJob>> handed;
+  auto hand = [&](const std::vector<uint32_t> &which) -> hipError_t {
+    handed.emplace_back();
+    std::vector<BlocksJob> &v = handed.back();
+    for (uint32_t j : which) v.push_back(jobs[j]);
+    return hipMemcpyAsync(d_jobs, v.data(), v.size() * sizeof(BlocksJob), hipMemcpyHostToDevice, ctx->stream);
+  };
+  // the span decoder's index, a slot per wave of a launch: every stream's waves behind those of the one before
+  auto span_slots = [&](const std::vector<uint32_t> &which) -> hipError_t {
+    size_t waves = 0;
+    for (uint32_t j : which) waves += jobs[j].n;
+    const hipError_t e = ctx->ensure(ctx->inflate_scratch, waves * INFLATE_SCRATCH_PER_STREAM);
+    if (e != hipSuccess) return e;
+    waves = 0;
+    for (uint32_t j : which) {
+      jobs[j].span = (uint16_t *)ctx->inflate_scratch.p + waves * (INFLATE_SCRATCH_PER_STREAM / 2);
+      waves += jobs[j].n;
+    }
+    return hipSuccess;
+  };
+  auto widest = [&](const std::vector<uint32_t> &which, auto need) {
+    unsigned w = 1;
+    for (uint32_t j : which) { const unsigned x = (unsigned)need(jobs[j], j); if (x > w) w = x; }
+    return w;
+  };
+  std::vector<uint32_t> alive(nj), keep;
+  for (size_t j = 0; j < nj; j++) alive[j] = (uint32_t)j;
+  const unsigned ny = (unsigned)nj;
 
-  uint32_t *d_tok = (uint32_t *)ctx->tok_scratch.p;
-  const unsigned out_grid = (out_len + 255u) / 256u;
+  HIP_TRY(ctx, hipMemsetAsync(d_counts, 0, nj * sizeof(FindCounts), ctx->stream));
+  HIP_TRY(ctx, hand(alive));
+  ZD_LAUNCH(ctx, "inflate_find_headers", inflate_find_headers_kernel,
+            dim3(widest(alive, [&](const BlocksJob &J, uint32_t) { return (sds[J.stream].src_len + 1023) / 1024; }), ny), dim3(256), 0, src, dd,
+            (const BlocksJob *)d_jobs);
+  ZD_LAUNCH(ctx, "inflate_find_lengths", inflate_find_lengths_kernel,
+            dim3(widest(alive, [](const BlocksJob &J, uint32_t) { return (J.first_cap + 63u) / 64u; }), ny), dim3(64), 0, src, dd,
+            (const BlocksJob *)d_jobs);
+  // (how many candidates there are: the host asks when the lists are long or many -- a wave each is launched -- and lets
+  // the kernels read it themselves for one stream of a few MiB: a round trip less)
+  if (nj > 1 || jobs[0].cand_cap > 8192u) {
+    HIP_TRY(ctx, read_counts());
+    keep.clear();
+    for (uint32_t j : alive)
+      if (fc[j].n_cand != 0 && fc[j].n_cand <= jobs[j].cand_cap) { jobs[j].n = fc[j].n_cand; keep.push_back(j); }
+    alive.swap(keep);
+    if (alive.empty()) return ZIPC_HIP_OK;
+  } else {
+    jobs[0].n = jobs[0].cand_cap;
+  }
+  HIP_TRY(ctx, span_slots(alive));
+  HIP_TRY(ctx, hand(alive));
+  unsigned na = (unsigned)alive.size();
+  const unsigned dry_waves = widest(alive, [](const BlocksJob &J, uint32_t) { return J.n; });
+  ZD_LAUNCH(ctx, "inflate_blocks_dry", inflate_blocks_dry_kernel, dim3(dry_waves, na), dim3(64), 0, src, dst, dd, (const BlocksJob *)d_jobs);
+  ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel, dim3((dry_waves + 255u) / 256u, na), dim3(256), 0, (const BlocksJob *)d_jobs);
+  ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1, na), dim3(64), 0, src, dst, dd, (const BlocksJob *)d_jobs, 0);
+  HIP_TRY(ctx, read_counts());
+  keep.clear();
+  std::vector<uint32_t> lost;  // streams whose chain came to a block nobody listed
+  for (uint32_t j : alive) {
+    if (fc[j].n_cand == 0 || fc[j].n_cand > jobs[j].cand_cap) continue;
+    if (!fc[j].chain_ok && fc[j].miss_bit != ~0ull) lost.push_back(j);
+    keep.push_back(j);
+  }
+  alive.swap(keep);
+  if (!lost.empty()) {
+    // explorers from there on, then the chain again (which now walks what is still missing itself)
+    for (uint32_t j : lost) {
+      const uint64_t bits_left = sds[jobs[j].stream].src_len * 8u - fc[j].miss_bit;
+      uint64_t ne = (bits_left + EXPLORE_STRIDE * 8u - 1) / (EXPLORE_STRIDE * 8u);
+      if (ne > max_explorers[j]) ne = max_explorers[j];
+      jobs[j].n = (uint32_t)ne;
+    }
+    HIP_TRY(ctx, span_slots(lost));
+    HIP_TRY(ctx, hand(lost));
+    const unsigned nl = (unsigned)lost.size();
+    ZD_LAUNCH(ctx, "inflate_explore", inflate_explore_kernel, dim3(widest(lost, [](const BlocksJob &J, uint32_t) { return J.n; }), nl), dim3(64), 0,
+              src, dst, dd, (const BlocksJob *)d_jobs, (uint32_t)(EXPLORE_STRIDE * 8u));
+    ZD_LAUNCH(ctx, "inflate_sort_blocks", inflate_sort_blocks_kernel,
+              dim3(widest(lost, [](const BlocksJob &J, uint32_t) { return (J.rec_cap + 255u) / 256u; }), nl), dim3(256), 0, (const BlocksJob *)d_jobs);
+    ZD_LAUNCH(ctx, "inflate_chain", inflate_chain_kernel, dim3(1, nl), dim3(64), 0, src, dst, dd, (const BlocksJob *)d_jobs, 1);
+    HIP_TRY(ctx, read_counts());
+  }
   // (sources written down as what they are copies of -- inflate_span.h -- cost the token run 0.2-0.4 ms a block and a
   // wave per block instead of one per interval, and save the resolve rounds of a long stream more: with 256 hops a
   // round, 64 MiB of text 6.3-10.8 -> 5.7-6.5 ms, 16 MiB 2.7-4.4 <- 3.3-4.2)
   const int follow_env = zd::tuning().inflate_follow;
-  // (... and nothing on data with few matches: 16 MiB of records that deflate to 0.85, resolve 0.13 ms either way)
-  const int follow = follow_env >= 0 ? follow_env : out_len >= (32u << 20) && (uint64_t)out_len * 2u >= sd.src_len * 3u;
-  // the token run: a wave per interval of a block (its checkpoints), or -- follow -- a wave per block
-  const uint32_t n_iv = follow ? nb : fc.n_intervals;
-  HIP_TRY(ctx, span_scratch(n_iv));
-  ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid), dim3(256), 0, d_tok, out_len);
-  ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(n_iv), dim3(64), 0, src, dst, dd, (const BlockStart *)d_chain,
-            (const BlockEnd *)d_chain_end, (const ChainIv *)d_chain_iv, (const BlockCk *)d_cks, nb, n_iv, (uint16_t *)ctx->inflate_scratch.p,
-            d_tok, d_counts, follow);
+  keep.clear();
+  size_t tok_words = 0;
+  for (uint32_t j : alive) {
+    if (!fc[j].chain_ok || fc[j].n_blocks < 2 || fc[j].out_len == 0) continue;  // (one block: nothing to gain)
+    BlocksJob &J = jobs[j];
+    J.out_len = (uint32_t)fc[j].out_len;
+    J.n_blocks = fc[j].n_blocks;
+    // (... and nothing on data with few matches: 16 MiB of records that deflate to 0.85, resolve 0.13 ms either way)
+    J.follow = follow_env >= 0 ? follow_env : J.out_len >= (32u << 20) && (uint64_t)J.out_len * 2u >= sds[J.stream].src_len * 3u;
+    // the token run: a wave per interval of a block (its checkpoints), or -- follow -- a wave per block
+    J.n = J.follow ? J.n_blocks : fc[j].n_intervals;
+    tok_words += ((size_t)J.out_len * 3 + 63) & ~(size_t)63;
+    keep.push_back(j);
+  }
+  alive.swap(keep);
+  if (alive.empty()) return ZIPC_HIP_OK;
+  if (ctx->ensure(ctx->tok_scratch, tok_words * 4) != hipSuccess) {  // tok[], and two lists of bytes still to resolve
+    (void)hipGetLastError();  // (no room for a word per byte and the lists: the streams' one waves need none)
+    return ZIPC_HIP_OK;
+  }
+  tok_words = 0;
+  for (uint32_t j : alive) {
+    jobs[j].tok = (uint32_t *)ctx->tok_scratch.p + tok_words;
+    tok_words += ((size_t)jobs[j].out_len * 3 + 63) & ~(size_t)63;
+  }
+  HIP_TRY(ctx, span_slots(alive));
+  HIP_TRY(ctx, hand(alive));
+  na = (unsigned)alive.size();
+  const unsigned out_grid = widest(alive, [](const BlocksJob &J, uint32_t) { return (J.out_len + 255u) / 256u; });
+  ZD_LAUNCH(ctx, "inflate_tok_init", inflate_tok_init_kernel, dim3(out_grid, na), dim3(256), 0, (const BlocksJob *)d_jobs);
+  ZD_LAUNCH(ctx, "inflate_blocks_token", inflate_blocks_token_kernel, dim3(widest(alive, [](const BlocksJob &J, uint32_t) { return J.n; }), na),
+            dim3(64), 0, src, dst, dd, (const BlocksJob *)d_jobs);
   // (hops a thread follows in a round: 8 left most bytes of a text for the next round -- 16 MiB: three rounds over nearly
   // everything, 3.4 ms; 64 and more let nearly every byte arrive in the first: 0.28 ms)
   const int hops0 = zd::tuning().resolve_hops0, hops1 = zd::tuning().resolve_hops1;
   const int rounds = hops0 >= 16 && hops1 >= 16 ? 6 : RESOLVE_ROUNDS;  // (16^6 links: more than a stream has bytes)
-  for (int r = 0; r < rounds; r++) {
-    uint32_t *list_in = d_tok + (size_t)out_len * (1 + ((r + 1) & 1)), *list_out = d_tok + (size_t)out_len * (1 + (r & 1));
-    ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u), dim3(256), 0, d_tok,
-              out_len, d_counts, r, (const uint32_t *)list_in, list_out, r == 0 ? hops0 : hops1);
-  }
-  ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid), dim3(256), 0, dst, dd, (const uint32_t *)d_tok, out_len);
-  HIP_TRY(ctx, hipMemcpyAsync(&fc, d_counts, sizeof fc, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < rounds; r++)
+    ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u, na), dim3(256), 0,
+              (const BlocksJob *)d_jobs, r, r == 0 ? hops0 : hops1);
+  ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid, na), dim3(256), 0, dst, dd, (const BlocksJob *)d_jobs);
+  HIP_TRY(ctx, read_counts());
   // (12 bytes of scratch per output byte: what a long stream took goes back -- a context lives as long as its thread,
   // and a 1 GiB member would pin 12 GiB per device; the stream is idle here, the gather has been waited for)
-  if (ctx->tok_scratch.cap > ((size_t)512 << 20)) free_buf(ctx->tok_scratch);
-  if (fc.token_bad != 0 || fc.more[rounds - 1] != 0) return ZIPC_HIP_OK;  // (the one-wave kernel writes the output again)
-  ZD_LAUNCH(ctx, "inflate_blocks_result", inflate_blocks_result_kernel, dim3(1), dim3(1), 0, (StreamResult *)d_results, (uint64_t)out_len);
-  ctx->last_inflate_blocks = nb;
+  if (ctx->tok_scratch.cap > BLOCKS_TOK_BUDGET) free_buf(ctx->tok_scratch);
+  keep.clear();
+  size_t n_chunks = 0;
+  for (uint32_t j : alive) {
+    if (fc[j].token_bad != 0 || fc[j].more[rounds - 1] != 0) continue;  // (the one-wave kernel writes the output again)
+    n_chunks += fc[j].n_chunks;
+    keep.push_back(j);
+  }
+  alive.swap(keep);
+  if (alive.empty()) return ZIPC_HIP_OK;
+  na = (unsigned)alive.size();
   if (adler) {  // block by block, every block's bytes in chunks of their own (inflate.hip)
-    if (fc.n_chunks) {
-      HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (size_t)fc.n_chunks * 12));
-      ZD_LAUNCH(ctx, "inflate_adler_chunks", inflate_adler_chunks_kernel, dim3(fc.n_chunks), dim3(64), 0, (const uint8_t *)dst, dd,
-                (const BlockStart *)d_chain, (const BlockEnd *)d_chain_end, nb, fc.n_chunks, (uint32_t *)ctx->adler_sums.p);
-    }
-    ZD_LAUNCH(ctx, "inflate_adler_fold", inflate_adler_fold_kernel, dim3(1), dim3(64), 0, (const uint32_t *)ctx->adler_sums.p, fc.n_chunks,
-              crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950 ? 1 : 0, (StreamResult *)d_results);
+    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (n_chunks + 1) * 12));
+    n_chunks = 0;
+    for (uint32_t j : alive) { jobs[j].sums = (uint32_t *)ctx->adler_sums.p + n_chunks * 3; n_chunks += fc[j].n_chunks; }
   }
-  if (crc_op == ZIPC_HIP_CRC_CRC32) {
-    const int st = crc32_pass(ctx, dst, RANGE_INFLATE_OUT, dd, (StreamResult *)d_results, 1, 0, 0, (size_t)out_len, nullptr);
-    if (st) return st;
+  HIP_TRY(ctx, hand(alive));
+  ZD_LAUNCH(ctx, "inflate_blocks_result", inflate_blocks_result_kernel, dim3((na + 63u) / 64u), dim3(64), 0, (const BlocksJob *)d_jobs, d_results, na);
+  if (adler) {
+    if (n_chunks)
+      ZD_LAUNCH(ctx, "inflate_adler_chunks", inflate_adler_chunks_kernel, dim3(widest(alive, [&](const BlocksJob &, uint32_t j) { return fc[j].n_chunks; }), na),
+                dim3(64), 0, (const uint8_t *)dst, dd, (const BlocksJob *)d_jobs);
+    ZD_LAUNCH(ctx, "inflate_adler_fold", inflate_adler_fold_kernel, dim3(1, na), dim3(64), 0, (const BlocksJob *)d_jobs,
+              crc_op == ZIPC_HIP_CRC_ADLER32_RFC1950 ? 1 : 0, d_results);
   }
-  *handled = true;
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));  // (the lists handed to the copies go with this frame)
+  for (uint32_t j : alive) { handled[jobs[j].stream] = 1; ctx->last_inflate_blocks += jobs[j].n_blocks; }
+  return ZIPC_HIP_OK;
+}
+
+// which of a call's streams go by blocks, group by group; *n_handled: how many did
+static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                             zipc_hip_stream_result *d_results, size_t n_streams, int crc_op, std::vector<StreamDesc> &sds,
+                             std::vector<uint8_t> &handled, size_t *n_handled) {
+  *n_handled = 0;
+  ctx->last_inflate_blocks = 0;
+  handled.assign(n_streams, 0);
+  if (!zd::tuning().inflate_blocks) return ZIPC_HIP_OK;
+  sds.resize(n_streams);
+  HIP_TRY(ctx, hipMemcpyAsync(sds.data(), d_descs, n_streams * sizeof(StreamDesc), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  std::vector<uint32_t> group;
+  size_t group_cap = 0;
+  auto run = [&]() -> int {
+    if (group.empty()) return ZIPC_HIP_OK;
+    const int st = inflate_blocks_group(ctx, (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, (const StreamDesc *)d_descs,
+                                        (StreamResult *)d_results, sds.data(), group.data(), group.size(), crc_op, handled.data());
+    group.clear();
+    group_cap = 0;
+    return st;
+  };
+  for (size_t i = 0; i < n_streams; i++) {
+    const StreamDesc &sd = sds[i];
+    if (sd.src_len < BLOCKS_MIN_SRC || sd.src_len > BLOCKS_MAX_SRC || sd.dst_cap < 8 || sd.dst_cap > MAX_STREAM_LEN) continue;
+    // Runs (zeros, short periods: output beyond 64 x the input) are not for this path: a word of tok[] per byte of a
+    // run costs more than the run (16 MiB of zeros as zlib codes them, 4 blocks: token run 10-11 ms, the one wave
+    // 3.4-6.9), and where the reference's encoder has coded them with the fixed code, the explorers' walks never fall
+    // into step with a bit stream that has a period (64 MiB: the chain walks nearly every block itself, 65 ms).
+    if (sd.dst_cap / 64 > sd.src_len) continue;
+    // (what a stream may produce: its capacity, or -- a capacity far beyond it, as callers without sizes give -- what
+    // 64 x its input would be; the group's share of tok[] is sized by what the chains then say)
+    const size_t may = (size_t)sd.dst_cap * 12;
+    if (!group.empty() && group_cap + may > BLOCKS_TOK_BUDGET) { const int st = run(); if (st) return st; }
+    group.push_back((uint32_t)i);
+    group_cap += may;
+  }
+  const int st = run();
+  if (st) return st;
+  for (size_t i = 0; i < n_streams; i++) *n_handled += handled[i];
   return ZIPC_HIP_OK;
 }
 
@@ -713,21 +834,33 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_streams == 1 && max_dst_cap > MAX_STREAM_LEN)
     return inflate_huge_stream(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op);
-  if (n_streams == 1 && max_dst_cap >= BLOCKS_MIN_SRC) {
-    bool handled = false;
-    const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, crc_op, &handled);
-    if (by != ZIPC_HIP_OK || handled) return by;
-  } else if (max_dst_cap <= MAX_STREAM_LEN && ((n_streams <= 4 && max_dst_cap >= (1u << 20)) || (n_streams <= 16 && max_dst_cap >= (8u << 20)))) {
-    // a few long streams (an archive of a few big members): one after the other by blocks -- about 2-8 ms each -- where
-    // their one waves, side by side, take 10-17 ms per MiB of the longest; a stream the block path leaves alone
-    // goes through the batch kernel as a batch of one
-    for (size_t i = 0; i < n_streams; i++) {
-      bool handled = false;
-      int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs + i, d_results + i, crc_op, &handled);
-      if (by == ZIPC_HIP_OK && !handled) by = inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, d_descs + i, d_results + i, 1, max_dst_cap, crc_op);
-      if (by != ZIPC_HIP_OK) return by;
+  // one long stream, or a call of long streams (an archive's big members): by blocks, side by side -- their one
+  // waves take 10-17 ms per MiB of the longest
+  if (max_dst_cap <= MAX_STREAM_LEN && n_streams <= BLOCKS_MAX_STREAMS &&
+      max_dst_cap >= (n_streams == 1 ? BLOCKS_MIN_SRC : BLOCKS_BATCH_MIN_DST)) {
+    std::vector<StreamDesc> sds;
+    std::vector<uint8_t> handled;
+    size_t n_handled = 0;
+    const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, crc_op, sds, handled, &n_handled);
+    if (by != ZIPC_HIP_OK) return by;
+    if (n_handled == n_streams) {
+      if (crc_op != ZIPC_HIP_CRC_CRC32) return ZIPC_HIP_OK;
+      return crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, (const StreamDesc *)d_descs, (StreamResult *)d_results,
+                        n_streams, 0, 0, max_dst_cap, nullptr);
     }
-    return ZIPC_HIP_OK;
+    if (n_handled) {
+      // the others by their one waves, over a copy of the descriptors that says which streams are through (the CRC
+      // pass behind the kernel takes every stream's output as it finds it in d_results)
+      for (size_t i = 0; i < n_streams; i++)
+        if (handled[i]) sds[i].flags |= STREAM_DONE;
+      HIP_TRY(ctx, ctx->ensure(ctx->descs_marked, n_streams * sizeof(StreamDesc)));
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->descs_marked.p, sds.data(), n_streams * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->stream));
+      const int st = inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, (const zipc_hip_stream_desc *)ctx->descs_marked.p, d_results,
+                                            n_streams, max_dst_cap, crc_op);
+      const hipError_t e = hipStreamSynchronize(ctx->stream);  // (sds goes with this frame)
+      if (st == ZIPC_HIP_OK) HIP_TRY(ctx, e);
+      return st;
+    }
   }
   return inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, max_dst_cap, crc_op);
 }

@@ -48,7 +48,8 @@ struct zipc_hip_ctx {
   Buf parse_scratch;                              // lz_parse by segments: their symbols, paths and verdicts (deflate.hip ParseSegs)
   Buf inflate_scratch;                            // inflate: the span decoder's index, 2304 bytes per stream
   Buf stored_list;                                // inflate of one stream beyond 4 GiB: the stored blocks a walk listed
-  Buf blocks_scratch, tok_scratch;                // inflate of one stream by a wave per block: candidates, chain; a word per output byte
+  Buf blocks_scratch, tok_scratch;                // inflate of streams by a wave per block: candidates, chains; a word per output byte
+  Buf descs_marked;                               // ... a call's descriptors with those streams marked as done, for the one waves of the rest
   uint32_t last_inflate_blocks = 0;               // blocks of the last one-stream inflate that went that way (0: it did not)
 
   int name_index(const char *name);

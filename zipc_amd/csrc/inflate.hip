@@ -932,6 +932,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
+  if (descs[stream].flags & STREAM_DONE) return;  // (it went by blocks: its result stands)
   BlockStart at;
   at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
@@ -948,6 +949,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
+  if (descs[stream].flags & STREAM_DONE) return;  // (it went by blocks: its result stands)
   BlockStart at;
   at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL, false, true>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
@@ -981,10 +983,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // list's counter sees one atomic per workgroup, not one per offset: 110 000 on one address took a millisecond)
 constexpr uint32_t FIND_WG_LIST = 512;
 __global__ __launch_bounds__(256) void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena,
-                                                                  const StreamDesc *__restrict__ descs, uint32_t *__restrict__ first,
-                                                                  uint32_t first_cap, FindCounts *__restrict__ counts) {
+                                                                  const StreamDesc *__restrict__ descs,
+                                                                  const BlocksJob *__restrict__ jobs) {
   __shared__ uint32_t l_n, l_base, l_list[FIND_WG_LIST];
-  const StreamDesc sd = descs[0];
+  const BlocksJob J = jobs[blockIdx.y];  // (a call's streams side by side: the grid's second dimension)
+  const StreamDesc sd = descs[J.stream];
+  uint32_t *first = J.first;
+  const uint32_t first_cap = J.first_cap;
+  FindCounts *counts = J.counts;
+  if ((uint64_t)blockIdx.x * 1024u >= sd.src_len) return;  // (the grid is the longest stream's)
   const uint8_t *s = src_arena + sd.src_off;
   const uint64_t t = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;  // first byte
   if (threadIdx.x == 0) l_n = 0;
@@ -1013,11 +1020,15 @@ __global__ __launch_bounds__(256) void inflate_find_headers_kernel(const uint8_t
 
 // the code lengths behind a header that passed: a thread per offset
 __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_arena,
-                                                                 const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ first,
-                                                                 uint32_t first_cap, uint32_t *__restrict__ cand, uint32_t cand_cap,
-                                                                 FindCounts *__restrict__ counts) {
+                                                                 const StreamDesc *__restrict__ descs,
+                                                                 const BlocksJob *__restrict__ jobs) {
   __shared__ uint8_t find_tbl[128 * 64];  // (a column per thread: entry e of thread t at e * 64 + t)
-  const StreamDesc sd = descs[0];
+  const BlocksJob J = jobs[blockIdx.y];
+  const StreamDesc sd = descs[J.stream];
+  const uint32_t *first = J.first;
+  const uint32_t first_cap = J.first_cap, cand_cap = J.cand_cap;
+  uint32_t *cand = J.cand;
+  FindCounts *counts = J.counts;
   const uint8_t *s = src_arena + sd.src_off;
   const uint32_t i = blockIdx.x * 64u + threadIdx.x;
   uint32_t n_first = counts->n_first;
@@ -1036,10 +1047,16 @@ __global__ __launch_bounds__(64) void inflate_find_lengths_kernel(const uint8_t 
 // A dry run per candidate: recs[b] = the candidate's bit and what became of its block
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_dry_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const uint32_t *__restrict__ cand, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t cand_cap,
-    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+    const BlocksJob *__restrict__ jobs) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint32_t ck_lds[2 * CK_MAX];
+  const BlocksJob J = jobs[blockIdx.y];
+  const uint32_t *cand = J.cand;
+  BlockRec *recs = J.recs;
+  BlockCk *cks = J.cks;
+  const uint32_t cand_cap = J.cand_cap;
+  uint16_t *span_scratch = J.span;
+  FindCounts *counts = J.counts;
   const uint32_t b = blockIdx.x;
   const uint32_t n = counts->n_cand <= cand_cap ? counts->n_cand : 0u;  // (more candidates than the list holds: the call gives up)
   if (b >= n) return;
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     next = wave_min(next);
     if (next != 0xFFFFFFFFu && next - (uint32_t)at.bit < (1u << 22)) X.est_bits = next - (uint32_t)at.bit;
   }
-  const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr,
+  const BlockEnd e = inflate_wave<IM_DRY>(lds_raw, src_arena, dst_arena, descs[J.stream], at, nullptr,
                                           span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP, X);
   if (threadIdx.x == 0) {
     BlockRec r;
@@ -1078,27 +1095,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 // before its walk was real are blocks that no chain leads to.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_explore_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const FindCounts *__restrict__ from, uint32_t stride_bits, uint32_t n, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks,
-    uint32_t rec_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts) {
+    const BlocksJob *__restrict__ jobs, uint32_t stride_bits) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint32_t ck_lds[2 * CK_MAX];
+  const BlocksJob J = jobs[blockIdx.y];
+  FindCounts *counts = J.counts;
+  const FindCounts *from = counts;
+  BlockRec *recs = J.recs;
+  BlockCk *cks = J.cks;
+  const uint32_t rec_cap = J.rec_cap, n = J.n;
+  uint16_t *span_scratch = J.span;
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
   at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.chunk0 = 0;
-  if (at.bit + 64u > descs[0].src_len * 8u) return;
+  if (at.bit + 64u > descs[J.stream].src_len * 8u) return;
   Explore X = no_explore();
   X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16; X.inside_fixed = b != 0;
   X.stop_bit = at.bit + stride_bits;
   X.ck_lds = ck_lds; X.cks = cks;
-  inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[0], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
+  inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[J.stream], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
                              nullptr, CRC_NOP, X);
 }
 
 // the listed blocks in stream order: each finds its rank (they are few; the same block may be listed more than once)
-__global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts,
-                                                                 uint32_t rec_cap, BlockRec *__restrict__ sorted,
-                                                                 uint32_t *__restrict__ sorted_src) {
+__global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlocksJob *__restrict__ jobs) {
+  const BlocksJob J = jobs[blockIdx.y];
+  const BlockRec *recs = J.recs;
+  const FindCounts *counts = J.counts;
+  const uint32_t rec_cap = J.rec_cap;
+  BlockRec *sorted = J.sorted;
+  uint32_t *sorted_src = J.sorted_src;
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
@@ -1118,12 +1145,20 @@ __global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlockRec
 // that block's dry run here and now, and goes on.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_chain_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockRec *__restrict__ sorted, const uint32_t *__restrict__ sorted_src, uint32_t rec_cap, BlockStart *__restrict__ chain,
-    BlockEnd *__restrict__ chain_end, ChainIv *__restrict__ chain_iv, BlockCk *__restrict__ cks, uint32_t chain_cap,
-    uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk) {
+    const BlocksJob *__restrict__ jobs, int walk) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint32_t ck_lds[2 * CK_MAX];
-  const StreamDesc sd = descs[0];
+  const BlocksJob J = jobs[blockIdx.y];
+  const BlockRec *sorted = J.sorted;
+  const uint32_t *sorted_src = J.sorted_src;
+  const uint32_t rec_cap = J.rec_cap, chain_cap = J.chain_cap;
+  BlockStart *chain = J.chain;
+  BlockEnd *chain_end = J.chain_end;
+  ChainIv *chain_iv = J.chain_iv;
+  BlockCk *cks = J.cks;
+  uint16_t *span_scratch = J.span;
+  FindCounts *counts = J.counts;
+  const StreamDesc sd = descs[J.stream];
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
   const uint64_t room = (sd.flags & STREAM_HAS_LIMIT) && sd.limit < sd.dst_cap ? sd.limit : sd.dst_cap;
   uint64_t out = 0, bit = 0, miss = NO_BIT;
@@ -1207,7 +1242,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   }
 }
 
-__global__ __launch_bounds__(256) void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n) {
+__global__ __launch_bounds__(256) void inflate_tok_init_kernel(const BlocksJob *__restrict__ jobs) {
+  const BlocksJob J = jobs[blockIdx.y];
+  uint32_t *tok = J.tok;
+  const uint32_t n = J.out_len;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) tok[i] = i;
 }
@@ -1220,11 +1258,19 @@ __global__ __launch_bounds__(256) void inflate_tok_init_kernel(uint32_t *__restr
 // next wave decodes too: the same literals, and for a match byte a source on the same chain of copies).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_token_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-    const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end, const ChainIv *__restrict__ chain_iv,
-    const BlockCk *__restrict__ cks, uint32_t n_blocks, uint32_t n,
-    uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok, FindCounts *__restrict__ counts, int follow) {
+    const BlocksJob *__restrict__ jobs) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint16_t srcpos[SPAN_TILE];
+  const BlocksJob J = jobs[blockIdx.y];
+  const BlockStart *chain = J.chain;
+  const BlockEnd *chain_end = J.chain_end;
+  const ChainIv *chain_iv = J.chain_iv;
+  const BlockCk *cks = J.cks;
+  const uint32_t n_blocks = J.n_blocks, n = J.n;
+  uint16_t *span_scratch = J.span;
+  uint32_t *tok = J.tok;
+  FindCounts *counts = J.counts;
+  const int follow = J.follow;
   const uint32_t w = blockIdx.x;
   if (w >= n) return;
   // (follow: a long stream, where a wave writes down what its sources are copies of -- inflate_span.h -- and that
@@ -1246,7 +1292,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     X.resume_out = blk.out_pos + ck->e[2u * (j - 1u) + 1u];
   }
   if (j < n_ck) X.until_bit = blk.bit + ck->e[2u * j];
-  const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[0], blk, nullptr,
+  const BlockEnd got = inflate_wave<IM_TOKEN>(lds_raw, src_arena, dst_arena, descs[J.stream], blk, nullptr,
                                               span_scratch + (size_t)w * SPAN_IDX_ENTRIES, tok, CRC_NOP, X, follow ? srcpos : nullptr);
   if (threadIdx.x == 0) {
     const BlockEnd want = chain_end[lo];
@@ -1283,11 +1329,17 @@ __device__ __forceinline__ void resolve_one(uint32_t *__restrict__ tok, uint32_t
     if (open) list_out[base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
   }
 }
-__global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts,
-                                                             int round, const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out,
-                                                             int hops) {
+__global__ __launch_bounds__(256) void inflate_resolve_kernel(const BlocksJob *__restrict__ jobs, int round, int hops) {
+  const BlocksJob J = jobs[blockIdx.y];
+  uint32_t *tok = J.tok;
+  const uint32_t n = J.out_len;
+  FindCounts *counts = J.counts;
+  // the two lists of bytes still open, behind tok[]: a round reads the one the round before wrote
+  const uint32_t *list_in = tok + (size_t)n * (1u + (uint32_t)((round + 1) & 1));
+  uint32_t *list_out = tok + (size_t)n * (1u + (uint32_t)(round & 1));
   if (round == 0) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x * 256u >= n) return;  // (the grid is the longest stream's)
     resolve_one(tok, i, i < n, list_out, &counts->more[0], hops);
     return;
   }
@@ -1302,8 +1354,12 @@ __global__ __launch_bounds__(256) void inflate_resolve_kernel(uint32_t *__restri
 // the value depend on that grid.  A wave per chunk: its two sums (sums[3 c .. 3 c + 2] = S1, S2, length); then one
 // wave folds the chunks in stream order, 64 loaded at a time, with the reference's step.
 __global__ __launch_bounds__(64) void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-                                                                 const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end,
-                                                                 uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums) {
+                                                                 const BlocksJob *__restrict__ jobs) {
+  const BlocksJob J = jobs[blockIdx.y];
+  const BlockStart *chain = J.chain;
+  const BlockEnd *chain_end = J.chain_end;
+  const uint32_t n_blocks = J.n_blocks, n_chunks = J.counts->n_chunks;
+  uint32_t *sums = J.sums;
   const uint32_t c = blockIdx.x;
   if (c >= n_chunks) return;
   uint32_t lo = 0, hi = n_blocks - 1u;  // the last block whose chunks start at or before c (and that has chunks)
@@ -1318,13 +1374,17 @@ __global__ __launch_bounds__(64) void inflate_adler_chunks_kernel(const uint8_t 
   const uint32_t n = chain_end[lo].out_len, j = c - b.chunk0, first = n % ADLER_CHUNK;
   const uint32_t start = j == 0u ? 0u : first + (j - 1u) * ADLER_CHUNK, len = j == 0u ? first : ADLER_CHUNK;
   uint32_t S1, S2;
-  wave_adler_chunk_sums(dst_arena + descs[0].dst_off + b.out_pos + start, len, (int)threadIdx.x, S1, S2);
+  wave_adler_chunk_sums(dst_arena + descs[J.stream].dst_off + b.out_pos + start, len, (int)threadIdx.x, S1, S2);
   // (bit 31 of the length: the block's last chunk -- the reference packs the value into one word between two blocks
   // and unpacks it again, zd.ml:178,198, which is not the identity once a signed remainder has gone negative)
   if (threadIdx.x == 0) { sums[3u * c] = S1; sums[3u * c + 1u] = S2; sums[3u * c + 2u] = len | (j == n / ADLER_CHUNK ? 0x80000000u : 0u); }
 }
-__global__ __launch_bounds__(64) void inflate_adler_fold_kernel(const uint32_t *__restrict__ sums, uint32_t n_chunks, int rfc,
-                                                               StreamResult *__restrict__ result) {
+__global__ __launch_bounds__(64) void inflate_adler_fold_kernel(const BlocksJob *__restrict__ jobs, int rfc,
+                                                               StreamResult *__restrict__ results) {
+  const BlocksJob J = jobs[blockIdx.y];
+  const uint32_t *sums = J.sums;
+  const uint32_t n_chunks = J.counts->n_chunks;
+  StreamResult *result = results + J.stream;
   uint32_t s1, s2;
   adler_unpack(1u, s1, s2);  // Adler_32.init zd.ml:173
   for (uint32_t c0 = 0; c0 < n_chunks; c0 += 64u) {
@@ -1341,14 +1401,19 @@ __global__ __launch_bounds__(64) void inflate_adler_fold_kernel(const uint32_t *
   if (threadIdx.x == 0) result->checksum = adler_pack(s1, s2);
 }
 // the stream's result, written where the caller reads it (no copy from the host, no wait for one)
-__global__ void inflate_blocks_result_kernel(StreamResult *__restrict__ result, uint64_t out_len) {
+__global__ void inflate_blocks_result_kernel(const BlocksJob *__restrict__ jobs, StreamResult *__restrict__ results, uint32_t n_jobs) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_jobs) return;
   StreamResult r;
-  r.status = ST_OK; r.checksum = 0; r.out_len = out_len;
-  *result = r;
+  r.status = ST_OK; r.checksum = 0; r.out_len = jobs[j].out_len;
+  results[jobs[j].stream] = r;
 }
 __global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-                                                            const uint32_t *__restrict__ tok, uint32_t n) {
-  uint8_t *o = dst_arena + descs[0].dst_off;
+                                                            const BlocksJob *__restrict__ jobs) {
+  const BlocksJob J = jobs[blockIdx.y];
+  const uint32_t *tok = J.tok;
+  const uint32_t n = J.out_len;
+  uint8_t *o = dst_arena + descs[J.stream].dst_off;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
   const uint32_t j = tok[i];

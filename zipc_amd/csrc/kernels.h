@@ -48,43 +48,48 @@ struct FindCounts {
   uint32_t n_intervals, pad2;  // inflate_chain_kernel: intervals of the chain's blocks (a block and its checkpoints)
   uint64_t miss_bit;  // inflate_chain_kernel without walking: where the chain could not go on (~0: nowhere)
 };
+// A stream of a call that goes by blocks: where its lists live and what this launch takes of it.  The kernels' grids
+// have the call's streams as their second dimension (jobs[blockIdx.y]) and the longest stream's need as their first.
+struct BlocksJob {
+  uint32_t stream;           // its descriptor and result
+  uint32_t first_cap, cand_cap, rec_cap, chain_cap;
+  uint32_t n;                // this launch's waves of the stream: explorers, or intervals / blocks of the token run
+  uint32_t n_blocks;         // blocks of its chain
+  uint32_t out_len;          // its output bytes
+  int32_t follow, pad;
+  FindCounts *counts;
+  uint32_t *first, *cand;
+  BlockRec *recs, *sorted;
+  uint32_t *sorted_src;
+  BlockStart *chain;
+  BlockEnd *chain_end;
+  ChainIv *chain_iv;
+  BlockCk *cks;
+  uint16_t *span;            // the span decoder's index, a slot per wave of the launch
+  uint32_t *tok;             // a word per output byte, then the two lists of the resolve rounds
+  uint32_t *sums;            // Adler-32: three words per chunk
+};
 __global__ void inflate_find_headers_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
-                                            uint32_t *__restrict__ first, uint32_t first_cap, FindCounts *__restrict__ counts);
+                                            const BlocksJob *__restrict__ jobs);
 __global__ void inflate_find_lengths_kernel(const uint8_t *__restrict__ src_arena, const StreamDesc *__restrict__ descs,
-                                            const uint32_t *__restrict__ first, uint32_t first_cap, uint32_t *__restrict__ cand,
-                                            uint32_t cand_cap, FindCounts *__restrict__ counts);
+                                            const BlocksJob *__restrict__ jobs);
 __global__ void inflate_blocks_dry_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                          const StreamDesc *__restrict__ descs, const uint32_t *__restrict__ cand,
-                                          BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t cand_cap,
-                                          uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts);
+                                          const StreamDesc *__restrict__ descs, const BlocksJob *__restrict__ jobs);
 __global__ void inflate_explore_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                       const StreamDesc *__restrict__ descs, const FindCounts *__restrict__ from, uint32_t stride_bits,
-                                       uint32_t n, BlockRec *__restrict__ recs, BlockCk *__restrict__ cks, uint32_t rec_cap,
-                                       uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts);
-__global__ void inflate_sort_blocks_kernel(const BlockRec *__restrict__ recs, const FindCounts *__restrict__ counts, uint32_t rec_cap,
-                                           BlockRec *__restrict__ sorted, uint32_t *__restrict__ sorted_src);
+                                       const StreamDesc *__restrict__ descs, const BlocksJob *__restrict__ jobs, uint32_t stride_bits);
+__global__ void inflate_sort_blocks_kernel(const BlocksJob *__restrict__ jobs);
 __global__ void inflate_chain_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                     const StreamDesc *__restrict__ descs, const BlockRec *__restrict__ sorted,
-                                     const uint32_t *__restrict__ sorted_src, uint32_t rec_cap, BlockStart *__restrict__ chain,
-                                     BlockEnd *__restrict__ chain_end, ChainIv *__restrict__ chain_iv, BlockCk *__restrict__ cks,
-                                     uint32_t chain_cap, uint16_t *__restrict__ span_scratch, FindCounts *__restrict__ counts, int walk);
-__global__ void inflate_tok_init_kernel(uint32_t *__restrict__ tok, uint32_t n);
+                                     const StreamDesc *__restrict__ descs, const BlocksJob *__restrict__ jobs, int walk);
+__global__ void inflate_tok_init_kernel(const BlocksJob *__restrict__ jobs);
 __global__ void inflate_blocks_token_kernel(const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena,
-                                            const StreamDesc *__restrict__ descs, const BlockStart *__restrict__ chain,
-                                            const BlockEnd *__restrict__ chain_end, const ChainIv *__restrict__ chain_iv,
-                                            const BlockCk *__restrict__ cks, uint32_t n_blocks, uint32_t n,
-                                            uint16_t *__restrict__ span_scratch, uint32_t *__restrict__ tok,
-                                            FindCounts *__restrict__ counts, int follow);
-__global__ void inflate_resolve_kernel(uint32_t *__restrict__ tok, uint32_t n, FindCounts *__restrict__ counts, int round,
-                                       const uint32_t *__restrict__ list_in, uint32_t *__restrict__ list_out, int hops);
+                                            const StreamDesc *__restrict__ descs, const BlocksJob *__restrict__ jobs);
+__global__ void inflate_resolve_kernel(const BlocksJob *__restrict__ jobs, int round, int hops);
 __global__ void inflate_adler_chunks_kernel(const uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-                                            const BlockStart *__restrict__ chain, const BlockEnd *__restrict__ chain_end,
-                                            uint32_t n_blocks, uint32_t n_chunks, uint32_t *__restrict__ sums);
-__global__ void inflate_adler_fold_kernel(const uint32_t *__restrict__ sums, uint32_t n_chunks, int rfc,
-                                          StreamResult *__restrict__ result);
-__global__ void inflate_blocks_result_kernel(StreamResult *__restrict__ result, uint64_t out_len);
+                                            const BlocksJob *__restrict__ jobs);
+__global__ void inflate_adler_fold_kernel(const BlocksJob *__restrict__ jobs, int rfc, StreamResult *__restrict__ results);
+__global__ void inflate_blocks_result_kernel(const BlocksJob *__restrict__ jobs, StreamResult *__restrict__ results, uint32_t n_jobs);
 __global__ void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
-                                      const uint32_t *__restrict__ tok, uint32_t n);
+                                      const BlocksJob *__restrict__ jobs);
 
 // a huge stream of equal stored blocks (inflate.hip, api.hip)
 struct StoredChain {

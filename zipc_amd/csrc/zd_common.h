@@ -63,6 +63,8 @@ struct StreamResult {
   uint64_t out_len;
 };
 constexpr uint32_t STREAM_HAS_LIMIT = 1u;
+// (never a caller's: the library's own copy of a call's descriptors, for streams that went by blocks -- api.hip)
+constexpr uint32_t STREAM_DONE = 1u << 31;
 
 // (base << 4) | extra_bits, zd.ml:245-255 and zd.ml:277-288
 #define ZD_V(bits, len) (uint16_t)(((len) << 4) | (bits))
