@@ -110,6 +110,34 @@ def test_one_stream_inflate_by_blocks_bounded(form):
     assert went >= (15 if form == "default" else 8), tail
 
 
+@pytest.mark.parametrize("form", ["default", "following", "few-hops"])
+def test_calls_of_long_streams_inflate_by_blocks_side_by_side(form):
+    """tools/fuzz_inflate_blocks.py BATCH=10: calls of 2 to 10 streams through zipc_hip_inflate_batch -- long ones, which go
+    by blocks side by side (the kernels' grids over stream x block, inflate.hip), short ones and ones the block path
+    refuses, which go by their one waves in the same call; damaged, cut and under-limited streams among them; CRC-32,
+    Adler-32 or none.  Every stream's status, bytes and checksum against the oracle."""
+    import subprocess
+    import sys
+
+    day = datetime.date.today().timetuple().tm_yday
+    e = dict(os.environ)
+    e["TRIALS"] = "12"
+    e["BATCH"] = "10"
+    e["SEED"] = str(900 + day)
+    if form == "following":
+        e["ZIPC_HIP_INFLATE_FOLLOW"] = "1"
+    elif form == "few-hops":
+        e["ZIPC_HIP_EXPLORE_STRIDE"] = "2048"
+        e["ZIPC_HIP_RESOLVE_HOPS0"] = "3"
+        e["ZIPC_HIP_RESOLVE_HOPS1"] = "5"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_inflate_blocks.py")], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-800:]
+    assert r.returncode == 0 and "0 mismatches" in tail, tail
+    went = int(tail.split(" blocks went by blocks")[0].split(", ")[-1])
+    assert went >= 200, tail
+
+
 def test_chains_are_built_by_ordered_exchange(gpu_ctx):
     """The context's probe (deflate.hip xchg_order_probe) passes on gfx950, so the suite's deflate tests run
     lz_chain_xchg_kernel; the peel kernel is compared with the oracle by the overrides above."""

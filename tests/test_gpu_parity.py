@@ -650,6 +650,53 @@ def test_one_stream_inflates_by_a_wave_per_block(gpu_ctx, oracle):
             assert Z.inflate(raw).get_ok() == data, (name, enc)
 
 
+def test_a_call_of_long_and_short_streams(gpu_ctx, oracle):
+    """zipc_hip_inflate_batch with streams of every kind in ONE call: long ones of the reference's encoder and of zlib (by
+    blocks, side by side), a long one of fixed blocks only and one of stored blocks only (the block path may refuse
+    them), short ones, an empty stored stream, a damaged long one, a cut one and one whose limit is too small (their
+    one waves own the message) -- status, length, bytes and checksum of every stream as the oracle has them, for
+    CRC-32, Adler-32 and none; the bytes behind every stream's output untouched."""
+    import torch
+    from zipc_amd import batch
+
+    n = 1100000
+    plain = {k: v for k, v in _one_stream_sources(n)}
+    text, symbols, records = plain["text"], plain["symbols"], plain["records"]
+    fixed = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    stored = zlib.compressobj(0, zlib.DEFLATED, -15)
+    good = _raw_zlib(text, 6)
+    at = len(good) // 2
+    cases = [("oracle-2 text", oracle.deflate(text, level=2)[1], n), ("zlib-6 text", good, n), ("short", _raw_zlib(text[:3000], 6), 3000),
+             ("zlib-1 symbols", _raw_zlib(symbols, 1), n), ("fixed", fixed.compress(records) + fixed.flush(), n),
+             ("empty", _raw_zlib(b"", 6), 0), ("stored", stored.compress(symbols[:400000]) + stored.flush(), 400000),
+             ("damaged", good[:at] + bytes([good[at] ^ 0x10]) + good[at + 1:], n), ("zlib-9 records, flushes", _raw_zlib(records, 9, 300000), n),
+             ("cut", good[:len(good) * 3 // 4], n), ("limit short", _raw_zlib(symbols, 6), n - 1), ("oracle-1 records", oracle.deflate(records, level=1)[1], n)]
+    dev = torch.device("cuda", 0)
+    caps = [max(lim, 8) + 64 for _, _, lim in cases]
+    src_off = np.cumsum([0] + [(len(raw) + 7) & ~7 for _, raw, _ in cases])
+    dst_off = np.cumsum([0] + [c + 13 for c in caps])  # (outputs at odd addresses)
+    arena = np.zeros(int(src_off[-1]) + 64, np.uint8)
+    for (_, raw, _), o in zip(cases, src_off):
+        arena[o:o + len(raw)] = np.frombuffer(raw, np.uint8)
+    descs = batch.make_descs(src_off[:-1], [len(raw) for _, raw, _ in cases], dst_off[:-1], caps, limit=[lim for _, _, lim in cases])
+    src = torch.from_numpy(arena).to(dev)
+    d_descs = batch.to_device(descs, dev)
+    for crc_op in (oracle.CRC_CRC32, oracle.CRC_ADLER32, oracle.CRC_NOP):
+        dst = torch.full((int(dst_off[-1]) + 64,), 0xA5, dtype=torch.uint8, device=dev)
+        d_res = torch.zeros(16 * len(cases), dtype=torch.uint8, device=dev)
+        batch.inflate_batch(gpu_ctx, src, dst, d_descs, d_res, len(cases), max(caps), crc_op)
+        assert gpu_ctx.last_inflate_blocks() >= 60, gpu_ctx.last_inflate_blocks()
+        res = batch.results_from_device(d_res)
+        out = dst.cpu().numpy()
+        for i, (name, raw, lim) in enumerate(cases):
+            st0, d0, c0 = oracle.inflate(raw, decompressed_size=lim, crc_op=crc_op)
+            assert int(res["status"][i]) == st0, (name, crc_op, res[i])
+            if st0 == 0:
+                assert int(res["out_len"][i]) == len(d0) and out[dst_off[i]:dst_off[i] + len(d0)].tobytes() == d0, (name, crc_op)
+                assert crc_op == oracle.CRC_NOP or int(res["checksum"][i]) == c0, (name, crc_op)
+            assert bool((out[dst_off[i] + caps[i]:dst_off[i + 1]] == 0xA5).all()), (name, crc_op)
+
+
 def test_one_stream_by_blocks_leaves_errors_to_the_streams_wave(gpu_ctx, oracle):
     """what the block path must not decide: damaged streams, cut streams, sizes that do not fit -- status and
     message of the oracle, whatever the blocks before the damage were decoded by"""

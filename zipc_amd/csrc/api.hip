@@ -707,6 +707,11 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
   // wave per block instead of one per interval, and save the resolve rounds of a long stream more: with 256 hops a
   // round, 64 MiB of text 6.3-10.8 -> 5.7-6.5 ms, 16 MiB 2.7-4.4 <- 3.3-4.2)
   const int follow_env = zd::tuning().inflate_follow;
+  // (what counts is the output of the whole call, whose bytes the rounds look at side by side: 64 x 1 MiB of text
+  // 5.8 -> 5.0 ms, 8 x 8 MiB 5.3 -> 4.7; 16 x 1 MiB 2.5 <- 3.2, one MiB 1.4 <- 2.4)
+  size_t call_out = 0;
+  for (uint32_t j : alive)
+    if (fc[j].chain_ok && fc[j].n_blocks >= 2) call_out += fc[j].out_len;
   keep.clear();
   size_t tok_words = 0;
   for (uint32_t j : alive) {
@@ -715,7 +720,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
     J.out_len = (uint32_t)fc[j].out_len;
     J.n_blocks = fc[j].n_blocks;
     // (... and nothing on data with few matches: 16 MiB of records that deflate to 0.85, resolve 0.13 ms either way)
-    J.follow = follow_env >= 0 ? follow_env : J.out_len >= (32u << 20) && (uint64_t)J.out_len * 2u >= sds[J.stream].src_len * 3u;
+    J.follow = follow_env >= 0 ? follow_env : call_out >= ((size_t)32 << 20) && (uint64_t)J.out_len * 2u >= sds[J.stream].src_len * 3u;
     // the token run: a wave per interval of a block (its checkpoints), or -- follow -- a wave per block
     J.n = J.follow ? J.n_blocks : fc[j].n_intervals;
     tok_words += ((size_t)J.out_len * 3 + 63) & ~(size_t)63;

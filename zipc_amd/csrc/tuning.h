@@ -31,7 +31,7 @@ struct Tuning {
                                //                          least 2048 streams each, api.hip batch_slices; tests force more and smaller ones)
   // ---- inflate of one long stream by blocks (api.hip inflate_by_blocks)
   bool inflate_blocks;         // ZIPC_HIP_INFLATE_BLOCKS=0  the stream's one wave instead
-  int inflate_follow;          // ZIPC_HIP_INFLATE_FOLLOW  -1 (default): sources followed inside the token run from 32 MiB on; 0 / 1 never / always
+  int inflate_follow;          // ZIPC_HIP_INFLATE_FOLLOW  -1 (default): sources followed inside the token run in calls of 32 MiB of output and more; 0 / 1 never / always
   uint64_t explore_stride;     // ZIPC_HIP_EXPLORE_STRIDE  input bytes between two explorers (default 8192)
   int resolve_hops0, resolve_hops1;  // ZIPC_HIP_RESOLVE_HOPS0 / 1  links a thread follows in the first / a later resolve round (default 256)
   // ---- checksums
