@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <deque>
 #include <thread>
@@ -558,7 +559,7 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
 // turns it off.
 constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
 constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
-constexpr size_t BLOCKS_BATCH_MIN_DST = 1u << 20, BLOCKS_MAX_STREAMS = 4096;
+constexpr size_t BLOCKS_BATCH_MIN_DST = 1u << 20, BLOCKS_MAX_STREAMS = 1u << 20;  // (a call whose descriptors are worth reading back: its longest stream alone is 15 ms of one wave)
 // tok[] and the two lists: 12 bytes of scratch per output byte.  Streams share a group while their capacities fit
 // this much of it (a stream that needs more has a group to itself, and its scratch goes back afterwards)
 constexpr size_t BLOCKS_TOK_BUDGET = (size_t)1 << 30;
@@ -806,6 +807,7 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
     group_cap = 0;
     return st;
   };
+  std::vector<uint32_t> fit;  // the streams the block path takes at all
   for (size_t i = 0; i < n_streams; i++) {
     const StreamDesc &sd = sds[i];
     if (sd.src_len < BLOCKS_MIN_SRC || sd.src_len > BLOCKS_MAX_SRC || sd.dst_cap < 8 || sd.dst_cap > MAX_STREAM_LEN) continue;
@@ -814,11 +816,41 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
     // 3.4-6.9), and where the reference's encoder has coded them with the fixed code, the explorers' walks never fall
     // into step with a bit stream that has a period (64 MiB: the chain walks nearly every block itself, 65 ms).
     if (sd.dst_cap / 64 > sd.src_len) continue;
-    // (what a stream may produce: its capacity, or -- a capacity far beyond it, as callers without sizes give -- what
-    // 64 x its input would be; the group's share of tok[] is sized by what the chains then say)
-    const size_t may = (size_t)sd.dst_cap * 12;
+    fit.push_back((uint32_t)i);
+  }
+  // Which of them go by blocks: the one waves of a call run side by side, and a call of thousands of streams fills
+  // the device with them -- its time is the longest stream's, about 15 ms per MiB of output -- while the block path
+  // takes the streams' bytes one after the other, about 0.09 ms per MiB and 1 ms for a group's launches and
+  // read-backs (64 x 1 MiB: 5.0 ms against 17; 4096 x 1 MiB: 370 ms against 16).  So the k longest streams go by
+  // blocks, with the k that makes the sum of both parts smallest: all of a few long streams, the few long members
+  // among an archive's many short ones, none of thousands of equal ones.
+  {
+    constexpr double WAVE_MS_PER_MIB = 15.0, BLOCKS_MS_PER_MIB = 0.09, BLOCKS_MS_FIXED = 1.0, MIB = 1048576.0;
+    std::sort(fit.begin(), fit.end(), [&](uint32_t x, uint32_t y) { return sds[x].dst_cap != sds[y].dst_cap ? sds[x].dst_cap > sds[y].dst_cap : x < y; });
+    uint64_t longest_other = 0;  // (of the streams the block path does not take)
+    {
+      std::vector<uint8_t> in_fit(n_streams, 0);
+      for (uint32_t i : fit) in_fit[i] = 1;
+      for (size_t i = 0; i < n_streams; i++)
+        if (!in_fit[i] && sds[i].dst_cap > longest_other) longest_other = sds[i].dst_cap;
+    }
+    size_t best_k = 0;
+    double best_ms = 0, taken_mib = 0;
+    for (size_t k = 0; k <= fit.size(); k++) {
+      const uint64_t longest_left = k < fit.size() ? (sds[fit[k]].dst_cap > longest_other ? sds[fit[k]].dst_cap : longest_other) : longest_other;
+      const bool any_left = k < n_streams;
+      const double ms = (k ? BLOCKS_MS_FIXED + taken_mib * BLOCKS_MS_PER_MIB : 0.0) + (any_left ? (double)longest_left / MIB * WAVE_MS_PER_MIB : 0.0);
+      if (k == 0 || ms < best_ms) { best_ms = ms; best_k = k; }
+      if (k < fit.size()) taken_mib += (double)sds[fit[k]].dst_cap / MIB;
+    }
+    fit.resize(best_k);
+    std::sort(fit.begin(), fit.end());
+  }
+  for (uint32_t i : fit) {
+    // (what a stream may produce: its capacity; the group's share of tok[] is sized by what the chains then say)
+    const size_t may = (size_t)sds[i].dst_cap * 12;
     if (!group.empty() && group_cap + may > BLOCKS_TOK_BUDGET) { const int st = run(); if (st) return st; }
-    group.push_back((uint32_t)i);
+    group.push_back(i);
     group_cap += may;
   }
   const int st = run();
