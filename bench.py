@@ -232,6 +232,10 @@ def leg_plain(source, j, stream_len):
         return synth.stream_bytes_np(source[1], j, stream_len, source[2]).tobytes()
     if source[0] == "text":
         return text_pieces(stream_len)[j % 4]
+    if source[0] == "textlong":  # a long member: the four 64 KiB text chunks over and over, begun at a place of its own
+        four = b"".join(text_pieces(65536))
+        o = (j * 7919) % len(four)
+        return ((four[o:] + four[:o]) * (stream_len // len(four) + 1))[:stream_len]
     if source[0] == "zeros":
         return bytes(stream_len)
     if ("corpus", stream_len) not in _PIECES:
@@ -253,6 +257,7 @@ LEGS = {
     "corpus_default": (("corpus",), 2, 65536, (0, 1, 2), True, 2.0),
     "corpus_best": (("corpus",), 3, 65536, (0, 1), True, 2.0),
     "c4_default": (("synth", 4, 3), 2, 1 << 20, (0, 1), False, 3.0),
+    "long_members": (("textlong",), 2, 1 << 20, (0, 63), True, 2.0),
     "one_c1_zeros_1mib": (("zeros",), 1, 1 << 20, (0,), True, 0.5),
     "one_symbols_1mib": (("synth", 2, 4), 2, 1 << 20, (0,), True, 0.5),
 }
@@ -343,7 +348,7 @@ def cpu_baseline(config):
         return line
     line = cpu_leg("c2_default")
     # the other legs the line reports GPU numbers for: a GPU-over-CPU ratio is context, not credit
-    line["legs"] = {k: cpu_leg(k) for k in ("text_default", "text_best", "c4_default")}
+    line["legs"] = {k: cpu_leg(k) for k in ("text_default", "text_best", "c4_default", "long_members")}
     line["samples"] = cpu_samples()
     return line
 
@@ -656,6 +661,18 @@ def extra_legs(ctx, dev, n, L, cpu):
         out["one_stream_ms"] = one
     except Exception as e:
         out["one_stream_ms"] = {"error": repr(e)}
+    try:  # an archive's few long members in one call: 64 x 1 MiB of text -- too few for a wave each to fill the device
+        m, ML = 64, 1 << 20
+        src = torch.from_numpy(np.frombuffer(b"".join(leg_plain(("textlong",), j, ML) for j in range(m)), np.uint8).copy()).to(dev)
+        leg = device_round_trip(ctx, dev, src, m, ML, 2, reps=3, expect=samples.get("long_members"))
+        leg["cpu_baseline"] = cpu_legs.get("long_members")
+        leg["deflate_ms"], leg["inflate_ms"] = m * ML / GIB / leg["deflate"] * 1e3, m * ML / GIB / leg["inflate"] * 1e3
+        leg["inflate_blocks"] = ctx.last_inflate_blocks()
+        leg["is"] = "%d members x 1 MiB of text in one call of the batch forms, device-resident: deflate runs them as segments on many " \
+                    "waves, inflate by blocks side by side (inflate_blocks: blocks decoded that way in the last call)" % m
+        out["long_members"] = leg
+    except Exception as e:
+        out["long_members"] = {"error": repr(e)}
     try:  # C4 shape on this GPU: 4096 members x 1 MiB of 3-bit symbols (a wave per member: half of them leaves the GPU half empty)
         m, ML = 4096, 1 << 20
         src = synth.batch_bytes_torch(4, 0, m, ML, 3, dev)
