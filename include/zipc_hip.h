@@ -231,12 +231,15 @@ typedef struct zipc_hip_stream_result_s {
 /* All pointers are DEVICE pointers (descs and results too).  Work is enqueued
  * on the context stream and NOT synchronised: call zipc_hip_synchronize (or
  * synchronise the stream) before reading results.  Two exceptions, both zipc_hip_inflate_batch: ONE stream with
- * max_dst_cap above ZIPC_HIP_MAX_STREAM_LEN (a stream of stored blocks beyond 4 GiB, below), and a call with one to
- * four streams of a MiB and more (up to 16 of 8 MiB and more; one stream: 96 KiB of input and more), which are decoded
- * by a wave per BLOCK -- block starts searched for, the blocks walked side by side, copies resolved afterwards: a MiB in
- * 1.2-1.9 ms instead of 10-30 -- read a few words back between their steps and so synchronise the stream themselves.
- * Results, messages and limits are the same whichever way a stream is decoded (zipc_hip_last_inflate_blocks tells;
- * ZIPC_HIP_INFLATE_BLOCKS=0 in the environment keeps every stream on its one wave). */
+ * max_dst_cap above ZIPC_HIP_MAX_STREAM_LEN (a stream of stored blocks beyond 4 GiB, below), and a call whose
+ * max_dst_cap is a MiB and more (one stream: 96 KiB of input and more): the library reads the descriptors back, and
+ * the call's long streams -- all of a few, the long ones among many short ones, none of thousands of equal ones: chosen
+ * by what each way costs -- are decoded by a wave per BLOCK, side by side: block starts searched for, the blocks walked
+ * at once, copies resolved afterwards (a MiB in 1.3-1.9 ms instead of 10-30, 64 of them in 5 instead of 17).  That path
+ * reads a few words back between its steps and so synchronises the stream itself.
+ * Results, messages and limits are the same whichever way a stream is decoded (zipc_hip_last_inflate_blocks tells how
+ * many blocks of the last call went that way; ZIPC_HIP_INFLATE_BLOCKS=0 in the environment keeps every stream on its
+ * one wave).  Bits of flags other than ZIPC_HIP_STREAM_HAS_LIMIT must be zero. */
 /* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream
  * whose output is longer than that reports ZIPC_HIP_ERR_INVALID_ARG in its result when a
  * CRC-32 is asked for (its checksum would cover only a part). A descriptor with src_len or

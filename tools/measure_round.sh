@@ -34,6 +34,10 @@ LEN=16777216 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks.jsonl" 
 LEN=67108864 REPS=3 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks.jsonl" 2> /dev/null
 ZIPC_HIP_INFLATE_BLOCKS=0 python3 tools/exp_inflate_blocks.py > "$OUT/inflate_blocks_one_wave.jsonl" 2> /dev/null
 ZIPC_HIP_INFLATE_BLOCKS=0 LEN=16777216 python3 tools/exp_inflate_blocks.py >> "$OUT/inflate_blocks_one_wave.jsonl" 2> /dev/null
+# a call of N long streams: by blocks side by side, by their one waves, and kernel by kernel
+{ REPS=5 python3 tools/exp_inflate_many.py; N=8 LEN=8388608 REPS=3 python3 tools/exp_inflate_many.py; N=16 REPS=5 python3 tools/exp_inflate_many.py;
+  echo "-- ZIPC_HIP_INFLATE_BLOCKS=0"; ZIPC_HIP_INFLATE_BLOCKS=0 REPS=3 python3 tools/exp_inflate_many.py; } 2> /dev/null | grep -v amdgpu.ids > "$OUT/inflate_many.txt"
+CFGS="64x1048576 8x8388608" bash tools/prof_inflate_many.sh 2> /dev/null | grep -v "^[WE]2026" > "$OUT/inflate_many_kernels.txt"
 python3 "$B" --config c4 --steps 3 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
 DEFLATE=1 bash tools/exp_sq_counters.sh > "$OUT/sq.log" 2>&1; cp gpurun_out/sq/sq_counters.json "$OUT/sq_counters.json"; cp gpurun_out/sq/summary.txt "$OUT/sq_counters.txt"
 echo "== bench"; python3 -c "
