@@ -56,6 +56,10 @@ def parse_args(argv=None):
     ap.add_argument("--level", type=int, default=2, help="0 none, 1 fast, 2 default, 3 best")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the untimed legs (host forms, real text)")
+    ap.add_argument("--alone-pass", action="store_true",
+                    help="a second profiled pass with ONE slice: every kernel launched over the whole batch with nothing beside it "
+                         "(roofline.*.alone).  Off by default so that a rocprofv3 summary of the default command holds only the "
+                         "launches the timed region makes")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)  # the cpu_baseline leg's own process
     return ap.parse_args(argv)
 
@@ -380,36 +384,86 @@ def timed_steps(step, barrier, steps, warmup, world, dev):
     return elapsed, info
 
 
-def roofline_of(ctx, per_step_fn, psteps, N, C):
-    """per-kernel durations from HIP events on the launch stream (separate, untimed steps)"""
-    ctx.set_profiling(True)
-    ctx.reset_kernel_times()
-    for _ in range(psteps):
-        per_step_fn()
-    times = ctx.kernel_times()
-    ctx.set_profiling(False)
+def roofline_of(ctx, per_step_fn, psteps, N, C, wall=None, alone_pass=False):
+    """Per-kernel durations from HIP events on the launch stream (separate, untimed steps).  A step of the batch forms
+    is cut into slices on side queues (two by default, api.hip batch_slices): a kernel is then launched once per slice,
+    over that slice's streams, beside the other slice's kernels.  `achieved` prices a LAUNCH: the bytes of the
+    streams it covers over its duration -- the duration rocprofv3 reports for it under the same command; `alone`
+    is the same kernel launched once over the whole batch with nothing beside it (--alone-pass: a second pass with one slice).
+    wall: {"def": s, "inf": s} filled by per_step_fn, the two directions' wall time over the psteps steps."""
+    from zipc_amd import _lib
+
+    def one_pass():
+        ctx.set_profiling(True)
+        ctx.reset_kernel_times()
+        if wall is not None:
+            wall["def"] = wall["inf"] = 0.0
+        for _ in range(psteps):
+            per_step_fn()
+        times = ctx.kernel_times()
+        ctx.set_profiling(False)
+        return times, (dict(wall) if wall is not None else None)
+
+    times, walls = one_pass()
+    alone_times = {}
+    if alone_pass:
+        _lib.lib().zipc_hip_debug_set_slices(1)
+        try:
+            alone_times, _ = one_pass()
+        finally:
+            _lib.lib().zipc_hip_debug_set_slices(0)
+    if wall is not None:
+        wall.update(walls)  # (the caller reads the default form's)
     kernels = {k: v[1] / v[0] for k, v in times.items()}  # ms per launch
-    per_step = {k: v[1] / psteps for k, v in times.items()}  # ms per step
+    per_step = {k: v[1] / psteps for k, v in times.items()}  # ms per step, summed over its launches (which overlap other kernels')
+    launches = {k: v[0] / psteps for k, v in times.items()}  # launches per step
+    alone = {k: v[1] / v[0] for k, v in alone_times.items()}
+    alone_launches = {k: v[0] / psteps for k, v in alone_times.items()}
+    has_inflate = "inflate_batch" in per_step
+    # passes over the batch per step: the CRC-32 kernels run once over the source and once over the output
+    passes = {k: (2.0 if k.startswith("crc32") and has_inflate else 1.0) for k in per_step}
+
+    def entry(k, brief):
+        share = passes[k] / launches[k] if launches[k] else 1.0  # of the batch, per launch
+        e = _roofline_entry(k, kernels[k], N, C, brief=brief, share=share)
+        e["launches_per_step"] = launches[k]
+        if k in alone:
+            a_share = passes[k] / alone_launches[k] if alone_launches.get(k) else 1.0
+            a = _roofline_entry(k, alone[k], N, C, brief=True, share=a_share)
+            e["alone"] = {"launch_ms": alone[k], "achieved": a["achieved"], "frac": a["frac"], "launches_per_step": alone_launches[k],
+                          "is": "one slice: the kernel launched over the whole batch, nothing beside it"}
+            if "issue_bound" in a:
+                e["alone"]["issue_bound"] = a["issue_bound"]
+        return e
+
     dom = max(per_step, key=per_step.get)
-    roof = _roofline_entry(dom, kernels[dom], N, C)
+    roof = entry(dom, False)
     # the other kernels of the step, the same way: "roofline" stays the longest launch's, the rest are
     # listed so that a kernel that stops being the longest (inflate_batch in round 2) stays in the line
-    roof["others"] = {k: _roofline_entry(k, kernels[k], N, C, brief=True) for k in sorted(per_step, key=per_step.get, reverse=True)
+    roof["others"] = {k: entry(k, True) for k in sorted(per_step, key=per_step.get, reverse=True)
                       if k != dom and per_step[k] >= 0.05 * per_step[dom]}
     # the two directions as wholes, against section 8(d)'s bytes: everything deflate launches (its CRC-32 pass
-    # over the source included: half of the step's crc32 launches) for N + C, the inflate kernel for C + N
+    # over the source included) for N + C, everything inflate launches for C + N -- over the direction's WALL time
+    # per step where it was measured (the kernels of two slices overlap: their durations do not add up to it)
     crc_ms = sum(per_step.get(k, 0.0) for k in ("crc32_segments", "crc32_finish"))
-    has_inflate = "inflate_batch" in per_step
-    defl_ms = sum(per_step.get(k, 0.0) for k in DEFLATE_KERNELS) + (crc_ms / 2 if has_inflate else crc_ms)
+    defl_sum = sum(per_step.get(k, 0.0) for k in DEFLATE_KERNELS) + (crc_ms / 2 if has_inflate else crc_ms)
+    defl_ms = walls["def"] / psteps * 1e3 if walls and walls.get("def") else defl_sum
     if defl_ms > 0:
         roof["deflate_pipeline"] = _path_entry(N + C, defl_ms, [k for k in DEFLATE_KERNELS if k in per_step] + ["crc32 (source)"],
-                                               sum_traffic([k for k in DEFLATE_KERNELS if k in per_step]))
+                                               sum_traffic([k for k in DEFLATE_KERNELS if k in per_step], launches))
+        roof["deflate_pipeline"]["kernels_ms_sum"] = defl_sum
+        roof["deflate_pipeline"]["ms_is"] = "wall time of the direction per step" if walls and walls.get("def") else "sum of its kernels' durations"
     if has_inflate:
-        roof["inflate"] = _path_entry(C + N, per_step["inflate_batch"], ["inflate_batch"], sum_traffic(["inflate_batch"]))
+        inf_sum = per_step["inflate_batch"] + crc_ms / 2
+        inf_ms = walls["inf"] / psteps * 1e3 if walls and walls.get("inf") else inf_sum
+        roof["inflate"] = _path_entry(C + N, inf_ms, ["inflate_batch", "crc32 (output)"], sum_traffic(["inflate_batch"], launches))
+        roof["inflate"]["kernels_ms_sum"] = inf_sum
+        roof["inflate"]["ms_is"] = roof["deflate_pipeline"]["ms_is"] if defl_ms > 0 else "sum of its kernels' durations"
     return roof, per_step
 
 
-def sum_traffic(kernels):
+def sum_traffic(kernels, launches=None):
+    """the kernels' counter traffic per STEP: the PMC passes give bytes per launch (profiles/*_hbm_traffic.json)"""
     tot = {"bytes": 0.0, "fetch_bytes": 0.0, "write_bytes": 0.0}
     src = None
     for k in kernels:
@@ -417,8 +471,9 @@ def sum_traffic(kernels):
         if not t:
             continue
         src = src_k
+        per = (launches or {}).get(k, 1.0)
         for f in tot:
-            tot[f] += t[f]
+            tot[f] += t[f] * per
     return (tot, src) if src else (None, None)
 
 
@@ -435,15 +490,17 @@ def _path_entry(alg, ms, kernels, traffic):
     return e
 
 
-def _roofline_entry(dom, dom_ms, N, C, brief=False):
-    alg = algorithmic_bytes(dom, N, C)
-    des = design_bytes(dom, N, C)
+def _roofline_entry(dom, dom_ms, N, C, brief=False, share=1.0):
+    """share: the part of the batch one launch covers (1 / slices; 1 with one slice)"""
+    alg = algorithmic_bytes(dom, N, C) * share
+    des = design_bytes(dom, N, C) * share
     achieved = alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     traffic, traffic_src = measured_traffic(dom)
     roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic["bytes"] if traffic else None,
             "traffic_source": traffic_src, "algorithmic_bytes": alg, "launch_ms": dom_ms,
-            "algorithmic_is": "SURVEY section 8(d): deflate N + C, inflate C + N, CRC-32 N (the path's minimum, not this kernel's own I/O)",
+            "algorithmic_is": "SURVEY section 8(d): deflate N + C, inflate C + N, CRC-32 N (the path's minimum, not this kernel's own I/O), of the streams ONE launch covers",
+            "batch_share_per_launch": share,
             "design_bytes": des, "design_gb_s": des / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0}
     if traffic:
         # "traffic" is the raw FETCH_SIZE + WRITE_SIZE.  Calibrated on the inflate kernel's stored-block
@@ -531,7 +588,7 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
         t["def"] += b - a
         t["inf"] += time.perf_counter() - b
 
-    roof, per_step = roofline_of(ctx, profiled, psteps, N, C)
+    roof, per_step = roofline_of(ctx, profiled, psteps, N, C, wall=t, alone_pass=args.alone_pass)
     if rank != 0:
         return None
     line = {

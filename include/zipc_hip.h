@@ -118,6 +118,10 @@ unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx);
  * order, which is the order insert_hash (zipc_deflate.ml:1150-1152) inserts positions in.  0: the probe failed and the
  * context keeps the kernel that orders them itself (same links either way).  For tests and measurements. */
 int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx);
+/* Measurements only: the number of slices the batch forms cut a call into (side queues, api.hip batch_slices), for
+ * every context of the process from now on; 0 = the default again (two slices of at least 2048 streams, or
+ * ZIPC_HIP_SLICES).  bench.py times a kernel alone on the device with 1.  Results are the same for every value. */
+void zipc_hip_debug_set_slices(long k);
 /* the reference's message for a status (format strings kept verbatim) */
 const char *zipc_hip_strerror(int status);
 

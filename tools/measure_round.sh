@@ -20,6 +20,7 @@ python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" --hbm
 python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" > "$OUT/pmc_hbm.txt"
 python3 "$B" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python3 "$B" --no-cpu-baseline --no-extra-legs > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || echo "kernel-trace pass failed"
+python3 "$B" --alone-pass --no-cpu-baseline --no-extra-legs > "$OUT/bench_alone.json" 2> /dev/null || echo "alone pass failed"
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 "$B" --gpus 1 --no-cpu-baseline > "$OUT/torchrun.json" 2> "$OUT/torchrun.err" || echo "torchrun failed"
 cd "$ROOT"
 python3 tools/bench_configs.py > "$OUT/configs.jsonl" 2> "$OUT/configs.err"

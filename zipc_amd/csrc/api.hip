@@ -233,11 +233,12 @@ const Tuning &tuning() {
   }();
   return t;
 }
+static long g_slices_override = 0;  // zipc_hip_debug_set_slices: measurements that want every kernel alone on the device
 size_t batch_slices(size_t n_streams) {
   // Two slices by default (each of at least 2048 streams): since lz_chain is four waves per CU (round 4) the second
   // slice's chain links are made beside the first one's parse and blocks -- C2 deflate 13.25 -> 12.67 ms, the step
   // 16.97 -> 16.34; text the same either way; 3 / 4 / 6 slices lose 7 / 3 / 8 % (one box, tools/exp_wall.py).
-  const long env = tuning().slices, env_min = tuning().slice_min;
+  const long env = g_slices_override > 0 ? g_slices_override : tuning().slices, env_min = tuning().slice_min;
   size_t k = env > 0 ? (size_t)env : 2;
   if (k > 8) k = 8;
   const size_t least = env_min > 0 ? (size_t)env_min : 2048;
@@ -390,6 +391,7 @@ int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx) { return ctx ? ctx->last_inflate_blocks : 0u; }
 int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx) { return ctx && ctx->xchg_ordered ? 1 : 0; }
+void zipc_hip_debug_set_slices(long k) { zd::g_slices_override = k; }
 
 int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled) {
   if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
