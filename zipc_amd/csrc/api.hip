@@ -589,7 +589,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
     if (J.cand_cap > BLOCKS_CAND_CAP) J.cand_cap = BLOCKS_CAND_CAP;
     // explorers (blocks without a findable header): one every EXPLORE_STRIDE bytes at most, 4 blocks listed each on average
     max_explorers[j] = (uint32_t)(sd.src_len / EXPLORE_STRIDE + 1);
-    uint64_t rec_cap64 = (uint64_t)J.cand_cap + 4ull * max_explorers[j];
+    uint64_t rec_cap64 = 2ull * J.cand_cap + 4ull * max_explorers[j];  // (candidates, the blocks behind them, the explorers')
     if (rec_cap64 > BLOCKS_REC_CAP) rec_cap64 = BLOCKS_REC_CAP;
     J.rec_cap = J.chain_cap = (uint32_t)rec_cap64;
     Lists &L = at[j];
@@ -694,7 +694,10 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
       const uint64_t bits_left = sds[jobs[j].stream].src_len * 8u - fc[j].miss_bit;
       uint64_t ne = (bits_left + EXPLORE_STRIDE * 8u - 1) / (EXPLORE_STRIDE * 8u);
       if (ne > max_explorers[j]) ne = max_explorers[j];
-      jobs[j].n = (uint32_t)ne;
+      // (behind the explorers a wave per block listed so far: the block that follows it, inflate.hip)
+      const uint32_t listed = fc[j].n_recs < jobs[j].rec_cap ? fc[j].n_recs : jobs[j].rec_cap;
+      jobs[j].n_blocks = (uint32_t)ne;
+      jobs[j].n = (uint32_t)ne + listed;
     }
     HIP_TRY(ctx, span_slots(lost));
     HIP_TRY(ctx, hand(lost));

@@ -1103,16 +1103,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   const FindCounts *from = counts;
   BlockRec *recs = J.recs;
   BlockCk *cks = J.cks;
-  const uint32_t rec_cap = J.rec_cap, n = J.n;
+  const uint32_t rec_cap = J.rec_cap, n = J.n, n_explorers = J.n_blocks;
   uint16_t *span_scratch = J.span;
   const uint32_t b = blockIdx.x;
   if (b >= n) return;
   BlockStart at;
-  at.bit = from->miss_bit + (uint64_t)b * stride_bits; at.out_pos = 0; at.chunk0 = 0;
-  if (at.bit + 64u > descs[J.stream].src_len * 8u) return;
+  at.out_pos = 0; at.chunk0 = 0;
   Explore X = no_explore();
-  X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16; X.inside_fixed = b != 0;
-  X.stop_bit = at.bit + stride_bits;
+  X.recs = recs; X.n_recs = &counts->n_recs; X.cap = rec_cap; X.max_recs = 16;
+  if (b < n_explorers) {
+    at.bit = from->miss_bit + (uint64_t)b * stride_bits;
+    X.inside_fixed = b != 0;
+    X.stop_bit = at.bit + stride_bits;
+  } else {
+    // a FOLLOWER: the block behind a listed (dynamic) block that lies behind the chain's stop.  An explorer that
+    // starts inside a dynamic block finds nothing, so the fixed block behind one was listed by nobody and the chain
+    // walked it itself, one after the other (the reference's encoder mixes the two kinds: 5 or 6 such walks of
+    // 0.35 ms in 64 MiB).  Where that block starts is known exactly -- the listed block's end -- and one wave each
+    // lists it.
+    const BlockRec r = recs[b - n_explorers];  // (listed before this launch: the explorers append behind them)
+    if (r.e.status != ST_OK || r.e.final_block || r.e.end_bit <= from->miss_bit) return;
+    at.bit = r.e.end_bit;
+    X.inside_fixed = 0;
+    X.stop_bit = at.bit;  // (the first block it lists starts there: one block)
+  }
+  if (at.bit + 64u > descs[J.stream].src_len * 8u) return;
   X.ck_lds = ck_lds; X.cks = cks;
   inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[J.stream], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
                              nullptr, CRC_NOP, X);
@@ -1127,14 +1142,25 @@ __global__ __launch_bounds__(256) void inflate_sort_blocks_kernel(const BlocksJo
   BlockRec *sorted = J.sorted;
   uint32_t *sorted_src = J.sorted_src;
   const uint32_t n = counts->n_recs < rec_cap ? counts->n_recs : rec_cap;
+  // (the others' bits 256 at a time through LDS: a load per comparison from memory was a round trip each, 0.5-0.8 ms
+  // of a stream whose explorers listed a few thousand blocks)
+  __shared__ uint64_t others[256];
+  if (blockIdx.x * 256u >= n) return;
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t mine = recs[i].bit;
+  const uint64_t mine = i < n ? recs[i].bit : 0ull;
   uint32_t r = 0;
-  for (uint32_t j = 0; j < n; j++) {
-    const uint64_t b = recs[j].bit;
-    r += b < mine || (b == mine && j < i) ? 1u : 0u;
+  for (uint32_t base = 0; base < n; base += 256u) {
+    const uint32_t j = base + threadIdx.x;
+    others[threadIdx.x] = j < n ? recs[j].bit : ~0ull;
+    __syncthreads();
+    const uint32_t m = n - base < 256u ? n - base : 256u;
+    for (uint32_t t = 0; t < m; t++) {
+      const uint64_t b = others[t];
+      r += b < mine || (b == mine && base + t < i) ? 1u : 0u;
+    }
+    __syncthreads();
   }
+  if (i >= n) return;
   sorted[r] = recs[i];
   sorted_src[r] = i;
 }
@@ -1193,12 +1219,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       // per block by lane 0 was 0.43 us: 0.39 ms of a 64 MiB stream's 5.2.  Whatever a run stops in front of (a
       // block that does not follow, an error, the limit, the chain's capacity) the one-block step below decides.
       const uint32_t l0 = (uint32_t)__builtin_ctzll(hit), lane = threadIdx.x;
-      const uint64_t prev_end = ((uint64_t)(uint32_t)__shfl_up((int)(we.end_bit >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)we.end_bit, 1);
+      // (a block listed more than once -- by a candidate's dry run, an explorer or two, a follower -- stands at
+      // neighbouring lanes: the first listing counts, as in the one-block step, and the others are passed over)
+      const uint64_t bit_before = ((uint64_t)(uint32_t)__shfl_up((int)(wbit >> 32), 1) << 32) | (uint32_t)__shfl_up((int)(uint32_t)wbit, 1);
+      const bool again = lane > l0 && wbit == bit_before;
+      int first_of = again ? -1 : (int)lane;  // the lane of the nearest listing at or before mine that counts
+      uint32_t counted = lane >= l0 && !again ? 1u : 0u;  // ... and how many count from l0 up to mine
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int fu = __shfl_up(first_of, d);
+        const uint32_t cu = (uint32_t)__shfl_up((int)counted, d);
+        if ((int)lane >= d) { first_of = first_of > fu ? first_of : fu; counted += cu; }
+      }
+      const int before = __shfl_up(first_of, 1);  // the listing that counts before mine
+      const uint64_t prev_end = ((uint64_t)(uint32_t)__shfl((int)(we.end_bit >> 32), before < 0 ? 0 : before) << 32) |
+                                (uint32_t)__shfl((int)(uint32_t)we.end_bit, before < 0 ? 0 : before);
       const bool follows = lane == l0 || wbit == prev_end;
       const bool sound = wbit != NO_BIT && we.status == ST_OK && we.end_bit > wbit;
-      const uint64_t len64 = lane >= l0 && sound ? (uint64_t)we.out_len : 0ull;
+      const bool counts_here = lane >= l0 && !again;
+      const uint64_t len64 = counts_here && sound ? (uint64_t)we.out_len : 0ull;
       uint64_t incl = len64;
-      uint32_t iv_incl = lane >= l0 ? 1u + we.pad : 0u, ch_incl = lane >= l0 && we.out_len ? 1u + we.out_len / ADLER_CHUNK : 0u;
+      uint32_t iv_incl = counts_here ? 1u + we.pad : 0u, ch_incl = counts_here && we.out_len ? 1u + we.out_len / ADLER_CHUNK : 0u;
       const uint32_t iv_own = iv_incl, ch_own = ch_incl;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
@@ -1206,15 +1247,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
         const uint32_t iu = (uint32_t)__shfl_up((int)iv_incl, d), cu = (uint32_t)__shfl_up((int)ch_incl, d);
         if ((int)lane >= d) { incl += up; iv_incl += iu; ch_incl += cu; }
       }
-      const bool fits = out + incl <= room && out + incl <= MAX_STREAM_LEN && (uint64_t)k + (lane - l0) < chain_cap;
+      const bool fits = out + incl <= room && out + incl <= MAX_STREAM_LEN && (uint64_t)k + (counted - 1u) < chain_cap;
       const unsigned long long from_l0 = ~0ull << l0;
-      const unsigned long long bad = __builtin_amdgcn_ballot_w64(lane >= l0 && !(follows && sound && fits)) & from_l0;
-      const unsigned long long fin = __builtin_amdgcn_ballot_w64(lane >= l0 && we.final_block != 0) & from_l0;
+      const unsigned long long bad = __builtin_amdgcn_ballot_w64(counts_here && !(follows && sound && fits)) & from_l0;
+      const unsigned long long fin = __builtin_amdgcn_ballot_w64(counts_here && we.final_block != 0) & from_l0;
       uint32_t last = bad ? (uint32_t)__builtin_ctzll(bad) : 64u;  // the run: lanes [l0, last)
       if (fin && (uint32_t)__builtin_ctzll(fin) < last) last = (uint32_t)__builtin_ctzll(fin) + 1u;  // (a final block ends it, and the chain)
-      if (last >= l0 + 2u) {
-        if (lane >= l0 && lane < last) {
-          const uint32_t r = k + (lane - l0);
+      const uint32_t run_blocks = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(counts_here && lane < last));
+      if (run_blocks >= 2u) {
+        if (counts_here && lane < last) {
+          const uint32_t r = k + (counted - 1u);
           BlockStart b;
           b.bit = wbit; b.out_pos = (uint32_t)(out + incl - len64); b.chunk0 = chunks + ch_incl - ch_own;
           chain[r] = b;
@@ -1223,12 +1265,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
           iv.first = intervals + iv_incl - iv_own; iv.ck = wsrc;
           chain_iv[r] = iv;
         }
-        const int ll = (int)last - 1;
+        int ll = (int)last - 1;  // the run's last listing that counts
+        ll = __builtin_amdgcn_readlane(first_of, ll);
         const uint64_t tot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(incl >> 32), ll) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, ll);
         out += tot;
         intervals += (uint32_t)__builtin_amdgcn_readlane((int)iv_incl, ll);
         chunks += (uint32_t)__builtin_amdgcn_readlane((int)ch_incl, ll);
-        k += last - l0;
+        k += run_blocks;
         if (__builtin_amdgcn_readlane((int)we.final_block, ll) != 0) break;
         bit = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(we.end_bit >> 32), ll) << 32) |
               (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)we.end_bit, ll);

@@ -54,7 +54,7 @@ struct BlocksJob {
   uint32_t stream;           // its descriptor and result
   uint32_t first_cap, cand_cap, rec_cap, chain_cap;
   uint32_t n;                // this launch's waves of the stream: explorers, or intervals / blocks of the token run
-  uint32_t n_blocks;         // blocks of its chain
+  uint32_t n_blocks;         // blocks of its chain (the explore launch: how many of its n waves are explorers, the rest followers)
   uint32_t out_len;          // its output bytes
   int32_t follow, pad;
   FindCounts *counts;
