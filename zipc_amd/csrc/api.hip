@@ -223,7 +223,7 @@ const Tuning &tuning() {
     x.slice_min = num("ZIPC_HIP_SLICE_MIN", 0);
     x.inflate_blocks = num("ZIPC_HIP_INFLATE_BLOCKS", 1) != 0;
     x.inflate_follow = (int)num("ZIPC_HIP_INFLATE_FOLLOW", -1);
-    x.explore_stride = (uint64_t)num("ZIPC_HIP_EXPLORE_STRIDE", 8192);
+    x.explore_stride = (uint64_t)num("ZIPC_HIP_EXPLORE_STRIDE", 16384);
     x.resolve_hops0 = (int)num("ZIPC_HIP_RESOLVE_HOPS0", 256);
     x.resolve_hops1 = (int)num("ZIPC_HIP_RESOLVE_HOPS1", 256);
     x.checksum_fused = num("ZIPC_HIP_CHECKSUM_FUSED", 1) != 0;

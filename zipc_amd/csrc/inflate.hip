@@ -583,6 +583,7 @@ struct Explore {
   BlockRec *recs;
   uint32_t *n_recs;
   uint32_t cap, max_recs, inside_fixed;
+  uint32_t *fate;  // (LDS, 3 words, or null) what became of an explorer: blocks listed, and the bit of the header it stood behind at the end
   uint64_t stop_bit;
   // every IM_DRY wave: where the checkpoints of the block being walked are gathered (2 * CK_MAX words of LDS) and,
   // for an explorer, where the listed blocks' go
@@ -601,7 +602,7 @@ static_assert(CK_MAX == BLOCK_CK_MAX, "kernels.h");
 constexpr uint64_t NO_BIT = ~0ull;
 __device__ __forceinline__ Explore no_explore() {
   Explore X;
-  X.recs = nullptr; X.n_recs = nullptr; X.cap = 0; X.max_recs = 0; X.inside_fixed = 0; X.stop_bit = 0;
+  X.recs = nullptr; X.n_recs = nullptr; X.cap = 0; X.max_recs = 0; X.inside_fixed = 0; X.stop_bit = 0; X.fate = nullptr;
   X.ck_lds = nullptr; X.cks = nullptr; X.resume = 0; X.resume_out = 0; X.resume_bit = 0; X.until_bit = NO_BIT;
   X.est_bits = 0;
   return X;
@@ -899,6 +900,11 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
     if (d.phase == PH_DONE && d.q_count == 0) break;
   }
 
+  if (MULTI && X.fate != nullptr && lane == 0) {
+    X.fate[0] = n_listed;
+    X.fate[1] = (uint32_t)blk_hdr_bit;
+    X.fate[2] = (uint32_t)(blk_hdr_bit >> 32);
+  }
   BlockEnd e;
   e.status = d.status;
   e.final_block = (uint32_t)d.final_block;
@@ -1098,6 +1104,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     const BlocksJob *__restrict__ jobs, uint32_t stride_bits) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   __shared__ uint32_t ck_lds[2 * CK_MAX];
+  __shared__ uint32_t fate[3];
   const BlocksJob J = jobs[blockIdx.y];
   FindCounts *counts = J.counts;
   const FindCounts *from = counts;
@@ -1127,10 +1134,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
     X.inside_fixed = 0;
     X.stop_bit = at.bit;  // (the first block it lists starts there: one block)
   }
-  if (at.bit + 64u > descs[J.stream].src_len * 8u) return;
   X.ck_lds = ck_lds; X.cks = cks;
-  inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[J.stream], at, nullptr, span_scratch + (size_t)b * SPAN_IDX_ENTRIES,
-                             nullptr, CRC_NOP, X);
+  X.fate = fate;
+  // An explorer that meets what reads as an end-of-block code before its walk has fallen into step (seven zero bits:
+  // one symbol in 128, and falling into step takes a few dozen) goes on to read a header that is none, and three of
+  // four such headers end it there.  Of the three or four explorers that start inside a block of 30 KiB, all ended that
+  // way for one block in 130, which the chain's one wave then walked itself (0.35 ms each, one after the other).
+  // Such an explorer starts again behind the false end, on what is once more taken for a symbol: a few times.
+  for (int attempt = 0; attempt < 4; attempt++) {
+    if (at.bit + 64u > descs[J.stream].src_len * 8u) return;
+    const BlockEnd e = inflate_wave<IM_DRY, true>(lds_raw, src_arena, dst_arena, descs[J.stream], at, nullptr,
+                                                  span_scratch + (size_t)b * SPAN_IDX_ENTRIES, nullptr, CRC_NOP, X);
+    __syncthreads();
+    const uint32_t listed = fate[0];
+    uint64_t stood = (uint64_t)fate[1] | ((uint64_t)fate[2] << 32);
+    __syncthreads();
+    if (stood == NO_BIT) stood = e.end_bit + 1u;  // (it met a code that is none before any end of block: on, a bit further)
+    if (e.status == ST_OK || listed != 0u || !X.inside_fixed || stood == NO_BIT || stood <= at.bit || stood >= X.stop_bit) return;
+    at.bit = stood;
+  }
 }
 
 // the listed blocks in stream order: each finds its rank (they are few; the same block may be listed more than once)

@@ -32,7 +32,7 @@ struct Tuning {
   // ---- inflate of one long stream by blocks (api.hip inflate_by_blocks)
   bool inflate_blocks;         // ZIPC_HIP_INFLATE_BLOCKS=0  the stream's one wave instead
   int inflate_follow;          // ZIPC_HIP_INFLATE_FOLLOW  -1 (default): sources followed inside the token run in calls of 32 MiB of output and more; 0 / 1 never / always
-  uint64_t explore_stride;     // ZIPC_HIP_EXPLORE_STRIDE  input bytes between two explorers (default 8192)
+  uint64_t explore_stride;     // ZIPC_HIP_EXPLORE_STRIDE  input bytes between two explorers (default 16384: an explorer that ends on a false end-of-block starts again, inflate.hip)
   int resolve_hops0, resolve_hops1;  // ZIPC_HIP_RESOLVE_HOPS0 / 1  links a thread follows in the first / a later resolve round (default 256)
   // ---- checksums
   bool checksum_fused;         // ZIPC_HIP_CHECKSUM_FUSED=0  both checksums of one buffer by two passes instead of one
