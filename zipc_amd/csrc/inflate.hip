@@ -1370,7 +1370,8 @@ __global__ __launch_bounds__(256) void inflate_tok_init_kernel(const BlocksJob *
 // checkpoint builds the block's tables from the header first.  The last wave of a block must end where and with as
 // many bytes as the dry run did; the others leave at or behind the next checkpoint (what they decode behind it the
 // next wave decodes too: the same literals, and for a match byte a source on the same chain of copies).
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_blocks_token_kernel(
+// (two waves per SIMD: its LDS -- the stream's 10 KiB and 8 KiB of source positions -- lets a CU hold eight workgroups)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void inflate_blocks_token_kernel(
     const uint8_t *__restrict__ src_arena, uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
     const BlocksJob *__restrict__ jobs) {
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
