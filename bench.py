@@ -21,10 +21,15 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT set), relay
 line and exits non-zero if any worker failed.  Under torch.distributed.run the environment's
 WORLD_SIZE must equal --gpus.
 
-Extra objects in the JSON line: "roofline" (dominant kernel: algorithmic bytes / HIP-event
-duration vs the 8 TB/s HBM peak; its "others" lists the step's other kernels the same way), "cpu_baseline" (the oracle's C port timed on this host on a
-bounded sample: 1 thread and all host threads; rank 0 / N=1 only), "kernels_ms_per_step",
-"inflate_gib_s" / "deflate_gib_s", "e2e_gib_s" (PCIe-inclusive host forms, untimed leg).
+Extra objects in the JSON line: "roofline" (dominant kernel: the algorithmic bytes of the streams ONE launch covers --
+a step is two slices on two queues, a launch half the batch -- over its HIP-event duration, against the 8 TB/s HBM peak;
+its "others" lists the step's other kernels the same way, "deflate_pipeline" / "inflate" the directions over their wall
+time; --alone-pass adds every kernel launched alone over the whole batch), "cpu_baseline" (the oracle's C port timed
+on this host on a bounded sample: 1 thread and all host threads, the headline's workload and the legs'; with the digests
+of sampled streams the legs check their bytes against; rank 0 / N=1 only), "kernels_ms_per_step", "inflate_gib_s" /
+"deflate_gib_s", and the untimed legs, each with its parity sample and its share of the roofline: "e2e_gib_s"
+(PCIe-inclusive host forms), "text_gib_s", "best_gib_s", "corpus_gib_s", "one_stream_ms", "long_members" (a call of 64
+members of 1 MiB), "c4_leg".
 """
 import argparse
 import json
