@@ -697,6 +697,59 @@ def test_a_call_of_long_and_short_streams(gpu_ctx, oracle):
             assert bool((out[dst_off[i] + caps[i]:dst_off[i + 1]] == 0xA5).all()), (name, crc_op)
 
 
+def test_the_long_members_among_thousands_of_short_ones(gpu_ctx, oracle):
+    """An archive's shape: 4 300 short members and six long ones in ONE call.  The long ones go by blocks, the short
+    ones by their one waves in two slices on two queues over the marked copy of the descriptors, one CRC-32 pass over
+    all of them -- every member's bytes and CRC-32 as zlib has them, the damaged long one as the oracle has it."""
+    import torch
+    from zipc_amd import batch
+
+    rnd = random.Random(31)
+    plain = {k: v for k, v in _one_stream_sources(1300000)}
+    longs = [plain["text"], plain["records"], plain["symbols"][:1100000], plain["text"][200000:1250000], plain["records"][:1048576]]
+    members = []
+    for i in range(4300):
+        n = rnd.choice((0, 1, 17, 300, 2000, 5000))
+        o = rnd.randrange(1000000)
+        members.append(plain["text"][o:o + n] if i % 3 else plain["symbols"][o:o + n])
+    at = [700, 701, 2222, 4000, 4299]
+    for k, a in enumerate(at):
+        members[a] = longs[k]
+    raws = [_raw_zlib(m, 6) for m in members]
+    bad = 3000  # a long member with a flipped bit
+    members[bad] = plain["text"][:1200000]
+    good = _raw_zlib(members[bad], 6)
+    raws[bad] = good[:len(good) // 2] + bytes([good[len(good) // 2] ^ 4]) + good[len(good) // 2 + 1:]
+    n = len(members)
+    dev = torch.device("cuda", 0)
+    caps = [max(len(m), 8) for m in members]
+    src_off = np.cumsum([0] + [(len(r) + 3) & ~3 for r in raws])
+    dst_off = np.cumsum([0] + [(c + 15) & ~15 for c in caps])
+    arena = np.zeros(int(src_off[-1]) + 64, np.uint8)
+    for r, o in zip(raws, src_off):
+        arena[o:o + len(r)] = np.frombuffer(r, np.uint8)
+    descs = batch.make_descs(src_off[:-1], [len(r) for r in raws], dst_off[:-1], caps, limit=[len(m) for m in members])
+    src = torch.from_numpy(arena).to(dev)
+    dst = torch.zeros(int(dst_off[-1]) + 64, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(16 * n, dtype=torch.uint8, device=dev)
+    batch.inflate_batch(gpu_ctx, src, dst, batch.to_device(descs, dev), d_res, n, max(caps), oracle.CRC_CRC32)
+    assert gpu_ctx.last_inflate_blocks() >= 40, gpu_ctx.last_inflate_blocks()
+    res = batch.results_from_device(d_res)
+    out = dst.cpu().numpy()
+    st_bad, d_bad, c_bad = oracle.inflate(raws[bad], decompressed_size=len(members[bad]), crc_op=oracle.CRC_CRC32)
+    assert int(res["status"][bad]) == st_bad  # (a flipped bit may leave a stream that still decodes, to other bytes)
+    if st_bad == 0:
+        assert int(res["out_len"][bad]) == len(d_bad) and int(res["checksum"][bad]) == c_bad
+        assert out[dst_off[bad]:dst_off[bad] + len(d_bad)].tobytes() == d_bad
+    for i in range(n):
+        if i == bad:
+            continue
+        assert int(res["status"][i]) == 0 and int(res["out_len"][i]) == len(members[i]), (i, res[i])
+        assert int(res["checksum"][i]) == zlib.crc32(members[i]), i
+        if i in at or i % 97 == 0:
+            assert out[dst_off[i]:dst_off[i] + len(members[i])].tobytes() == members[i], i
+
+
 def test_one_stream_by_blocks_leaves_errors_to_the_streams_wave(gpu_ctx, oracle):
     """what the block path must not decide: damaged streams, cut streams, sizes that do not fit -- status and
     message of the oracle, whatever the blocks before the damage were decoded by"""
