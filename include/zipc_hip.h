@@ -236,7 +236,7 @@ typedef struct zipc_hip_stream_result_s {
  * on the context stream and NOT synchronised: call zipc_hip_synchronize (or
  * synchronise the stream) before reading results.  Two exceptions, both zipc_hip_inflate_batch: ONE stream with
  * max_dst_cap above ZIPC_HIP_MAX_STREAM_LEN (a stream of stored blocks beyond 4 GiB, below), and a call whose
- * max_dst_cap is a MiB and more (one stream: 96 KiB of input and more): the library reads the descriptors back, and
+ * max_dst_cap is 256 KiB and more (one stream: 40 KiB of input and more): the library reads the descriptors back, and
  * the call's long streams -- all of a few, the long ones among many short ones, none of thousands of equal ones: chosen
  * by what each way costs -- are decoded by a wave per BLOCK, side by side: block starts searched for, the blocks walked
  * at once, copies resolved afterwards (a MiB in 1.3-1.9 ms instead of 10-30, 64 of them in 5 instead of 17).  That path

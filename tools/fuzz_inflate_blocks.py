@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomized parity of the one-stream inflate (a wave per block, inflate.hip) against the oracle: sources of mixed
 content, the reference's encoder and zlib with random levels, memory levels, strategies and flushes, some streams
-damaged or cut or given too small a limit.  TRIALS (default 200), SEED.  BATCH=k: the same streams k to a call of the
+damaged or cut or given too small a limit.  TRIALS (default 200), SEED; SIZES=a,b,c: source sizes to draw from.  BATCH=k: the same streams k to a call of the
 batch form (zipc_hip_inflate_batch: the call's long streams go by blocks side by side, the others by their one waves),
 with short streams mixed in."""
 import os, random, sys, zlib
@@ -122,6 +122,7 @@ if __name__ == "__main__":
         blocks, bad = run_batches(TRIALS, SEED, int(os.environ["BATCH"]))
         print("fuzz_inflate_blocks: %d calls of up to %s streams (seed %d), %d blocks went by blocks, %d mismatches" % (TRIALS, os.environ["BATCH"], SEED, blocks, bad))
         sys.exit(1 if bad else 0)
-    by_blocks, bad = run(TRIALS, SEED)
+    sizes = tuple(int(x) for x in os.environ["SIZES"].split(",")) if os.environ.get("SIZES") else None
+    by_blocks, bad = run(TRIALS, SEED, sizes) if sizes else run(TRIALS, SEED)
     print("fuzz_inflate_blocks: %d trials (seed %d), %d went by blocks, %d mismatches" % (TRIALS, SEED, by_blocks, bad))
     sys.exit(1 if bad else 0)

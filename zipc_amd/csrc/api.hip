@@ -559,9 +559,12 @@ static int inflate_huge_stream(zipc_hip_ctx *ctx, const void *d_src_arena, void 
 // that is not a chain of dynamic blocks behind its first block, anything the dry run or the chain did not like: the
 // one-wave kernel owns the reference's messages.  It SYNCHRONISES the context's stream.  ZIPC_HIP_INFLATE_BLOCKS=0
 // turns it off.
-constexpr size_t BLOCKS_MIN_SRC = 96u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
+constexpr size_t BLOCKS_MIN_SRC = 40u << 10, BLOCKS_MAX_SRC = 0x1FFFFFFFull;  // (bit offsets are 32-bit words here)
 constexpr uint32_t BLOCKS_CAND_CAP = 65536, BLOCKS_REC_CAP = 262144;
-constexpr size_t BLOCKS_BATCH_MIN_DST = 1u << 20, BLOCKS_MAX_STREAMS = 1u << 20;  // (a call whose descriptors are worth reading back: its longest stream alone is 15 ms of one wave)
+// (a call whose descriptors are worth reading back: its longest stream alone is 4 ms of one wave.  Round 4 began with
+// 1 MiB here and 96 KiB of input above: 64 x 512 KiB of text 8.5 -> 4.0 ms, 64 x 256 KiB 4.3 -> 2.6, one stream of
+// 256 KiB 3.8 -> 1.3, of 128 KiB 2.0 -> 1.2; the block path's own floor is a good millisecond)
+constexpr size_t BLOCKS_BATCH_MIN_DST = 256u << 10, BLOCKS_MAX_STREAMS = 1u << 20;
 // tok[] and the two lists: 12 bytes of scratch per output byte.  Streams share a group while their capacities fit
 // this much of it (a stream that needs more has a group to itself, and its scratch goes back afterwards)
 constexpr size_t BLOCKS_TOK_BUDGET = (size_t)1 << 30;
