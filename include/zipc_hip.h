@@ -271,6 +271,18 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
 int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len,
                              int want_crc32, int want_adler32, uint32_t *d_out);
 
+/* Tests only: the hash-chain links (zipc_deflate.ml:1150-1152, insert_hash: per position the distance to the previous
+ * position of equal hash, 0 beyond 32768) of a batch of device-resident streams as ONE of the library's two chain
+ * kernels makes them -- which = 0: by ordered LDS exchange (ZIPC_HIP_ERR_HIP where the context's probe failed), 1: by
+ * the kernel that orders equal hashes itself -- copied to d_links (links_cap 16-bit slots, at least
+ * zipc_hip_debug_chain_positions(n_streams, total_src_len); slots no kernel writes are zero) with every stream's first
+ * slot in d_pos_base (n_streams 64-bit words, may be null).  The batch must fit one pass (8 GiB of source).  The
+ * suite requires the two kernels' links to be equal over the benchmark's whole batches (tests/test_gpu_limits.py). */
+size_t zipc_hip_debug_chain_positions(size_t n_streams, size_t total_src_len);
+int zipc_hip_debug_chain_links(zipc_hip_ctx *ctx, const void *d_src_arena, const zipc_hip_stream_desc *d_descs,
+                               size_t n_streams, size_t max_src_len, size_t total_src_len, int which, void *d_links,
+                               size_t links_cap, void *d_pos_base);
+
 /* grow the context scratch up front (keeps hipMalloc out of timed regions) */
 int zipc_hip_reserve(zipc_hip_ctx *ctx, size_t n_streams, size_t max_src_len,
                      size_t total_src_len);

@@ -74,3 +74,66 @@ def test_matches_at_the_edge_of_the_window(gpu_ctx, oracle):
     for s, (st, comp, adler) in zip(range(30, 40), got):
         st0, c0, a0 = oracle.deflate(util.far_match_data(s), level=2, crc_op=oracle.CRC_ADLER32)
         assert st == 0 and comp == c0 and adler == a0, s
+
+
+@pytest.mark.parametrize("shape", ["c2-16384x64KiB-4bit", "c4-1024x1MiB-3bit", "text-16384x64KiB", "ragged"])
+def test_both_chain_kernels_make_the_same_links(gpu_ctx, shape):
+    """insert_hash (zd.ml:1150-1152) two ways over WHOLE batches: lz_chain_xchg_kernel, whose order of equal hashes
+    inside one LDS exchange is a property of the hardware that the context's probe vouches for, against lz_chain_kernel,
+    which orders them itself -- every link of the benchmark's batch, of 1024 members of C4's shape, of the text batch
+    and of a batch of ragged lengths (the fuzz runs and the full-size tests compare a few streams with the oracle; a
+    rare reordering under load would only show in a stream nobody sampled)."""
+    import torch
+
+    from zipc_amd import batch, synth
+
+    assert gpu_ctx.lds_exchange_ordered()
+    dev = torch.device("cuda", 0)
+    if shape.startswith("c2"):
+        n, L = 16384, 65536
+        src = synth.batch_bytes_torch(2, 0, n, L, 4, dev)
+        lens = [L] * n
+    elif shape.startswith("c4"):
+        n, L = 1024, 1 << 20
+        src = synth.batch_bytes_torch(4, 0, n, L, 3, dev)
+        lens = [L] * n
+    elif shape.startswith("text"):
+        import io
+        import zipfile
+
+        z = zipfile.ZipFile(io.BytesIO(util.zip_docs()))
+        app, rfc = z.read("zip-docs/APPNOTE.TXT"), z.read("zip-docs/rfc1951.txt")
+        n, L = 16384, 65536
+        pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+        src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(n)), np.uint8).copy()).to(dev)
+        lens = [L] * n
+    else:  # lengths from 0 to 300 000, text, symbols, runs and random bytes: the window's edge, short streams, streams of one tile and of many
+        rng = np.random.default_rng(77)
+        lens = [0, 1, 3, 4, 5, 63, 64, 65, 1023, 8192, 8193, 32767, 32768, 32769, 65535, 65536, 65537, 100000, 262144, 300000]
+        lens += [int(x) for x in rng.integers(0, 200000, 400)]
+        n = len(lens)
+        parts = []
+        for i, ln in enumerate(lens):
+            kind = i % 4
+            if kind == 0:
+                parts.append(rng.integers(0, 1 << (1 + i % 8), ln, dtype=np.uint8).tobytes())
+            elif kind == 1:
+                parts.append((util.zip_docs() * (ln // 50000 + 1))[:ln])
+            elif kind == 2:
+                parts.append((bytes([i & 255]) * 700 + bytes(range(256)) * 3)[: max(1, min(ln, 1468))] * (ln // 1400 + 1))
+                parts[-1] = parts[-1][:ln]
+            else:
+                parts.append(rng.integers(0, 256, ln, dtype=np.uint8).tobytes())
+        src = torch.from_numpy(np.frombuffer(b"".join(parts) + b"\0" * 64, np.uint8).copy()).to(dev)
+    off = np.cumsum([0] + lens[:-1]).astype(np.uint64)
+    descs = batch.make_descs(off, lens, np.zeros(n, np.uint64), [0] * n)
+    d_descs = batch.to_device(descs, dev)
+    total, longest = int(sum(lens)), int(max(lens))
+    a, base_a = batch.debug_chain_links(gpu_ctx, src, d_descs, n, longest, total, 0)
+    b, base_b = batch.debug_chain_links(gpu_ctx, src, d_descs, n, longest, total, 1)
+    assert torch.equal(base_a, base_b)
+    if not torch.equal(a, b):
+        bad = torch.nonzero(a != b).flatten()
+        assert False, "%d links differ, the first at slot %d (exchange %d, peel %d)" % (
+            bad.numel(), int(bad[0]), int(a[bad[0]]) & 0xFFFF, int(b[bad[0]]) & 0xFFFF)
+    assert int(torch.count_nonzero(a)) > total // 8 or shape == "ragged"  # (the links are there: most positions of these inputs have one)

@@ -61,6 +61,8 @@ SYMBOLS = [
     ("zipc_hip_last_inflate_blocks", C.c_uint, [_P]),
     ("zipc_hip_lds_exchange_ordered", C.c_int, [_P]),
     ("zipc_hip_debug_set_slices", None, [C.c_long]),
+    ("zipc_hip_debug_chain_positions", _SZ, [_SZ, _SZ]),
+    ("zipc_hip_debug_chain_links", C.c_int, [_P, _P, _P, _SZ, _SZ, _SZ, C.c_int, _P, _SZ, _P]),
     ("zipc_hip_strerror", C.c_char_p, [C.c_int]),
     ("zipc_hip_set_profiling", C.c_int, [_P, C.c_int]),
     ("zipc_hip_set_adler_rfc1950", C.c_int, [_P, C.c_int]),

@@ -68,6 +68,23 @@ def deflate_batch(ctx: Context, src, dst, descs_dev, results_dev, n_streams: int
         ctx.synchronize()
 
 
+def debug_chain_links(ctx: Context, src, descs_dev, n_streams: int, max_src_len: int, total_src_len: int, which: int):
+    """Tests only (include/zipc_hip.h zipc_hip_debug_chain_links): the hash-chain links of a device-resident batch as the
+    library's chain kernel `which` makes them (0: ordered LDS exchange, 1: the kernel that orders equal hashes itself):
+    (links, pos_base) as an int16 and an int64 cuda tensor."""
+    import torch
+
+    _sync_torch(src)
+    cap = int(lib().zipc_hip_debug_chain_positions(n_streams, total_src_len))
+    links = torch.empty(cap, dtype=torch.int16, device=src.device)
+    base = torch.empty(n_streams, dtype=torch.int64, device=src.device)
+    torch.cuda.current_stream(src.device).synchronize()
+    ctx.check(lib().zipc_hip_debug_chain_links(ctx.handle, src.data_ptr(), descs_dev.data_ptr(), n_streams, max_src_len,
+                                               total_src_len, which, links.data_ptr(), cap, base.data_ptr()))
+    ctx.synchronize()
+    return links, base
+
+
 def checksum_device(ctx: Context, buf, want_crc32=True, want_adler32=True):
     """(crc32, adler32) of a uint8 cuda tensor, computed on the device."""
     import torch

@@ -971,6 +971,18 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
   return ZIPC_HIP_OK;
 }
 
+size_t zipc_hip_debug_chain_positions(size_t n_streams, size_t total_src_len) { return zd::debug_chain_positions(n_streams, total_src_len); }
+int zipc_hip_debug_chain_links(zipc_hip_ctx *ctx, const void *d_src_arena, const zipc_hip_stream_desc *d_descs, size_t n_streams,
+                               size_t max_src_len, size_t total_src_len, int which, void *d_links, size_t links_cap, void *d_pos_base) {
+  if (!ctx || !d_descs || !d_links || which < 0 || which > 1 || n_streams == 0 || n_streams > 0x7FFFFFFFull || max_src_len > MAX_STREAM_LEN)
+    return ZIPC_HIP_ERR_INVALID_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, ctx->ensure(ctx->deflate_scratch, deflate_scratch_bytes(n_streams, max_src_len, total_src_len, ZIPC_HIP_LEVEL_DEFAULT)));
+  HIP_TRY(ctx, zd::debug_chain_links(ctx, (const uint8_t *)d_src_arena, (const StreamDesc *)d_descs, n_streams, max_src_len, total_src_len,
+                                     which, (uint16_t *)d_links, links_cap, (uint64_t *)d_pos_base));
+  return ZIPC_HIP_OK;
+}
+
 int zipc_hip_reserve(zipc_hip_ctx *ctx, size_t n_streams, size_t max_src_len, size_t total_src_len) {
   if (!ctx) return ZIPC_HIP_ERR_INVALID_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));

@@ -94,6 +94,10 @@ hipError_t crc32_finish_launch(zipc_hip_ctx *ctx, int mode, const StreamDesc *d_
 bool xchg_order_probe(zipc_hip_ctx *ctx);
 // deflate.hip: bytes of scratch the pipeline needs, and the pipeline itself
 size_t deflate_scratch_bytes(size_t n_streams, size_t max_src_len, size_t total_src_len, int level);
+// deflate.hip (tests): the links one of the two chain kernels makes of a batch, and how many link slots that takes
+hipError_t debug_chain_links(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *d_descs, size_t n, size_t max_src_len,
+                             size_t total_src_len, int which, uint16_t *d_links, size_t links_cap, uint64_t *d_pos_base);
+size_t debug_chain_positions(size_t n, size_t total_src_len);
 hipError_t launch_deflate(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
                           const StreamDesc *d_descs, StreamResult *d_results, size_t n_streams,
                           size_t max_src_len, size_t total_src_len, int level, int crc_op);

@@ -2494,6 +2494,39 @@ __global__ __launch_bounds__(64) void deflate_stored_kernel(const uint8_t *__res
 }
 
 // ---------------------------------------------------------------------------------
+// Tests only (zipc_hip_debug_chain_links): the hash-chain links of a batch as ONE of the two kernels makes them -- by
+// ordered LDS exchange (which = 0) or by the kernel that orders equal hashes itself (1) -- copied out with the streams'
+// position bases, so that a test can require the two to be equal over whole batches (insert_hash, zd.ml:1150-1152: the
+// exchange kernel's order rests on a property of the hardware that only a probe vouches for).  The scratch is zeroed
+// first: what no kernel writes compares equal.
+hipError_t debug_chain_links(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *d_descs, size_t n, size_t max_src_len,
+                             size_t total_src_len, int which, uint16_t *d_links, size_t links_cap, uint64_t *d_pos_base) {
+  size_t per_group, group_total;
+  deflate_grouping(n, max_src_len, total_src_len, per_group, group_total);
+  if (per_group != n) return hipErrorInvalidValue;  // one group (a batch of up to 8 GiB)
+  DeflateScratch S = carve(ctx->deflate_scratch.p, n, total_src_len, LEVEL_DEFAULT);
+  if (S.cap_positions > links_cap) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(S.prev, 0, S.cap_positions * 2, ctx->cur);
+  if (e != hipSuccess) return e;
+  ZD_LAUNCH(ctx, "deflate_offsets", deflate_offsets_kernel, dim3(1), dim3(1024), 0, d_descs, (uint32_t)n, S, (uint64_t)max_src_len);
+  if (which == 0) {
+    if (!ctx->xchg_ordered) return hipErrorNotSupported;
+    ZD_LAUNCH(ctx, "lz_chain", lz_chain_xchg_kernel, dim3((unsigned)n), dim3(64 * XCHG_WAVES), 0, d_src, d_descs, S);
+  } else {
+    ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)n), dim3(CHAIN_THREADS), 0, d_src, d_descs, S);
+  }
+  e = hipMemcpyAsync(d_links, S.prev, S.cap_positions * 2, hipMemcpyDeviceToDevice, ctx->cur);
+  if (e == hipSuccess && d_pos_base) e = hipMemcpyAsync(d_pos_base, S.pos_base, n * 8, hipMemcpyDeviceToDevice, ctx->cur);
+  if (e == hipSuccess) e = hipGetLastError();
+  return e;
+}
+size_t debug_chain_positions(size_t n, size_t total_src_len) {
+  uint64_t P, Bk;
+  scratch_caps(n, total_src_len, P, Bk);
+  return (size_t)P;
+}
+
+// ---------------------------------------------------------------------------------
 static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, uint8_t *d_dst,
                                        const StreamDesc *d_descs, StreamResult *d_results, size_t n,
                                        size_t max_src_len, size_t total_src_len, int level, int crc_op);

@@ -75,6 +75,11 @@ ZD_HD uint32_t common_prefix_t(const uint8_t *s, uint32_t q, uint32_t p, uint32_
   return i;
 }
 
+// (A chain link out of the LDS window is read as it is, 16 bits.  ds_read_u16 at a random address of 2 mod 4 measures 41
+// clocks per wave instruction where ds_read_b32 measures 6 -- tools/probes/lds_costs.hip -- and half of a walk's links sit at
+// such addresses; but the walks wait for vector instruction issue, not for the LDS: reading the aligned word that holds
+// the link and taking the half out of it cost lz_match 6 % on the benchmark's symbols, 4 % on text and 11 % on 3-bit
+// symbols, round 5.)
 // find_backref zd.ml:1176-1201 as a pure function of the position: walks the
 // hash chain of p (prev[] holds the distance to the previous position with the
 // same hash, 0 = none within 32768) and returns, packed like the reference's
@@ -390,6 +395,7 @@ struct ScanProbe {
   uint32_t b0, b1;  // its bytes at best_len - 1 and best_len
   uint32_t dn;      // its link
 };
+template <bool WORDS>
 ZD_HD ScanProbe scan_run_probe(const ScanRun &r, const uint8_t *s, const uint16_t *prev) {
   ScanProbe x;
   x.q = r.q - (r.state == RUN_WALK ? r.dn : 0u);
@@ -412,8 +418,9 @@ ZD_HD void scan_run_take(ScanRun &r, const ScanProbe &x, uint32_t K, uint32_t Kq
   r.dn = x.dn;
   r.state = w ? after : r.state;
 }
+template <bool WORDS>
 ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
-  const ScanProbe x = scan_run_probe(r, s, prev);
+  const ScanProbe x = scan_run_probe<WORDS>(r, s, prev);
   scan_run_take(r, x, K, Kq);
 }
 // the full compare of a run that stands on a candidate which passed the byte test
@@ -469,7 +476,7 @@ ZD_HD void lz_match_scan_serial(const uint8_t *s, uint32_t len, uint32_t first, 
     ScanRun r;
     scan_run_start<WORDS>(r, s, len, p, pend, prev, (uint32_t)K);
     while (r.state != RUN_FIN) {
-      for (int i = 0; i < SCAN_ROUNDS; i++) scan_run_step(r, s, prev, (uint32_t)K, (uint32_t)Kq);
+      for (int i = 0; i < SCAN_ROUNDS; i++) scan_run_step<WORDS>(r, s, prev, (uint32_t)K, (uint32_t)Kq);
       scan_run_compare<WORDS>(r, s, prev, (uint32_t)K, (uint32_t)Kq);
     }
     out[p] = scan_run_result(r, (uint32_t)Kq);
@@ -585,7 +592,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_
       iters++;
       ScanProbe x[NP];
 #pragma unroll
-      for (int i = 0; i < NP; i++) x[i] = scan_run_probe(r[i], s, prev);
+      for (int i = 0; i < NP; i++) x[i] = scan_run_probe<true>(r[i], s, prev);
 #pragma unroll
       for (int i = 0; i < NP; i++) {
         scan_run_take(r[i], x[i], (uint32_t)K, (uint32_t)Kq);
