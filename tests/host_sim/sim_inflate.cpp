@@ -271,13 +271,7 @@ extern "C" int sim_inflate(const uint8_t *src, uint64_t src_len, uint8_t *dst, u
           const uint32_t out_before = d.out_pos;
           const int sr = span_model(d, L, src, dst, span_desc);
           if (sr != SPAN_NONE) {
-            d.span_off = sr == SPAN_OFF;
-            if (sr == SPAN_LATER) {
-              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
-              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
-            } else {
-              d.span_fails = 0;
-            }
+            span_after(d, sr, d.out_pos != out_before);
             break;
           }
           d.span_off = 1;
@@ -374,13 +368,7 @@ extern "C" int sim_inflate_token(const uint8_t *src, uint64_t src_len, uint8_t *
           const uint32_t out_before = d.out_pos;
           const int sr = span_model(d, L, src, dst, descending != 0, tok.data(), follow ? srcpos : nullptr, cut_every ? cut_every : 0xFFFFFFFFu);
           if (sr != SPAN_NONE) {
-            d.span_off = sr == SPAN_OFF;
-            if (sr == SPAN_LATER) {
-              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
-              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
-            } else {
-              d.span_fails = 0;
-            }
+            span_after(d, sr, d.out_pos != out_before);
             break;
           }
           if (!cut_every) d.span_off = 1;  // (a span cut short is tried again behind a few plain symbols)

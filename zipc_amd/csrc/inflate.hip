@@ -822,15 +822,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
 #endif
           if (sr != SPAN_NONE) {
             uniformize(d);
-            d.span_off = sr == SPAN_OFF;
-            if (sr == SPAN_LATER) {
-              // the wide turns take the next granule at least; a span that committed nothing costs about what
-              // 150 bytes cost them, so the wait doubles while spans keep failing (runs of runs) up to 1 Ki words
-              d.span_fails = d.out_pos != out_before ? 0u : (d.span_fails < 7u ? d.span_fails + 1u : 7u);
-              d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << d.span_fails);
-            } else {
-              d.span_fails = 0;
-            }
+            span_after(d, sr, d.out_pos != out_before);  // (inflate_span.h: when the next span is tried, and how large)
             ZD_PH(ph_plain);  // (timing build: the span's clocks are booked as "plain")
             break;  // the input ring starts over at the new position
           }

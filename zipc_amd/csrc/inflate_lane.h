@@ -174,7 +174,7 @@ struct InflateLane {
   uint32_t prev_block_bits;        // bits of the previous compressed block's symbols (0: none yet): sizes the regions
   int32_t span_off;                // the rest of this block is left to the wide turns
   uint32_t span_retry_word;        // no span before the input has reached this word (after one that met a stretch it cannot take)
-  uint32_t span_fails;             // such spans in a row that committed nothing: the wait doubles with each
+  uint32_t span_fails;             // such spans in a row that committed nothing (the wait doubles with each) | SPAN_SMALL (inflate_span.h span_after)
   int32_t fixed_lazy;              // > 0: a fixed block whose tables are not built yet; symbols left before they are
 
   ZD_HD void fail(uint32_t st) { status = st; phase = PH_DONE; }

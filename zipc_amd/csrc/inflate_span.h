@@ -77,7 +77,9 @@ constexpr uint32_t SPAN_BITS_OFF = LDS_SPAN_BITS_BYTE;   // u32[128 + 2]: a bit 
 constexpr uint32_t SPAN_IDX_ENTRIES = 64 * SPAN_K_MAX;
 static_assert(SPAN_TILE + 16 == LDS_SPAN_TILE_BYTES && SPAN_RING * 64 * 4 <= LDS_WIDE_LIT * 4 && SPAN_IDX_ENTRIES * 2 <= SPAN_TILE, "inflate_lane.h's map");
 
-enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_LATER = 2, SPAN_OFF = 3 };
+enum : int { SPAN_NONE = 0, SPAN_AGAIN = 1, SPAN_LATER = 2, SPAN_OFF = 3, SPAN_POOR = 4 };
+// d.span_fails: bits 0-3 the count that doubles the wait, SPAN_SMALL: the next span takes regions of SPAN_K_MIN granules
+constexpr uint32_t SPAN_FAILS_MASK = 15u, SPAN_SMALL = 0x100u;
 constexpr uint32_t SPAN_RETRY_WORDS = 8;  // input words (a granule) the wide turns take before a span is tried again
 enum : uint32_t { WK_NONE = 0, WK_END = 1, WK_STOP = 2, WK_MERGED = 4, WK_NOMERGE = 5 };
 
@@ -522,6 +524,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   uint32_t K = (est + 64u * SPAN_G - 1u) / (64u * SPAN_G);
   if (K < SPAN_K_MIN) K = SPAN_K_MIN;
   if (K > SPAN_K_MAX) K = SPAN_K_MAX;
+  if (wv::uni(d.span_fails) & SPAN_SMALL) K = SPAN_K_MIN;  // behind a span whose walks did not fall into step: a cheap one (span_after)
   // the span: TG granules -- all the input allows, 64 regions of K at most -- over as many lanes as get
   // SPAN_K_MIN each; cut evenly, lane i starts at granule i * TG / n_lanes
   uint32_t TG = usable / SPAN_G;
@@ -1127,7 +1130,35 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   // block's end the chain got: a kilobyte said twice in a row in the middle of a block of text left the 60 KiB
   // behind it to the wide turns, 4.7 ms of a stream that takes 1.4)
   if ((end_stop && !cut) || limit_cut) return SPAN_OFF;
-  return !progress || cut || poor ? SPAN_LATER : SPAN_AGAIN;
+  if (poor) return SPAN_POOR;
+  return !progress || cut ? SPAN_LATER : SPAN_AGAIN;
+}
+
+// What the stream's wave does with a span's verdict (the same lines for the kernel and for tests/host_sim).  A span that
+// was cut (SPAN_LATER: a granule too rich for a tile, a refused tile) leaves the next granule at least to the wide turns,
+// and the wait doubles while such spans commit nothing (runs of runs), up to 1 Ki words.  A span whose chain of walks
+// broke within a quarter of its regions (SPAN_POOR) is evidence about the CODE, not about a stretch: walks from arbitrary
+// bits fall into step because code lengths differ, and where nearly all symbols of a block have one length -- base64,
+// hex dumps, uniform bytes: corpus chunks of tests/golden/zlib_streams.json, 6-bit codes for 64 letters -- a walk that
+// starts between two symbols stays between them.  Every such span costs its whole first pass over 64 regions (about
+// 1 500 wave steps at 18 granules a region) and commits a region or two, which the wide turns decode in a tenth of
+// that: 34 spans and 4.1 ms for one such 64 KiB stream where a stream of the benchmark's symbols takes 0.9.  So after a
+// poor span the wait quadruples (to 4 Ki words: the rest of most blocks) and the next span is a small one, regions of
+// SPAN_K_MIN granules, which costs a quarter to find out whether the walks meet again; a span that does well ends both.
+ZD_HD void span_after(InflateLane &d, int sr, bool progressed) {
+  d.span_off = sr == SPAN_OFF;
+  const uint32_t cnt = d.span_fails & SPAN_FAILS_MASK;
+  if (sr == SPAN_POOR) {
+    const uint32_t c = cnt + 2u < 9u ? cnt + 2u : 9u;
+    d.span_fails = c | SPAN_SMALL;
+    d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << c);
+  } else if (sr == SPAN_LATER) {
+    const uint32_t c = progressed ? 0u : (cnt < 7u ? cnt + 1u : 7u);
+    d.span_fails = c | (progressed ? 0u : d.span_fails & SPAN_SMALL);
+    d.span_retry_word = d.in_word + (SPAN_RETRY_WORDS << c);
+  } else {
+    d.span_fails = 0;
+  }
 }
 
 }  // namespace zd
