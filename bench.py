@@ -192,24 +192,35 @@ def measured_traffic(kernel):
 SHADER_CLOCK_HZ = 2.38e9  # s_memtime against s_memrealtime under load, profiles/r01_match_phases.txt
 
 
-def issue_bound(kernel, launch_ms):
-    """What the instruction-issue ports allow for `kernel`, from the committed SQ counter pass
-    (profiles/*sq_counters.json, tools/exp_sq_counters.sh): a CDNA4 SIMD is 32 lanes wide and issues a
-    wave64 vector instruction over 2 clocks (1024 SIMDs; ONE wave's stream sustains one per 4,
-    MI355X_MICROARCH.md 'Wave scheduling' -- rounds 1 and 2 priced the SIMD at 4 and called kernels
-    vector-bound that are not), a CU one scalar instruction per clock for all its waves (256 CUs).
-    None of the path's kernels is bound by HBM or MFMA; the scalar port is the bound that is close."""
+VALU_CLOCKS = 4.0  # clocks of its SIMD per wave64 vector instruction of these kernels' mix (tools/probes/valu_costs.hip, below)
+
+
+def issue_bound(kernel, launch_ms, share=None):
+    """What instruction issue allows for `kernel`, from the committed SQ counter pass (profiles/*sq_counters.json,
+    tools/exp_sq_counters.sh).  Round 5 measured the vector side on the hardware (tools/probes/valu_costs.hip, four
+    waves per SIMD): v_add / sub / and / or / xor / lshrrev_b32 and v_fma_f32 take 2.4-2.7 clocks of their SIMD per
+    wave64 instruction -- the guide's SIMD-32 figure -- but everything else these kernels are made of (v_cmp,
+    v_cndmask, v_lshlrev, v_lshl_or, v_and_or, v_bfe, v_min / max, v_alignbit, v_ffbl, v_mbcnt, DPP moves, v_readlane)
+    takes 4.2-4.4, and a scalar instruction between vector ones about 2 of the same SIMD's issue clocks.  So the
+    vector side is priced at VALU_CLOCKS = 4 again (rounds 3 and 4 priced it at 2 and called the kernels scalar-bound:
+    they are vector-issue bound -- lz_match alone: 2.56 G vector instructions x 4 / 1024 SIMDs / clock = its time).
+    share: the part of the batch the priced launch covers; the counters are per launch of the counter run
+    ("launch_share" in the file, 0.5: two slices) and are scaled to it."""
     f = latest_profile("*sq_counters.json")
     if not f:
         return None
     try:
-        k = json.load(open(f))["kernels"][kernel]
-        vec = k["SQ_INSTS_VALU"] * 2 / (1024 * SHADER_CLOCK_HZ) * 1e3
-        sca = (k["SQ_INSTS_SALU"] + k["SQ_INSTS_BRANCH"] + k.get("SQ_INSTS_SMEM", 0)) / (256 * SHADER_CLOCK_HZ) * 1e3
+        d = json.load(open(f))
+        k = d["kernels"][kernel]
+        scale = (share / d.get("launch_share", 0.5)) if share else 1.0
+        vec = k["SQ_INSTS_VALU"] * scale * VALU_CLOCKS / (1024 * SHADER_CLOCK_HZ) * 1e3
+        sca = (k["SQ_INSTS_SALU"] + k["SQ_INSTS_BRANCH"] + k.get("SQ_INSTS_SMEM", 0)) * scale / (256 * SHADER_CLOCK_HZ) * 1e3
         bound = max(vec, sca)
         return {"vector_ms": vec, "scalar_ms": sca, "launch_ms": launch_ms, "frac": bound / launch_ms if launch_ms else None,
-                "clock_hz": SHADER_CLOCK_HZ, "source": os.path.basename(f),
-                "is": "max(vector, scalar) issue time / measured launch time; counters from a separate profiled run"}
+                "clock_hz": SHADER_CLOCK_HZ, "valu_clocks": VALU_CLOCKS, "counters_scaled_by": scale, "source": os.path.basename(f),
+                "is": "max(vector, scalar) issue time / measured launch time at the nominal clock (the kernels run at 1.7-2.1 GHz under "
+                      "load: the true fraction is higher); counters from a separate profiled run, scaled to this launch's share of the batch; "
+                      "a launch beside the other slice's kernels shares its SIMDs with them"}
     except Exception:
         return None
 
@@ -518,7 +529,7 @@ def _roofline_entry(dom, dom_ms, N, C, brief=False, share=1.0):
         roof["traffic_over_algorithmic"] = [traffic["bytes"] / alg if alg else None,
                                             roof["traffic_corrected"] / alg if alg else None]
         roof["traffic_is"] = "raw FETCH_SIZE+WRITE_SIZE per launch (L2->fabric); corrected = 2 x fetch + write"
-    ib = issue_bound(dom, dom_ms)
+    ib = issue_bound(dom, dom_ms, share if dom not in ("crc32_segments", "crc32_finish") else None)
     if ib:
         roof["issue_bound"] = ib
     if brief:

@@ -265,9 +265,10 @@ int zipc_hip_deflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
                            size_t max_src_len, size_t total_src_len, int level,
                            int crc_op);
 
-/* CRC-32 and Adler-32 of one device buffer (Crc_32.string + Adler_32.string): one pass over the
- * bytes for each of the two, by their own kernels (2 x len bytes of traffic when both are asked
- * for).  d_out receives {crc32, adler32}.  Either selector may be 0 to skip that checksum. */
+/* CRC-32 and Adler-32 of one device buffer (Crc_32.string + Adler_32.string).  Both asked for: ONE pass over the bytes
+ * leaves the CRC-32 partials and the Adler-32 chunk sums (len bytes of traffic; ZIPC_HIP_CHECKSUM_FUSED=0 keeps the two
+ * passes of rounds 1-2), then the two short finishes.  d_out receives {crc32, adler32}.  Either selector may be 0 to
+ * skip that checksum. */
 int zipc_hip_checksum_device(zipc_hip_ctx *ctx, const void *d_buf, size_t len,
                              int want_crc32, int want_adler32, uint32_t *d_out);
 

@@ -44,8 +44,9 @@ for k, v in agg.items():
         out[name] = {"fetch_bytes": fetch, "write_bytes": write, "bytes": fetch + write}
 if sq_out:
     json.dump({"note": "mean wave-instructions per launch, rocprofv3 --pmc SQ passes of tools/exp_inflate.py on C2 "
-                       "(tools/exp_sq_counters.sh); issue bounds: vector = VALU x 4 clocks / (1024 SIMDs x f), "
-                       "scalar = (SALU + BRANCH + SMEM) / (256 CUs x f), f = shader clock",
+                       "(tools/exp_sq_counters.sh: 16 384 streams in two slices, a launch covers half the batch); issue bounds: "
+                       "vector = VALU x 4 clocks / (1024 SIMDs x f), scalar = (SALU + BRANCH + SMEM) / (256 CUs x f), f = shader clock",
+               "launch_share": 0.5,
                "kernels": out}, open(sq_out, "w"), indent=1)
 if hbm_out:
     json.dump({"note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes; on gfx950 "

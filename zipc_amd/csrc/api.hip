@@ -267,7 +267,7 @@ hipError_t crc32_finish_launch(zipc_hip_ctx *ctx, int mode, const StreamDesc *d_
     ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_streams_kernel, dim3((unsigned)((n_ranges + 255) / 256)), dim3(256), 0,
               mode, d_descs, d_results, (uint32_t)n_ranges, (uint32_t)segs, ctx->crc_consts, partials);
   else
-    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(256), 0, mode,
+    ZD_LAUNCH(ctx, "crc32_finish", crc32_finish_kernel, dim3((unsigned)n_ranges), dim3(segs > 4096 ? 1024 : 256), 0, mode,
               d_descs, d_results, single_len, (uint32_t)segs, ctx->crc_consts, (const uint32_t *)ctx->crc_nib.p,
               partials, d_single_out);
   return hipGetLastError();

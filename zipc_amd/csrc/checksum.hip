@@ -73,10 +73,13 @@ __device__ __forceinline__ void crc32_segment(
     uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials,
     uint32_t *__restrict__ adler_sums, uint64_t n_chunks) {
   __shared__ uint32_t T[4][256];
-  __shared__ __attribute__((aligned(16))) uint32_t N[8 * GF2_NIB_WORDS];  // xpiece[0..7] as nibble tables (4 KiB)
   static_assert(8 * GF2_NIB_WORDS == 4 * CRC_THREADS, "one 16-byte load per thread");
   __shared__ __attribute__((aligned(16))) uint8_t stage[CRC_THREADS * CRC_PIECE_STRIDE];
-  __shared__ uint32_t wave_part[CRC_THREADS / 64];
+  // xpiece[0..7] as nibble tables (4 KiB) and the waves' partials: in the staged segment's place once every thread has walked
+  // its piece -- 40 KiB of LDS a workgroup, so that FOUR fit a CU (three with tables of their own: the table walk of one
+  // workgroup hides behind the loads of the others, and C3 is the one kernel here that waits for memory)
+  uint32_t *N = (uint32_t *)stage;
+  uint32_t *wave_part = (uint32_t *)(stage + 8 * GF2_NIB_WORDS * 4);
   const int t = threadIdx.x;
   const uint32_t range = blockIdx.x / segs_per_range;
   const uint32_t seg = blockIdx.x % segs_per_range;
@@ -93,7 +96,6 @@ __device__ __forceinline__ void crc32_segment(
   const uint8_t *p = base + off;
   constexpr int UNITS = CRC_SEG / 16 / CRC_THREADS;  // 16-byte units per thread
   u32x4 v[UNITS];
-  const u32x4 nib_mine = ((const u32x4 *)nib)[t];  // in flight with the data
   if (len >= 16) {
     // unit u = i * 256 + t: consecutive threads, consecutive 16 bytes; all loads in flight together
 #pragma unroll
@@ -126,7 +128,6 @@ __device__ __forceinline__ void crc32_segment(
     const uint32_t u = (uint32_t)i * CRC_THREADS + (uint32_t)t;
     *(u32x4 *)(stage + (u / (CRC_PIECE / 16)) * CRC_PIECE_STRIDE + (u % (CRC_PIECE / 16)) * 16) = v[i];
   }
-  ((u32x4 *)N)[t] = nib_mine;
   __syncthreads();
   // my piece (Crc_32.string_update's word loop, src/zipc_deflate.ml:141-150; leading
   // zero bytes leave c = 0)
@@ -162,6 +163,9 @@ __device__ __forceinline__ void crc32_segment(
       s2 += 16u * s1 + u2;
       s1 += u1;
     }
+#ifdef ZD_CRC_FAKE  // timing only (wrong checksums): what the pass costs without the table walk
+    c ^= w.x ^ w.y ^ w.z ^ w.w;
+#else
     uint32_t u = c ^ w.x;
     c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
     u = c ^ w.y;
@@ -170,10 +174,15 @@ __device__ __forceinline__ void crc32_segment(
     c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
     u = c ^ w.w;
     c = T[3][u & 0xFF] ^ T[2][(u >> 8) & 0xFF] ^ T[1][(u >> 16) & 0xFF] ^ T[0][u >> 24];
+#endif
   }
   // merge the 256 equal-length pieces: tree over lanes, then over waves.  The
   // multipliers are constants: nibble-table products (the bit-serial gf2_mul here was
   // two thirds of the kernel's instructions)
+  const u32x4 nib_mine = ((const u32x4 *)nib)[t];  // (requested here, not beside the data: four more registers held through the walk spill others)
+  __syncthreads();  // every piece has been read: the segment's place takes the tables
+  ((u32x4 *)N)[t] = nib_mine;
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     const uint32_t other = __shfl_down(c, 1u << k, 64);
@@ -214,7 +223,7 @@ __device__ __forceinline__ void crc32_segment(
   }
 }
 
-__global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
+__global__ __launch_bounds__(CRC_THREADS, 4) void crc32_segments_kernel(
     const uint8_t *__restrict__ base, int mode, const StreamDesc *__restrict__ descs,
     const StreamResult *__restrict__ results, uint64_t single_off, uint64_t single_len,
     uint32_t segs_per_range, const uint32_t *__restrict__ nib, uint32_t *__restrict__ partials) {
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(CRC_THREADS) void crc32_segments_kernel(
 }
 
 // CRC-32 partials and Adler-32 chunk sums of ONE buffer in one pass over its bytes
-__global__ __launch_bounds__(CRC_THREADS) void crc32_adler_segments_kernel(
+__global__ __launch_bounds__(CRC_THREADS, 4) void crc32_adler_segments_kernel(
     const uint8_t *__restrict__ p, uint64_t len, uint32_t n_segs, const uint32_t *__restrict__ nib,
     uint32_t *__restrict__ partials, uint2 *__restrict__ adler_sums, uint64_t n_chunks) {
   crc32_segment<true>(p, RANGE_SINGLE, nullptr, nullptr, 0, len, n_segs, nib, partials, (uint32_t *)adler_sums, n_chunks);
@@ -272,11 +281,14 @@ __global__ __launch_bounds__(256) void crc32_finish_streams_kernel(
   results[range].checksum = state ^ 0xFFFFFFFFu;
 }
 
-__global__ __launch_bounds__(256) void crc32_finish_kernel(
+// (NT = blockDim.x threads, a power of two up to 1024: the launch takes 1024 for ranges of many segments -- C3's 131 072
+// partials as 256 Horner runs of 512 dependent steps took 0.118 ms, a tenth of the pass over the 4 GiB themselves)
+__global__ __launch_bounds__(1024) void crc32_finish_kernel(
     int mode, const StreamDesc *__restrict__ descs, StreamResult *__restrict__ results,
     uint64_t single_len, uint32_t segs_per_range, CrcConsts K, const uint32_t *__restrict__ nib,
     const uint32_t *__restrict__ partials, uint32_t *__restrict__ single_out) {
-  __shared__ uint32_t sh[256];
+  __shared__ uint32_t sh[1024];
+  const uint32_t NT = blockDim.x;
   __shared__ uint32_t NS[GF2_NIB_WORDS];  // xseg as a nibble table
   const int t = threadIdx.x;
   const uint32_t range = blockIdx.x;
@@ -296,21 +308,32 @@ __global__ __launch_bounds__(256) void crc32_finish_kernel(
     if (t == 0)
       for (uint32_t j = 0; j < (uint32_t)nseg; j++) raw = gf2_mul(raw, K.xseg) ^ P[j];
   } else {
-    // right-aligned grid of 256 runs of R partials each
-    const uint64_t R = (nseg + 255) / 256;
-    const uint64_t padp = 256 * R - nseg;
-    if (t < GF2_NIB_WORDS) NS[t] = nib[CRC_NIB_XSEG * GF2_NIB_WORDS + t];
+    // right-aligned grid of R rows of NT partials: thread t takes column t -- consecutive threads, consecutive words of every row
+    // (a run of consecutive partials per thread read a cache line per thread and step: C3's finish took 0.11 ms, a tenth
+    // of the pass over the 4 GiB themselves) -- so its Horner step is a shift by a whole ROW, x^(8 * segment * NT), whose
+    // nibble table the workgroup makes first; the tree then shifts by a segment, two, four ...
+    const uint64_t R = (nseg + NT - 1) / NT;
+    const uint64_t padp = NT * R - nseg;
+    const uint32_t xrow = xpow8n_tab(K, (uint64_t)CRC_SEG * NT);
+    if (t < GF2_NIB_WORDS) NS[t] = gf2_mul(((uint32_t)t & 15u) << (4 * (t >> 4)), xrow);  // (gf2_nib_table's entries, one per thread)
     __syncthreads();
     uint32_t c = 0;
-    for (uint64_t j = 0; j < R; j++) {
-      const int64_t idx = (int64_t)((uint64_t)t * R + j) - (int64_t)padp;
-      const uint32_t v = idx >= 0 ? P[idx] : 0u;
-      c = gf2_mul_nib(c, NS) ^ v;
+    for (uint64_t j0 = 0; j0 < R; j0 += 8) {  // eight rows' words requested together (clamped index, value selected afterwards: one
+      uint32_t v[8];                          // load at a time behind a branch cost a memory round trip per row)
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int64_t idx = (int64_t)((j0 + (uint64_t)u) * NT + (uint64_t)t) - (int64_t)padp;
+        const uint32_t w = P[idx >= 0 && j0 + (uint64_t)u < R ? idx : 0];
+        v[u] = idx >= 0 ? w : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j0 + (uint64_t)u < R) c = gf2_mul_nib(c, NS) ^ v[u];
     }
     sh[t] = c;
     __syncthreads();
-    uint32_t xr = xpow8n_tab(K, (uint64_t)CRC_SEG * R);  // shift of one run
-    for (int s = 1; s < 256; s <<= 1) {
+    uint32_t xr = K.xseg;  // shift of one segment
+    for (int s = 1; s < (int)NT; s <<= 1) {
       if ((t & (2 * s - 1)) == 0) sh[t] = gf2_mul(sh[t], xr) ^ sh[t + s];
       xr = gf2_mul(xr, xr);
       __syncthreads();
