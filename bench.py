@@ -611,6 +611,9 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
         "metric": METRIC,
         "value": world * N / GIB * args.steps / elapsed,
         "unit": "GiB/s",
+        # the two directions by themselves (one rank's, over the profiled steps): at the head of the line, where a cut tail keeps them
+        "deflate_gib_s": N / GIB * psteps / t["def"],
+        "inflate_gib_s": N / GIB * psteps / t["inf"],
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
@@ -630,8 +633,6 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
         },
         **ranks,
         "roofline": roof,
-        "deflate_gib_s": N / GIB * psteps / t["def"],
-        "inflate_gib_s": N / GIB * psteps / t["inf"],
         "kernels_ms_per_step": per_step,
     }
     if world == 1 and not args.no_extra_legs:

@@ -243,7 +243,8 @@ typedef struct zipc_hip_stream_result_s {
  * reads a few words back between its steps and so synchronises the stream itself.
  * Results, messages and limits are the same whichever way a stream is decoded (zipc_hip_last_inflate_blocks tells how
  * many blocks of the last call went that way; ZIPC_HIP_INFLATE_BLOCKS=0 in the environment keeps every stream on its
- * one wave).  Bits of flags other than ZIPC_HIP_STREAM_HAS_LIMIT must be zero. */
+ * one wave).  Bits of flags other than ZIPC_HIP_STREAM_HAS_LIMIT must be zero: a stream whose descriptor has one set
+ * reports ZIPC_HIP_ERR_INVALID_ARG and nothing is written to its destination. */
 /* max_dst_cap: upper bound of dst_cap over the batch (sizes the CRC-32 pass). A stream
  * whose output is longer than that reports ZIPC_HIP_ERR_INVALID_ARG in its result when a
  * CRC-32 is asked for (its checksum would cover only a part). A descriptor with src_len or

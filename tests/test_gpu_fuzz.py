@@ -1,7 +1,8 @@
 """A bounded run of tools/fuzz_gpu.py's randomized parity loop inside the -m gpu suite: deflate of
 assorted streams at a random level (bytes and Adler-32 against the oracle), then inflate of the valid
 streams, of damaged copies and of random block headers (status, bytes, checksum).  Fresh seeds every
-day of the year; the long runs stay with the tool."""
+day of the year; the long runs stay with the tool.  Every assertion names the seeds it ran with, and
+ZIPC_TEST_DAY=<day of the year> runs the suite with another day's seeds: a red run can be repeated."""
 import datetime
 import importlib.util
 import os
@@ -13,12 +14,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _day():
+    """what the seeds are made of: the day of the year, or ZIPC_TEST_DAY to repeat another day's run"""
+    return int(os.environ.get("ZIPC_TEST_DAY", datetime.date.today().timetuple().tm_yday))
+
+
 def test_randomized_parity_bounded(gpu_ctx, oracle):
     spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(ROOT, "tools", "fuzz_gpu.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     fuzz.ctx = gpu_ctx
-    day = datetime.date.today().timetuple().tm_yday
+    day = _day()
     t0 = time.time()
     total = bad = 0
     lines = []
@@ -28,7 +34,7 @@ def test_randomized_parity_bounded(gpu_ctx, oracle):
         bad += b
         if time.time() - t0 > 25:  # about 20 s of GPU and oracle time
             break
-    assert bad == 0, lines[:10]
+    assert bad == 0, ("seeds %d + k, ZIPC_TEST_DAY=%d" % (50000 + 100 * day, day), lines[:10])
     assert total > 1000
 
 
@@ -44,24 +50,21 @@ def test_randomized_parity_bounded(gpu_ctx, oracle):
     {"ZIPC_HIP_CHAIN": "peel"},                                     # hash chains by the kernel that orders equal hashes itself (default: ordered LDS exchange)
     {"ZIPC_HIP_CHAIN": "peel", "ZIPC_HIP_PARSE_SEGMENTS": "0"},
     {"ZIPC_HIP_PARSE_SEGMENTS": "0"},                               # a wave per stream for parse and blocks (what 16 384 streams take)
-    {"ZIPC_HIP_TILE": "1", "ZIPC_HIP_PARSE_SEGMENTS": "0"},         # search and parse in one workgroup (lz_tile.hip)
-    {"ZIPC_HIP_TILE": "1", "ZIPC_HIP_TILE_PUNT": "1", "ZIPC_HIP_PARSE_SEGMENTS": "0"},  # ... every stream left to the kernels behind it
 ], ids=["scan-walk", "first-walk", "slices", "scan-walk+groups+slices", "parse-segments", "parse-segments+slices",
-        "batch-groups", "batch-groups+parse-segments", "chain-peel", "chain-peel+one-wave-forms", "one-wave-forms",
-        "tile-kernel", "tile-kernel-punts"])
+        "batch-groups", "batch-groups+parse-segments", "chain-peel", "chain-peel+one-wave-forms", "one-wave-forms"])
 def test_randomized_parity_under_overrides(env):
     """The same loop in a process of its own under the library's overrides (read once per process), so that
     the paths a 120-stream batch would not reach by itself are compared with the oracle too."""
     import subprocess
     import sys
 
-    day = datetime.date.today().timetuple().tm_yday
+    day = _day()
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_gpu.py"), str(70000 + 10 * day), "2"],
                        env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-600:]
-    assert r.returncode == 0 and "FUZZ ok" in tail, tail
+    assert r.returncode == 0 and "FUZZ ok" in tail, ("tools/fuzz_gpu.py %d 2 under %s (ZIPC_TEST_DAY=%d)" % (70000 + 10 * day, env, day), tail)
 
 
 @pytest.mark.parametrize("seg", ["default", "8192", "32768"])
@@ -72,14 +75,14 @@ def test_long_mixed_streams_bounded(seg):
     import subprocess
     import sys
 
-    day = datetime.date.today().timetuple().tm_yday
+    day = _day()
     e = dict(os.environ)
     if seg != "default":
         e["ZIPC_HIP_PARSE_SEG"] = seg
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_long.py"), str(9000 + 10 * day), "8"],
                        env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     tail = r.stdout.decode()[-600:]
-    assert r.returncode == 0 and "FUZZ ok" in tail, tail
+    assert r.returncode == 0 and "FUZZ ok" in tail, ("tools/fuzz_long.py %d 8, ZIPC_HIP_PARSE_SEG=%s (ZIPC_TEST_DAY=%d)" % (9000 + 10 * day, seg, day), tail)
 
 
 @pytest.mark.parametrize("form", ["default", "following", "explorers-everywhere"])
@@ -92,7 +95,7 @@ def test_one_stream_inflate_by_blocks_bounded(form):
     import subprocess
     import sys
 
-    day = datetime.date.today().timetuple().tm_yday
+    day = _day()
     e = dict(os.environ)
     e["TRIALS"] = "40" if form == "default" else "25"
     e["SEED"] = str(500 + day)
@@ -105,7 +108,7 @@ def test_one_stream_inflate_by_blocks_bounded(form):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_inflate_blocks.py")], env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-800:]
-    assert r.returncode == 0 and "0 mismatches" in tail, tail
+    assert r.returncode == 0 and "0 mismatches" in tail, ("tools/fuzz_inflate_blocks.py SEED=%s TRIALS=%s form %s (ZIPC_TEST_DAY=%d)" % (e["SEED"], e["TRIALS"], form, day), tail)
     went = int(tail.split(" went by blocks")[0].split(", ")[-1])
     assert went >= (15 if form == "default" else 8), tail
 
@@ -119,7 +122,7 @@ def test_calls_of_long_streams_inflate_by_blocks_side_by_side(form):
     import subprocess
     import sys
 
-    day = datetime.date.today().timetuple().tm_yday
+    day = _day()
     e = dict(os.environ)
     e["TRIALS"] = "12"
     e["BATCH"] = "10"
@@ -133,7 +136,7 @@ def test_calls_of_long_streams_inflate_by_blocks_side_by_side(form):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_inflate_blocks.py")], env=e, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=900)
     tail = r.stdout.decode()[-800:]
-    assert r.returncode == 0 and "0 mismatches" in tail, tail
+    assert r.returncode == 0 and "0 mismatches" in tail, ("tools/fuzz_inflate_blocks.py SEED=%s TRIALS=12 BATCH=10 form %s (ZIPC_TEST_DAY=%d)" % (e["SEED"], form, day), tail)
     went = int(tail.split(" blocks went by blocks")[0].split(", ")[-1])
     assert went >= 200, tail
 

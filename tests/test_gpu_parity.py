@@ -798,3 +798,32 @@ def test_one_stream_by_blocks_every_kind_of_block(gpu_ctx, oracle):
             st0, d0, _ = oracle.inflate(raw[:len(raw) // 2], decompressed_size=n)
             r = Z.inflate(raw[:len(raw) // 2], decompressed_size=n)
             assert (not r.is_ok()) and st0 != 0 and r.error == oracle.MESSAGES[st0], (name, make)
+
+
+def test_unknown_descriptor_flags_are_an_invalid_argument(gpu_ctx, oracle):
+    """include/zipc_hip.h: bits of a descriptor's flags other than ZIPC_HIP_STREAM_HAS_LIMIT must be zero.  Bit 31 is the
+    mark the library sets in its OWN copy of a call's descriptors (a stream that went by blocks); in a caller's descriptor
+    it used to skip the stream and leave its result slot as it was.  Now the stream reports ZIPC_HIP_ERR_INVALID_ARG, in
+    calls of a few streams (the kernel that shares tables) and of many, and its neighbours are decoded as ever."""
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    data = util.text(20000, 5)
+    comp = oracle.deflate(data, level=2)[1]
+    for n in (3, 300):
+        src = torch.from_numpy(np.frombuffer(comp * n + b"\0" * 64, np.uint8).copy()).to(dev)
+        descs = batch.make_descs(np.arange(n, dtype=np.uint64) * len(comp), [len(comp)] * n, np.arange(n, dtype=np.uint64) * 20480, [20000] * n)
+        descs["flags"][1] = 1 << 31
+        descs["flags"][2] = 2
+        dst = torch.zeros(n * 20480, dtype=torch.uint8, device=dev)
+        d_res = torch.full((n * 16,), 0xAB, dtype=torch.uint8, device=dev)
+        batch.inflate_batch(gpu_ctx, src, dst, batch.to_device(descs, dev), d_res, n, 20000, 1)
+        res = batch.results_from_device(d_res)
+        assert int(res["status"][1]) == 18 and int(res["status"][2]) == 18, (n, res["status"][:4])
+        assert int(res["status"][0]) == 0 and int(res["out_len"][0]) == len(data)
+        assert dst[:len(data)].cpu().numpy().tobytes() == data
+        assert not bool(dst[20480:20480 * 3].any())
+        if n > 3:
+            assert (res["status"][3:] == 0).all() and dst[20480 * (n - 1):20480 * (n - 1) + len(data)].cpu().numpy().tobytes() == data

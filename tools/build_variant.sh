@@ -10,7 +10,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/zipc_amd/csrc
 make -s -C "$C" -j4 all
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OBJS=""
-for o in api inflate checksum deflate lz_tile; do
+for o in api inflate checksum deflate; do
   if [[ " $SRCS " == *" $o "* ]]; then
     $HIPCC -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $FLAGS -c "$C/$o.hip" -o "$C/build/${o}_$NAME.o"
     OBJS="$OBJS $C/build/${o}_$NAME.o"

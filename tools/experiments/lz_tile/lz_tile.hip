@@ -1,4 +1,10 @@
-// lz_tile.hip -- match search and lazy parse of a batch of streams in ONE kernel, a workgroup per stream.
+// lz_tile.hip -- EXPERIMENT (round 4), not part of the library since round 5: match search and lazy parse of a batch of
+// streams in ONE kernel, a workgroup per stream.  Exact, and 1.6 x slower than the two kernels it replaces (DESIGN.md
+// section 6, round 4's record in profiles/HISTORY.md).  It shipped behind ZIPC_HIP_TILE=1 with a hand-over of the streams
+// it refuses (S.punt / S.n_punt, a word per stream in the scratch; `punted_only` arguments of lz_match_window_kernel and
+// lz_parse_kernel); round 5 took the file, the switch and the hand-over out of the library.  To build it again: put the
+// file beside deflate.hip, add it to the Makefile, give DeflateScratch its punt / n_punt words back and launch it in front
+// of lz_match (git history: the commit before this file moved).
 //
 // Round 1-3's pipeline ran find_backref (zd.ml:1176-1201) for every position in lz_match_window_kernel, wrote both
 // answers (8 bytes per position) to memory and read them back in lz_parse_kernel, one wave per stream
@@ -28,8 +34,8 @@
 // Output as lz_parse_kernel's: S.syms, S.blocks, S.n_blocks.
 #include <type_traits>
 
-#include "deflate_pipeline.h"
-#include "tuning.h"
+#include "../../../zipc_amd/csrc/deflate_pipeline.h"
+#include "../../../zipc_amd/csrc/tuning.h"
 
 namespace zd {
 

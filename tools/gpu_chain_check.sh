@@ -9,7 +9,7 @@ echo "== long streams"; timeout 600 python3 tools/fuzz_long.py $SEED 1 2>&1 | ta
 for data in ${DATAS:-c2 text c4}; do
   for chain in xchg peel; do
     echo "== $data chain=$chain"
-    ZIPC_HIP_TILE=0 ZIPC_HIP_CHAIN=$chain DATA=$data CHECK=1 KERNELS=1 REPS=3 timeout 600 python3 tools/exp_wall.py 2>&1 | tail -1 | cut -c1-900
+    ZIPC_HIP_CHAIN=$chain DATA=$data CHECK=1 KERNELS=1 REPS=3 timeout 600 python3 tools/exp_wall.py 2>&1 | tail -1 | cut -c1-900
   done
 done
 echo "== one stream"; timeout 300 python3 tools/bench_single.py 2>/dev/null | cut -c1-400

@@ -210,8 +210,6 @@ const Tuning &tuning() {
     auto is = [](const char *name, const char *v) { const char *e = getenv(name); return e && !strcmp(e, v); };
     Tuning x;
     x.chain_peel = is("ZIPC_HIP_CHAIN", "peel");
-    x.tile = num("ZIPC_HIP_TILE", 0) != 0;
-    x.tile_punt = num("ZIPC_HIP_TILE_PUNT", 0) != 0;
     x.parse_segments = num("ZIPC_HIP_PARSE_SEGMENTS", -1);
     x.parse_seg = num("ZIPC_HIP_PARSE_SEG", 0);
     x.match_tiles_per_group = num("ZIPC_HIP_MATCH_TILES_PER_GROUP", 0);
@@ -224,6 +222,7 @@ const Tuning &tuning() {
     x.inflate_blocks = num("ZIPC_HIP_INFLATE_BLOCKS", 1) != 0;
     x.inflate_follow = (int)num("ZIPC_HIP_INFLATE_FOLLOW", -1);
     x.explore_stride = (uint64_t)num("ZIPC_HIP_EXPLORE_STRIDE", 16384);
+    if (x.explore_stride < 1024) x.explore_stride = 1024;  // (a divisor: never 0 or negative, whatever the environment says)
     x.resolve_hops0 = (int)num("ZIPC_HIP_RESOLVE_HOPS0", 256);
     x.resolve_hops1 = (int)num("ZIPC_HIP_RESOLVE_HOPS1", 256);
     x.checksum_fused = num("ZIPC_HIP_CHECKSUM_FUSED", 1) != 0;
@@ -795,16 +794,23 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
 }
 
 // which of a call's streams go by blocks, group by group; *n_handled: how many did
+// h_descs: the caller's own host copy of the descriptors (the many-stream host forms have one), or null: they are read
+// back from the device, which waits for everything the stream holds -- the host forms feed sub-batch g + 1 while g's
+// kernels run, and a read-back per sub-batch (before the model below had even said whether any stream goes by blocks:
+// for an archive of equal members none does) put the host behind every sub-batch's copies and kernels.
 static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
                              zipc_hip_stream_result *d_results, size_t n_streams, int crc_op, std::vector<StreamDesc> &sds,
-                             std::vector<uint8_t> &handled, size_t *n_handled) {
+                             std::vector<uint8_t> &handled, size_t *n_handled, const StreamDesc *h_descs) {
   *n_handled = 0;
-  ctx->last_inflate_blocks = 0;
   handled.assign(n_streams, 0);
   if (!zd::tuning().inflate_blocks) return ZIPC_HIP_OK;
-  sds.resize(n_streams);
-  HIP_TRY(ctx, hipMemcpyAsync(sds.data(), d_descs, n_streams * sizeof(StreamDesc), hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_descs) {
+    sds.assign(h_descs, h_descs + n_streams);
+  } else {
+    sds.resize(n_streams);
+    HIP_TRY(ctx, hipMemcpyAsync(sds.data(), d_descs, n_streams * sizeof(StreamDesc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
   std::vector<uint32_t> group;
   size_t group_cap = 0;
   auto run = [&]() -> int {
@@ -868,13 +874,24 @@ static int inflate_by_blocks(zipc_hip_ctx *ctx, const void *d_src_arena, void *d
 }
 
 static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
-                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op);
+                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op, bool marked = false);
+static int inflate_batch_impl(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                              zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op, const StreamDesc *h_descs,
+                              bool first_of_call);
 
 int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena,
                            const zipc_hip_stream_desc *d_descs, zipc_hip_stream_result *d_results,
                            size_t n_streams, size_t max_dst_cap, int crc_op) {
+  return inflate_batch_impl(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, max_dst_cap, crc_op, nullptr, true);
+}
+
+// first_of_call: zipc_hip_last_inflate_blocks counts from zero (the host forms' sub-batches add up)
+static int inflate_batch_impl(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
+                              zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op, const StreamDesc *h_descs,
+                              bool first_of_call) {
   if (!ctx || !d_descs || !d_results) return ZIPC_HIP_ERR_INVALID_ARG;
   if (crc_op < 0 || crc_op > 3 || n_streams > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
+  if (first_of_call) ctx->last_inflate_blocks = 0;  // (also for a call that never reaches the block path: "0 when the stream's one wave decoded it")
   if (n_streams == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (n_streams == 1 && max_dst_cap > MAX_STREAM_LEN)
@@ -886,7 +903,7 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
     std::vector<StreamDesc> sds;
     std::vector<uint8_t> handled;
     size_t n_handled = 0;
-    const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, crc_op, sds, handled, &n_handled);
+    const int by = inflate_by_blocks(ctx, d_src_arena, d_dst_arena, d_descs, d_results, n_streams, crc_op, sds, handled, &n_handled, h_descs);
     if (by != ZIPC_HIP_OK) return by;
     if (n_handled == n_streams) {
       if (crc_op != ZIPC_HIP_CRC_CRC32) return ZIPC_HIP_OK;
@@ -901,7 +918,7 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
       HIP_TRY(ctx, ctx->ensure(ctx->descs_marked, n_streams * sizeof(StreamDesc)));
       HIP_TRY(ctx, hipMemcpyAsync(ctx->descs_marked.p, sds.data(), n_streams * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->stream));
       const int st = inflate_batch_one_wave(ctx, d_src_arena, d_dst_arena, (const zipc_hip_stream_desc *)ctx->descs_marked.p, d_results,
-                                            n_streams, max_dst_cap, crc_op);
+                                            n_streams, max_dst_cap, crc_op, true);
       const hipError_t e = hipStreamSynchronize(ctx->stream);  // (sds goes with this frame)
       if (st == ZIPC_HIP_OK) HIP_TRY(ctx, e);
       return st;
@@ -912,7 +929,8 @@ int zipc_hip_inflate_batch(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_d
 
 // the batch kernel: one wave per stream
 static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, void *d_dst_arena, const zipc_hip_stream_desc *d_descs,
-                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op) {
+                                  zipc_hip_stream_result *d_results, size_t n_streams, size_t max_dst_cap, int crc_op, bool marked) {
+  const int k_crc_op = crc_op | (marked ? CRC_OP_MARKED : 0);  // what the kernels are told (inflate.hip inflate_skips_stream)
   // one wave per stream (ZIPC_HIP_SLICES > 1: in slices on queues of their own, the CRC pass of one slice
   // beside the inflate kernel of the next; measured, not the default: deflate.hip)
   HIP_TRY(ctx, ctx->ensure(ctx->inflate_scratch, n_streams * INFLATE_SCRATCH_PER_STREAM));
@@ -932,11 +950,11 @@ static int inflate_batch_one_wave(zipc_hip_ctx *ctx, const void *d_src_arena, vo
     if (n_streams <= 256)  // (a few streams: the form that shares the tables of blocks with one and the same header, inflate.hip)
       ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_few_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
                 (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
-                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
+                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), k_crc_op);
     else
       ZD_LAUNCH(ctx, "inflate_batch", inflate_batch_kernel, dim3((unsigned)(hi - lo)), dim3(64), 0,
                 (const uint8_t *)d_src_arena, (uint8_t *)d_dst_arena, dd, dr, (uint32_t)(hi - lo),
-                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), crc_op);
+                (uint16_t *)ctx->inflate_scratch.p + lo * (INFLATE_SCRATCH_PER_STREAM / 2), k_crc_op);
     if (hipGetLastError() != hipSuccess) { ctx->last_error = "inflate_batch launch failed"; st = ZIPC_HIP_ERR_HIP; break; }
     if (crc_op == ZIPC_HIP_CRC_CRC32)
       st = crc32_pass(ctx, (const uint8_t *)d_dst_arena, RANGE_INFLATE_OUT, dd, dr, hi - lo, 0, 0, max_dst_cap, nullptr,
@@ -1269,6 +1287,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
   auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
   int failed = 0;
+  bool first_batch = true;
   for (size_t g = 0; g < K && !failed; g++) {
     const size_t lo = cut[g], hi = cut[g + 1];
     if (lo == hi) continue;
@@ -1284,10 +1303,11 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
     size_t total_g = 0;
     for (size_t i = lo; i < hi; i++) total_g += src_len[i];
-    if (is_inflate)
-      failed = zipc_hip_inflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op);
+    if (is_inflate)  // (with the descriptors it has on the host: no read-back, nothing waited for unless a stream goes by blocks)
+      failed = inflate_batch_impl(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op, descs.data() + lo, first_batch);
     else
       failed = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
+    first_batch = false;
     if (failed) break;
     PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
                                 hipMemcpyDeviceToHost, ctx->stream));

@@ -74,7 +74,7 @@ size_t deflate_scratch_bytes(size_t n_all, size_t max_src_len, size_t total_all,
   uint64_t P, Bk;
   scratch_caps(n, total_src_len, P, Bk);
   size_t b = 0;
-  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) * 2 + 256;
+  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
   if (level != LEVEL_NONE) {
     b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
@@ -90,9 +90,7 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.pos_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
-  s.punt = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
-  s.n_punt = s.error + 1;
   s.prev = nullptr; s.match = nullptr;
   s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
@@ -139,7 +137,6 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
       ap += vp; ab += vb;
     }
     S.error[0] = (ap > S.cap_positions || ab > S.cap_blocks || too_long) ? 1u : 0u;
-    S.n_punt[0] = 0;
   }
   __syncthreads();
   sp = part_p[t];
@@ -643,7 +640,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
                                                                          uint32_t tiles_per_group, int K, int Kq,
-                                                                         int form, int punted_only) {
+                                                                         int form) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
   __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
@@ -655,7 +652,6 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   if (threadIdx.x < 4) ph_acc[threadIdx.x] = 0;
 #endif
   if (S.error[0]) return;
-  if (punted_only && S.n_punt[0] == 0) return;  // behind lz_tile_kernel: only the streams it left (almost always none)
   // XCD-aware order as in lz_match_kernel: the groups of a stream re-read each
   // other's windows, so they go to one XCD's L2
   const uint32_t nb = gridDim.x;
@@ -665,7 +661,6 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint32_t stream = logical / groups_per_stream;
   const uint32_t group = logical % groups_per_stream;
   if (stream >= n_streams) return;  // grid is padded to a multiple of 8
-  if (punted_only && S.punt[stream] == 0) return;
   const StreamDesc sd = descs[stream];
   if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
@@ -1107,8 +1102,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
                                                       const StreamDesc *__restrict__ descs,
-                                                      DeflateScratch S, int good_match, int punted_only) {
-  if (punted_only && (S.n_punt[0] == 0 || S.punt[blockIdx.x] == 0)) return;  // behind lz_tile_kernel: only the streams it left
+                                                      DeflateScratch S, int good_match) {
   lz_parse_wave<0>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
 }
 
@@ -2643,12 +2637,11 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     while (n * ((max_src_len + 2 * xseg - 1) / (2 * xseg)) >= 2048) xseg *= 2;  // twice the chip's CUs of waves is plenty
     xsegs = (max_src_len + xseg - 1) / xseg;
   }
-  const bool tile_env = tuning().tile;  // lz_tile_kernel in place of lz_match + lz_parse (exact; slower on every shape measured: lz_tile.hip)
   hipError_t slice_err = hipSuccess;
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;
     DeflateScratch Q = S;
-    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo; Q.punt += lo;
+    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo;
     const StreamDesc *dd = d_descs + lo;
     if (xchg_chain) {  // one wave per stream (per segment of a long one while there are few): ordered LDS exchange
       if (m * xsegs > m && m * xsegs <= 0x7FFFFFFFull)
@@ -2661,19 +2654,12 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
                 Q, (uint32_t)csegs, (uint32_t)chain_seg);
     else
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_kernel, dim3((unsigned)m), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
-    // Many streams of more than a few KiB: search and parse in one kernel, a workgroup per stream (lz_tile.hip); the two
-    // kernels behind it then only take the streams it left to them (S.punt)
-    const bool tiled = tile_env && !segmented && max_src_len > MATCHW_SMALL && K >= 4;
-    if (tiled) {
-      const hipError_t te = launch_lz_tile(ctx, d_src, dd, Q, m, K, good_match);
-      if (te != hipSuccess) { slice_err = te; return; }
-    }
     if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
       ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((m * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
                 d_src, dd, Q, (uint32_t)m, (uint32_t)cps, K, K / 4);
     else
       ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((m * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env, tiled ? 1 : 0);
+                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env);
     if (segmented) {
       ParseSegs G = segs;
       const size_t o = lo * sps;  // the slice's segment slots
@@ -2689,7 +2675,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
                 good_match, G);
       ZD_LAUNCH(ctx, "lz_parse_gather", lz_parse_gather_kernel, dim3((unsigned)(m * sps)), dim3(64), 0, dd, Q, G);
     } else {
-      ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match, tiled ? 1 : 0);
+      ZD_LAUNCH(ctx, "lz_parse", lz_parse_kernel, dim3((unsigned)m), dim3(64), 0, d_src, dd, Q, good_match);
     }
     if (segmented) {
       ZD_LAUNCH(ctx, "deflate_plan", deflate_plan_kernel, dim3((unsigned)(m * bps)), dim3(64), 0, d_src, dd, Q, crc_op,

@@ -1,4 +1,4 @@
-// deflate_pipeline.h -- what the kernels of the deflate pipeline share (deflate.hip, lz_tile.hip): the layout of the
+// deflate_pipeline.h -- what the kernels of the deflate pipeline share (deflate.hip): the layout of the
 // context's scratch and the barrier that waits for LDS only.
 #pragma once
 
@@ -27,8 +27,6 @@ struct DeflateScratch {
   uint64_t *pos_base;   // [n] first position slot of stream i
   uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
   uint32_t *n_blocks;   // [n]
-  uint32_t *punt;       // [n] lz_tile_kernel: != 0, the stream's search and parse are left to lz_match_window_kernel + lz_parse_kernel
-  uint32_t *n_punt;     // [1] streams so left (zeroed by deflate_offsets_kernel)
   uint32_t *error;      // [1] != 0: the batch does not fit what the caller declared (total_src_len too small,
                         //     or a stream longer than max_src_len: the grids are sized from it)
   uint16_t *prev;       // [P] chain links
@@ -44,10 +42,5 @@ struct DeflateScratch {
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
-
-// lz_tile.hip: the match search and the lazy parse of a batch of streams in one kernel (a workgroup per stream).
-// S.punt[i] != 0 afterwards: stream i is left to lz_match_window_kernel + lz_parse_kernel.
-hipError_t launch_lz_tile(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *d_descs, DeflateScratch S,
-                          size_t n, int K, int good_match);
 
 }  // namespace zd

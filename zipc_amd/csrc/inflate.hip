@@ -922,6 +922,24 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   return e;
 }
 
+// A descriptor's flags before its wave starts.  STREAM_DONE is the library's own mark, in its own copy of a call's
+// descriptors (api.hip: the stream went by blocks, its result stands) -- such launches say so in crc_op (CRC_OP_MARKED).
+// In a caller's descriptors that bit, like every bit but STREAM_HAS_LIMIT, is an invalid argument and is reported as one
+// (it used to skip the stream silently and leave whatever its result slot held).
+__device__ __forceinline__ bool inflate_skips_stream(uint32_t flags, int &crc_op, StreamResult *result) {
+  const bool marked = (crc_op & CRC_OP_MARKED) != 0;
+  crc_op &= ~CRC_OP_MARKED;
+  const uint32_t other = flags & ~STREAM_HAS_LIMIT;
+  if (other == 0) return false;
+  if (other == STREAM_DONE && marked) return true;
+  if ((threadIdx.x & 63u) == 0) {
+    StreamResult r;
+    r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0;
+    *result = r;
+  }
+  return true;
+}
+
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void inflate_batch_kernel(const uint8_t *__restrict__ src_arena,
                                                            uint8_t *__restrict__ dst_arena,
                                                            const StreamDesc *__restrict__ descs,
@@ -930,7 +948,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
-  if (descs[stream].flags & STREAM_DONE) return;  // (it went by blocks: its result stands)
+  if (inflate_skips_stream(descs[stream].flags, crc_op, results + stream)) return;
   BlockStart at;
   at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,
@@ -947,7 +965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   __shared__ __attribute__((aligned(16))) uint8_t lds_raw[LDS_BYTES_PER_LANE];
   const uint32_t stream = blockIdx.x;
   if (stream >= n_streams) return;
-  if (descs[stream].flags & STREAM_DONE) return;  // (it went by blocks: its result stands)
+  if (inflate_skips_stream(descs[stream].flags, crc_op, results + stream)) return;
   BlockStart at;
   at.bit = 0; at.out_pos = 0; at.chunk0 = 0;
   inflate_wave<IM_REAL, false, true>(lds_raw, src_arena, dst_arena, descs[stream], at, results + stream,

@@ -18,9 +18,6 @@ struct Tuning {
   bool chain_peel;             // ZIPC_HIP_CHAIN=peel     hash chains by the kernel that orders equal hashes itself (lz_chain_kernel)
                                //                          instead of ordered LDS exchange (lz_chain_xchg_kernel, the default where the
                                //                          context's probe passes)
-  bool tile;                   // ZIPC_HIP_TILE=1          search + parse in one workgroup (lz_tile.hip) instead of lz_match + lz_parse
-                               //                          (exact; slower on every shape measured, hence off)
-  bool tile_punt;              // ZIPC_HIP_TILE_PUNT=1     ... and every stream left to the two kernels behind it (tests the hand-over)
   long parse_segments;         // ZIPC_HIP_PARSE_SEGMENTS  -1 (default): parse and blocks by many waves for few long streams; 0 never;
                                //                          1 whenever a stream has two segments
   long parse_seg;              // ZIPC_HIP_PARSE_SEG       positions per parse segment (default 0: by stream length, 4096-16384)

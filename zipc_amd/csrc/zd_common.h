@@ -65,6 +65,7 @@ struct StreamResult {
 constexpr uint32_t STREAM_HAS_LIMIT = 1u;
 // (never a caller's: the library's own copy of a call's descriptors, for streams that went by blocks -- api.hip)
 constexpr uint32_t STREAM_DONE = 1u << 31;
+constexpr int CRC_OP_MARKED = 0x100;  // in a kernel's crc_op argument: the descriptors are the library's marked copy (inflate.hip)
 
 // (base << 4) | extra_bits, zd.ml:245-255 and zd.ml:277-288
 #define ZD_V(bits, len) (uint16_t)(((len) << 4) | (bits))
