@@ -604,20 +604,34 @@ constexpr int ZD_PH_SLOTS = 1024;
 __device__ unsigned long long zd_match_phases[ZD_PH_SLOTS * 8];
 #endif
 
+// A stream's FIRST tile has no window in front of it, so the LDS that holds a window and a tile holds three tiles' worth of
+// the stream's start: tile 0 is 48 Ki positions, the others 16 Ki.  Every tile ends with its workgroup's waves running dry
+// one after the other -- the pool is empty, a wave's last walks go on with few lanes, and the longest chain of the last
+// positions sets how long: about 5 of a wave's 17 iterations of a 16 Ki tile on the benchmark's symbols (its lane use of
+// 0.58 is mostly that) -- and a 64 KiB stream now has two such ends where it had four (round 5).
+constexpr uint32_t MATCHW_TILE0 = MAX_MATCH_DIST + MATCHW_TILE;  // positions of a stream's first tile
+__host__ __device__ inline uint32_t match_tile_start(uint32_t tile) { return tile == 0 ? 0u : MATCHW_TILE0 + (tile - 1u) * MATCHW_TILE; }
+// tiles of a stream of len bytes (len >= 4): a tile exists when its first position can start a match
+__host__ __device__ inline uint64_t match_tiles_of(uint64_t len) {
+  const uint64_t last = len - 4;  // the last position that can
+  return last < MATCHW_TILE0 ? 1 : 2 + (last - MATCHW_TILE0) / MATCHW_TILE;
+}
 // What one tile stages: source bytes [w0, src_end) and links [w0, link_end) of its stream
 struct MatchTile {
   uint32_t t0, w0;            // first position of the tile, first staged position
+  uint32_t t1;                // one past the tile's last position (not cut at the stream's end)
   uint32_t src_end;           // one past the last staged source byte
   uint32_t n_src, n_links;    // staged in whole 16-byte units: source bytes, links
 };
 __device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
   MatchTile g;
-  g.t0 = tile * MATCHW_TILE;
+  g.t0 = match_tile_start(tile);
+  g.t1 = match_tile_start(tile + 1u);  // (< 2^32: streams end 64 KiB below it)
   g.w0 = g.t0 > MAX_MATCH_DIST ? g.t0 - MAX_MATCH_DIST : 0;
-  const uint64_t want = (uint64_t)g.t0 + MATCHW_TILE + 264;
+  const uint64_t want = (uint64_t)g.t1 + 264;
   g.src_end = want < len ? (uint32_t)want : len;
   g.n_src = (g.src_end - g.w0) & ~15u;  // whole 16-byte units; the rest byte by byte
-  const uint32_t link_end = (uint64_t)g.t0 + MATCHW_TILE < len ? g.t0 + MATCHW_TILE : len;
+  const uint32_t link_end = g.t1 < len ? g.t1 : len;
   g.n_links = (link_end - g.w0 + 7u) & ~7u;  // the scratch is padded past len
   return g;
 }
@@ -645,6 +659,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
   __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
   __shared__ uint32_t tile_iters[2];  // loop iterations of the workgroup's waves in the tile they walk (by tile parity)
+  __shared__ uint32_t probe_deep;     // probed chains of the workgroup's first tile that hold three candidates
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
   unsigned long long ph0 = __builtin_readcyclecounter();
@@ -665,7 +680,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
   const uint32_t len = (uint32_t)sd.src_len;
   // tiles [tile, tile_end) of the stream; a tile exists when its first position can start a match
-  const uint32_t stream_tiles = (uint32_t)(((uint64_t)len - 4) / MATCHW_TILE) + 1;
+  const uint32_t stream_tiles = (uint32_t)match_tiles_of(len);
   uint32_t tile = group * tiles_per_group;
   if (tile >= stream_tiles) return;
   const uint32_t tile_end = tile + tiles_per_group < stream_tiles ? tile + tiles_per_group : stream_tiles;
@@ -712,16 +727,37 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   MatchTile g = match_tile(tile, len);
   issue(g.w0, g.n_src, g.n_links);
   store(g);
-  if (tid == 0) { pool_next = 0; tile_iters[0] = 0; tile_iters[1] = 0; }
+  if (tid == 0) { pool_next = 0; tile_iters[0] = 0; tile_iters[1] = 0; probe_deep = 0; }
   __syncthreads();
   // Two forms of the walk (deflate_lane.h): the first reads every candidate's 8 bytes and is the
   // faster one where chains hold a candidate or two (the benchmark's 4-bit symbols: 1.2 per
   // position); the second looks at one byte first and compares in bulk, and is the faster one on
   // long chains (3-bit symbols 8.5, text 34 per position: -14 % and -39 % of the kernel; +8 % on the
   // 4-bit symbols).  Same results; a workgroup takes the second form for a tile when the tile
-  // before it took more than MATCHW_SCAN_STEPS run-slot steps per position (its first tile: the first form).
+  // before it took more than MATCHW_SCAN_STEPS run-slot steps per position.  The workgroup's FIRST tile has no tile before
+  // it (and is three quarters of a 64 KiB stream since round 5): every thread follows the links of one position of the tile
+  // through three candidates -- three dependent reads of the window the barrier above has just completed -- and the tile
+  // takes the second form when more than half of the probed chains get that far (the benchmark's symbols: one in seven;
+  // 3-bit symbols and text: nine in ten).  Only speed depends on it.
   // form: 0 that rule, 1 / 2 always the first / second form (ZIPC_HIP_MATCH_FORM: tests and tuning).
   bool scan_form = form == 2;
+  if (form == 0) {
+    const uint32_t t_last = (uint64_t)g.t1 < (uint64_t)len - 3 ? g.t1 : len - 3;  // one past the tile's last position
+    const uint32_t n_pos = t_last - g.t0;                                            // (>= 1)
+    uint32_t p = g.t0 + (uint32_t)(((uint64_t)tid * n_pos) >> 10), hops = 0;
+    const uint16_t *wp0 = win_prev - g.w0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const uint32_t d = wp0[p];
+      const bool on = d != 0 && p - d >= g.w0 && hops == (uint32_t)k;
+      p = on ? p - d : p;
+      hops += on ? 1u : 0u;
+    }
+    const unsigned long long deep = __builtin_amdgcn_ballot_w64(hops == 3u);
+    if ((tid & 63u) == 0) atomicAdd(&probe_deep, (uint32_t)__builtin_popcountll(deep));
+    __syncthreads();
+    scan_form = probe_deep > MATCHW_THREADS / 2;
+  }
   for (;;) {
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
@@ -737,9 +773,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     // the phase timers, more on text) and a wave as long as its slowest lane.  Same box, the pool
     // against that: 5.46 vs 5.83-5.87 ms on C2, 171.8 vs 174.7 ms on C4, 153 vs 241 ms on real text.
     // the parse reads up to PARSE_PAD entries behind the last position without a range test
-    if ((uint64_t)g.t0 + MATCHW_TILE > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
+    if ((uint64_t)g.t1 > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     {
-      const uint64_t tend64 = (uint64_t)g.t0 + MATCHW_TILE < (uint64_t)len - 3 ? (uint64_t)g.t0 + MATCHW_TILE : (uint64_t)len - 3;
+      const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)len - 3 ? (uint64_t)g.t1 : (uint64_t)len - 3;
       const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base)
                                        : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
       if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
@@ -773,7 +809,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     // run-slot steps the tile took per position (a tile with a successor is a full one): chain steps / lane use
-    if (form == 0) scan_form = tile_iters[tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > MATCHW_SCAN_STEPS * MATCHW_TILE;
+    if (form == 0) scan_form = (uint64_t)tile_iters[tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > (uint64_t)MATCHW_SCAN_STEPS * (g.t1 - g.t0);
     store(gn);
     if (tid == 0) { pool_next = 0; tile_iters[(tile + 1) & 1u] = 0; }  // the next tile's counter: nobody touches it now
     __syncthreads();
@@ -2562,7 +2598,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // The pipeline of a slice of the group's streams: the slices share the scratch arrays (one
   // scan above gave every stream its base) and the error word, and differ in where their
   // per-stream arrays start.
-  const size_t tps = (max_src_len + MATCHW_TILE - 1) / MATCHW_TILE;
+  const size_t tps = max_src_len >= 4 ? (size_t)match_tiles_of(max_src_len) : 1;
   const size_t cps = max_src_len ? (max_src_len + MATCH_TILE - 1) / MATCH_TILE : 1;
   if (n * (max_src_len <= MATCHW_SMALL ? cps : tps) > 0x7FFFFFFFull) return hipErrorInvalidValue;
   // consecutive tiles of a stream per workgroup: as many as leave the grid >= 8192
