@@ -74,9 +74,9 @@ size_t deflate_scratch_bytes(size_t n_all, size_t max_src_len, size_t total_all,
   uint64_t P, Bk;
   scratch_caps(n, total_src_len, P, Bk);
   size_t b = 0;
-  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) + 256;
+  b += align_up(n * 8, 256) * 2 + align_up(n * 4, 256) * 2 + 256;
   if (level != LEVEL_NONE) {
-    b += align_up(P * 2, 256) + align_up(P * 8, 256) + align_up(P * 4, 256);
+    b += align_up(P * 2, 256) + 2 * align_up(P * 4, 256) + align_up(P * 4, 256);
     b += align_up(Bk * sizeof(BlockDesc), 256);
   }
   return b + 1024;
@@ -90,12 +90,14 @@ static DeflateScratch carve(void *base, size_t n, size_t total_src_len, int leve
   s.pos_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.blk_base = (uint64_t *)p; p += align_up(n * 8, 256);
   s.n_blocks = (uint32_t *)p; p += align_up(n * 4, 256);
+  s.snap_used = (uint32_t *)p; p += align_up(n * 4, 256);
   s.error = (uint32_t *)p; p += 256;
-  s.prev = nullptr; s.match = nullptr;
+  s.prev = nullptr; s.match = nullptr; s.snap = nullptr;
   s.syms = nullptr; s.blocks = nullptr;
   if (level != LEVEL_NONE) {
     s.prev = (uint16_t *)p; p += align_up(P * 2, 256);
-    s.match = (uint64_t *)p; p += align_up(P * 8, 256);
+    s.match = (uint32_t *)p; p += align_up(P * 4, 256);
+    s.snap = (uint32_t *)p; p += align_up(P * 4, 256);
     s.syms = (uint32_t *)p; p += align_up(P * 4, 256);
     s.blocks = (BlockDesc *)p; p += align_up(Bk * sizeof(BlockDesc), 256);
   }
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(1024) void deflate_offsets_kernel(const StreamDesc 
   for (uint32_t i = lo; i < hi; i++) {
     S.pos_base[i] = sp;
     S.blk_base[i] = sb;
+    S.snap_used[i] = 0;
     sp += padded_positions(descs[i].src_len);
     sb += max_blocks_of(descs[i].src_len);
   }
@@ -529,6 +532,14 @@ constexpr uint32_t MATCH_THREADS = 256;
 constexpr int MATCH_NP = 4;  // positions per lane, their chain walks interleaved
 constexpr uint32_t MATCH_TILE = MATCH_THREADS * MATCH_NP;
 
+// A position's two answers into the tables; true when the second one went to snap[]
+__device__ __forceinline__ bool match_store(uint32_t *__restrict__ match, uint32_t *__restrict__ snap, uint32_t p, uint32_t best, uint32_t first) {
+  const bool two = first != best;
+  match[p] = best | (two ? MATCH_SNAP : 0u);
+  if (two) snap[p] = first;
+  return two;
+}
+
 __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *__restrict__ src_arena,
                                                                  const StreamDesc *__restrict__ descs,
                                                                  DeflateScratch S, uint32_t n_streams,
@@ -561,9 +572,11 @@ __global__ __launch_bounds__(MATCH_THREADS) void lz_match_kernel(const uint8_t *
   if ((uint64_t)chunk * MATCH_TILE + MATCH_TILE > (uint64_t)len - 4 && threadIdx.x < PARSE_PAD)
     S.match[base + (len - 3) + threadIdx.x] = 0;  // what the parse may read behind the last position
   lz_match_positions<MATCH_NP>(src_arena + sd.src_off, len, p, act, S.prev + base, K, Kq, out);
+  bool any = false;
 #pragma unroll
   for (int i = 0; i < MATCH_NP; i++)
-    if (act[i]) S.match[base + p[i]] = out[i];
+    if (act[i]) any |= match_store(S.match + base, S.snap + base, p[i], (uint32_t)out[i], (uint32_t)(out[i] >> 32));
+  if (any) S.snap_used[stream] = 1;  // (every writer writes the same word)
 }
 
 // The same search for longer streams, out of LDS: a workgroup takes a tile of
@@ -776,8 +789,11 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     if ((uint64_t)g.t1 > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
     {
       const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)len - 3 ? (uint64_t)g.t1 : (uint64_t)len - 3;
-      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base)
-                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, S.match + base);
+      uint32_t two = 0;  // some position of mine left a second answer
+      auto sink = [&](uint32_t p, uint32_t best, uint32_t first) { two |= match_store(S.match + base, S.snap + base, p, best, first) ? 1u : 0u; };
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink)
+                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
+      if (two) S.snap_used[stream] = 1;  // (every writer writes the same word; read by the parse, a kernel later)
       if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
     }
 #ifdef ZD_MATCH_PHASES
@@ -836,7 +852,7 @@ constexpr int PARSE_TILE = 64;
 // next tile's).  br: the match the step ends with (0: the position is a literal), st: advance | literals << 16.
 __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool valid, bool has_match, uint32_t max_pos,
                                                uint32_t len, uint64_t m_cur, uint64_t m_nxt,
-                                               const uint64_t *__restrict__ match, int good_match, uint32_t &br,
+                                               const uint32_t *__restrict__ match, const uint32_t *__restrict__ snap, int good_match, uint32_t &br,
                                                uint32_t &st) {
   br = 0; st = 1u | (1u << 16);
   uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
@@ -888,7 +904,7 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
   // (kept out of the loop above: its load would make that loop wait for memory)
   if (__builtin_amdgcn_ballot_w64(chaining != 0)) {
     while (chaining) {
-      const uint64_t mj = j <= max_pos ? match[j] : 0ull;
+      const uint64_t mj = j <= max_pos ? match_pair(match, snap, j) : 0ull;
       chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
     }
   }
@@ -919,7 +935,7 @@ struct ParseSegs {
 
 // MODE 0: one wave parses a whole stream and cuts its blocks.  MODE 1: one wave parses ONE SEGMENT of a stream as if
 // a symbol started at the segment's first position, into ParseSegs (no blocks: lz_parse_stitch_kernel).
-template <int MODE>
+template <int MODE, bool SNAP>
 __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_arena,
                                               const StreamDesc *__restrict__ descs,
                                               DeflateScratch S, int good_match, uint32_t stream, uint32_t seg,
@@ -934,7 +950,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   const uint32_t len = (uint32_t)sd.src_len;
   const uint8_t *s = src_arena + sd.src_off;
   const uint64_t base = S.pos_base[stream];
-  const uint64_t *match = S.match + base;
+  const uint32_t *match = S.match + base, *snap = S.snap + base;
   const bool has_match = len >= (uint32_t)MIN_MATCH_LEN;
   const uint32_t max_pos = has_match ? len - MIN_MATCH_LEN : 0;  // positions <= max_pos have a match entry
   if (MODE == 1 && (uint64_t)seg * G.seg_positions >= len && !(len == 0 && seg == 0)) return;
@@ -972,9 +988,14 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   // per-lane 64-bit address arithmetic costs vector instructions this kernel is bound by)
   // (no branch and no select around a load: the compiler waits for EVERYTHING in flight at the join of a
   // conditional load, and a select on the loaded value is an instruction it may place early)
+  // (SNAP: the stream has positions whose best of the first K/4 is not their best of the first K -- S.snap_used -- and both
+  // tables are read side by side, unconditionally like every load here; else one word a position is all there is)
   auto load_match = [&](uint32_t tile) -> uint64_t {
-    const uint64_t *mt = match + (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);  // the tile's entries
-    return mt[lane];
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    const uint32_t lo = (match + t)[lane];  // the tile's entries
+    if (!SNAP) return (uint64_t)lo | ((uint64_t)lo << 32);
+    const uint32_t second = (snap + t)[lane];
+    return (uint64_t)(lo & ~MATCH_SNAP) | ((uint64_t)((lo & MATCH_SNAP) ? second : lo) << 32);
   };
   // A lane's source byte travels as the 4-byte word it was loaded in and is extracted where it is used
   // (lit_byte) -- NOT loaded as a byte: a byte load is zero-extended by an instruction the compiler put at
@@ -1014,7 +1035,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     // macro step of every position of the tile (lz_macro_position, with the
     // following positions' matches taken from the neighbouring lanes)
     uint32_t br, st;
-    parse_tile_macro(lane, p, valid, has_match, max_pos, len, m_cur, m_nxt, match, good_match, br, st);
+    parse_tile_macro(lane, p, valid, has_match, max_pos, len, m_cur, m_nxt, match, snap, good_match, br, st);
     const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
     const uint32_t lits = br ? macro_lits(st) : 0u;
     const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
@@ -1139,7 +1160,8 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict__ src_arena,
                                                       const StreamDesc *__restrict__ descs,
                                                       DeflateScratch S, int good_match) {
-  lz_parse_wave<0>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
+  if (S.snap_used[blockIdx.x]) lz_parse_wave<0, true>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
+  else lz_parse_wave<0, false>(src_arena, descs, S, good_match, blockIdx.x, 0, ParseSegs{});
 }
 
 // ---------------------------------------------------------------------------------
@@ -1165,7 +1187,10 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint8_t *__restrict_
 __global__ __launch_bounds__(64) void lz_parse_spec_kernel(const uint8_t *__restrict__ src_arena,
                                                            const StreamDesc *__restrict__ descs,
                                                            DeflateScratch S, int good_match, ParseSegs G) {
-  lz_parse_wave<1>(src_arena, descs, S, good_match, blockIdx.x / G.segs_per_stream, blockIdx.x % G.segs_per_stream, G);
+  if (S.snap_used[blockIdx.x / G.segs_per_stream])
+    lz_parse_wave<1, true>(src_arena, descs, S, good_match, blockIdx.x / G.segs_per_stream, blockIdx.x % G.segs_per_stream, G);
+  else
+    lz_parse_wave<1, false>(src_arena, descs, S, good_match, blockIdx.x / G.segs_per_stream, blockIdx.x % G.segs_per_stream, G);
 }
 
 // What the waves that re-parse parts of a stream share (lz_parse_meet_kernel, lz_parse_stitch_kernel).
@@ -1173,7 +1198,7 @@ struct ParseStream {
   int lane;
   uint32_t len, max_pos;
   const uint8_t *s;
-  const uint64_t *match;
+  const uint32_t *match, *snap;
   int good_match;
   const unsigned long long *own_vis;  // per tile: the path of the segment's own parse (read only after lz_parse_spec_kernel),
   const uint32_t *own_sym0;           //   and the segment's symbols before the tile
@@ -1192,9 +1217,9 @@ __device__ __forceinline__ ParseTile parse_eval_tile(const ParseStream &P, uint3
   const int lane = P.lane;
   const uint32_t p = B + (uint32_t)lane;
   const bool valid = p < P.len;
-  const uint64_t m_cur = P.match[p], m_nxt = P.match[p + PARSE_TILE];  // (PARSE_PAD zero entries behind the last position)
+  const uint64_t m_cur = match_pair(P.match, P.snap, p), m_nxt = match_pair(P.match, P.snap, p + PARSE_TILE);  // (PARSE_PAD zero entries behind the last position)
   uint32_t st;
-  parse_tile_macro(lane, p, valid, true, P.max_pos, P.len, m_cur, m_nxt, P.match, P.good_match, t.br, st);
+  parse_tile_macro(lane, p, valid, true, P.max_pos, P.len, m_cur, m_nxt, P.match, P.snap, P.good_match, t.br, st);
   t.adv = valid ? (t.br ? macro_advance(st) : 1u) : 0u;
   t.lits = t.br ? macro_lits(st) : 0u;
   t.cnt = valid ? (t.br ? t.lits + 1u : 1u) : 0u;
@@ -1307,8 +1332,8 @@ __device__ __forceinline__ ParseAgain parse_again(const ParseStream &P, uint32_t
       const uint64_t ahead = (uint64_t)lane * stride;
       const bool in = ahead < (uint64_t)(ext_end - entry);
       const uint32_t p = in ? entry + (uint32_t)ahead : entry;
-      const uint64_t *match = P.match;
-      const MacroStep m = lz_macro_position(p, P.len, P.good_match, [&](uint32_t j) -> uint64_t { return match[j]; });
+      const uint32_t *match = P.match, *snap = P.snap;
+      const MacroStep m = lz_macro_position(p, P.len, P.good_match, [&](uint32_t j) -> uint64_t { return match_pair(match, snap, j); });
       const uint32_t adv = m.bref ? macro_advance(m.step) : 1u;
       const unsigned long long go = __builtin_amdgcn_ballot_w64(in && adv == stride);
       const uint32_t lead = ~go ? (uint32_t)__builtin_ctzll(~go) : 64u;  // lanes [0, lead) are on the path, and step alike
@@ -1359,7 +1384,7 @@ __global__ __launch_bounds__(64) void lz_parse_meet_kernel(const uint8_t *__rest
   const size_t slot = (size_t)stream * G.segs_per_stream + k;
   ParseStream P;
   P.lane = threadIdx.x; P.len = len; P.max_pos = len - MIN_MATCH_LEN; P.s = src_arena + sd.src_off;
-  P.match = S.match + base; P.good_match = good_match;
+  P.match = S.match + base; P.snap = S.snap + base; P.good_match = good_match;
   P.own_vis = G.vis + (base >> 6); P.own_sym0 = G.tile_sym0 + (base >> 6);
   P.vis2 = G.vis2 + (base >> 6); P.sym02 = G.sym02 + (base >> 6);
   const uint32_t seg_start = k * G.seg_positions;
@@ -1409,7 +1434,7 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
   }
   ParseStream P;
   P.lane = lane; P.len = len; P.max_pos = len - MIN_MATCH_LEN; P.s = s;
-  P.match = S.match + base; P.good_match = good_match;
+  P.match = S.match + base; P.snap = S.snap + base; P.good_match = good_match;
   P.own_vis = G.vis + (base >> 6); P.own_sym0 = G.tile_sym0 + (base >> 6);
   P.vis2 = G.vis2 + (base >> 6); P.sym02 = G.sym02 + (base >> 6);
   const size_t slot0 = (size_t)stream * G.segs_per_stream;
@@ -2677,7 +2702,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   auto slice = [&](size_t lo, size_t hi) {
     const size_t m = hi - lo;
     DeflateScratch Q = S;
-    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo;
+    Q.pos_base += lo; Q.blk_base += lo; Q.n_blocks += lo; Q.snap_used += lo;
     const StreamDesc *dd = d_descs + lo;
     if (xchg_chain) {  // one wave per stream (per segment of a long one while there are few): ordered LDS exchange
       if (m * xsegs > m && m * xsegs <= 0x7FFFFFFFull)

@@ -500,10 +500,11 @@ constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any on
                                       // C2 5.58 / 5.44-5.48 / 5.83 ms, real text 145.5 / 150.1 / 167.5 ms
 // first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
 // where chains are a candidate or two long.  Returns the wave's iterations: x 64 NP / positions = steps per position / lane use.
-template <int NP>
+// (sink(p, best, first): where a finished position's two answers go -- the kernel's tables)
+template <int NP, typename Sink>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
                                                         uint32_t pbeg, uint32_t pend, uint32_t lane,
-                                                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
+                                                        const uint16_t *prev, int K, int Kq, Sink sink) {
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
@@ -531,7 +532,7 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
     iters++;
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const bool fin = match_run_step<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, out);
+      const bool fin = match_run_step_to<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, sink);
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
@@ -558,10 +559,10 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
 }
 
 // second form (scan_run_*): the faster one on long chains.  Returns the wave's rounds of cheap steps.
-template <int NP>
+template <int NP, typename Sink>
 __device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
                                                         uint32_t pbeg, uint32_t pend, uint32_t lane,
-                                                        const uint16_t *prev, int K, int Kq, uint64_t *out) {
+                                                        const uint16_t *prev, int K, int Kq, Sink sink) {
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   ScanRun r[NP];
   uint32_t iters = 0;  // rounds of cheap steps (what is returned: the same measure as the first form's iterations)
@@ -617,7 +618,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_
       const bool fin = r[i].state == RUN_FIN;
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
-        if (fin) out[r[i].p] = scan_run_result(r[i], (uint32_t)Kq);
+        if (fin) { const uint64_t both = scan_run_result(r[i], (uint32_t)Kq); sink(r[i].p, (uint32_t)both, (uint32_t)(both >> 32)); }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;

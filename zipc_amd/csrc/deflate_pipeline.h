@@ -23,6 +23,14 @@ __host__ __device__ inline uint64_t max_blocks_of(uint64_t src_len) {
   return src_len / MIN_BLOCK_SRC + 2;
 }
 
+constexpr uint32_t MATCH_SNAP = 1u << 31;
+// both answers of a position as the 64-bit word the parse works on (best of K | best of K/4 << 32) from the two tables
+__device__ __forceinline__ uint64_t match_pair(const uint32_t *__restrict__ match, const uint32_t *__restrict__ snap, uint64_t i) {
+  const uint32_t lo = match[i];
+  const uint32_t hi = (lo & MATCH_SNAP) ? snap[i] : lo;
+  return (uint64_t)(lo & ~MATCH_SNAP) | ((uint64_t)hi << 32);
+}
+
 struct DeflateScratch {
   uint64_t *pos_base;   // [n] first position slot of stream i
   uint64_t *blk_base;   // [n] first BlockDesc slot of stream i
@@ -30,7 +38,10 @@ struct DeflateScratch {
   uint32_t *error;      // [1] != 0: the batch does not fit what the caller declared (total_src_len too small,
                         //     or a stream longer than max_src_len: the grids are sized from it)
   uint16_t *prev;       // [P] chain links
-  uint64_t *match;      // [P] lz_match_position: best-of-K | best-of-K/4 << 32
+  uint32_t *match;      // [P] lz_match_position's best of the first K candidates (dist << 9 | len, 0: none) | MATCH_SNAP when the best of the
+                        //     first K/4 is another: that one is then in snap[] (round 5: 4 bytes a position where 8 were written and read)
+  uint32_t *snap;       // [P] the best of the first K/4, written for positions with MATCH_SNAP only
+  uint32_t *snap_used;  // [n] != 0: the stream has such positions (its parse then reads both tables side by side; zeroed by deflate_offsets_kernel)
   uint32_t *syms;       // [P]
   BlockDesc *blocks;    // [Bk]
   uint64_t cap_positions, cap_blocks;
