@@ -791,8 +791,9 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)len - 3 ? (uint64_t)g.t1 : (uint64_t)len - 3;
       uint32_t two = 0;  // some position of mine left a second answer
       auto sink = [&](uint32_t p, uint32_t best, uint32_t first) { two |= match_store(S.match + base, S.snap + base, p, best, first) ? 1u : 0u; };
-      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink)
-                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, &pool_next, g.t0, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
+      TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u};
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink)
+                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
       if (two) S.snap_used[stream] = 1;  // (every writer writes the same word; read by the parse, a kernel later)
       if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
     }

@@ -52,9 +52,12 @@ ZD_HD uint32_t common_prefix(const uint8_t *s, uint32_t q, uint32_t p, uint32_t 
 // ... in the LDS window (WORDS: s 4-byte aligned, may be over-read by 11 bytes): aligned words and a funnel shift, like
 // every other read of the window -- a misaligned 8-byte LDS read stalls the pipe for ~55 clocks (SQ_LDS_IDX_ACTIVE per
 // instruction on 1 MiB of zeros, where every position's one candidate is compared over 258 bytes)
-template <bool WORDS>
-ZD_HD uint32_t common_prefix_t(const uint8_t *s, uint32_t q, uint32_t p, uint32_t maxlen, uint32_t from) {
-  if (!WORDS) return common_prefix(s, q, p, maxlen, from);
+// (S: what the window's bytes are read through -- a pointer indexed by stream position, or deflate.hip's RingSrc, which
+// maps a position to its place in a ring; P likewise for the links.  The walks below are written on s[x], s + x,
+// load_u64_words(s, x) and prev[x] alone.)
+template <bool WORDS, typename S>
+ZD_HD uint32_t common_prefix_t(S s, uint32_t q, uint32_t p, uint32_t maxlen, uint32_t from) {
+  if constexpr (!WORDS) return common_prefix(s, q, p, maxlen, from);
   uint32_t i = from;
   // (the first 16 bytes as they come: on text most compares end there, and three aligned reads and two funnel shifts
   // per 8 bytes cost it more than the odd stall -- lz_match 95.5 -> 101.3 ms with words from the first byte on)
@@ -216,9 +219,8 @@ struct MatchRun {
   uint64_t pw;
 };
 constexpr uint32_t SNAP_NONE = 0xFFFFFFFFu;  // no snapshot yet (a real one has length bits <= 258)
-template <bool WORDS>
-ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend,
-                           const uint16_t *prev) {
+template <bool WORDS, typename S, typename P>
+ZD_HD void match_run_start(MatchRun &r, S s, uint32_t len, uint32_t p, uint32_t pend, P prev) {
   r.alive = p < pend ? 1u : 0u;
   r.p = r.alive ? p : (pend ? pend - 1u : 0u);  // a finished run parks on a valid position
   r.q = r.p;
@@ -241,9 +243,8 @@ ZD_HD void match_run_start(MatchRun &r, const uint8_t *s, uint32_t len, uint32_t
 // step like any other (it parks on a valid position and never walks); only the long compare and
 // the store of a finished position stay behind branches.
 // (sink(p, best, snap): where a finished position's two answers go)
-template <bool WORDS, typename Sink>
-ZD_HD bool match_run_step_to(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
-                             Sink sink) {
+template <bool WORDS, typename Sink, typename S, typename P>
+ZD_HD bool match_run_step_to(MatchRun &r, S s, P prev, uint32_t K, uint32_t Kq, Sink sink) {
   const uint32_t qn = r.q - r.dn;
   const bool walk = r.alive != 0 && r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
   const uint32_t qc = walk ? qn : r.p;
@@ -283,9 +284,8 @@ ZD_HD bool match_run_step_to(MatchRun &r, const uint8_t *s, const uint16_t *prev
   }
   return fin;
 }
-template <bool WORDS>
-ZD_HD bool match_run_step(MatchRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq,
-                          uint64_t *out) {
+template <bool WORDS, typename S, typename P>
+ZD_HD bool match_run_step(MatchRun &r, S s, P prev, uint32_t K, uint32_t Kq, uint64_t *out) {
   return match_run_step_to<WORDS>(r, s, prev, K, Kq, [out](uint32_t p, uint32_t best, uint32_t snap) {
     out[p] = (uint64_t)best | ((uint64_t)snap << 32);
   });
@@ -362,9 +362,8 @@ struct ScanRun {
 ZD_HD bool scan_next_ok(uint32_t p, uint32_t steps, uint32_t q, uint32_t dn, uint32_t K) {
   return dn != 0 && steps != K && p - q + dn <= (uint32_t)MAX_MATCH_DIST;
 }
-template <bool WORDS>
-ZD_HD void scan_run_start(ScanRun &r, const uint8_t *s, uint32_t len, uint32_t p, uint32_t pend, const uint16_t *prev,
-                          uint32_t K) {
+template <bool WORDS, typename S, typename P>
+ZD_HD void scan_run_start(ScanRun &r, S s, uint32_t len, uint32_t p, uint32_t pend, P prev, uint32_t K) {
   const bool alive = p < pend;
   r.p = alive ? p : (pend ? pend - 1u : 0u);  // a run without a position parks on a valid one
   r.q = r.p;
@@ -395,8 +394,8 @@ struct ScanProbe {
   uint32_t b0, b1;  // its bytes at best_len - 1 and best_len
   uint32_t dn;      // its link
 };
-template <bool WORDS>
-ZD_HD ScanProbe scan_run_probe(const ScanRun &r, const uint8_t *s, const uint16_t *prev) {
+template <bool WORDS, typename S, typename P>
+ZD_HD ScanProbe scan_run_probe(const ScanRun &r, S s, P prev) {
   ScanProbe x;
   x.q = r.q - (r.state == RUN_WALK ? r.dn : 0u);
   x.b0 = s[x.q + r.best_len - 1u];  // 2 <= best_len - 1, best_len < maxlen: inside both strings
@@ -418,14 +417,14 @@ ZD_HD void scan_run_take(ScanRun &r, const ScanProbe &x, uint32_t K, uint32_t Kq
   r.dn = x.dn;
   r.state = w ? after : r.state;
 }
-template <bool WORDS>
-ZD_HD void scan_run_step(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
+template <bool WORDS, typename S, typename P>
+ZD_HD void scan_run_step(ScanRun &r, S s, P prev, uint32_t K, uint32_t Kq) {
   const ScanProbe x = scan_run_probe<WORDS>(r, s, prev);
   scan_run_take(r, x, K, Kq);
 }
 // the full compare of a run that stands on a candidate which passed the byte test
-template <bool WORDS>
-ZD_HD void scan_run_compare(ScanRun &r, const uint8_t *s, const uint16_t *prev, uint32_t K, uint32_t Kq) {
+template <bool WORDS, typename S, typename P>
+ZD_HD void scan_run_compare(ScanRun &r, S s, P prev, uint32_t K, uint32_t Kq) {
   if (r.state != RUN_HIT) return;
   const uint32_t q = r.q;
   uint32_t l;
@@ -501,22 +500,43 @@ constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any on
 // first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
 // where chains are a candidate or two long.  Returns the wave's iterations: x 64 NP / positions = steps per position / lane use.
 // (sink(p, best, first): where a finished position's two answers go -- the kernel's tables)
-template <int NP, typename Sink>
-__device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
-                                                        uint32_t pbeg, uint32_t pend, uint32_t lane,
-                                                        const uint16_t *prev, int K, int Kq, Sink sink) {
-  static_assert(64u * NP <= POOL_CHUNK, "chunk");
-  MatchRun r[NP];
-  uint32_t iters = 0;
-  // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
-  // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
-  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
+// Where a wave's chunks come from.  take(oldest): wave-uniform, the first position of a fresh chunk of POOL_CHUNK positions, or pend:
+// the pool is empty.  oldest (pools with WANTS_OLDEST): the lowest position one of the wave's run slots still walks, ~0 for none.
+// TilePool: a counter in LDS over the positions [pbeg, pend) of one tile (it counts from 0: it overshoots the tile by a chunk per
+// wave at the end, which must not wrap for a stream near the 4 GiB limit).
+struct TilePool {
+  static constexpr bool WANTS_OLDEST = false;
+  uint32_t *pool_next;
+  uint32_t pbeg, pend, lane;
+  __device__ __forceinline__ uint32_t take(uint32_t) const {
     uint32_t c = 0;
     if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
     return c < pend - pbeg ? pbeg + c : pend;
+  }
+};
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
+  return v;
+}
+
+template <int NP, typename Sink, typename S, typename P, typename Pool>
+__device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
+                                                        P prev, int K, int Kq, Sink sink) {
+  static_assert(64u * NP <= POOL_CHUNK, "chunk");
+  MatchRun r[NP];
+  uint32_t iters = 0;
+  auto fetch = [&](bool first) -> uint32_t {
+    uint32_t oldest = 0xFFFFFFFFu;
+    if (Pool::WANTS_OLDEST && !first) {
+#pragma unroll
+      for (int i = 0; i < NP; i++) oldest = r[i].alive && r[i].p < oldest ? r[i].p : oldest;
+      oldest = wave_min_u32(oldest);
+    }
+    return pool.take(oldest);
   };
-  uint32_t next = fetch();  // my chunk is [next, cend)
+  uint32_t next = fetch(true);  // my chunk is [next, cend)
   uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
   bool empty = next >= pend;
   // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
@@ -540,7 +560,7 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
         const uint32_t rem = cend - next;
         uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
-          const uint32_t c = fetch();
+          const uint32_t c = fetch(false);
           const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
           empty = c >= pend;
           if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
@@ -559,22 +579,22 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(const uint8_t *s, uint32_
 }
 
 // second form (scan_run_*): the faster one on long chains.  Returns the wave's rounds of cheap steps.
-template <int NP, typename Sink>
-__device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_t len, uint32_t *pool_next,
-                                                        uint32_t pbeg, uint32_t pend, uint32_t lane,
-                                                        const uint16_t *prev, int K, int Kq, Sink sink) {
+template <int NP, typename Sink, typename S, typename P, typename Pool>
+__device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
+                                                        P prev, int K, int Kq, Sink sink) {
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   ScanRun r[NP];
   uint32_t iters = 0;  // rounds of cheap steps (what is returned: the same measure as the first form's iterations)
-  // *pool_next counts the tile's positions handed out, from 0 (relative to pbeg: it overshoots the
-  // tile by a chunk per wave at the end, which must not wrap for a stream near the 4 GiB limit)
-  auto fetch = [&]() -> uint32_t {  // wave-uniform: the first position of a fresh chunk (pend: the pool is empty)
-    uint32_t c = 0;
-    if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
-    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-    return c < pend - pbeg ? pbeg + c : pend;
+  auto fetch = [&](bool first) -> uint32_t {
+    uint32_t oldest = 0xFFFFFFFFu;
+    if (Pool::WANTS_OLDEST && !first) {
+#pragma unroll
+      for (int i = 0; i < NP; i++) oldest = r[i].state != RUN_DEAD && r[i].p < oldest ? r[i].p : oldest;
+      oldest = wave_min_u32(oldest);
+    }
+    return pool.take(oldest);
   };
-  uint32_t next = fetch();  // my chunk is [next, cend)
+  uint32_t next = fetch(true);  // my chunk is [next, cend)
   uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
   bool empty = next >= pend;
   // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
@@ -624,7 +644,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(const uint8_t *s, uint32_
         const uint32_t rem = cend - next;
         uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
-          const uint32_t c = fetch();
+          const uint32_t c = fetch(false);
           const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
           empty = c >= pend;
           if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
