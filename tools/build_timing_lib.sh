@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds a timing-only variant of libzipc_hip.so for the phase tools:
 #   tools/build_timing_lib.sh ZD_MATCH_PHASES   [out.so]   -> tools/exp_match_phases.py
+#   tools/build_timing_lib.sh ZD_MATCH_COUNTS   [out.so]   -> tools/exp_wall.py with MATCH_COUNTS=1 (what the pools' waves do, counted)
 #   tools/build_timing_lib.sh ZD_EMIT_PHASES    [out.so]   -> tools/exp_emit_phases.py
 #   tools/build_timing_lib.sh ZD_INFLATE_PHASES [out.so]   -> tools/exp_inflate_phases.py
 # then run the tool with ZIPC_HIP_LIB=<out.so>.  The product library is not touched: the one
@@ -8,7 +9,7 @@
 # other objects (make -C zipc_amd/csrc first).  Such a build returns clock stamps where the
 # product returns results, or exports a debug entry point: never ship or test parity with it.
 set -eu
-MACRO=${1:?ZD_MATCH_PHASES | ZD_EMIT_PHASES | ZD_INFLATE_PHASES}
+MACRO=${1:?ZD_MATCH_PHASES | ZD_MATCH_COUNTS | ZD_EMIT_PHASES | ZD_INFLATE_PHASES}
 ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/zipc_amd/csrc
 OUT=${2:-$C/build/timing_$MACRO.so}
 case $MACRO in ZD_INFLATE_PHASES) SRC=inflate;; *) SRC=deflate;; esac

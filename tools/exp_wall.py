@@ -101,6 +101,17 @@ def main():
             "deflate_ms": td[0], "inflate_ms": ti[0], "step_ms": ts[0], "best": [td[1], ti[1], ts[1]],
             "deflate_gib_s": round(gib / td[0] * 1e3, 2), "inflate_gib_s": round(gib / ti[0] * 1e3, 2),
             "step_gib_s": round(gib / ts[0] * 1e3, 2)}
+    if os.environ.get("MATCH_COUNTS", "0") == "1":  # a -DZD_MATCH_COUNTS build (tools/build_timing_lib.sh ZD_MATCH_COUNTS)
+        import ctypes as C
+        from zipc_amd import _lib
+        dbg = C.CDLL(_lib.LIB_PATH).zipc_hip_debug_match_counts
+        dbg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        cnt = (C.c_ulonglong * 16)()
+        assert dbg(cnt, 1) == 0
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, crc)
+        assert dbg(cnt, 0) == 0
+        names = ["waves", "outer_iterations", "rounds", "walking_slots", "compare_phases", "hit_slots", "handouts", "fin_slots", "alive_slots_first_form"]
+        line["match_counts"] = {k: int(cnt[i]) for i, k in enumerate(names)}
     if os.environ.get("KERNELS", "0") == "1":
         ctx.set_profiling(True); ctx.reset_kernel_times()
         for _ in range(2):

@@ -12,7 +12,7 @@ constexpr int ITERS = 512, UNROLL = 8;
 
 enum Mode {
   R32_RANDOM, R32_SEQ, U16_EVEN, U16_ANY, U8_ANY, R64_ALIGNED8, R64_ALIGNED4, R64_ANY, R2X32, R96_ALIGNED4, R128_ALIGNED16,
-  R128_SEQ, W64_SEQ, W128_SEQ, W32_SEQ, R64_SEQ, BPERM, MAX_RANDOM, W64_RANDOM_HALF, U16_AL4, U16_OFF2, U16D16_OFF2, U16D16HI_OFF2, R2X64, W16_OFF2, W16_AL4, W8_ANY, U16_SEQ, N_MODES
+  R128_SEQ, W64_SEQ, W128_SEQ, W32_SEQ, R64_SEQ, BPERM, MAX_RANDOM, W64_RANDOM_HALF, U16_AL4, U16_OFF2, U16D16_OFF2, U16D16HI_OFF2, R2X64, W16_OFF2, W16_AL4, W8_ANY, U16_SEQ, U16D16_ANY, U8D16_ANY, U16D16_EVEN, U16D16_AL4, R32_ANY, N_MODES
 };
 static const char *names[N_MODES] = {
   "ds_read_b32 random", "ds_read_b32 consecutive", "ds_read_u16 random even", "ds_read_u16 random any byte", "ds_read_u8 random",
@@ -21,7 +21,8 @@ static const char *names[N_MODES] = {
   "ds_write_b128 consecutive", "ds_write_b32 consecutive", "ds_read_b64 consecutive", "ds_bpermute_b32 random lanes", "ds_max_u32 random",
   "ds_write_b64 consecutive, a third of the lanes", "ds_read_u16 random 4-aligned", "ds_read_u16 random at 4k+2", "ds_read_u16_d16 random at 4k+2",
   "ds_read_u16_d16_hi random at 4k+2", "ds_read2_b64 random 8-aligned (0,1)", "ds_write_b16 random at 4k+2", "ds_write_b16 random 4-aligned", "ds_write_b8 random",
-  "ds_read_u16 consecutive (2 B per lane)"};
+  "ds_read_u16 consecutive (2 B per lane)", "ds_read_u16_d16 random any byte", "ds_read_u8_d16 random", "ds_read_u16_d16 random even",
+  "ds_read_u16_d16 random 4-aligned", "ds_read_b32 random any byte"};
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void probe(unsigned long long *clocks, unsigned *sink, unsigned seed) {
@@ -43,7 +44,9 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *clocks, unsign
       case U16_SEQ: a[k] = wave_base + lane * 2u + (unsigned)k * 128u; break;
       case R32_SEQ: case W32_SEQ: a[k] = wave_base + lane * 4u + (unsigned)k * 256u; break;
       case U16_EVEN: a[k] = r & ~1u; break;
-      case U16_ANY: case U8_ANY: case R64_ANY: a[k] = r; break;
+      case U16_ANY: case U8_ANY: case R64_ANY: case U16D16_ANY: case U8D16_ANY: case R32_ANY: a[k] = r; break;
+      case U16D16_EVEN: a[k] = r & ~1u; break;
+      case U16D16_AL4: a[k] = r & ~3u; break;
       case R64_ALIGNED8: a[k] = r & ~7u; break;
       case R128_ALIGNED16: a[k] = r & ~15u; break;
       case R128_SEQ: case W128_SEQ: a[k] = wave_base + lane * 16u + (unsigned)(k & 3) * 1024u; break;
@@ -62,7 +65,9 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *clocks, unsign
       switch (MODE) {
         case R32_RANDOM: case R32_SEQ: asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(a[k])); break;
         case U16_EVEN: case U16_ANY: case U16_AL4: case U16_OFF2: case U16_SEQ: asm volatile("ds_read_u16 %0, %1" : "=v"(v0) : "v"(a[k])); break;
-        case U16D16_OFF2: asm volatile("ds_read_u16_d16 %0, %1" : "+v"(v0) : "v"(a[k])); break;
+        case U16D16_OFF2: case U16D16_ANY: case U16D16_EVEN: case U16D16_AL4: asm volatile("ds_read_u16_d16 %0, %1" : "+v"(v0) : "v"(a[k])); break;
+        case U8D16_ANY: asm volatile("ds_read_u8_d16 %0, %1" : "+v"(v0) : "v"(a[k])); break;
+        case R32_ANY: asm volatile("ds_read_b32 %0, %1" : "=v"(v0) : "v"(a[k])); break;
         case U16D16HI_OFF2: asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(v0) : "v"(a[k])); break;
         case R2X64: {
           typedef unsigned u4 __attribute__((ext_vector_type(4)));
@@ -122,10 +127,10 @@ __global__ __launch_bounds__(1024) void probe(unsigned long long *clocks, unsign
       asm volatile("s_waitcnt lgkmcnt(7)");
       acc += v0;
       // next address of this slot: a fixed odd stride through the window (random forms), the same place (consecutive forms)
-      if (MODE == R32_RANDOM || MODE == R2X32 || MODE == R96_ALIGNED4 || MODE == R64_ALIGNED4 || MODE == MAX_RANDOM || MODE == U16_AL4 || MODE == W16_AL4 ||
+      if (MODE == R32_RANDOM || MODE == R2X32 || MODE == R96_ALIGNED4 || MODE == R64_ALIGNED4 || MODE == MAX_RANDOM || MODE == U16_AL4 || MODE == W16_AL4 || MODE == U16D16_AL4 ||
           MODE == U16_OFF2 || MODE == U16D16_OFF2 || MODE == U16D16HI_OFF2 || MODE == W16_OFF2) { a[k] += 4u * 7919u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64) & ~3u; }
-      if (MODE == U16_EVEN) { a[k] += 2u * 15013u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64) & ~1u; }
-      if (MODE == U16_ANY || MODE == U8_ANY || MODE == R64_ANY || MODE == W8_ANY) { a[k] += 30011u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64); }
+      if (MODE == U16_EVEN || MODE == U16D16_EVEN) { a[k] += 2u * 15013u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64) & ~1u; }
+      if (MODE == U16_ANY || MODE == U8_ANY || MODE == R64_ANY || MODE == W8_ANY || MODE == U16D16_ANY || MODE == U8D16_ANY || MODE == R32_ANY) { a[k] += 30011u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64); }
       if (MODE == R64_ALIGNED8 || MODE == R2X64) { a[k] += 8u * 3761u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64) & ~7u; }
       if (MODE == R128_ALIGNED16) { a[k] += 16u * 1877u; if (a[k] >= (unsigned)(WIN - 64)) a[k] -= (unsigned)(WIN - 64) & ~15u; }
     }
@@ -185,6 +190,11 @@ int main() {
   run<U16D16_OFF2>(d_clk, d_sink, n_wg);
   run<U16D16HI_OFF2>(d_clk, d_sink, n_wg);
   run<U16_SEQ>(d_clk, d_sink, n_wg);
+  run<U16D16_ANY>(d_clk, d_sink, n_wg);
+  run<U8D16_ANY>(d_clk, d_sink, n_wg);
+  run<U16D16_EVEN>(d_clk, d_sink, n_wg);
+  run<U16D16_AL4>(d_clk, d_sink, n_wg);
+  run<R32_ANY>(d_clk, d_sink, n_wg);
   run<R2X64>(d_clk, d_sink, n_wg);
   run<W16_OFF2>(d_clk, d_sink, n_wg);
   run<W16_AL4>(d_clk, d_sink, n_wg);

@@ -649,6 +649,14 @@ __device__ __forceinline__ MatchTile match_tile(uint32_t tile, uint32_t len) {
   return g;
 }
 
+// Eight links on their way into the window: "no link", 0 in the table, is 0xFFFF there (LinkNone<WinLinks>): x - 1 wraps
+// a 0 to 0xFFFF and the saturating + 1 leaves it there (two packed 16-bit instructions a word)
+__device__ __forceinline__ u32x4 links_for_window(u32x4 v) {
+  typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+  const u16x8 one = {1, 1, 1, 1, 1, 1, 1, 1};
+  return __builtin_bit_cast(u32x4, __builtin_elementwise_add_sat((u16x8)(__builtin_bit_cast(u16x8, v) - one), one));
+}
+
 // A workgroup takes tiles_per_group consecutive tiles of one stream: between workgroups
 // a CU sat idle for 4.4 us of a 29.3 us tile on C2 (tools/exp_match_phases.py).  A wave
 // requests its share of the next tile's window into registers as soon as it has walked
@@ -733,7 +741,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 #pragma unroll
     for (int j = 0; j < LINK_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
-      if (o < g.n_links) *(u32x4 *)(win_prev + o) = vl[j];
+      if (o < g.n_links) *(u32x4 *)(win_prev + o) = links_for_window(vl[j]);
     }
     if (tid < ((g.src_end - g.w0) & 15u)) win_src[g.n_src + tid] = s[g.w0 + g.n_src + tid];
   };
@@ -762,7 +770,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       const uint32_t d = wp0[p];
-      const bool on = d != 0 && p - d >= g.w0 && hops == (uint32_t)k;
+      const bool on = d != LinkNone<WinLinks>::value && p - d >= g.w0 && hops == (uint32_t)k;
       p = on ? p - d : p;
       hops += on ? 1u : 0u;
     }
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     const bool has_next = tile + 1 < tile_end;  // uniform over the workgroup
     const MatchTile gn = match_tile(has_next ? tile + 1 : tile, len);
     const uint8_t *ws = win_src - g.w0;  // indexed by stream position
-    const uint16_t *wp = win_prev - g.w0;
+    const WinLinks wp{win_prev - g.w0};
     // The tile's positions are ONE pool for the workgroup's 16 waves (lz_match_runs_pool): a wave
     // fetches chunks of 256 from pool_next and hands them to its run slots as they finish.  The
     // first schedule gave every wave a fixed 1 Ki positions and every lane every 64th of them: a
@@ -791,8 +799,15 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)len - 3 ? (uint64_t)g.t1 : (uint64_t)len - 3;
       uint32_t two = 0;  // some position of mine left a second answer
       auto sink = [&](uint32_t p, uint32_t best, uint32_t first) { two |= match_store(S.match + base, S.snap + base, p, best, first) ? 1u : 0u; };
-      TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u};
-      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>(ws, len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink)
+      // (the second form in coordinates of its own: the LDS addresses of the window's bytes -- its range test is signed, and
+      // its reads take no base)
+      typedef __attribute__((address_space(3))) uint8_t lds_u8;
+      const uint32_t lds_src = (uint32_t)(uintptr_t)(lds_u8 *)win_src, lds_links = (uint32_t)(uintptr_t)(lds_u8 *)win_prev;
+      const uint32_t off_w = g.w0 - lds_src;  // coordinate + off_w = stream position
+      auto sink_w = [&](uint32_t p, uint32_t best, uint32_t first) { sink(p + off_w, best, first); };
+      TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u}, pool_w{&pool_next, g.t0 - off_w, (uint32_t)tend64 - off_w, tid & 63u};
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>((const uint8_t *)win_src - lds_src, len - off_w, pool_w, (uint32_t)tend64 - off_w, tid & 63u,
+                                                                          WinLinks{win_prev - lds_src}, lds_links - 2u * lds_src, K, Kq, sink_w)
                                        : lz_match_runs_pool<MATCHW_NP>(ws, len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
       if (two) S.snap_used[stream] = 1;  // (every writer writes the same word; read by the parse, a kernel later)
       if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
@@ -2796,6 +2811,14 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
 
 }  // namespace zd
 
+#ifdef ZD_MATCH_COUNTS
+extern "C" int zipc_hip_debug_match_counts(unsigned long long *out16, int reset) {
+  unsigned long long host[16] = {};
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(zd::zd_match_counts), sizeof host) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_match_counts), host, sizeof host) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 #ifdef ZD_MATCH_PHASES
 extern "C" int zipc_hip_debug_match_phases(unsigned long long *out8, int reset) {
   static unsigned long long host[zd::ZD_PH_SLOTS * 8];

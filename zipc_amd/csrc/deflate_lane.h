@@ -211,6 +211,15 @@ ZD_HD void lz_match_positions(const uint8_t *s, uint32_t len, const uint32_t *p,
 // WORDS: read candidates with load_u64_words (s is 4-byte aligned and may be
 // over-read by 11 bytes) -- the LDS window.  out is indexed by position.  Same
 // results as lz_match_position.
+// What "no link" reads as through a links accessor P: 0 in the tables of lz_chain; 0xFFFF in an LDS window, whose kernel
+// stages them that way (a candidate that far back is out of range whatever the position: the second form of the walk
+// has no test for it).
+template <typename P> struct LinkNone { static constexpr uint32_t value = 0u; };
+struct WinLinks {
+  const uint16_t *b;
+  ZD_HD uint32_t operator[](uint32_t i) const { return b[i]; }
+};
+template <> struct LinkNone<WinLinks> { static constexpr uint32_t value = 0xFFFFu; };
 struct MatchRun {
   uint32_t p, q, best_len, best, maxlen, steps;
   uint32_t snap;   // best after Kq candidates, SNAP_NONE before
@@ -246,7 +255,7 @@ ZD_HD void match_run_start(MatchRun &r, S s, uint32_t len, uint32_t p, uint32_t 
 template <bool WORDS, typename Sink, typename S, typename P>
 ZD_HD bool match_run_step_to(MatchRun &r, S s, P prev, uint32_t K, uint32_t Kq, Sink sink) {
   const uint32_t qn = r.q - r.dn;
-  const bool walk = r.alive != 0 && r.dn != 0 && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
+  const bool walk = r.alive != 0 && r.dn != LinkNone<P>::value && r.steps != K && r.best_len < r.maxlen && r.p - qn <= (uint32_t)MAX_MATCH_DIST;  // zd.ml:1181,1187
   const uint32_t qc = walk ? qn : r.p;
   uint64_t x = 0;
   if (WORDS) x = load_u64_words(s, qc) ^ r.pw;
@@ -276,7 +285,7 @@ ZD_HD bool match_run_step_to(MatchRun &r, S s, P prev, uint32_t K, uint32_t Kq, 
   r.dn = d2;
   // would the next step walk?  (l < maxlen implies best_len < maxlen; zd.ml:1194:
   // after l == maxlen nothing later can be longer)
-  const bool more = walk && l != r.maxlen && d2 != 0 && steps != K && r.p - qc + d2 <= (uint32_t)MAX_MATCH_DIST;
+  const bool more = walk && l != r.maxlen && d2 != LinkNone<P>::value && steps != K && r.p - qc + d2 <= (uint32_t)MAX_MATCH_DIST;
   const bool fin = r.alive != 0 && !more;
   if (fin) {
     const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : best);
@@ -342,116 +351,115 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 // its common prefix is <= best_len, it changes neither the best match nor -- being shorter than
 // maxlen -- the end of the walk (zd.ml:1190-1194), and it still counts as one of the K
 // candidates.  On 3-bit symbols 7 of 8 candidates go that way, on text about as many.  What makes
-// this pay on a wave is the shape of the loop: lanes do up to SCAN_ROUNDS cheap steps (link, byte,
+// this pay on a wave is the shape of the loop: lanes do up to SCAN_ROUNDS cheap steps (link, two bytes,
 // compare) until they stand on a candidate that passes -- or their chain ends -- and only then
 // all lanes with such a candidate go through the full compare TOGETHER.  In the first form every
 // step of every lane paid for the long-compare branches, because some lane of the 64 always
 // took them.
-//   state WALK: the next candidate (q - dn) exists and is in range; HIT: q passed the byte test
-//   and waits for the compare; FIN: the position is done and waits for its store; DEAD: no position.
-enum : uint32_t { RUN_WALK = 0, RUN_HIT = 1, RUN_FIN = 2, RUN_DEAD = 3 };
+//
+// Round 5 counted what the waves of this form do on text (tools/exp_wall.py MATCH_COUNTS=1): 41 % of their vector
+// instructions were cheap steps (49 a round of two run slots, 74 % of the slots walking), 30 % compares (15 % of the slots
+// in one had a hit) and 23 % the handing out of positions (a tenth of a slot's lanes finishing at a time) -- and all of it
+// waits for vector issue.  Since then:
+//   * a cheap step is 8 vector instructions under the walking lanes' mask (it was 24 of selects): the run keeps the NEXT
+//     candidate t (the step's one subtraction: t - link doubles as the range test, see lim), "no link" reads as 0xFFFF
+//     out of the LDS window (LinkNone: the candidate then lies out of range, no test of its own), and the two limits on the
+//     count of candidates -- K, and K/4 for the second answer -- are ONE compare with klim: a run that reaches K/4 stops
+//     like one at its chain's end, notes its second answer where stopped runs are looked at anyway, and walks on;
+//   * the compares of a lane's run slots are one piece of code (a lane with hits in both slots takes them one after the
+//     other, which is rare);
+//   * finished positions wait until SCAN_HANDOUT lanes of the wave have one in the same slot (or nothing else is left to do).
+// A run is in ONE of: walking (t is a candidate in range and steps < klim), hit (it stands on q = t + dn, which passed
+// the byte test), fin (done, waits for its store), none of them with live set (stopped: scan_run_settle says which
+// of the others it becomes) or dead (!live: no position).
+// Positions are COORDINATES below 2^31 (the window kernel's are relative to its window): the range test is signed.
 struct ScanRun {
-  uint32_t p, q, best_len, best, maxlen, steps;
-  uint32_t snap;   // best after Kq candidates, SNAP_NONE before
-  uint32_t dn;     // prev[q], read with the candidate
-  uint32_t pb;     // s[p + best_len - 1] | s[p + best_len] << 8
-  uint32_t state;  // RUN_*
+  uint32_t p;      // the position
+  uint32_t t;      // the next candidate
+  uint32_t dn;     // the link of the candidate last looked at, q = t + dn
+  uint32_t blm1;   // best_len - 1
+  uint32_t pb;     // s[p + best_len - 1] | s[p + best_len] << 16
+  uint32_t steps;  // candidates looked at
+  uint32_t klim;   // ... at which the run stops next: K/4 (the second answer is noted there), then K
+  uint32_t maxlen, best;
+  uint32_t snap;   // best after K/4 candidates, SNAP_NONE before
+  int32_t lim;     // p - MAX_MATCH_DIST: candidates below are out of range (zd.ml:1187)
   uint64_t pw;     // s[p .. p+8)
 };
-// is there a candidate behind q (whose link is dn)?  zd.ml:1185-1187
-ZD_HD bool scan_next_ok(uint32_t p, uint32_t steps, uint32_t q, uint32_t dn, uint32_t K) {
-  return dn != 0 && steps != K && p - q + dn <= (uint32_t)MAX_MATCH_DIST;
+struct ScanFlags { bool walking, hit, fin, live; };  // (the device keeps them as four lane masks per run slot)
+template <typename P>
+ZD_HD bool scan_far(const ScanRun &r) {  // is there no candidate t?  zd.ml:1185-1187
+  if constexpr (LinkNone<P>::value == 0xFFFFu) return (int32_t)r.t < r.lim;  // (no link: t = q - 0xFFFF < p - 32768)
+  else return r.dn == LinkNone<P>::value || (int32_t)r.t < r.lim;
 }
 template <bool WORDS, typename S, typename P>
-ZD_HD void scan_run_start(ScanRun &r, S s, uint32_t len, uint32_t p, uint32_t pend, P prev, uint32_t K) {
+ZD_HD ScanFlags scan_run_start(ScanRun &r, S s, uint32_t len, uint32_t p, uint32_t pend, P prev, uint32_t K, uint32_t Kq) {
   const bool alive = p < pend;
-  r.p = alive ? p : (pend ? pend - 1u : 0u);  // a run without a position parks on a valid one
-  r.q = r.p;
-  r.best_len = MIN_MATCH_LEN - 1;
+  r.p = alive ? p : pend - 1u;  // a run without a position parks on a valid one (pend >= 1)
+  r.blm1 = MIN_MATCH_LEN - 2;
   r.best = 0; r.snap = SNAP_NONE; r.steps = 0;
+  r.klim = Kq ? Kq : K;
   r.maxlen = len - r.p < (uint32_t)MAX_MATCH_LEN ? len - r.p : (uint32_t)MAX_MATCH_LEN;
+  r.lim = (int32_t)r.p - (int32_t)MAX_MATCH_DIST;
   r.pw = 0;
   if (WORDS) r.pw = load_u64_words(s, r.p);
   else if (r.maxlen >= 8) r.pw = load_u64_le(s + r.p);
   else for (uint32_t i = 0; i < r.maxlen; i++) r.pw |= (uint64_t)s[r.p + i] << (8 * i);
-  r.pb = (uint32_t)(r.pw >> 16) & 0xFFFFu;  // s[p + 2], s[p + 3]
+  r.pb = ((uint32_t)(r.pw >> 16) & 0xFFu) | (((uint32_t)(r.pw >> 24) & 0xFFu) << 16);  // s[p + 2], s[p + 3]
   r.dn = prev[r.p];
+  r.t = r.p - r.dn;
   // zd.ml:1181: no search when even the shortest match does not fit
-  const bool walk = r.best_len < r.maxlen && scan_next_ok(r.p, 0, r.p, r.dn, K);
-  r.state = !alive ? RUN_DEAD : walk ? RUN_WALK : RUN_FIN;
+  const bool walk = alive && r.blm1 + 1u < r.maxlen && K != 0 && !scan_far<P>(r);
+  return ScanFlags{walk, false, alive && !walk, alive};
 }
-// One cheap step of a walking run: on to the next candidate, its link and its byte at best_len.
-// Straight-line on purpose (selects, no branches, flags as integers): the workgroup's 16 waves
-// share the CU's one scalar issue per clock, and a divergent branch costs 4-8 scalar instructions
-// (the first form of this step had 20 of them per 14 vector ones and the kernel sat on its
-// scalar bound on text and on 3-bit symbols).  Runs in another state read the bytes of the
-// candidate they stand on again and keep everything.
-// (in two halves, so that a lane's run slots can have their reads in flight TOGETHER: issued one slot after
-// the other with the slot's own use in between, every slot waited for its own LDS round trip -- and an `if` the
-// compiler made of the nested selects kept the second slot's reads behind the first one's exec mask)
-struct ScanProbe {
-  uint32_t q;       // the candidate looked at: the next one for a walking run, the one it stands on otherwise
-  uint32_t b0, b1;  // its bytes at best_len - 1 and best_len
-  uint32_t dn;      // its link
-};
-template <bool WORDS, typename S, typename P>
-ZD_HD ScanProbe scan_run_probe(const ScanRun &r, S s, P prev) {
-  ScanProbe x;
-  x.q = r.q - (r.state == RUN_WALK ? r.dn : 0u);
-  x.b0 = s[x.q + r.best_len - 1u];  // 2 <= best_len - 1, best_len < maxlen: inside both strings
-  x.b1 = s[x.q + r.best_len];
-  x.dn = prev[x.q];
-  return x;
+// One cheap step of a walking run: its candidate's two bytes at best_len - 1 and best_len, its link, the next candidate.
+// (the device's is scan_rounds_lds below)
+template <typename S, typename P>
+ZD_HD void scan_run_step(ScanRun &r, ScanFlags &f, S s, P prev) {
+  const uint32_t h = (uint32_t)s[r.t + r.blm1] | ((uint32_t)s[r.t + r.blm1 + 1u] << 16);  // 2 <= best_len - 1, best_len < maxlen: inside both strings
+  r.dn = prev[r.t];
+  r.steps++;
+  r.t -= r.dn;
+  f.hit = h == r.pb;
+  f.walking = !(f.hit | scan_far<P>(r) | (r.steps == r.klim));
 }
-ZD_HD void scan_run_take(ScanRun &r, const ScanProbe &x, uint32_t K, uint32_t Kq) {
-  const uint32_t w = r.state == RUN_WALK ? 1u : 0u;
-  const uint32_t steps = r.steps + w;
-  const uint32_t hit = (x.b0 | (x.b1 << 8)) == r.pb ? 1u : 0u;
-  // is there a candidate behind this one (scan_next_ok)?  Worked out whether or not it is needed: no branch
-  const uint32_t ok = (x.dn != 0 ? 1u : 0u) & (steps != K ? 1u : 0u) & (r.p - x.q + x.dn <= (uint32_t)MAX_MATCH_DIST ? 1u : 0u);
-  static_assert(RUN_WALK == 0 && RUN_HIT == 1 && RUN_FIN == 2, "the arithmetic below");
-  const uint32_t after = hit | (((hit | ok) ^ 1u) << 1);  // hit: HIT; else a candidate behind: WALK; else FIN (arithmetic: the compiler made a branch of the selects)
-  r.snap = (w & (hit ^ 1u) & (steps == Kq ? 1u : 0u)) ? r.best : r.snap;
-  r.q = x.q;
-  r.steps = steps;
-  r.dn = x.dn;
-  r.state = w ? after : r.state;
-}
-template <bool WORDS, typename S, typename P>
-ZD_HD void scan_run_step(ScanRun &r, S s, P prev, uint32_t K, uint32_t Kq) {
-  const ScanProbe x = scan_run_probe<WORDS>(r, s, prev);
-  scan_run_take(r, x, K, Kq);
-}
-// the full compare of a run that stands on a candidate which passed the byte test
-template <bool WORDS, typename S, typename P>
-ZD_HD void scan_run_compare(ScanRun &r, S s, P prev, uint32_t K, uint32_t Kq) {
-  if (r.state != RUN_HIT) return;
-  const uint32_t q = r.q;
-  uint32_t l;
-  if (r.maxlen >= 8) {
-    const uint64_t x = (WORDS ? load_u64_words(s, q) : load_u64_le(s + q)) ^ r.pw;
-    l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-    if (x == 0) {
-      // the first 8 bytes agree: before the long compare, the 8 bytes that END at best_len
-      // (they include the byte already tested); what fails here is at most best_len long
-      bool compare = true;
-      if (r.best_len >= 8u) {
-        const uint32_t toff = r.best_len - 7u;
-        compare = WORDS ? load_u64_words(s, q + toff) == load_u64_words(s, r.p + toff)
-                        : load_u64_le(s + q + toff) == load_u64_le(s + r.p + toff);
-      }
-      if (compare) l = common_prefix_t<WORDS>(s, q, r.p, r.maxlen, 8u);
-    }
-  } else {
-    l = common_prefix_t<WORDS>(s, q, r.p, r.maxlen, 0u);
+// the full compare of the candidate q = t + dn of the run at p: its common prefix if that is above best_len, else
+// something that is not
+template <bool WORDS, typename S>
+ZD_HD uint32_t scan_hit_length(S s, uint32_t q, uint32_t p, uint64_t pw, uint32_t best_len, uint32_t maxlen) {
+  if (maxlen < 8) return common_prefix_t<WORDS>(s, q, p, maxlen, 0u);
+  const uint64_t x = (WORDS ? load_u64_words(s, q) : load_u64_le(s + q)) ^ pw;
+  if (x) return (uint32_t)(__builtin_ctzll(x) >> 3);
+  // the first 8 bytes agree: before the long compare, the 8 bytes that END at best_len
+  // (they include the bytes already tested); what fails here is at most best_len long
+  if (best_len >= 8u) {
+    const uint32_t toff = best_len - 7u;
+    const bool same = WORDS ? load_u64_words(s, q + toff) == load_u64_words(s, p + toff)
+                            : load_u64_le(s + q + toff) == load_u64_le(s + p + toff);
+    if (!same) return 8u;
   }
-  const bool better = l > r.best_len;
-  r.best_len = better ? l : r.best_len;
-  r.best = better ? (((r.p - q) << 9) | l) : r.best;
-  if (better && l < r.maxlen) r.pb = (uint32_t)s[r.p + l - 1u] | ((uint32_t)s[r.p + l] << 8);
-  r.snap = r.steps == Kq ? r.best : r.snap;
-  // zd.ml:1194: after l == maxlen nothing later can be longer
-  r.state = (l != r.maxlen && scan_next_ok(r.p, r.steps, q, r.dn, K)) ? RUN_WALK : RUN_FIN;
+  return common_prefix_t<WORDS>(s, q, p, maxlen, 8u);
+}
+// ... and what it does to the run; true: the match is as long as a match can be, the run is done (zd.ml:1194)
+template <typename S>
+ZD_HD bool scan_run_hit_done(ScanRun &r, S s, uint32_t q, uint32_t l) {
+  if (l > r.blm1 + 1u) {
+    r.blm1 = l - 1u;
+    r.best = ((r.p - q) << 9) | l;
+    if (l < r.maxlen) r.pb = (uint32_t)s[r.p + l - 1u] | ((uint32_t)s[r.p + l] << 16);
+  }
+  return l == r.maxlen;
+}
+// a run that neither walks nor stands on a hit (full: its last compare was scan_run_hit_done's true): true, it is done;
+// false, it walks on
+template <typename P>
+ZD_HD bool scan_run_settle(ScanRun &r, bool full, uint32_t K) {
+  bool fin = full;
+  if (r.steps == r.klim) {
+    if (r.klim == K) fin = true;
+    else { r.snap = r.best; r.klim = K; }  // the first K/4 candidates' answer
+  }
+  return fin | scan_far<P>(r);
 }
 ZD_HD uint64_t scan_run_result(const ScanRun &r, uint32_t Kq) {
   const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : r.best);
@@ -463,20 +471,31 @@ ZD_HD uint64_t scan_run_result(const ScanRun &r, uint32_t Kq) {
 #ifndef ZD_SCAN_MIN_WALKERS
 #define ZD_SCAN_MIN_WALKERS 16
 #endif
+#ifndef ZD_SCAN_HANDOUT
+#define ZD_SCAN_HANDOUT 16
+#endif
 constexpr int SCAN_ROUNDS = ZD_SCAN_ROUNDS;  // cheap steps between two compares, at most
 constexpr int SCAN_MIN_WALKERS = ZD_SCAN_MIN_WALKERS;  // ... and only while this many lanes of the wave still walk
+constexpr uint32_t SCAN_HANDOUT = ZD_SCAN_HANDOUT;  // finished positions of a slot wait for this many lanes
 
 // The same walk for one lane's positions first, first + step, ... < pend, serially (the host
 // model's form; the device runs lz_match_scan_pool below on the same pieces).
 template <bool WORDS>
 ZD_HD void lz_match_scan_serial(const uint8_t *s, uint32_t len, uint32_t first, uint32_t step, uint32_t pend,
                                 const uint16_t *prev, int K, int Kq, uint64_t *out) {
+  typedef const uint16_t *P;
   for (uint32_t p = first; p < pend; p += step) {
     ScanRun r;
-    scan_run_start<WORDS>(r, s, len, p, pend, prev, (uint32_t)K);
-    while (r.state != RUN_FIN) {
-      for (int i = 0; i < SCAN_ROUNDS; i++) scan_run_step<WORDS>(r, s, prev, (uint32_t)K, (uint32_t)Kq);
-      scan_run_compare<WORDS>(r, s, prev, (uint32_t)K, (uint32_t)Kq);
+    ScanFlags f = scan_run_start<WORDS>(r, s, len, p, pend, prev, (uint32_t)K, (uint32_t)Kq);
+    while (!f.fin) {
+      for (int i = 0; i < SCAN_ROUNDS && f.walking; i++) scan_run_step(r, f, s, prev);
+      bool full = false;
+      if (f.hit) {
+        const uint32_t q = r.t + r.dn;
+        full = scan_run_hit_done(r, s, q, scan_hit_length<WORDS>(s, q, r.p, r.pw, r.blm1 + 1u, r.maxlen));
+        f.hit = false;
+      }
+      if (!f.walking) { f.fin = scan_run_settle<P>(r, full, (uint32_t)K); f.walking = !f.fin; }
     }
     out[p] = scan_run_result(r, (uint32_t)Kq);
     if (pend - p <= step) break;  // (no wrap near 2^32)
@@ -500,6 +519,22 @@ constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any on
 // first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
 // where chains are a candidate or two long.  Returns the wave's iterations: x 64 NP / positions = steps per position / lane use.
 // (sink(p, best, first): where a finished position's two answers go -- the kernel's tables)
+#ifdef ZD_MATCH_COUNTS  // counting-only build (tools/exp_wall.py MATCH_COUNTS=1): what the waves of the pools below do, summed
+// [0] waves  [1] outer iterations  [2] rounds of cheap steps (first form: iterations)  [3] run slots walking in them (of 64 NP a round)
+// [4] compare phases run  [5] run slots with a hit in them  [6] handouts run (per slot)  [7] run slots finishing in them
+// [8] first form: run slots alive over its iterations
+static __device__ unsigned long long zd_match_counts[16];
+struct MatchCounts {
+  uint32_t c[9] = {1, 0, 0, 0, 0, 0, 0, 0, 0};
+  __device__ void flush(uint32_t lane) {
+    if (lane == 0)
+      for (int i = 0; i < 9; i++) atomicAdd(&zd_match_counts[i], (unsigned long long)c[i]);
+  }
+};
+#define ZD_COUNT(i, v) (mc.c[i] += (uint32_t)(v))
+#else
+#define ZD_COUNT(i, v) ((void)0)
+#endif
 // Where a wave's chunks come from.  take(oldest): wave-uniform, the first position of a fresh chunk of POOL_CHUNK positions, or pend:
 // the pool is empty.  oldest (pools with WANTS_OLDEST): the lowest position one of the wave's run slots still walks, ~0 for none.
 // TilePool: a counter in LDS over the positions [pbeg, pend) of one tile (it counts from 0: it overshoots the tile by a chunk per
@@ -527,6 +562,9 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
+#ifdef ZD_MATCH_COUNTS
+  MatchCounts mc;
+#endif
   auto fetch = [&](bool first) -> uint32_t {
     uint32_t oldest = 0xFFFFFFFFu;
     if (Pool::WANTS_OLDEST && !first) {
@@ -550,11 +588,14 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
   for (;;) {
     bool alive = false;
     iters++;
+    ZD_COUNT(1, 1); ZD_COUNT(2, 1);
 #pragma unroll
     for (int i = 0; i < NP; i++) {
+      ZD_COUNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(r[i].alive != 0)));
       const bool fin = match_run_step_to<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, sink);
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
       if (fm) {  // wave-uniform
+        ZD_COUNT(6, 1); ZD_COUNT(7, __builtin_popcountll(fm));
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
         const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;
@@ -575,21 +616,118 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
     }
     if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
   }
+#ifdef ZD_MATCH_COUNTS
+  mc.flush(lane);
+#endif
   return iters;
 }
 
 // second form (scan_run_*): the faster one on long chains.  Returns the wave's rounds of cheap steps.
+// Up to SCAN_ROUNDS rounds of cheap steps of a lane's two run slots in the LDS window (scan_run_step by hand: the compiler
+// kept the runs' flags as integers in vector registers and turned them into masks and back every round; then the scalar
+// instructions around the masks were the kernel's bound: 25 a round, now 12).  The runs' coordinates are LDS addresses of
+// the window's bytes; cs: address of the window's links - 2 x address of its bytes.  W: the slots' walking runs (lane
+// masks).  A round: each slot's three reads are issued under the slot's mask before either is waited for; then, slot by
+// slot, the three tests that end a walk -- the bytes are the position's (a hit), the next candidate is out of range,
+// K/4 or K candidates are done -- are v_cmpx, each of which takes its lanes out of exec, and what is left of exec is the
+// slot's new mask.  WHICH test stopped a run is asked afterwards, of the stopped runs only: h (the two bytes read last)
+// stays with the run.  The loop ends after SCAN_ROUNDS rounds or when fewer than SCAN_MIN_WALKERS lanes walk on.
+// The link is read with ds_read_u16_d16: the d16 reads of this chip ZERO the half of the register they do not load
+// (tools/probes/d16_loads.hip; SRAM ECC -- which is why the compiler never emits them) and take 7 ticks a wave at any even
+// address, where ds_read_u16 takes 41 at 2 mod 4 (tools/probes/lds_costs.hip); the bytes with ds_read_u8, 4.7 each.
+// Returns the rounds done.
+#define ZD_SCAN_ROUND_ASM(EXIT)                                                                                          \
+  "s_and_b64 exec, %[sv], %[W0]\n\t"                                                                                    \
+  "v_add_u32 %[a], %[t0], %[bl0]\n\t"                                                                                   \
+  "v_lshl_add_u32 %[la], %[t0], 1, %[cs]\n\t"                                                                           \
+  "ds_read_u8 %[h0], %[a]\n\t"                                                                                          \
+  "ds_read_u8 %[g0], %[a] offset:1\n\t"                                                                                 \
+  "ds_read_u16_d16 %[dn0], %[la]\n\t"                                                                                   \
+  "s_and_b64 exec, %[sv], %[W1]\n\t"                                                                                    \
+  "v_add_u32 %[a], %[t1], %[bl1]\n\t"                                                                                   \
+  "v_lshl_add_u32 %[la], %[t1], 1, %[cs]\n\t"                                                                           \
+  "ds_read_u8 %[h1], %[a]\n\t"                                                                                          \
+  "ds_read_u8 %[g1], %[a] offset:1\n\t"                                                                                 \
+  "ds_read_u16_d16 %[dn1], %[la]\n\t"                                                                                   \
+  "s_and_b64 exec, %[sv], %[W0]\n\t"                                                                                    \
+  "v_add_u32 %[st0], 1, %[st0]\n\t"                                                                                     \
+  "s_waitcnt lgkmcnt(3)\n\t"                                                                                            \
+  "v_lshl_or_b32 %[h0], %[g0], 16, %[h0]\n\t"                                                                           \
+  "v_sub_u32 %[t0], %[t0], %[dn0]\n\t"                                                                                  \
+  "v_cmpx_ne_u32 %[h0], %[pb0]\n\t"                                                                                     \
+  "v_cmpx_ge_i32 %[t0], %[lim0]\n\t"                                                                                    \
+  "v_cmpx_ne_u32 %[st0], %[kl0]\n\t"                                                                                    \
+  "s_mov_b64 %[W0], exec\n\t"                                                                                           \
+  "s_and_b64 exec, %[sv], %[W1]\n\t"                                                                                    \
+  "v_add_u32 %[st1], 1, %[st1]\n\t"                                                                                     \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
+  "v_lshl_or_b32 %[h1], %[g1], 16, %[h1]\n\t"                                                                           \
+  "v_sub_u32 %[t1], %[t1], %[dn1]\n\t"                                                                                  \
+  "v_cmpx_ne_u32 %[h1], %[pb1]\n\t"                                                                                     \
+  "v_cmpx_ge_i32 %[t1], %[lim1]\n\t"                                                                                    \
+  "v_cmpx_ne_u32 %[st1], %[kl1]\n\t"                                                                                    \
+  "s_mov_b64 %[W1], exec\n\t"                                                                                           \
+  "s_or_b64 %[any], %[W0], %[W1]\n\t"                                                                                   \
+  "s_bcnt1_i32_b64 %[n], %[any]\n\t"                                                                                    \
+  "s_cmp_lt_u32 %[n], %[minw]\n\t"                                                                                      \
+  "s_cbranch_scc1 " EXIT "\n\t"
+struct ScanSlotMasks { unsigned long long W, H, F, L; };  // walking, hit, fin, live
+__device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun &r0, ScanRun &r1, ScanSlotMasks &m0, ScanSlotMasks &m1, uint32_t &h0, uint32_t &h1,
+                                                    uint32_t cs) {
+  static_assert(SCAN_ROUNDS == 4, "the loop below is unrolled by hand");
+  unsigned long long sv, any;
+  uint32_t a, la, g0, g1, n;
+  asm volatile(
+      "s_mov_b64 %[sv], exec\n\t"
+      ZD_SCAN_ROUND_ASM("1f")
+      ZD_SCAN_ROUND_ASM("2f")
+      ZD_SCAN_ROUND_ASM("3f")
+      ZD_SCAN_ROUND_ASM("4f")
+      "s_branch 4f\n"
+      "1:\n\t"
+      "s_mov_b32 %[n], 1\n\t"
+      "s_branch 5f\n"
+      "2:\n\t"
+      "s_mov_b32 %[n], 2\n\t"
+      "s_branch 5f\n"
+      "3:\n\t"
+      "s_mov_b32 %[n], 3\n\t"
+      "s_branch 5f\n"
+      "4:\n\t"
+      "s_mov_b32 %[n], 4\n"
+      "5:\n\t"
+      "s_mov_b64 exec, %[sv]"
+      : [sv] "=&s"(sv), [any] "=&s"(any), [n] "=&s"(n), [a] "=&v"(a), [la] "=&v"(la), [g0] "=&v"(g0), [g1] "=&v"(g1),
+        [h0] "+v"(h0), [h1] "+v"(h1), [W0] "+s"(m0.W), [W1] "+s"(m1.W),
+        [t0] "+v"(r0.t), [t1] "+v"(r1.t), [st0] "+v"(r0.steps), [st1] "+v"(r1.steps), [dn0] "+v"(r0.dn), [dn1] "+v"(r1.dn)
+      : [bl0] "v"(r0.blm1), [bl1] "v"(r1.blm1), [pb0] "v"(r0.pb), [pb1] "v"(r1.pb), [lim0] "v"(r0.lim), [lim1] "v"(r1.lim),
+        [kl0] "v"(r0.klim), [kl1] "v"(r1.klim), [cs] "s"(cs), [minw] "s"((uint32_t)SCAN_MIN_WALKERS)
+      : "vcc", "scc", "memory");
+  return n;
+}
+#undef ZD_SCAN_ROUND_ASM
+
+// s, prev: the window's bytes and links indexed by coordinate (for the LDS window: s + c is the byte at LDS address c),
+// cs: see scan_rounds_lds.
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
-                                                        P prev, int K, int Kq, Sink sink) {
+                                                        P prev, uint32_t cs, int K, int Kq, Sink sink) {
+  static_assert(NP == 2, "scan_rounds_lds steps two run slots");
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   ScanRun r[NP];
+  ScanSlotMasks m[NP];
+  uint32_t h[NP] = {0, 0};  // the two bytes a run's last step read (scan_rounds_lds)
   uint32_t iters = 0;  // rounds of cheap steps (what is returned: the same measure as the first form's iterations)
+#ifdef ZD_MATCH_COUNTS
+  MatchCounts mc;
+#endif
+  auto ballot = [](bool b) { return (unsigned long long)__builtin_amdgcn_ballot_w64(b); };
+  auto mine = [](unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); };  // my lane's bit of a mask
   auto fetch = [&](bool first) -> uint32_t {
     uint32_t oldest = 0xFFFFFFFFu;
     if (Pool::WANTS_OLDEST && !first) {
 #pragma unroll
-      for (int i = 0; i < NP; i++) oldest = r[i].state != RUN_DEAD && r[i].p < oldest ? r[i].p : oldest;
+      for (int i = 0; i < NP; i++) oldest = mine(m[i].L) && r[i].p < oldest ? r[i].p : oldest;
       oldest = wave_min_u32(oldest);
     }
     return pool.take(oldest);
@@ -602,45 +740,65 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
 #pragma unroll
   for (int i = 0; i < NP; i++) {
     const uint32_t off = lane + 64u * (uint32_t)i;
-    scan_run_start<true>(r[i], s, len, off < cend - next ? next + off : cend, cend, prev, (uint32_t)K);
+    const ScanFlags f = scan_run_start<true>(r[i], s, len, off < cend - next ? next + off : cend, cend, prev, (uint32_t)K, (uint32_t)Kq);
+    m[i].W = ballot(f.walking); m[i].H = 0; m[i].F = ballot(f.fin); m[i].L = ballot(f.live);
   }
   next = cend - next > 64u * NP ? next + 64u * NP : cend;
   for (;;) {
-    // cheap steps: every walking run goes from candidate to candidate until one passes the byte test
-#pragma unroll 1
-    for (int round = 0; round < SCAN_ROUNDS; round++) {
-      bool walking = false;
-      iters++;
-      ScanProbe x[NP];
+    ZD_COUNT(1, 1);
+    // cheap steps: every walking run goes from candidate to candidate until one passes the byte test -- or its walk ends
+    bool full[NP];
 #pragma unroll
-      for (int i = 0; i < NP; i++) x[i] = scan_run_probe<true>(r[i], s, prev);
+    for (int i = 0; i < NP; i++) full[i] = false;
+    const unsigned long long w0 = m[0].W, w1 = m[1].W;
+    if (w0 | w1) {
+      const uint32_t n = scan_rounds_lds(r[0], r[1], m[0], m[1], h[0], h[1], cs);
+      iters += n;
+      ZD_COUNT(2, n);
+      // of the runs that stopped, those whose last candidate passed the test (the others: scan_run_settle)
 #pragma unroll
       for (int i = 0; i < NP; i++) {
-        scan_run_take(r[i], x[i], (uint32_t)K, (uint32_t)Kq);
-        walking |= r[i].state == RUN_WALK;
-      }
-      if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(walking)) < SCAN_MIN_WALKERS) break;
-    }
-    // the compares of all runs that stand on such a candidate, together
-    {
-      bool hit = false;
-#pragma unroll
-      for (int i = 0; i < NP; i++) hit |= r[i].state == RUN_HIT;
-      if (__builtin_amdgcn_ballot_w64(hit)) {
-#pragma unroll
-        for (int i = 0; i < NP; i++) scan_run_compare<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq);
+        const unsigned long long st = (i == 0 ? w0 : w1) & ~m[i].W;
+        if (st) m[i].H |= ballot(mine(st) && h[i] == r[i].pb);
       }
     }
-    // finished positions are stored and their slots take the pool's next positions
-    bool alive = false;
+    // the compares of the runs that stand on such a candidate, together: a lane's first such slot
+    if (m[0].H | m[1].H) {
+      ZD_COUNT(4, 1); ZD_COUNT(5, __builtin_popcountll(m[0].H) + __builtin_popcountll(m[1].H));
+      const unsigned long long h0 = m[0].H, h1 = m[1].H & ~m[0].H;  // the runs compared now
+      if (mine(h0 | h1)) {
+        const bool first = mine(h0);
+        const ScanRun &c = first ? r[0] : r[1];
+        const uint32_t q = c.t + c.dn, p = c.p;
+        const uint32_t l = scan_hit_length<true>(s, q, p, c.pw, c.blm1 + 1u, c.maxlen);
+        if (first) full[0] = scan_run_hit_done(r[0], s, q, l);
+        else full[1] = scan_run_hit_done(r[1], s, q, l);
+      }
+      m[0].H = 0; m[1].H &= ~h1;
+    }
+    // stopped runs: done, or on with the walk
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const bool fin = r[i].state == RUN_FIN;
-      const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
-      if (fm) {  // wave-uniform
+      const unsigned long long st = m[i].L & ~(m[i].W | m[i].H | m[i].F);
+      if (st) {
+        bool fin = false;
+        if (mine(st)) fin = scan_run_settle<P>(r[i], full[i], (uint32_t)K);
+        const unsigned long long fm = ballot(fin);
+        m[i].F |= fm;
+        m[i].W |= st & ~fm;
+      }
+    }
+    const bool busy = (m[0].W | m[1].W | m[0].H | m[1].H) != 0;
+    // finished positions are stored and their slots take the pool's next positions
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const unsigned long long fm = m[i].F;
+      const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
+      if (taken >= SCAN_HANDOUT || (fm && !busy)) {  // wave-uniform
+        ZD_COUNT(6, 1); ZD_COUNT(7, taken);
+        const bool fin = mine(fm);
         if (fin) { const uint64_t both = scan_run_result(r[i], (uint32_t)Kq); sink(r[i].p, (uint32_t)both, (uint32_t)(both >> 32)); }
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-        const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
         const uint32_t rem = cend - next;
         uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
@@ -653,12 +811,18 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         } else {
           next = rem > taken ? next + taken : cend;
         }
-        if (fin) scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K);
+        ScanFlags f{false, false, false, false};
+        if (fin) f = scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K, (uint32_t)Kq);
+        m[i].W |= ballot(f.walking);
+        m[i].F = ballot(f.fin);
+        m[i].L = (m[i].L & ~fm) | ballot(f.live);
       }
-      alive |= r[i].state != RUN_DEAD;
     }
-    if (__builtin_amdgcn_ballot_w64(alive) == 0) break;
+    if ((m[0].L | m[1].L) == 0) break;
   }
+#ifdef ZD_MATCH_COUNTS
+  mc.flush(lane);
+#endif
   return iters;
 }
 #endif
