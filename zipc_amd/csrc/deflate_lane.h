@@ -630,8 +630,8 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
 // masks).  A round: each slot's three reads are issued under the slot's mask before either is waited for; then, slot by
 // slot, the three tests that end a walk -- the bytes are the position's (a hit), the next candidate is out of range,
 // K/4 or K candidates are done -- are v_cmpx, each of which takes its lanes out of exec, and what is left of exec is the
-// slot's new mask.  WHICH test stopped a run is asked afterwards, of the stopped runs only: h (the two bytes read last)
-// stays with the run.  The loop ends after SCAN_ROUNDS rounds or when fewer than SCAN_MIN_WALKERS lanes walk on.
+// slot's new mask.  WHICH test stopped a run is asked after the rounds, of the stopped runs only (H: those that stand on a
+// hit; h, the two bytes read last, stays with the run).  The loop ends after SCAN_ROUNDS rounds or when fewer than SCAN_MIN_WALKERS lanes walk on.
 // The link is read with ds_read_u16_d16: the d16 reads of this chip ZERO the half of the register they do not load
 // (tools/probes/d16_loads.hip; SRAM ECC -- which is why the compiler never emits them) and take 7 ticks a wave at any even
 // address, where ds_read_u16 takes 41 at 2 mod 4 (tools/probes/lds_costs.hip); the bytes with ds_read_u8, 4.7 each.
@@ -674,38 +674,59 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
 struct ScanSlotMasks { unsigned long long W, H, F, L; };  // walking, hit, fin, live
 __device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun &r0, ScanRun &r1, ScanSlotMasks &m0, ScanSlotMasks &m1, uint32_t &h0, uint32_t &h1,
                                                     uint32_t cs) {
-  static_assert(SCAN_ROUNDS == 4, "the loop below is unrolled by hand");
-  unsigned long long sv, any;
+  static_assert(SCAN_ROUNDS >= 1 && SCAN_ROUNDS <= 8, "the loop below is unrolled by hand");
+  unsigned long long sv, any, ws0, ws1;
   uint32_t a, la, g0, g1, n;
+#define ZD_SCAN_EXIT_ASM(L, N) L ":\n\ts_mov_b32 %[n], " N "\n\ts_branch 99f\n"
   asm volatile(
       "s_mov_b64 %[sv], exec\n\t"
-      ZD_SCAN_ROUND_ASM("1f")
-      ZD_SCAN_ROUND_ASM("2f")
-      ZD_SCAN_ROUND_ASM("3f")
-      ZD_SCAN_ROUND_ASM("4f")
-      "s_branch 4f\n"
-      "1:\n\t"
-      "s_mov_b32 %[n], 1\n\t"
-      "s_branch 5f\n"
-      "2:\n\t"
-      "s_mov_b32 %[n], 2\n\t"
-      "s_branch 5f\n"
-      "3:\n\t"
-      "s_mov_b32 %[n], 3\n\t"
-      "s_branch 5f\n"
-      "4:\n\t"
-      "s_mov_b32 %[n], 4\n"
-      "5:\n\t"
+      "s_mov_b64 %[ws0], %[W0]\n\t"
+      "s_mov_b64 %[ws1], %[W1]\n\t"
+      ZD_SCAN_ROUND_ASM("11f")
+#if ZD_SCAN_ROUNDS >= 2
+      ZD_SCAN_ROUND_ASM("12f")
+#endif
+#if ZD_SCAN_ROUNDS >= 3
+      ZD_SCAN_ROUND_ASM("13f")
+#endif
+#if ZD_SCAN_ROUNDS >= 4
+      ZD_SCAN_ROUND_ASM("14f")
+#endif
+#if ZD_SCAN_ROUNDS >= 5
+      ZD_SCAN_ROUND_ASM("15f")
+#endif
+#if ZD_SCAN_ROUNDS >= 6
+      ZD_SCAN_ROUND_ASM("16f")
+#endif
+#if ZD_SCAN_ROUNDS >= 7
+      ZD_SCAN_ROUND_ASM("17f")
+#endif
+#if ZD_SCAN_ROUNDS >= 8
+      ZD_SCAN_ROUND_ASM("18f")
+#endif
+      "s_mov_b32 %[n], %[rounds]\n\t"
+      "s_branch 99f\n"
+      ZD_SCAN_EXIT_ASM("11", "1") ZD_SCAN_EXIT_ASM("12", "2") ZD_SCAN_EXIT_ASM("13", "3") ZD_SCAN_EXIT_ASM("14", "4")
+      ZD_SCAN_EXIT_ASM("15", "5") ZD_SCAN_EXIT_ASM("16", "6") ZD_SCAN_EXIT_ASM("17", "7") ZD_SCAN_EXIT_ASM("18", "8")
+      "99:\n\t"  // of the runs that stopped, those whose last candidate passed the test
+      "s_andn2_b64 exec, %[ws0], %[W0]\n\t"
+      "v_cmp_eq_u32 vcc, %[h0], %[pb0]\n\t"
+      "s_or_b64 %[H0], %[H0], vcc\n\t"
+      "s_andn2_b64 exec, %[ws1], %[W1]\n\t"
+      "v_cmp_eq_u32 vcc, %[h1], %[pb1]\n\t"
+      "s_or_b64 %[H1], %[H1], vcc\n\t"
       "s_mov_b64 exec, %[sv]"
       : [sv] "=&s"(sv), [any] "=&s"(any), [n] "=&s"(n), [a] "=&v"(a), [la] "=&v"(la), [g0] "=&v"(g0), [g1] "=&v"(g1),
+        [ws0] "=&s"(ws0), [ws1] "=&s"(ws1), [H0] "+s"(m0.H), [H1] "+s"(m1.H),
         [h0] "+v"(h0), [h1] "+v"(h1), [W0] "+s"(m0.W), [W1] "+s"(m1.W),
         [t0] "+v"(r0.t), [t1] "+v"(r1.t), [st0] "+v"(r0.steps), [st1] "+v"(r1.steps), [dn0] "+v"(r0.dn), [dn1] "+v"(r1.dn)
       : [bl0] "v"(r0.blm1), [bl1] "v"(r1.blm1), [pb0] "v"(r0.pb), [pb1] "v"(r1.pb), [lim0] "v"(r0.lim), [lim1] "v"(r1.lim),
-        [kl0] "v"(r0.klim), [kl1] "v"(r1.klim), [cs] "s"(cs), [minw] "s"((uint32_t)SCAN_MIN_WALKERS)
+        [kl0] "v"(r0.klim), [kl1] "v"(r1.klim), [cs] "s"(cs), [minw] "s"((uint32_t)SCAN_MIN_WALKERS), [rounds] "i"(SCAN_ROUNDS)
       : "vcc", "scc", "memory");
   return n;
 }
 #undef ZD_SCAN_ROUND_ASM
+#undef ZD_SCAN_EXIT_ASM
 
 // s, prev: the window's bytes and links indexed by coordinate (for the LDS window: s + c is the byte at LDS address c),
 // cs: see scan_rounds_lds.
@@ -750,30 +771,44 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     bool full[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) full[i] = false;
-    const unsigned long long w0 = m[0].W, w1 = m[1].W;
-    if (w0 | w1) {
+    if (m[0].W | m[1].W) {
       const uint32_t n = scan_rounds_lds(r[0], r[1], m[0], m[1], h[0], h[1], cs);
       iters += n;
       ZD_COUNT(2, n);
-      // of the runs that stopped, those whose last candidate passed the test (the others: scan_run_settle)
-#pragma unroll
-      for (int i = 0; i < NP; i++) {
-        const unsigned long long st = (i == 0 ? w0 : w1) & ~m[i].W;
-        if (st) m[i].H |= ballot(mine(st) && h[i] == r[i].pb);
-      }
     }
-    // the compares of the runs that stand on such a candidate, together: a lane's first such slot
+    // the compares of the runs that stand on such a candidate, together: a lane's first such slot.  Straight-line for the
+    // candidate that differs within its first 8 bytes (on text: nearly all of them); the others behind one branch.
     if (m[0].H | m[1].H) {
       ZD_COUNT(4, 1); ZD_COUNT(5, __builtin_popcountll(m[0].H) + __builtin_popcountll(m[1].H));
       const unsigned long long h0 = m[0].H, h1 = m[1].H & ~m[0].H;  // the runs compared now
+      bool fl = false;
       if (mine(h0 | h1)) {
         const bool first = mine(h0);
-        const ScanRun &c = first ? r[0] : r[1];
-        const uint32_t q = c.t + c.dn, p = c.p;
-        const uint32_t l = scan_hit_length<true>(s, q, p, c.pw, c.blm1 + 1u, c.maxlen);
-        if (first) full[0] = scan_run_hit_done(r[0], s, q, l);
-        else full[1] = scan_run_hit_done(r[1], s, q, l);
+        const uint32_t p = first ? r[0].p : r[1].p, q = first ? r[0].t + r[0].dn : r[1].t + r[1].dn;
+        const uint32_t bl = (first ? r[0].blm1 : r[1].blm1) + 1u, ml = first ? r[0].maxlen : r[1].maxlen;
+        const uint64_t x = load_u64_words(s, q) ^ (first ? r[0].pw : r[1].pw);
+        uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+        l = l < ml ? l : ml;  // (the last 7 positions of a stream: what lies behind its end does not count)
+        const bool more = x == 0 && ml > 8u;  // the first 8 bytes agree and there are others
+        if (__builtin_amdgcn_ballot_w64(more)) {
+          if (more) {
+            // before the long compare, the 8 bytes that END at best_len (they include the bytes already tested); what fails
+            // here is at most best_len long
+            bool same = true;
+            if (bl >= 8u) same = load_u64_words(s, q + bl - 7u) == load_u64_words(s, p + bl - 7u);
+            if (same) l = common_prefix_t<true>(s, q, p, ml, 8u);
+          }
+        }
+        const bool better = l > bl;
+        const uint32_t nb = better ? l - 1u : bl - 1u;
+        const uint32_t npb = (uint32_t)s[p + nb] | ((uint32_t)s[p + nb + 1u] << 16);  // (of a run that is done: never looked at)
+        const uint32_t nbest = ((p - q) << 9) | l;
+        fl = l == ml;  // zd.ml:1194: after l == maxlen nothing later can be longer
+        if (first) { r[0].blm1 = nb; r[0].pb = npb; r[0].best = better ? nbest : r[0].best; }
+        else { r[1].blm1 = nb; r[1].pb = npb; r[1].best = better ? nbest : r[1].best; }
       }
+      const unsigned long long fm = ballot(fl);
+      full[0] = mine(fm & h0); full[1] = mine(fm & h1);
       m[0].H = 0; m[1].H &= ~h1;
     }
     // stopped runs: done, or on with the walk
