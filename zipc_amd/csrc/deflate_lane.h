@@ -768,9 +768,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
   for (;;) {
     ZD_COUNT(1, 1);
     // cheap steps: every walking run goes from candidate to candidate until one passes the byte test -- or its walk ends
-    bool full[NP];
-#pragma unroll
-    for (int i = 0; i < NP; i++) full[i] = false;
+    unsigned long long full[NP] = {0, 0};  // runs whose compare found a match as long as a match can be
     if (m[0].W | m[1].W) {
       const uint32_t n = scan_rounds_lds(r[0], r[1], m[0], m[1], h[0], h[1], cs);
       iters += n;
@@ -781,44 +779,46 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     if (m[0].H | m[1].H) {
       ZD_COUNT(4, 1); ZD_COUNT(5, __builtin_popcountll(m[0].H) + __builtin_popcountll(m[1].H));
       const unsigned long long h0 = m[0].H, h1 = m[1].H & ~m[0].H;  // the runs compared now
-      bool fl = false;
-      if (mine(h0 | h1)) {
-        const bool first = mine(h0);
-        const uint32_t p = first ? r[0].p : r[1].p, q = first ? r[0].t + r[0].dn : r[1].t + r[1].dn;
-        const uint32_t bl = (first ? r[0].blm1 : r[1].blm1) + 1u, ml = first ? r[0].maxlen : r[1].maxlen;
-        const uint64_t x = load_u64_words(s, q) ^ (first ? r[0].pw : r[1].pw);
-        uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
-        l = l < ml ? l : ml;  // (the last 7 positions of a stream: what lies behind its end does not count)
-        const bool more = x == 0 && ml > 8u;  // the first 8 bytes agree and there are others
-        if (__builtin_amdgcn_ballot_w64(more)) {
-          if (more) {
-            // before the long compare, the 8 bytes that END at best_len (they include the bytes already tested); what fails
-            // here is at most best_len long
-            bool same = true;
-            if (bl >= 8u) same = load_u64_words(s, q + bl - 7u) == load_u64_words(s, p + bl - 7u);
-            if (same) l = common_prefix_t<true>(s, q, p, ml, 8u);
-          }
+      // (every lane goes through it -- a run's q = t + dn and p are positions of the window whatever the run's state -- and
+      // the runs compared take the results: masks stay masks, where a value set under a lane's condition went through a
+      // vector register and back)
+      const bool first = mine(h0);
+      const uint32_t p = first ? r[0].p : r[1].p, q = first ? r[0].t + r[0].dn : r[1].t + r[1].dn;
+      const uint32_t bl = (first ? r[0].blm1 : r[1].blm1) + 1u, ml = first ? r[0].maxlen : r[1].maxlen;
+      const uint64_t x = load_u64_words(s, q) ^ (first ? r[0].pw : r[1].pw);
+      uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+      l = l < ml ? l : ml;  // (the last 7 positions of a stream: what lies behind its end does not count)
+      const unsigned long long more = ballot(x == 0 && ml > 8u) & (h0 | h1);  // the first 8 bytes agree and there are others
+      if (more) {
+        if (mine(more)) {
+          // before the long compare, the 8 bytes that END at best_len (they include the bytes already tested); what fails
+          // here is at most best_len long
+          bool same = true;
+          if (bl >= 8u) same = load_u64_words(s, q + bl - 7u) == load_u64_words(s, p + bl - 7u);
+          if (same) l = common_prefix_t<true>(s, q, p, ml, 8u);
         }
-        const bool better = l > bl;
-        const uint32_t nb = better ? l - 1u : bl - 1u;
-        const uint32_t npb = (uint32_t)s[p + nb] | ((uint32_t)s[p + nb + 1u] << 16);  // (of a run that is done: never looked at)
-        const uint32_t nbest = ((p - q) << 9) | l;
-        fl = l == ml;  // zd.ml:1194: after l == maxlen nothing later can be longer
-        if (first) { r[0].blm1 = nb; r[0].pb = npb; r[0].best = better ? nbest : r[0].best; }
-        else { r[1].blm1 = nb; r[1].pb = npb; r[1].best = better ? nbest : r[1].best; }
       }
-      const unsigned long long fm = ballot(fl);
-      full[0] = mine(fm & h0); full[1] = mine(fm & h1);
+      const bool better = l > bl;
+      const uint32_t nb = better ? l - 1u : bl - 1u;
+      const uint32_t npb = (uint32_t)s[p + nb] | ((uint32_t)s[p + nb + 1u] << 16);  // (of a run that is done: never looked at)
+      const uint32_t nbest = ((p - q) << 9) | l;
+      const unsigned long long fm = ballot(l == ml);  // zd.ml:1194: after l == maxlen nothing later can be longer
+      const unsigned long long bm = ballot(better);
+      { const bool w = mine(h0); r[0].blm1 = w ? nb : r[0].blm1; r[0].pb = w ? npb : r[0].pb; r[0].best = mine(h0 & bm) ? nbest : r[0].best; }
+      { const bool w = mine(h1); r[1].blm1 = w ? nb : r[1].blm1; r[1].pb = w ? npb : r[1].pb; r[1].best = mine(h1 & bm) ? nbest : r[1].best; }
+      full[0] = fm & h0; full[1] = fm & h1;
       m[0].H = 0; m[1].H &= ~h1;
     }
     // stopped runs: done, or on with the walk
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const unsigned long long st = m[i].L & ~(m[i].W | m[i].H | m[i].F);
-      if (st) {
-        bool fin = false;
-        if (mine(st)) fin = scan_run_settle<P>(r[i], full[i], (uint32_t)K);
-        const unsigned long long fm = ballot(fin);
+      if (st) {  // (scan_run_settle on masks)
+        const unsigned long long at = ballot(r[i].steps == r[i].klim) & st, last = ballot(r[i].klim == (uint32_t)K);
+        const bool note = mine(at & ~last);  // the first K/4 candidates' answer; on with K
+        r[i].snap = note ? r[i].best : r[i].snap;
+        r[i].klim = note ? (uint32_t)K : r[i].klim;
+        const unsigned long long fm = ((at & last) | full[i] | ballot(scan_far<P>(r[i]))) & st;
         m[i].F |= fm;
         m[i].W |= st & ~fm;
       }
@@ -846,11 +846,13 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         } else {
           next = rem > taken ? next + taken : cend;
         }
-        ScanFlags f{false, false, false, false};
-        if (fin) f = scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K, (uint32_t)Kq);
-        m[i].W |= ballot(f.walking);
-        m[i].F = ballot(f.fin);
-        m[i].L = (m[i].L & ~fm) | ballot(f.live);
+        if (fin) scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K, (uint32_t)Kq);
+        // (the new runs' flags, scan_run_start's, from their registers)
+        const unsigned long long alive = ballot(np < lim) & fm;
+        const unsigned long long walk = K != 0 ? ballot(r[i].blm1 + 1u < r[i].maxlen && !scan_far<P>(r[i])) & alive : 0;
+        m[i].W |= walk;
+        m[i].F = alive & ~walk;
+        m[i].L = (m[i].L & ~fm) | alive;
       }
     }
     if ((m[0].L | m[1].L) == 0) break;
