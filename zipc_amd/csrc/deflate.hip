@@ -598,11 +598,20 @@ constexpr int MATCHW_SCAN_NP = ZD_SCAN_NP;  // run slots per lane of the second 
 constexpr uint32_t MATCHW_LINKS = MAX_MATCH_DIST + MATCHW_TILE;           // u16 each
 constexpr uint32_t MATCHW_SRC_BYTES = MAX_MATCH_DIST + MATCHW_TILE + 272;  // + MAX_MATCH_LEN + an 8-byte read, 16-aligned
 #ifndef ZD_SCAN_STEPS
-#define ZD_SCAN_STEPS 6
+#define ZD_SCAN_STEPS 4
 #endif
 // run-slot steps per position (iterations x lanes x slots / positions) from which the second form of the walk
 // pays: 4-bit symbols take 2.7 of the first form's (1.56 chain steps at 0.58 lane use), 3-bit symbols ~12, text ~48
 constexpr uint32_t MATCHW_SCAN_STEPS = ZD_SCAN_STEPS;
+#ifndef ZD_PROBE_DEEP
+#define ZD_PROBE_DEEP 192
+#endif
+// of the 1024 chains a workgroup probes in its first tile, those that hold three candidates: above this many the tile takes the
+// second form.  Round 5's second form costs a third less than round 4's, and the rule moved with it (it was 512, and 6 steps
+// a position): the benchmark's symbols probe 143 +- 11 deep and keep the first form (1.57 ms per 4096 streams against 1.75 in the
+// second); the corpus' binaries -- a few long chains among many empty ones -- now take the second: 9.1 -> 3.6 ms per 64 MiB of
+// such chunks, the corpus' lz_match 17.1 -> 12.6 ms per 256 MiB (tools/sweep_form_rule.sh)
+constexpr uint32_t MATCHW_PROBE_DEEP = ZD_PROBE_DEEP;
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
 static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
 static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
@@ -777,7 +786,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     const unsigned long long deep = __builtin_amdgcn_ballot_w64(hops == 3u);
     if ((tid & 63u) == 0) atomicAdd(&probe_deep, (uint32_t)__builtin_popcountll(deep));
     __syncthreads();
-    scan_form = probe_deep > MATCHW_THREADS / 2;
+    scan_form = probe_deep > MATCHW_PROBE_DEEP;
   }
   for (;;) {
 #ifdef ZD_MATCH_PHASES
