@@ -112,6 +112,16 @@ def main():
         assert dbg(cnt, 0) == 0
         names = ["waves", "outer_iterations", "rounds", "walking_slots", "compare_phases", "hit_slots", "handouts", "fin_slots", "alive_slots_first_form"]
         line["match_counts"] = {k: int(cnt[i]) for i, k in enumerate(names)}
+    if os.environ.get("PARSE_COUNTS", "0") == "1":  # a -DZD_PARSE_COUNTS build
+        import ctypes as C
+        from zipc_amd import _lib
+        dbg = C.CDLL(_lib.LIB_PATH).zipc_hip_debug_parse_counts
+        dbg.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        cnt = (C.c_ulonglong * 8)()
+        assert dbg(cnt, 1) == 0
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, crc)
+        assert dbg(cnt, 0) == 0
+        line["parse_counts"] = {k: int(cnt[i]) for i, k in enumerate(["tiles", "turns", "tiles_with_a_turn", "chaining_lanes"])}
     if os.environ.get("KERNELS", "0") == "1":
         ctx.set_profiling(True); ctx.reset_kernel_times()
         for _ in range(2):

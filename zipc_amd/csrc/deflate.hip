@@ -871,6 +871,12 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 // from a wave scan and write their symbols.  The only serial dependency left
 // between tiles is the entry position.
 constexpr int PARSE_TILE = 64;
+#ifdef ZD_PARSE_COUNTS  // counting-only build: [0] tiles, [1] turns of the lazy chains' loop, [2] tiles with a turn, [3] chaining lanes over the turns
+static __device__ unsigned long long zd_parse_counts[8];
+#define ZD_PCOUNT(i, v) do { if (lane == 0) atomicAdd(&zd_parse_counts[i], (unsigned long long)(v)); } while (0)
+#else
+#define ZD_PCOUNT(i, v) ((void)0)
+#endif
 
 // The macro step of the 64 positions of a tile, one per lane (lz_macro_position, with the following
 // positions' entries taken from the neighbouring lanes: m_cur is this tile's entry of the lane, m_nxt the
@@ -906,7 +912,9 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
   // them by two ds_bpermute a turn: no LDS operation and no address -- and no measurable difference (C2 lz_parse 2.90-2.93
   // against 2.86-2.97 ms beside the other slice's kernels): the shuffles' round trips are not what a tile waits for.
   uint32_t sh_cur = cur_lo, sh_nxt = nxt_lo;  // after k turns: the words of positions p + k (this tile's lanes), p + 64 + k
+  ZD_PCOUNT(0, 1); ZD_PCOUNT(2, __builtin_amdgcn_ballot_w64(chaining != 0) ? 1 : 0);
   for (uint32_t ahead = 1; ahead < 128u - 63u && __builtin_amdgcn_ballot_w64(chaining != 0); ahead++) {
+    ZD_PCOUNT(1, 1); ZD_PCOUNT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(chaining != 0)));
     const uint32_t off = (uint32_t)lane + ahead;
     const uint32_t addr = (off & 63u) * 4u;
     const bool in_cur = off < 64u;
@@ -2820,6 +2828,14 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
 
 }  // namespace zd
 
+#ifdef ZD_PARSE_COUNTS
+extern "C" int zipc_hip_debug_parse_counts(unsigned long long *out8, int reset) {
+  unsigned long long host[8] = {};
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(zd::zd_parse_counts), sizeof host) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_parse_counts), host, sizeof host) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 #ifdef ZD_MATCH_COUNTS
 extern "C" int zipc_hip_debug_match_counts(unsigned long long *out16, int reset) {
   unsigned long long host[16] = {};

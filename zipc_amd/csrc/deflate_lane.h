@@ -644,104 +644,100 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
 // (tools/probes/d16_loads.hip; SRAM ECC -- which is why the compiler never emits them) and take 7 ticks a wave at any even
 // address, where ds_read_u16 takes 41 at 2 mod 4 (tools/probes/lds_costs.hip); the bytes with ds_read_u8, 4.7 each.
 // Returns the rounds done.
-#define ZD_SCAN_ROUND_ASM(EXIT)                                                                                          \
-  "s_and_b64 exec, %[sv], %[W0]\n\t"                                                                                    \
-  "v_add_u32 %[a], %[t0], %[bl0]\n\t"                                                                                   \
-  "v_lshl_add_u32 %[la], %[t0], 1, %[cs]\n\t"                                                                           \
-  "ds_read_u8 %[h0], %[a]\n\t"                                                                                          \
-  "ds_read_u8 %[g0], %[a] offset:1\n\t"                                                                                 \
-  "ds_read_u16_d16 %[dn0], %[la]\n\t"                                                                                   \
-  "s_and_b64 exec, %[sv], %[W1]\n\t"                                                                                    \
-  "v_add_u32 %[a], %[t1], %[bl1]\n\t"                                                                                   \
-  "v_lshl_add_u32 %[la], %[t1], 1, %[cs]\n\t"                                                                           \
-  "ds_read_u8 %[h1], %[a]\n\t"                                                                                          \
-  "ds_read_u8 %[g1], %[a] offset:1\n\t"                                                                                 \
-  "ds_read_u16_d16 %[dn1], %[la]\n\t"                                                                                   \
-  "s_and_b64 exec, %[sv], %[W0]\n\t"                                                                                    \
-  "v_add_u32 %[st0], 1, %[st0]\n\t"                                                                                     \
-  "s_waitcnt lgkmcnt(3)\n\t"                                                                                            \
-  "v_lshl_or_b32 %[h0], %[g0], 16, %[h0]\n\t"                                                                           \
-  "v_sub_u32 %[t0], %[t0], %[dn0]\n\t"                                                                                  \
-  "v_cmpx_ne_u32 %[h0], %[pb0]\n\t"                                                                                     \
-  "v_cmpx_ge_i32 %[t0], %[lim0]\n\t"                                                                                    \
-  "v_cmpx_ne_u32 %[st0], %[kl0]\n\t"                                                                                    \
-  "s_mov_b64 %[W0], exec\n\t"                                                                                           \
-  "s_and_b64 exec, %[sv], %[W1]\n\t"                                                                                    \
-  "v_add_u32 %[st1], 1, %[st1]\n\t"                                                                                     \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                            \
-  "v_lshl_or_b32 %[h1], %[g1], 16, %[h1]\n\t"                                                                           \
-  "v_sub_u32 %[t1], %[t1], %[dn1]\n\t"                                                                                  \
-  "v_cmpx_ne_u32 %[h1], %[pb1]\n\t"                                                                                     \
-  "v_cmpx_ge_i32 %[t1], %[lim1]\n\t"                                                                                    \
-  "v_cmpx_ne_u32 %[st1], %[kl1]\n\t"                                                                                    \
-  "s_mov_b64 %[W1], exec\n\t"                                                                                           \
-  "s_or_b64 %[any], %[W0], %[W1]\n\t"                                                                                   \
-  "s_bcnt1_i32_b64 %[n], %[any]\n\t"                                                                                    \
-  "s_cmp_lt_u32 %[n], %[minw]\n\t"                                                                                      \
-  "s_cbranch_scc1 " EXIT "\n\t"
 struct ScanSlotMasks { unsigned long long W, H, F, L; };  // walking, hit, fin, live
-__device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun &r0, ScanRun &r1, ScanSlotMasks &m0, ScanSlotMasks &m1, uint32_t &h0, uint32_t &h1,
-                                                    uint32_t cs, uint32_t dense) {
-  static_assert(ZD_SCAN_ROUNDS_DENSE == 4 || ZD_SCAN_ROUNDS_DENSE >= ZD_SCAN_ROUNDS, "the exit for dense hits sits behind the fourth round");
-  static_assert(SCAN_ROUNDS >= 1 && SCAN_ROUNDS <= 8, "the loop below is unrolled by hand");
-  unsigned long long sv, any, ws0, ws1;
-  uint32_t a, la, g0, g1, n;
+#define ZD_SCAN_PROBE(i)                                       \
+  "s_and_b64 exec, %[sv], %[W" #i "]\n\t"                      \
+  "v_add_u32 %[a], %[t" #i "], %[bl" #i "]\n\t"                \
+  "v_lshl_add_u32 %[la], %[t" #i "], 1, %[cs]\n\t"             \
+  "ds_read_u8 %[h" #i "], %[a]\n\t"                            \
+  "ds_read_u8 %[g" #i "], %[a] offset:1\n\t"                   \
+  "ds_read_u16_d16 %[dn" #i "], %[la]\n\t"
+#define ZD_SCAN_TAKE(i, BEHIND)                                \
+  "s_and_b64 exec, %[sv], %[W" #i "]\n\t"                      \
+  "v_add_u32 %[st" #i "], 1, %[st" #i "]\n\t"                  \
+  "s_waitcnt lgkmcnt(" BEHIND ")\n\t"                          \
+  "v_lshl_or_b32 %[h" #i "], %[g" #i "], 16, %[h" #i "]\n\t"   \
+  "v_sub_u32 %[t" #i "], %[t" #i "], %[dn" #i "]\n\t"          \
+  "v_cmpx_ne_u32 %[h" #i "], %[pb" #i "]\n\t"                  \
+  "v_cmpx_ge_i32 %[t" #i "], %[lim" #i "]\n\t"                 \
+  "v_cmpx_ne_u32 %[st" #i "], %[kl" #i "]\n\t"                 \
+  "s_mov_b64 %[W" #i "], exec\n\t"
+#define ZD_SCAN_HITS(i)                                        \
+  "s_andn2_b64 exec, %[ws" #i "], %[W" #i "]\n\t"              \
+  "v_cmp_eq_u32 vcc, %[h" #i "], %[pb" #i "]\n\t"              \
+  "s_or_b64 %[H" #i "], %[H" #i "], vcc\n\t"
+#define ZD_SCAN_CHECK(EXIT)                                    \
+  "s_bcnt1_i32_b64 %[n], %[any]\n\t"                           \
+  "s_cmp_lt_u32 %[n], %[minw]\n\t"                             \
+  "s_cbranch_scc1 " EXIT "\n\t"
+#define ZD_SCAN_ROUND2(EXIT) ZD_SCAN_PROBE(0) ZD_SCAN_PROBE(1) ZD_SCAN_TAKE(0, "3") ZD_SCAN_TAKE(1, "0") \
+  "s_or_b64 %[any], %[W0], %[W1]\n\t" ZD_SCAN_CHECK(EXIT)
+#define ZD_SCAN_ROUND3(EXIT) ZD_SCAN_PROBE(0) ZD_SCAN_PROBE(1) ZD_SCAN_PROBE(2) ZD_SCAN_TAKE(0, "6") ZD_SCAN_TAKE(1, "3") ZD_SCAN_TAKE(2, "0") \
+  "s_or_b64 %[any], %[W0], %[W1]\n\ts_or_b64 %[any], %[any], %[W2]\n\t" ZD_SCAN_CHECK(EXIT)
+#define ZD_SCAN_ROUND4(EXIT) ZD_SCAN_PROBE(0) ZD_SCAN_PROBE(1) ZD_SCAN_PROBE(2) ZD_SCAN_PROBE(3) \
+  ZD_SCAN_TAKE(0, "9") ZD_SCAN_TAKE(1, "6") ZD_SCAN_TAKE(2, "3") ZD_SCAN_TAKE(3, "0") \
+  "s_or_b64 %[any], %[W0], %[W1]\n\ts_or_b64 %[any], %[any], %[W2]\n\ts_or_b64 %[any], %[any], %[W3]\n\t" ZD_SCAN_CHECK(EXIT)
+#define ZD_SCAN_EXIT_ASM(L, N) L ":\n\ts_mov_b32 %[n], " N "\n\ts_branch 99f\n"
 #define ZD_STR_(x) #x
 #define ZD_STR(x) ZD_STR_(x)
-#define ZD_SCAN_EXIT_ASM(L, N) L ":\n\ts_mov_b32 %[n], " N "\n\ts_branch 99f\n"
-  asm volatile(
-      "s_mov_b64 %[sv], exec\n\t"
-      "s_mov_b64 %[ws0], %[W0]\n\t"
-      "s_mov_b64 %[ws1], %[W1]\n\t"
-      ZD_SCAN_ROUND_ASM("11f")
-#if ZD_SCAN_ROUNDS >= 2
-      ZD_SCAN_ROUND_ASM("12f")
-#endif
-#if ZD_SCAN_ROUNDS >= 3
-      ZD_SCAN_ROUND_ASM("13f")
-#endif
-#if ZD_SCAN_ROUNDS >= 4
-      ZD_SCAN_ROUND_ASM("14f")
-#endif
-#if ZD_SCAN_ROUNDS > ZD_SCAN_ROUNDS_DENSE
-      "s_cmp_lg_u32 %[dense], 0\n\t"
-      "s_cbranch_scc1 14f\n\t"
-#endif
-#if ZD_SCAN_ROUNDS >= 5
-      ZD_SCAN_ROUND_ASM("15f")
-#endif
-#if ZD_SCAN_ROUNDS >= 6
-      ZD_SCAN_ROUND_ASM("16f")
-#endif
-#if ZD_SCAN_ROUNDS >= 7
-      ZD_SCAN_ROUND_ASM("17f")
-#endif
-#if ZD_SCAN_ROUNDS >= 8
-      ZD_SCAN_ROUND_ASM("18f")
-#endif
-      "s_mov_b32 %[n], " ZD_STR(ZD_SCAN_ROUNDS) "\n\t"
-      "s_branch 99f\n"
-      ZD_SCAN_EXIT_ASM("11", "1") ZD_SCAN_EXIT_ASM("12", "2") ZD_SCAN_EXIT_ASM("13", "3") ZD_SCAN_EXIT_ASM("14", "4")
-      ZD_SCAN_EXIT_ASM("15", "5") ZD_SCAN_EXIT_ASM("16", "6") ZD_SCAN_EXIT_ASM("17", "7") ZD_SCAN_EXIT_ASM("18", "8")
-      "99:\n\t"  // of the runs that stopped, those whose last candidate passed the test
-      "s_andn2_b64 exec, %[ws0], %[W0]\n\t"
-      "v_cmp_eq_u32 vcc, %[h0], %[pb0]\n\t"
-      "s_or_b64 %[H0], %[H0], vcc\n\t"
-      "s_andn2_b64 exec, %[ws1], %[W1]\n\t"
-      "v_cmp_eq_u32 vcc, %[h1], %[pb1]\n\t"
-      "s_or_b64 %[H1], %[H1], vcc\n\t"
-      "s_mov_b64 exec, %[sv]"
-      : [sv] "=&s"(sv), [any] "=&s"(any), [n] "=&s"(n), [a] "=&v"(a), [la] "=&v"(la), [g0] "=&v"(g0), [g1] "=&v"(g1),
-        [ws0] "=&s"(ws0), [ws1] "=&s"(ws1), [H0] "+s"(m0.H), [H1] "+s"(m1.H),
-        [h0] "+v"(h0), [h1] "+v"(h1), [W0] "+s"(m0.W), [W1] "+s"(m1.W),
-        [t0] "+v"(r0.t), [t1] "+v"(r1.t), [st0] "+v"(r0.steps), [st1] "+v"(r1.steps), [dn0] "+v"(r0.dn), [dn1] "+v"(r1.dn)
-      : [bl0] "v"(r0.blm1), [bl1] "v"(r1.blm1), [pb0] "v"(r0.pb), [pb1] "v"(r1.pb), [lim0] "v"(r0.lim), [lim1] "v"(r1.lim),
-        [kl0] "v"(r0.klim), [kl1] "v"(r1.klim), [cs] "s"(cs), [minw] "s"((uint32_t)SCAN_MIN_WALKERS), [dense] "s"(dense)
-      : "vcc", "scc", "memory");
+// (SCAN_ROUNDS rounds at most, ZD_SCAN_ROUNDS_DENSE -- the exit behind the fourth -- when dense is set)
+#define ZD_SCAN_BODY(ROUND, SAVE, HITS)                                                                                 \
+  "s_mov_b64 %[sv], exec\n\t" SAVE                                                                                      \
+  ROUND("11f") ROUND("12f") ROUND("13f") ROUND("14f")                                                                   \
+  "s_cmp_lg_u32 %[dense], 0\n\t"                                                                                        \
+  "s_cbranch_scc1 14f\n\t"                                                                                              \
+  ROUND("15f") ROUND("16f") ROUND("17f") ROUND("18f")                                                                   \
+  "s_mov_b32 %[n], 8\n\t"                                                                                               \
+  "s_branch 99f\n"                                                                                                      \
+  ZD_SCAN_EXIT_ASM("11", "1") ZD_SCAN_EXIT_ASM("12", "2") ZD_SCAN_EXIT_ASM("13", "3") ZD_SCAN_EXIT_ASM("14", "4")       \
+  ZD_SCAN_EXIT_ASM("15", "5") ZD_SCAN_EXIT_ASM("16", "6") ZD_SCAN_EXIT_ASM("17", "7") ZD_SCAN_EXIT_ASM("18", "8")       \
+  "99:\n\t" /* of the runs that stopped, those whose last candidate passed the test */                                 \
+  HITS "s_mov_b64 exec, %[sv]"
+#define ZD_SCAN_OUT(i) [g##i] "=&v"(g[i]), [ws##i] "=&s"(ws[i]), [H##i] "+s"(m[i].H), [h##i] "+v"(h[i]), [W##i] "+s"(m[i].W), \
+                       [t##i] "+v"(r[i].t), [st##i] "+v"(r[i].steps), [dn##i] "+v"(r[i].dn)
+#define ZD_SCAN_IN(i) [bl##i] "v"(r[i].blm1), [pb##i] "v"(r[i].pb), [lim##i] "v"(r[i].lim), [kl##i] "v"(r[i].klim)
+#define ZD_SCAN_SHARED_OUT [sv] "=&s"(sv), [any] "=&s"(any), [n] "=&s"(n), [a] "=&v"(a), [la] "=&v"(la)
+#define ZD_SCAN_SHARED_IN [cs] "s"(cs), [minw] "s"((uint32_t)SCAN_MIN_WALKERS), [dense] "s"(dense)
+template <int NP>
+__device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun (&r)[NP], ScanSlotMasks (&m)[NP], uint32_t (&h)[NP], uint32_t cs, uint32_t dense) {
+  static_assert(SCAN_ROUNDS == 8 && ZD_SCAN_ROUNDS_DENSE == 4, "the loop below is unrolled by hand");
+  static_assert(NP >= 2 && NP <= 4, "written out for two to four run slots");
+  unsigned long long sv, any, ws[NP];
+  uint32_t a, la, g[NP], n;
+  if constexpr (NP == 2) {
+    asm volatile(ZD_SCAN_BODY(ZD_SCAN_ROUND2, "s_mov_b64 %[ws0], %[W0]\n\ts_mov_b64 %[ws1], %[W1]\n\t", ZD_SCAN_HITS(0) ZD_SCAN_HITS(1))
+                 : ZD_SCAN_SHARED_OUT, ZD_SCAN_OUT(0), ZD_SCAN_OUT(1)
+                 : ZD_SCAN_IN(0), ZD_SCAN_IN(1), ZD_SCAN_SHARED_IN
+                 : "vcc", "scc", "memory");
+  } else if constexpr (NP == 3) {
+    asm volatile(ZD_SCAN_BODY(ZD_SCAN_ROUND3, "s_mov_b64 %[ws0], %[W0]\n\ts_mov_b64 %[ws1], %[W1]\n\ts_mov_b64 %[ws2], %[W2]\n\t",
+                              ZD_SCAN_HITS(0) ZD_SCAN_HITS(1) ZD_SCAN_HITS(2))
+                 : ZD_SCAN_SHARED_OUT, ZD_SCAN_OUT(0), ZD_SCAN_OUT(1), ZD_SCAN_OUT(2)
+                 : ZD_SCAN_IN(0), ZD_SCAN_IN(1), ZD_SCAN_IN(2), ZD_SCAN_SHARED_IN
+                 : "vcc", "scc", "memory");
+  } else {
+    asm volatile(ZD_SCAN_BODY(ZD_SCAN_ROUND4,
+                              "s_mov_b64 %[ws0], %[W0]\n\ts_mov_b64 %[ws1], %[W1]\n\ts_mov_b64 %[ws2], %[W2]\n\ts_mov_b64 %[ws3], %[W3]\n\t",
+                              ZD_SCAN_HITS(0) ZD_SCAN_HITS(1) ZD_SCAN_HITS(2) ZD_SCAN_HITS(3))
+                 : ZD_SCAN_SHARED_OUT, ZD_SCAN_OUT(0), ZD_SCAN_OUT(1), ZD_SCAN_OUT(2), ZD_SCAN_OUT(3)
+                 : ZD_SCAN_IN(0), ZD_SCAN_IN(1), ZD_SCAN_IN(2), ZD_SCAN_IN(3), ZD_SCAN_SHARED_IN
+                 : "vcc", "scc", "memory");
+  }
   return n;
 }
-#undef ZD_SCAN_ROUND_ASM
+#undef ZD_SCAN_PROBE
+#undef ZD_SCAN_TAKE
+#undef ZD_SCAN_HITS
+#undef ZD_SCAN_CHECK
+#undef ZD_SCAN_ROUND2
+#undef ZD_SCAN_ROUND3
+#undef ZD_SCAN_ROUND4
 #undef ZD_SCAN_EXIT_ASM
+#undef ZD_SCAN_BODY
+#undef ZD_SCAN_OUT
+#undef ZD_SCAN_IN
+#undef ZD_SCAN_SHARED_OUT
+#undef ZD_SCAN_SHARED_IN
 #undef ZD_STR
 #undef ZD_STR_
 
@@ -750,18 +746,21 @@ __device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun &r0, ScanRun &r1, Sc
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, uint32_t cs, int K, int Kq, Sink sink) {
-  static_assert(NP == 2, "scan_rounds_lds steps two run slots");
   static_assert(64u * NP <= POOL_CHUNK, "chunk");
   ScanRun r[NP];
   ScanSlotMasks m[NP];
-  uint32_t h[NP] = {0, 0};  // the two bytes a run's last step read (scan_rounds_lds)
-  uint32_t hits = 0;        // runs in the last compare
+  uint32_t h[NP];      // the two bytes a run's last step read (scan_rounds_lds)
+  uint32_t hits = 0;   // runs in the last compare
   uint32_t iters = 0;  // rounds of cheap steps (what is returned: the same measure as the first form's iterations)
 #ifdef ZD_MATCH_COUNTS
   MatchCounts mc;
 #endif
   auto ballot = [](bool b) { return (unsigned long long)__builtin_amdgcn_ballot_w64(b); };
   auto mine = [](unsigned long long mask) { return __builtin_amdgcn_inverse_ballot_w64(mask); };  // my lane's bit of a mask
+  auto any_of = [&](auto pick) { unsigned long long o = 0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) o |= pick(m[i]);
+    return o; };
   auto fetch = [&](bool first) -> uint32_t {
     uint32_t oldest = 0xFFFFFFFFu;
     if (Pool::WANTS_OLDEST && !first) {
@@ -781,33 +780,44 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     const uint32_t off = lane + 64u * (uint32_t)i;
     const ScanFlags f = scan_run_start<true>(r[i], s, len, off < cend - next ? next + off : cend, cend, prev, (uint32_t)K, (uint32_t)Kq);
     m[i].W = ballot(f.walking); m[i].H = 0; m[i].F = ballot(f.fin); m[i].L = ballot(f.live);
+    h[i] = 0;
   }
   next = cend - next > 64u * NP ? next + 64u * NP : cend;
   for (;;) {
     ZD_COUNT(1, 1);
     // cheap steps: every walking run goes from candidate to candidate until one passes the byte test -- or its walk ends
-    unsigned long long full[NP] = {0, 0};  // runs whose compare found a match as long as a match can be
-    if (m[0].W | m[1].W) {
-      const uint32_t n = scan_rounds_lds(r[0], r[1], m[0], m[1], h[0], h[1], cs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >= SCAN_DENSE_HITS ? 1u : 0u)));
+    unsigned long long full[NP];  // runs whose compare found a match as long as a match can be
+#pragma unroll
+    for (int i = 0; i < NP; i++) full[i] = 0;
+    if (any_of([](const ScanSlotMasks &x) { return x.W; })) {
+      const uint32_t n = scan_rounds_lds<NP>(r, m, h, cs, (uint32_t)__builtin_amdgcn_readfirstlane((int)(hits >= SCAN_DENSE_HITS ? 1u : 0u)));
       iters += n;
       ZD_COUNT(2, n);
     }
-    // the compares of the runs that stand on such a candidate, together: a lane's first such slot.  Straight-line for the
+    // the compares of the runs that stand on a candidate which passed, together: a lane's first such slot.  Straight-line for the
     // candidate that differs within its first 8 bytes (on text: nearly all of them); the others behind one branch.
-    if (m[0].H | m[1].H) {
-      hits = (uint32_t)__builtin_popcountll(m[0].H) + (uint32_t)__builtin_popcountll(m[1].H);
+    const unsigned long long hall = any_of([](const ScanSlotMasks &x) { return x.H; });
+    if (hall) {
+      unsigned long long hm[NP], seen = 0;  // the runs compared now
+      hits = 0;
+#pragma unroll
+      for (int i = 0; i < NP; i++) { hits += (uint32_t)__builtin_popcountll(m[i].H); hm[i] = m[i].H & ~seen; seen |= m[i].H; }
       ZD_COUNT(4, 1); ZD_COUNT(5, hits);
-      const unsigned long long h0 = m[0].H, h1 = m[1].H & ~m[0].H;  // the runs compared now
       // (every lane goes through it -- a run's q = t + dn and p are positions of the window whatever the run's state -- and
       // the runs compared take the results: masks stay masks, where a value set under a lane's condition went through a
       // vector register and back)
-      const bool first = mine(h0);
-      const uint32_t p = first ? r[0].p : r[1].p, q = first ? r[0].t + r[0].dn : r[1].t + r[1].dn;
-      const uint32_t bl = (first ? r[0].blm1 : r[1].blm1) + 1u, ml = first ? r[0].maxlen : r[1].maxlen;
-      const uint64_t x = load_u64_words(s, q) ^ (first ? r[0].pw : r[1].pw);
+      uint32_t p = r[NP - 1].p, q = r[NP - 1].t + r[NP - 1].dn, bl = r[NP - 1].blm1, ml = r[NP - 1].maxlen;
+      uint64_t pw = r[NP - 1].pw;
+#pragma unroll
+      for (int i = NP - 2; i >= 0; i--) {
+        const bool w = mine(hm[i]);
+        p = w ? r[i].p : p; q = w ? r[i].t + r[i].dn : q; bl = w ? r[i].blm1 : bl; ml = w ? r[i].maxlen : ml; pw = w ? r[i].pw : pw;
+      }
+      bl += 1u;
+      const uint64_t x = load_u64_words(s, q) ^ pw;
       uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
       l = l < ml ? l : ml;  // (the last 7 positions of a stream: what lies behind its end does not count)
-      const unsigned long long more = ballot(x == 0 && ml > 8u) & (h0 | h1);  // the first 8 bytes agree and there are others
+      const unsigned long long more = ballot(x == 0 && ml > 8u) & hall;  // the first 8 bytes agree and there are others
       if (more) {
         if (mine(more)) {
           // before the long compare, the 8 bytes that END at best_len (they include the bytes already tested); what fails
@@ -823,10 +833,13 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
       const uint32_t nbest = ((p - q) << 9) | l;
       const unsigned long long fm = ballot(l == ml);  // zd.ml:1194: after l == maxlen nothing later can be longer
       const unsigned long long bm = ballot(better);
-      { const bool w = mine(h0); r[0].blm1 = w ? nb : r[0].blm1; r[0].pb = w ? npb : r[0].pb; r[0].best = mine(h0 & bm) ? nbest : r[0].best; }
-      { const bool w = mine(h1); r[1].blm1 = w ? nb : r[1].blm1; r[1].pb = w ? npb : r[1].pb; r[1].best = mine(h1 & bm) ? nbest : r[1].best; }
-      full[0] = fm & h0; full[1] = fm & h1;
-      m[0].H = 0; m[1].H &= ~h1;
+#pragma unroll
+      for (int i = 0; i < NP; i++) {
+        const bool w = mine(hm[i]);
+        r[i].blm1 = w ? nb : r[i].blm1; r[i].pb = w ? npb : r[i].pb; r[i].best = mine(hm[i] & bm) ? nbest : r[i].best;
+        full[i] = fm & hm[i];
+        m[i].H &= ~hm[i];
+      }
     }
     // stopped runs: done, or on with the walk
 #pragma unroll
@@ -842,7 +855,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         m[i].W |= st & ~fm;
       }
     }
-    const bool busy = (m[0].W | m[1].W | m[0].H | m[1].H) != 0;
+    const bool busy = any_of([](const ScanSlotMasks &x) { return x.W | x.H; }) != 0;
     // finished positions are stored and their slots take the pool's next positions
 #pragma unroll
     for (int i = 0; i < NP; i++) {
@@ -874,7 +887,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         m[i].L = (m[i].L & ~fm) | alive;
       }
     }
-    if ((m[0].L | m[1].L) == 0) break;
+    if (any_of([](const ScanSlotMasks &x) { return x.L; }) == 0) break;
   }
 #ifdef ZD_MATCH_COUNTS
   mc.flush(lane);
