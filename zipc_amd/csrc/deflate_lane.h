@@ -478,7 +478,10 @@ ZD_HD uint64_t scan_run_result(const ScanRun &r, uint32_t Kq) {
 #define ZD_SCAN_MIN_WALKERS 16
 #endif
 #ifndef ZD_SCAN_HANDOUT
-#define ZD_SCAN_HANDOUT 16
+#define ZD_SCAN_HANDOUT 24
+#endif
+#ifndef ZD_SCAN_MERGED_HANDOUT
+#define ZD_SCAN_MERGED_HANDOUT 1
 #endif
 constexpr int SCAN_ROUNDS = ZD_SCAN_ROUNDS;  // cheap steps between two compares, at most ...
 constexpr uint32_t SCAN_DENSE_HITS = ZD_SCAN_DENSE_HITS;  // ... ZD_SCAN_ROUNDS_DENSE when the compare before had this many runs in it (of 128): measured,
@@ -796,6 +799,8 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     }
     // the compares of the runs that stand on a candidate which passed, together: a lane's first such slot.  Straight-line for the
     // candidate that differs within its first 8 bytes (on text: nearly all of them); the others behind one branch.
+    // (a lane with hits in two slots takes the second next time: a second turn of this code at once, for 1, 8 or 16 such
+    // lanes and more, measured 1-4 % slower on text, 3-bit symbols and the corpus)
     const unsigned long long hall = any_of([](const ScanSlotMasks &x) { return x.H; });
     if (hall) {
       unsigned long long hm[NP], seen = 0;  // the runs compared now
@@ -857,6 +862,46 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     }
     const bool busy = any_of([](const ScanSlotMasks &x) { return x.W | x.H; }) != 0;
     // finished positions are stored and their slots take the pool's next positions
+#if ZD_SCAN_MERGED_HANDOUT
+    {  // one handout for the lane's slots: a lane's first finished slot (another one of the same lane waits for the next)
+      unsigned long long fk[NP], fu = 0;
+#pragma unroll
+      for (int i = 0; i < NP; i++) { fk[i] = m[i].F & ~fu; fu |= m[i].F; }
+      const uint32_t taken = (uint32_t)__builtin_popcountll(fu);
+      if (taken >= SCAN_HANDOUT || (fu && !busy)) {  // wave-uniform
+        ZD_COUNT(6, 1); ZD_COUNT(7, taken);
+        const bool fin = mine(fu);
+        uint32_t fp = r[NP - 1].p, fbest = r[NP - 1].best, fsnap = r[NP - 1].snap;
+#pragma unroll
+        for (int i = NP - 2; i >= 0; i--) { const bool w = mine(fk[i]); fp = w ? r[i].p : fp; fbest = w ? r[i].best : fbest; fsnap = w ? r[i].snap : fsnap; }
+        if (fin) sink(fp, fbest, Kq == 0 ? 0u : (fsnap != SNAP_NONE ? fsnap : fbest));
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fu >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fu, 0u));
+        const uint32_t rem = cend - next;
+        uint32_t np = rank < rem ? next + rank : cend, lim = cend;
+        if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
+          const uint32_t c = fetch(false);
+          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
+          empty = c >= pend;
+          if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
+          next = ce - c > taken - rem ? c + (taken - rem) : ce;
+          cend = ce;
+        } else {
+          next = rem > taken ? next + taken : cend;
+        }
+        ScanRun nr;
+        scan_run_start<true>(nr, s, len, np < lim ? np : lim, lim, prev, (uint32_t)K, (uint32_t)Kq);
+        const unsigned long long alive = ballot(np < lim) & fu;
+        const unsigned long long walk = K != 0 ? ballot(nr.blm1 + 1u < nr.maxlen && !scan_far<P>(nr)) & alive : 0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+          if (mine(fk[i])) r[i] = nr;
+          m[i].W |= walk & fk[i];
+          m[i].F = (m[i].F & ~fk[i]) | (alive & ~walk & fk[i]);
+          m[i].L = (m[i].L & ~fk[i]) | (alive & fk[i]);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       const unsigned long long fm = m[i].F;
@@ -887,6 +932,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         m[i].L = (m[i].L & ~fm) | alive;
       }
     }
+#endif
     if (any_of([](const ScanSlotMasks &x) { return x.L; }) == 0) break;
   }
 #ifdef ZD_MATCH_COUNTS
