@@ -18,6 +18,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmcF" -o p --output-format cs
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmcW" -o p --output-format csv -- python3 "$B" --no-cpu-baseline --no-extra-legs --steps 3 --warmup 1 > "$OUT/pmcW.log" 2>&1 || echo "WRITE_SIZE pass failed"
 python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" --hbm-json "$ROOT/profiles/${TAG}_hbm_traffic.json" && cp "$ROOT/profiles/${TAG}_hbm_traffic.json" "$OUT/hbm_traffic.json"
 python3 "$ROOT/tools/pmc_report.py" "$OUT/pmc[FW]/*counter_collection.csv" > "$OUT/pmc_hbm.txt"
+# the SQ counter pass too comes BEFORE the bench line it is quoted in (roofline.issue_bound reads profiles/*sq_counters.json)
+(cd "$ROOT" && DEFLATE=1 bash tools/exp_sq_counters.sh > "$OUT/sq.log" 2>&1; cp gpurun_out/sq/sq_counters.json "$OUT/sq_counters.json"; cp gpurun_out/sq/summary.txt "$OUT/sq_counters.txt"; cp gpurun_out/sq/sq_counters.json "profiles/${TAG}_sq_counters.json")
 python3 "$B" > "$OUT/bench.json" 2> "$OUT/bench.err"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o t --output-format csv -- python3 "$B" --no-cpu-baseline --no-extra-legs > "$OUT/trace_bench.json" 2> "$OUT/trace.err" || echo "kernel-trace pass failed"
 python3 "$B" --alone-pass --no-cpu-baseline --no-extra-legs > "$OUT/bench_alone.json" 2> /dev/null || echo "alone pass failed"
@@ -40,7 +42,6 @@ ZIPC_HIP_INFLATE_BLOCKS=0 LEN=16777216 python3 tools/exp_inflate_blocks.py >> "$
   echo "-- ZIPC_HIP_INFLATE_BLOCKS=0"; ZIPC_HIP_INFLATE_BLOCKS=0 REPS=3 python3 tools/exp_inflate_many.py; } 2> /dev/null | grep -v amdgpu.ids > "$OUT/inflate_many.txt"
 CFGS="64x1048576 8x8388608" bash tools/prof_inflate_many.sh 2> /dev/null | grep -v "^[WE]2026" > "$OUT/inflate_many_kernels.txt"
 python3 "$B" --config c4 --steps 3 --warmup 1 > "$OUT/bench_c4.json" 2> "$OUT/bench_c4.err"
-DEFLATE=1 bash tools/exp_sq_counters.sh > "$OUT/sq.log" 2>&1; cp gpurun_out/sq/sq_counters.json "$OUT/sq_counters.json"; cp gpurun_out/sq/summary.txt "$OUT/sq_counters.txt"
 echo "== bench"; python3 -c "
 import json,sys
 d=json.load(open('$OUT/bench.json'))
