@@ -674,7 +674,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
   } else {
     jobs[0].n = jobs[0].cand_cap;
   }
-  HIP_TRY(ctx, span_slots(alive));
+  if (span_slots(alive) != hipSuccess) { (void)hipGetLastError(); return ZIPC_HIP_OK; }  // (no room for the waves' span index: the streams' one waves need 2304 bytes each)
   HIP_TRY(ctx, hand(alive));
   unsigned na = (unsigned)alive.size();
   const unsigned dry_waves = widest(alive, [](const BlocksJob &J, uint32_t) { return J.n; });
@@ -701,7 +701,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
       jobs[j].n_blocks = (uint32_t)ne;
       jobs[j].n = (uint32_t)ne + listed;
     }
-    HIP_TRY(ctx, span_slots(lost));
+    if (span_slots(lost) != hipSuccess) { (void)hipGetLastError(); return ZIPC_HIP_OK; }
     HIP_TRY(ctx, hand(lost));
     const unsigned nl = (unsigned)lost.size();
     ZD_LAUNCH(ctx, "inflate_explore", inflate_explore_kernel, dim3(widest(lost, [](const BlocksJob &J, uint32_t) { return J.n; }), nl), dim3(64), 0,
@@ -745,7 +745,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
     jobs[j].tok = (uint32_t *)ctx->tok_scratch.p + tok_words;
     tok_words += ((size_t)jobs[j].out_len * 3 + 63) & ~(size_t)63;
   }
-  HIP_TRY(ctx, span_slots(alive));
+  if (span_slots(alive) != hipSuccess) { (void)hipGetLastError(); return ZIPC_HIP_OK; }  // (no room for the waves' span index: the streams' one waves need 2304 bytes each)
   HIP_TRY(ctx, hand(alive));
   na = (unsigned)alive.size();
   const unsigned out_grid = widest(alive, [](const BlocksJob &J, uint32_t) { return (J.out_len + 255u) / 256u; });
@@ -775,7 +775,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
   if (alive.empty()) return ZIPC_HIP_OK;
   na = (unsigned)alive.size();
   if (adler) {  // block by block, every block's bytes in chunks of their own (inflate.hip)
-    HIP_TRY(ctx, ctx->ensure(ctx->adler_sums, (n_chunks + 1) * 12));
+    if (ctx->ensure(ctx->adler_sums, (n_chunks + 1) * 12) != hipSuccess) { (void)hipGetLastError(); return ZIPC_HIP_OK; }  // (the one waves write output and checksum again)
     n_chunks = 0;
     for (uint32_t j : alive) { jobs[j].sums = (uint32_t *)ctx->adler_sums.p + n_chunks * 3; n_chunks += fc[j].n_chunks; }
   }
