@@ -646,6 +646,8 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
 // The link is read with ds_read_u16_d16: the d16 reads of this chip ZERO the half of the register they do not load
 // (tools/probes/d16_loads.hip; SRAM ECC -- which is why the compiler never emits them) and take 7 ticks a wave at any even
 // address, where ds_read_u16 takes 41 at 2 mod 4 (tools/probes/lds_costs.hip); the bytes with ds_read_u8, 4.7 each.
+// (A slot without a walking lane issues its reads under an empty mask; they count in lgkmcnt like any other -- the waits
+// below rely on it, the compiler's own code does, and tools/probes/exec0_lgkm.hip looked: profiles/r05_exec0_lgkm.txt.)
 // Returns the rounds done.
 struct ScanSlotMasks { unsigned long long W, H, F, L; };  // walking, hit, fin, live
 #define ZD_SCAN_PROBE(i)                                       \
