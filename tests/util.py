@@ -3,6 +3,7 @@ import base64
 import json
 import os
 import random
+import struct
 import zlib
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -90,6 +91,21 @@ def far_match_data(seed=21):
     return bytes(b)
 
 
+def record_table(n_records, seed=31):
+    """A table of 24-byte records, most fields of a record the one before's (an ELF symbol table): its matches are a few
+    long chains side by side, each link a copy of the record before -- the one-wave inflate's hole rounds took a round a
+    link (corpus chunks of libhost_sim.so: 55 % of their time, round 5)"""
+    r = random.Random(seed)
+    out = bytearray()
+    name, value = 1, 0x401000
+    for _ in range(n_records):
+        name += r.randrange(4, 40)
+        value += r.choice([16, 16, 32, 48, 64, 176, 4096])
+        out += struct.pack("<IBBHQQ", name, r.choice([0x12, 0x12, 0x12, 0x11, 0x22]), 0, r.choice([14, 14, 14, 16, 25]), value,
+                           r.choice([0, 0, 8, 16, 16, 43, 176]))
+    return bytes(out)
+
+
 def deflate_cases(small=False):
     """name -> plaintext: the edge cases the reference tests plus multi-block, run,
     period, incompressible and mixed inputs"""
@@ -119,6 +135,7 @@ def deflate_cases(small=False):
             # multi-block stream where the code-length counts carry over: Q1) and the window's edge
             "fib_litlen": fib_block(16, 5), "fib_codelen": fib_block(14, 2), "fib_both": fib_block(18, 2),
             "fib_multi": fib_block(18, 2) * 4 + fib_block(17, 5), "far_match": far_match_data(),
+            "record_table": record_table(3000),
         })
         for m, raw in zip_docs_members():
             c[m["path"]] = zlib.decompress(raw, -15)

@@ -953,16 +953,24 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         wv::sync();
       }
       ZD_SPAN_PH(4);
+      // (The list's open part is [head, n_open).  A round looks at all of it -- until one fills less than an eighth of 128
+      // holes and more: tables of records, each field a copy of the record before's, are a few long chains side by side, a
+      // round fills a link of each and looked at hundreds of holes to find them (an ELF symbol table: 170 rounds over 400
+      // holes a tile, 55 % of the stream's time).  From then on a round looks at the FRONT 64 only -- the earliest open
+      // hole is always ready, and what a hole waits for lies before it -- until a round fills 48 of them again.)
+      uint32_t head = 0;
+      bool front = false;
       for (;;) {
         uint32_t kept = 0;
 #ifdef SPAN_TRACE
         if (lane == 0) span_trace_steps[3]++;
 #endif
-        for (uint32_t c0 = 0; c0 < n_open; c0 += 64u) {
+        const uint32_t lim = front && n_open - head > 64u ? head + 64u : n_open;
+        for (uint32_t c0 = head; c0 < lim; c0 += 64u) {
 #ifdef SPAN_TRACE
           if (lane == 0) span_trace_steps[7]++;
 #endif
-          const uint32_t dp = c0 + ulane < n_open ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
+          const uint32_t dp = c0 + ulane < lim ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
           const bool open = dp != 0xFFFFu;
           uint32_t dist = 1, len = 0;
           if (open) {
@@ -1031,11 +1039,19 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
             span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
           }
           if (ready) span_bits_clear(mbits, dp, len);
-          // what is still open moves up in the list
+          // what is still open moves up in the list (a round over the front only: back against what it did not look at)
           const uint64_t km = wv::ballot(open && !ready);
-          if (open && !ready) list[kept + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
-          kept += (uint32_t)__builtin_popcountll(km);
+          const uint32_t nk = (uint32_t)__builtin_popcountll(km);
+          const uint32_t to = lim != n_open ? lim - nk : head + kept;
+          if (open && !ready) list[to + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
+          kept += nk;
           wv::sync();
+        }
+        if (lim != n_open) {  // a round over the front: what it kept sits in front of the rest
+          const uint32_t filled = 64u - kept;
+          head = lim - kept;
+          front = filled < 48u;
+          continue;
         }
         if (kept == 0u) break;
         // A round that filled one or two of many open holes: they form a chain (each
@@ -1044,10 +1060,10 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         // final when its turn comes: the rest one after the other, each by the whole wave.
         // (Holes that follow each other at one distance -- a period cut into short matches -- are one
         // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
-        if (n_open - kept <= 2u && kept >= 64u) {
+        if (n_open - head - kept <= 2u && kept >= 64u) {
           for (uint32_t h = 0; h < kept;) {
             const bool have = h + ulane < kept;
-            const uint32_t dp = have ? (uint32_t)list[h + ulane] : 0u;
+            const uint32_t dp = have ? (uint32_t)list[head + h + ulane] : 0u;
             uint32_t dist = 0, len = 0;
             if (have) {
               const uint32_t rec = span_rec(tile, dp);
@@ -1068,7 +1084,8 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
           }
           break;
         }
-        n_open = kept;
+        front = (n_open - head - kept) * 8u < n_open - head && kept >= 128u;
+        n_open = head + kept;
       }
       if (h_total <= SPAN_LIST_MAX) break;
       {  // what is still open of my own holes
