@@ -15,6 +15,10 @@ if os.environ.get("ZEROS"):
 elif os.environ.get("DOC"):  # tools/bench_single.py's text: this repo's SURVEY.md over and over
     doc = open(os.path.join(ROOT, "SURVEY.md"), "rb").read()
     src = torch.from_numpy(np.frombuffer((doc * (n * L // len(doc) + 1))[:n * L], np.uint8).copy()).to(dev)
+elif os.environ.get("JSON_AT"):  # a 64 KiB slice of tests/golden/zlib_streams.json (base64), n copies
+    js = open(os.path.join(ROOT, "tests/golden/zlib_streams.json"), "rb").read()
+    o = int(os.environ["JSON_AT"]); c = js[o:o + L]; c = c + bytes(L - len(c))
+    src = torch.from_numpy(np.frombuffer(c * n, np.uint8).copy()).to(dev)
 elif os.environ.get("CORPUS_CHUNK"):  # one chunk of tools/corpus.py, n copies
     from tools import corpus
     c = corpus.chunks(L)[int(os.environ["CORPUS_CHUNK"])]

@@ -537,6 +537,34 @@ __device__ __forceinline__ bool wide_turns(InflateLane &d, const LaneLds &L, uin
   }
 }
 
+// A turn for the stretches a wide turn is worst at: literals that all have ONE code length n (base64: 64 letters of 6 bits --
+// a wide turn's 64 bit offsets hold ten of them).  Lane k looks at the bits n k behind the position; while every lane before
+// it found a literal of n bits, what it finds is the k-th symbol from here.  The literals in front of the first lane that
+// found something else are stored side by side and the position moves behind them; that lane's symbol is the next turn's.
+// (n <= LIT_TBITS: the table's entry is the whole code.  ready: words of input staged from the position's word on.)
+#ifndef ZD_STRIDE_MIN
+#define ZD_STRIDE_MIN 4
+#endif
+#ifndef ZD_STRIDE_WAIT
+#define ZD_STRIDE_WAIT 8
+#endif
+template <int MODE>
+__device__ __forceinline__ uint32_t strided_turn(InflateLane &d, const LaneLds &L, uint8_t *__restrict__ dst, int lane, uint32_t n, uint32_t ready) {
+  const uint32_t p = d.boff + n * (uint32_t)lane;
+  const int s = (int)((d.in_word + (p >> 5)) & (uint32_t)(RING_WORDS - 1));
+  const uint32_t w0 = L.slot(s), w1 = L.slot(s + 1);
+  const uint32_t e = L.wide_lit((int)(funnel32(w1, w0, p) & ((1u << LIT_TBITS) - 1)));
+  const bool ok = (p >> 5) + 2u <= ready && n * ((uint32_t)lane + 1u) <= d.bits_left() && (int32_t)e < 0 && ((e >> 17) & 63u) == n;
+  const unsigned long long m = wave_mask(ok);
+  uint32_t c = ~m == 0ull ? 64u : (uint32_t)__builtin_ctzll(~m);
+  const uint32_t room = d.cap_min - d.out_pos;
+  c = c < room ? c : room;
+  if (MODE != IM_DRY && (uint32_t)lane < c) dst[d.out_pos + (uint32_t)lane] = (uint8_t)(e >> 8);
+  d.out_pos += c;
+  d.advance(c * n);
+  return c;
+}
+
 // Are the n bits from bit a on the n bits from bit b on (b < a, all inside the input)?  32 bits a lane.
 __device__ __forceinline__ bool same_bits(const uint8_t *__restrict__ src, uint32_t src_len, uint64_t a, uint64_t b, uint32_t n, int lane) {
   bool differ = false;
@@ -644,6 +672,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
   SpanCk ck;
   ck.lds = X.ck_lds; ck.n = 0; ck.last = 0; ck.hdr_bit = at.bit; ck.out_base = BLOCK_DRY_BASE;
   bool resume_pending = MODE == IM_TOKEN && X.resume != 0u;
+  uint32_t lit_stride = 0;  // the one code length of most of the block's literals, or 0 (strided_turn)
   bool left_early = false;  // IM_TOKEN: the wave stopped at until_bit
   bool fixed_tables = false;  // MULTI: the tables in LDS are the fixed codes'
   // REUSE (inflate_batch_few_kernel: calls of a few streams): the last dynamic header read -- where it stood and how
@@ -715,7 +744,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
     uniformize(d);
 
     // ---- decode
-    int plain_run = 0;
+    int plain_run = 0, stride_wait = 0;
     for (int turn = 0; turn < ROUND_TURNS;) {
       if (d.phase == PH_HDR_LENGTHS) {
         turn++;
@@ -760,6 +789,15 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         if (d.phase == PH_SYMBOLS) {
           const uint32_t shortest = build_wide_tables(d, L, lane);
           d.levels = levels_for(wave_min(shortest));
+          {  // the length that 32 and more of the block's literal / length codes have (strided_turn), 0: none
+            const uint32_t cnt = lane < 16 ? (uint32_t)L.u16(LDS_LIT_COUNTS, lane) : 0u;
+            uint32_t bl = 0, bn = 31;
+            for (int l = 1; l <= LIT_TBITS; l++) {
+              const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)cnt, l);
+              if (nl > bn) { bn = nl; bl = (uint32_t)l; }
+            }
+            lit_stride = bl;
+          }
           if (REUSE && !d.hdr_fixed && !d.final_block) {  // (a dynamic header's tables stand: its bits are hdr_at .. here)
             prev_hdr_at = hdr_at;
             const uint64_t len = (uint64_t)d.in_word * 32u + d.boff - hdr_at;
@@ -833,8 +871,16 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
         bool stopped = true;
         // (where the wide turns commit nothing -- runs of long matches: zeros, periods -- they are
         // skipped for a few symbols after one that stopped at its very first symbol)
+        const bool try_stride = plain_run == 0 && lit_stride != 0u && stride_wait == 0 && d.ring_wr - d.in_word >= 8u;
+        const uint32_t stride_got = try_stride ? strided_turn<MODE>(d, L, dst, lane, lit_stride, d.ring_wr - d.in_word) : 0u;
         if (plain_run > 0) { plain_run--; turn++; }
-        else {
+        else if (stride_got >= 16u) {
+          turn++;  // (a turn that went well: the next is one of the same)
+          stopped = false;
+        } else {
+          // (a strided turn that got little: wide turns for a while -- the stretch is not of one length)
+          if (try_stride) stride_wait = stride_got < (uint32_t)ZD_STRIDE_MIN ? ZD_STRIDE_WAIT : 0;  // (a strided turn costs a quarter of a wide one: four symbols pay for it)
+          else if (stride_wait > 0) stride_wait--;
           const uint32_t before = d.out_pos;
           if (d.levels == 4) stopped = wide_turns<4, MODE>(d, L, dst, tok, lane, turn);
           else if (d.levels == 5) stopped = wide_turns<5, MODE>(d, L, dst, tok, lane, turn);
