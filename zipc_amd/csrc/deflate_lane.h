@@ -368,7 +368,8 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 //     like one at its chain's end, notes its second answer where stopped runs are looked at anyway, and walks on;
 //   * the compares of a lane's run slots are one piece of code (a lane with hits in both slots takes them one after the
 //     other, which is rare);
-//   * finished positions wait until SCAN_HANDOUT lanes of the wave have one in the same slot (or nothing else is left to do).
+//   * finished positions wait until SCAN_HANDOUT lanes of the wave have one (or nothing else is left to do), and one handout
+//     serves a lane's first finished slot, whichever it is.
 // A run is in ONE of: walking (t is a candidate in range and steps < klim), hit (it stands on q = t + dn, which passed
 // the byte test), fin (done, waits for its store), none of them with live set (stopped: scan_run_settle says which
 // of the others it becomes) or dead (!live: no position).
@@ -480,14 +481,11 @@ ZD_HD uint64_t scan_run_result(const ScanRun &r, uint32_t Kq) {
 #ifndef ZD_SCAN_HANDOUT
 #define ZD_SCAN_HANDOUT 24
 #endif
-#ifndef ZD_SCAN_MERGED_HANDOUT
-#define ZD_SCAN_MERGED_HANDOUT 1
-#endif
 constexpr int SCAN_ROUNDS = ZD_SCAN_ROUNDS;  // cheap steps between two compares, at most ...
 constexpr uint32_t SCAN_DENSE_HITS = ZD_SCAN_DENSE_HITS;  // ... ZD_SCAN_ROUNDS_DENSE when the compare before had this many runs in it (of 128): measured,
                                                           // text (20 a compare) is 6 % faster with 8 rounds than with 4, 3-bit symbols (56) 5 % slower
 constexpr int SCAN_MIN_WALKERS = ZD_SCAN_MIN_WALKERS;  // ... and only while this many lanes of the wave still walk
-constexpr uint32_t SCAN_HANDOUT = ZD_SCAN_HANDOUT;  // finished positions of a slot wait for this many lanes
+constexpr uint32_t SCAN_HANDOUT = ZD_SCAN_HANDOUT;  // finished positions wait for this many lanes with one
 
 // The same walk for one lane's positions first, first + step, ... < pend, serially (the host
 // model's form; the device runs lz_match_scan_pool below on the same pieces).
@@ -864,7 +862,6 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     }
     const bool busy = any_of([](const ScanSlotMasks &x) { return x.W | x.H; }) != 0;
     // finished positions are stored and their slots take the pool's next positions
-#if ZD_SCAN_MERGED_HANDOUT
     {  // one handout for the lane's slots: a lane's first finished slot (another one of the same lane waits for the next)
       unsigned long long fk[NP], fu = 0;
 #pragma unroll
@@ -903,38 +900,6 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         }
       }
     }
-#else
-#pragma unroll
-    for (int i = 0; i < NP; i++) {
-      const unsigned long long fm = m[i].F;
-      const uint32_t taken = (uint32_t)__builtin_popcountll(fm);
-      if (taken >= SCAN_HANDOUT || (fm && !busy)) {  // wave-uniform
-        ZD_COUNT(6, 1); ZD_COUNT(7, taken);
-        const bool fin = mine(fm);
-        if (fin) { const uint64_t both = scan_run_result(r[i], (uint32_t)Kq); sink(r[i].p, (uint32_t)both, (uint32_t)(both >> 32)); }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-        const uint32_t rem = cend - next;
-        uint32_t np = rank < rem ? next + rank : cend, lim = cend;
-        if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
-          const uint32_t c = fetch(false);
-          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
-          empty = c >= pend;
-          if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
-          next = ce - c > taken - rem ? c + (taken - rem) : ce;
-          cend = ce;
-        } else {
-          next = rem > taken ? next + taken : cend;
-        }
-        if (fin) scan_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev, (uint32_t)K, (uint32_t)Kq);
-        // (the new runs' flags, scan_run_start's, from their registers)
-        const unsigned long long alive = ballot(np < lim) & fm;
-        const unsigned long long walk = K != 0 ? ballot(r[i].blm1 + 1u < r[i].maxlen && !scan_far<P>(r[i])) & alive : 0;
-        m[i].W |= walk;
-        m[i].F = alive & ~walk;
-        m[i].L = (m[i].L & ~fm) | alive;
-      }
-    }
-#endif
     if (any_of([](const ScanSlotMasks &x) { return x.L; }) == 0) break;
   }
 #ifdef ZD_MATCH_COUNTS
