@@ -373,7 +373,7 @@ ZD_HD uint32_t lz_match_runs(const uint8_t *s, uint32_t len, uint32_t first, uin
 // A run is in ONE of: walking (t is a candidate in range and steps < klim), hit (it stands on q = t + dn, which passed
 // the byte test), fin (done, waits for its store), none of them with live set (stopped: scan_run_settle says which
 // of the others it becomes) or dead (!live: no position).
-// Positions are COORDINATES below 2^31 (the window kernel's are relative to its window): the range test is signed.
+// Positions are COORDINATES below 2^31 (the window kernel's are the LDS addresses of its window's bytes): the range test is signed.
 struct ScanRun {
   uint32_t p;      // the position
   uint32_t t;      // the next candidate
