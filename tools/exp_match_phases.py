@@ -8,10 +8,17 @@ sys.path.insert(0, ROOT)
 import torch
 import zipc_amd
 from zipc_amd import batch, synth, _lib
-n = int(os.environ.get("N_STREAMS", "16384")); L = 65536; bits = int(os.environ.get("BITS", "4"))
+n = int(os.environ.get("N_STREAMS", "16384")); L = int(os.environ.get("LEN", "65536")); bits = int(os.environ.get("BITS", "4"))
 reps = int(os.environ.get("REPS", "3"))
 dev = torch.device("cuda", 0); ctx = zipc_amd.Context(0)
-src = synth.batch_bytes_torch(2, 0, n, L, bits, dev)
+if os.environ.get("TEXT"):  # 64 KiB chunks of the reference's zip-docs texts instead of synthetic symbols
+    import zipfile, numpy as np
+    z = zipfile.ZipFile(os.path.join(ROOT, "tests/golden/zip-docs.zip"))
+    app = z.read("zip-docs/APPNOTE.TXT"); rfc = z.read("zip-docs/rfc1951.txt")
+    pieces = [app[0:L], app[L:2 * L], (rfc + rfc)[:L], app[100000:100000 + L]]
+    src = torch.from_numpy(np.frombuffer(b"".join(pieces[i % 4] for i in range(n)), np.uint8).copy()).to(dev)
+else:
+    src = synth.batch_bytes_torch(4 if L > 65536 else 2, 0, n, L, bits, dev)
 descs = batch.uniform_layout(n, L, batch.deflate_bound(L))
 comp = torch.zeros(n * int(descs["dst_off"][1]) + 256, dtype=torch.uint8, device=dev)
 d_descs = batch.to_device(descs, dev); d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)

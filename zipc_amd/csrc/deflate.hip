@@ -612,6 +612,9 @@ constexpr uint32_t MATCHW_SCAN_STEPS = ZD_SCAN_STEPS;
 // second); the corpus' binaries -- a few long chains among many empty ones -- now take the second: 9.1 -> 3.6 ms per 64 MiB of
 // such chunks, the corpus' lz_match 17.1 -> 12.6 ms per 256 MiB (tools/sweep_form_rule.sh)
 constexpr uint32_t MATCHW_PROBE_DEEP = ZD_PROBE_DEEP;
+#ifndef ZD_MATCH_GROUPS_PER_WG
+#define ZD_MATCH_GROUPS_PER_WG 8
+#endif
 constexpr size_t MATCHW_SMALL = 8192;  // streams up to this long keep the global-memory kernel
 static_assert(MATCHW_TILE % MATCHW_THREADS == 0 && MATCHW_SRC_BYTES % 16 == 0, "tile shape");
 static_assert(MATCHW_SRC_BYTES + 2 * MATCHW_LINKS <= 160 * 1024, "LDS of one CU");
@@ -683,13 +686,13 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
                                                                          const StreamDesc *__restrict__ descs,
                                                                          DeflateScratch S, uint32_t n_streams,
                                                                          uint32_t tiles_per_stream,
-                                                                         uint32_t tiles_per_group, int K, int Kq,
+                                                                         uint32_t tiles_per_group, uint32_t groups_per_wg, int K, int Kq,
                                                                          int form) {
   __shared__ __attribute__((aligned(16))) uint8_t win_src[MATCHW_SRC_BYTES];
   __shared__ __attribute__((aligned(16))) uint16_t win_prev[MATCHW_LINKS];
   __shared__ uint32_t pool_next;  // positions of the tile handed out to waves so far
   __shared__ uint32_t tile_iters[2];  // loop iterations of the workgroup's waves in the tile they walk (by tile parity)
-  __shared__ uint32_t probe_deep;     // probed chains of the workgroup's first tile that hold three candidates
+  __shared__ uint32_t probe_deep;     // probed chains of a group's first tile that hold three candidates
 #ifdef ZD_MATCH_PHASES
   __shared__ unsigned long long ph_acc[4];  // stage sum, loop sum, waves, latest loop end
   unsigned long long ph0 = __builtin_readcyclecounter();
@@ -703,32 +706,51 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
   const uint32_t per_xcd = (nb + 7) / 8;
   const uint32_t logical = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
   const uint32_t groups_per_stream = (tiles_per_stream + tiles_per_group - 1) / tiles_per_group;
-  const uint32_t stream = logical / groups_per_stream;
-  const uint32_t group = logical % groups_per_stream;
-  if (stream >= n_streams) return;  // grid is padded to a multiple of 8
-  const StreamDesc sd = descs[stream];
-  if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
-  const uint32_t len = (uint32_t)sd.src_len;
-  // tiles [tile, tile_end) of the stream; a tile exists when its first position can start a match
-  const uint32_t stream_tiles = (uint32_t)match_tiles_of(len);
-  uint32_t tile = group * tiles_per_group;
-  if (tile >= stream_tiles) return;
-  const uint32_t tile_end = tile + tiles_per_group < stream_tiles ? tile + tiles_per_group : stream_tiles;
-  const uint64_t base = S.pos_base[stream];
-  const uint8_t *s = src_arena + sd.src_off;
+  // A workgroup takes groups_per_wg GROUPS one behind the other -- consecutive ones: the next group of its stream, or the next
+  // stream's first -- and a group's first window is requested like any next tile's: while the waves finish the tile before.
+  // (A workgroup per group paid for that window's memory round trip with all its waves waiting, 5 of a tile's 39 us on the
+  // benchmark's streams -- tools/exp_match_phases.py -- and for a CU's turn from one workgroup to the next.)
+  const uint64_t n_groups = (uint64_t)n_streams * groups_per_stream;
+  uint64_t item = (uint64_t)logical * groups_per_wg;
+  const uint64_t item_end = item + groups_per_wg < n_groups ? item + groups_per_wg : n_groups;
+  struct Group {  // a group of tiles of one stream
+    uint32_t stream, len, tile, tile_end;
+    uint64_t base;
+    const uint8_t *s;
+  };
+  // the next group from `item` on that has work (a stream too short or too long has none), or false
+  auto open = [&](Group &c) -> bool {
+    for (; item < item_end; item++) {
+      c.stream = (uint32_t)(item / groups_per_stream);
+      const uint32_t group = (uint32_t)(item % groups_per_stream);
+      const StreamDesc sd = descs[c.stream];
+      if (sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) continue;
+      c.len = (uint32_t)sd.src_len;
+      // tiles [tile, tile_end) of the stream; a tile exists when its first position can start a match
+      const uint32_t stream_tiles = (uint32_t)match_tiles_of(c.len);
+      c.tile = group * tiles_per_group;
+      if (c.tile >= stream_tiles) continue;
+      c.tile_end = c.tile + tiles_per_group < stream_tiles ? c.tile + tiles_per_group : stream_tiles;
+      c.base = S.pos_base[c.stream];
+      c.s = src_arena + sd.src_off;
+      item++;
+      return true;
+    }
+    return false;
+  };
   const uint32_t tid = threadIdx.x;
   constexpr int SRC_ROUNDS = (MATCHW_SRC_BYTES / 16 + MATCHW_THREADS - 1) / MATCHW_THREADS;
   constexpr int LINK_ROUNDS = (MATCHW_LINKS / 8 + MATCHW_THREADS - 1) / MATCHW_THREADS;
   u32x4 vs[SRC_ROUNDS], vl[LINK_ROUNDS];
   // every thread issues all its 16-byte loads of a window at once (clamped indices) ...
-  auto issue = [&](uint32_t w0, uint32_t n_src, uint32_t n_links) {
-    const uint16_t *pv = S.prev + base + w0;
+  auto issue = [&](const Group &c, uint32_t w0, uint32_t n_src, uint32_t n_links) {
+    const uint16_t *pv = S.prev + c.base + w0;
     const uint32_t last_src = n_src ? n_src - 16u : 0u;
     // A stream shorter than one unit (in a batch of long ones) has no source to load here; its
     // lanes read scratch instead and the values are never stored.  NOT a branch around the
     // loads: at the join the compiler waits for every load issued so far (vmcnt(0)), which
     // put one full memory latency between the source and the link loads of every tile.
-    const uint8_t *sp = n_src ? s + w0 : (const uint8_t *)pv;
+    const uint8_t *sp = n_src ? c.s + w0 : (const uint8_t *)pv;
 #pragma unroll
     for (int j = 0; j < SRC_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
@@ -741,7 +763,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     }
   };
   // ... and stores them to the window later
-  auto store = [&](const MatchTile &g) {
+  auto store = [&](const Group &c, const MatchTile &g) {
 #pragma unroll
     for (int j = 0; j < SRC_ROUNDS; j++) {
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 16u;
@@ -752,48 +774,49 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       const uint32_t o = (tid + (uint32_t)j * MATCHW_THREADS) * 8u;
       if (o < g.n_links) *(u32x4 *)(win_prev + o) = links_for_window(vl[j]);
     }
-    if (tid < ((g.src_end - g.w0) & 15u)) win_src[g.n_src + tid] = s[g.w0 + g.n_src + tid];
+    if (tid < ((g.src_end - g.w0) & 15u)) win_src[g.n_src + tid] = c.s[g.w0 + g.n_src + tid];
   };
-  MatchTile g = match_tile(tile, len);
-  issue(g.w0, g.n_src, g.n_links);
-  store(g);
+  Group c;
+  if (!open(c)) return;
+  MatchTile g = match_tile(c.tile, c.len);
+  issue(c, g.w0, g.n_src, g.n_links);
+  store(c, g);
   if (tid == 0) { pool_next = 0; tile_iters[0] = 0; tile_iters[1] = 0; probe_deep = 0; }
   __syncthreads();
   // Two forms of the walk (deflate_lane.h): the first reads every candidate's 8 bytes and is the
   // faster one where chains hold a candidate or two (the benchmark's 4-bit symbols: 1.2 per
-  // position); the second looks at one byte first and compares in bulk, and is the faster one on
-  // long chains (3-bit symbols 8.5, text 34 per position: -14 % and -39 % of the kernel; +8 % on the
-  // 4-bit symbols).  Same results; a workgroup takes the second form for a tile when the tile
-  // before it took more than MATCHW_SCAN_STEPS run-slot steps per position.  The workgroup's FIRST tile has no tile before
-  // it (and is three quarters of a 64 KiB stream since round 5): every thread follows the links of one position of the tile
-  // through three candidates -- three dependent reads of the window the barrier above has just completed -- and the tile
-  // takes the second form when more than half of the probed chains get that far (the benchmark's symbols: one in seven;
-  // 3-bit symbols and text: nine in ten).  Only speed depends on it.
+  // position); the second looks at two bytes first and compares in bulk, and is the faster one on
+  // longer chains (3-bit symbols 8.5, text 34 per position).  Same results; a workgroup takes the second form for a tile
+  // when the tile before it took more than MATCHW_SCAN_STEPS run-slot steps per position.  A group's FIRST tile has no tile
+  // before it (and is three quarters of a 64 KiB stream since round 5): every thread follows the links of one position of
+  // the tile through three candidates -- three dependent reads of the window the barrier above has just completed -- and the
+  // tile takes the second form when more than MATCHW_PROBE_DEEP of the probed chains get that far (the benchmark's symbols:
+  // one in seven; 3-bit symbols and text: nine in ten).  Only speed depends on it.
   // form: 0 that rule, 1 / 2 always the first / second form (ZIPC_HIP_MATCH_FORM: tests and tuning).
   bool scan_form = form == 2;
-  if (form == 0) {
-    const uint32_t t_last = (uint64_t)g.t1 < (uint64_t)len - 3 ? g.t1 : len - 3;  // one past the tile's last position
-    const uint32_t n_pos = t_last - g.t0;                                            // (>= 1)
-    uint32_t p = g.t0 + (uint32_t)(((uint64_t)tid * n_pos) >> 10), hops = 0;
-    const uint16_t *wp0 = win_prev - g.w0;
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      const uint32_t d = wp0[p];
-      const bool on = d != LinkNone<WinLinks>::value && p - d >= g.w0 && hops == (uint32_t)k;
-      p = on ? p - d : p;
-      hops += on ? 1u : 0u;
-    }
-    const unsigned long long deep = __builtin_amdgcn_ballot_w64(hops == 3u);
-    if ((tid & 63u) == 0) atomicAdd(&probe_deep, (uint32_t)__builtin_popcountll(deep));
-    __syncthreads();
-    scan_form = probe_deep > MATCHW_PROBE_DEEP;
-  }
+  bool first_of_group = true;
   for (;;) {
+    if (first_of_group && form == 0) {
+      const uint32_t t_last = (uint64_t)g.t1 < (uint64_t)c.len - 3 ? g.t1 : c.len - 3;  // one past the tile's last position
+      const uint32_t n_pos = t_last - g.t0;                                                // (>= 1)
+      uint32_t p = g.t0 + (uint32_t)(((uint64_t)tid * n_pos) >> 10), hops = 0;
+      const uint16_t *wp0 = win_prev - g.w0;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const uint32_t d = wp0[p];
+        const bool on = d != LinkNone<WinLinks>::value && p - d >= g.w0 && hops == (uint32_t)k;
+        p = on ? p - d : p;
+        hops += on ? 1u : 0u;
+      }
+      const unsigned long long deep = __builtin_amdgcn_ballot_w64(hops == 3u);
+      if ((tid & 63u) == 0) atomicAdd(&probe_deep, (uint32_t)__builtin_popcountll(deep));
+      __syncthreads();
+      scan_form = probe_deep > MATCHW_PROBE_DEEP;
+    }
 #ifdef ZD_MATCH_PHASES
     const unsigned long long ph1 = __builtin_readcyclecounter();
 #endif
-    const bool has_next = tile + 1 < tile_end;  // uniform over the workgroup
-    const MatchTile gn = match_tile(has_next ? tile + 1 : tile, len);
+    const bool has_next = c.tile + 1 < c.tile_end;  // (of the same group; uniform over the workgroup)
     const uint8_t *ws = win_src - g.w0;  // indexed by stream position
     const WinLinks wp{win_prev - g.w0};
     // The tile's positions are ONE pool for the workgroup's 16 waves (lz_match_runs_pool): a wave
@@ -803,11 +826,11 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     // the phase timers, more on text) and a wave as long as its slowest lane.  Same box, the pool
     // against that: 5.46 vs 5.83-5.87 ms on C2, 171.8 vs 174.7 ms on C4, 153 vs 241 ms on real text.
     // the parse reads up to PARSE_PAD entries behind the last position without a range test
-    if ((uint64_t)g.t1 > (uint64_t)len - 4 && tid < PARSE_PAD) S.match[base + (len - 3) + tid] = 0;
+    if ((uint64_t)g.t1 > (uint64_t)c.len - 4 && tid < PARSE_PAD) S.match[c.base + (c.len - 3) + tid] = 0;
     {
-      const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)len - 3 ? (uint64_t)g.t1 : (uint64_t)len - 3;
+      const uint64_t tend64 = (uint64_t)g.t1 < (uint64_t)c.len - 3 ? (uint64_t)g.t1 : (uint64_t)c.len - 3;
       uint32_t two = 0;  // some position of mine left a second answer
-      auto sink = [&](uint32_t p, uint32_t best, uint32_t first) { two |= match_store(S.match + base, S.snap + base, p, best, first) ? 1u : 0u; };
+      auto sink = [&](uint32_t p, uint32_t best, uint32_t first) { two |= match_store(S.match + c.base, S.snap + c.base, p, best, first) ? 1u : 0u; };
       // (the second form in coordinates of its own: the LDS addresses of the window's bytes -- its range test is signed, and
       // its reads take no base)
       typedef __attribute__((address_space(3))) uint8_t lds_u8;
@@ -815,11 +838,11 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       const uint32_t off_w = g.w0 - lds_src;  // coordinate + off_w = stream position
       auto sink_w = [&](uint32_t p, uint32_t best, uint32_t first) { sink(p + off_w, best, first); };
       TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u}, pool_w{&pool_next, g.t0 - off_w, (uint32_t)tend64 - off_w, tid & 63u};
-      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>((const uint8_t *)win_src - lds_src, len - off_w, pool_w, (uint32_t)tend64 - off_w, tid & 63u,
+      const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>((const uint8_t *)win_src - lds_src, c.len - off_w, pool_w, (uint32_t)tend64 - off_w, tid & 63u,
                                                                           WinLinks{win_prev - lds_src}, lds_links - 2u * lds_src, K, Kq, sink_w)
-                                       : lz_match_runs_pool<MATCHW_NP>(ws, len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
-      if (two) S.snap_used[stream] = 1;  // (every writer writes the same word; read by the parse, a kernel later)
-      if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[tile & 1u], iters);
+                                       : lz_match_runs_pool<MATCHW_NP>(ws, c.len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);
+      if (two) S.snap_used[c.stream] = 1;  // (every writer writes the same word; read by the parse, a kernel later)
+      if (has_next && (tid & 63u) == 0) atomicAdd(&tile_iters[c.tile & 1u], iters);
     }
 #ifdef ZD_MATCH_PHASES
     {
@@ -846,15 +869,20 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       pr0 = __builtin_amdgcn_s_memrealtime();
     }
 #endif
-    if (!has_next) break;
-    issue(gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
+    // what comes next: the group's next tile, or the next group's first
+    Group n = c;
+    if (has_next) n.tile++;
+    else if (!open(n)) break;
+    const MatchTile gn = match_tile(n.tile, n.len);
+    issue(n, gn.w0, gn.n_src, gn.n_links);  // in flight while the slower waves finish
     __syncthreads();  // every wave is done with this tile's window
     // run-slot steps the tile took per position (a tile with a successor is a full one): chain steps / lane use
-    if (form == 0) scan_form = (uint64_t)tile_iters[tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > (uint64_t)MATCHW_SCAN_STEPS * (g.t1 - g.t0);
-    store(gn);
-    if (tid == 0) { pool_next = 0; tile_iters[(tile + 1) & 1u] = 0; }  // the next tile's counter: nobody touches it now
+    if (has_next && form == 0) scan_form = (uint64_t)tile_iters[c.tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > (uint64_t)MATCHW_SCAN_STEPS * (g.t1 - g.t0);
+    store(n, gn);
+    if (tid == 0) { pool_next = 0; tile_iters[0] = tile_iters[1] = 0; probe_deep = 0; }  // the next tile's counters: nobody touches them now
     __syncthreads();
-    tile++;
+    first_of_group = !has_next;
+    c = n;
     g = gn;
   }
 }
@@ -2751,9 +2779,15 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     if (max_src_len <= MATCHW_SMALL)  // short streams: a whole-CU window per tile would sit mostly idle
       ZD_LAUNCH(ctx, "lz_match", lz_match_kernel, dim3((unsigned)((m * cps + 7) / 8 * 8)), dim3(MATCH_THREADS), 0,
                 d_src, dd, Q, (uint32_t)m, (uint32_t)cps, K, K / 4);
-    else
-      ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((m * gps + 7) / 8 * 8)), dim3(MATCHW_THREADS),
-                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, K, K / 4, form_env);
+    else {
+      // groups a workgroup takes one behind the other: as many as leave 2048 workgroups and more, 8 at most (measured 1 / 2 / 4 / 8:
+      // the benchmark's streams 4.70 / 4.60 / 4.50 / 4.50 ms, text 48.6 / 47.0 / 45.7 / 46.2, 1 MiB members of 3-bit symbols 31.9 / 32.2 / 32.7 / 30.6)
+      size_t gpw = m * gps / 2048;
+      gpw = gpw < 1 ? 1 : gpw > (size_t)ZD_MATCH_GROUPS_PER_WG ? (size_t)ZD_MATCH_GROUPS_PER_WG : gpw;
+      const size_t wgs = (m * gps + gpw - 1) / gpw;
+      ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(MATCHW_THREADS),
+                0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, (uint32_t)gpw, K, K / 4, form_env);
+    }
     if (segmented) {
       ParseSegs G = segs;
       const size_t o = lo * sps;  // the slice's segment slots
