@@ -837,7 +837,7 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
       const uint32_t lds_src = (uint32_t)(uintptr_t)(lds_u8 *)win_src, lds_links = (uint32_t)(uintptr_t)(lds_u8 *)win_prev;
       const uint32_t off_w = g.w0 - lds_src;  // coordinate + off_w = stream position
       auto sink_w = [&](uint32_t p, uint32_t best, uint32_t first) { sink(p + off_w, best, first); };
-      TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u}, pool_w{&pool_next, g.t0 - off_w, (uint32_t)tend64 - off_w, tid & 63u};
+      TilePool pool{&pool_next, g.t0, (uint32_t)tend64, tid & 63u, 0u}, pool_w{&pool_next, g.t0 - off_w, (uint32_t)tend64 - off_w, tid & 63u, POOL_TAPER};
       const uint32_t iters = scan_form ? lz_match_scan_pool<MATCHW_SCAN_NP>((const uint8_t *)win_src - lds_src, c.len - off_w, pool_w, (uint32_t)tend64 - off_w, tid & 63u,
                                                                           WinLinks{win_prev - lds_src}, lds_links - 2u * lds_src, K, Kq, sink_w)
                                        : lz_match_runs_pool<MATCHW_NP>(ws, c.len, pool, (uint32_t)tend64, tid & 63u, wp, K, Kq, sink);

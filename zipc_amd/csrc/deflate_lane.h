@@ -523,6 +523,10 @@ ZD_HD void lz_match_scan_serial(const uint8_t *s, uint32_t len, uint32_t first, 
 // everywhere: -6.5 % on the benchmark's symbols, -2 % on 3-bit symbols, -36 % on text.  Results
 // are stored per position, so who walks which position does not matter.  Returns the wave's
 // iteration count.
+#ifndef ZD_POOL_TAPER
+#define ZD_POOL_TAPER 4096
+#endif
+constexpr uint32_t POOL_TAPER = ZD_POOL_TAPER;
 constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any one handout.  Measured, same box, 128 / 256 / 512:
                                       // C2 5.58 / 5.44-5.48 / 5.83 ms, real text 145.5 / 150.1 / 167.5 ms
 // first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
@@ -548,14 +552,31 @@ struct MatchCounts {
 // the pool is empty.  oldest (pools with WANTS_OLDEST): the lowest position one of the wave's run slots still walks, ~0 for none.
 // TilePool: a counter in LDS over the positions [pbeg, pend) of one tile (it counts from 0: it overshoots the tile by a chunk per
 // wave at the end, which must not wrap for a stream near the 4 GiB limit).
+// (size: what the chunk taken last holds.  A pool with a taper hands its tile's last positions out in chunks of half the size: a
+// tile ends when its last wave has walked its last chunk, and the waves that found the pool empty wait for it at the barrier -- the
+// gap between a tile's mean wave and its slowest is 7 to 12 % of the tile, tools/exp_match_phases.py.  The second form's pool has
+// one, of POOL_TAPER positions: text 46.0 -> 44.0 ms per GiB (2048 and 8192: the same); the first form's has none: its handouts
+// run out of their chunk more often with the small ones, the benchmark's streams 4.5 -> 4.8 ms.)
 struct TilePool {
   static constexpr bool WANTS_OLDEST = false;
   uint32_t *pool_next;
   uint32_t pbeg, pend, lane;
-  __device__ __forceinline__ uint32_t take(uint32_t) const {
+  uint32_t taper;  // the tile's last `taper` positions in chunks of half the size (0: none)
+  uint32_t size = POOL_CHUNK;
+  __device__ __forceinline__ uint32_t take(uint32_t) {
     uint32_t c = 0;
-    if (lane == 0) c = atomicAdd(pool_next, POOL_CHUNK);
+    if (lane == 0) {
+      if (taper) {
+        const uint32_t seen = __hip_atomic_load(pool_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t small = pend - pbeg - seen <= taper || seen > pend - pbeg ? 1u : 0u;  // (what another wave takes in between: a chunk more or less)
+        c = atomicAdd(pool_next, small ? POOL_CHUNK / 2u : POOL_CHUNK) | (small << 31);
+      } else {
+        c = atomicAdd(pool_next, POOL_CHUNK);
+      }
+    }
     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    size = c >> 31 ? POOL_CHUNK / 2u : POOL_CHUNK;
+    c &= 0x7FFFFFFFu;
     return c < pend - pbeg ? pbeg + c : pend;
   }
 };
@@ -568,7 +589,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, int K, int Kq, Sink sink) {
-  static_assert(64u * NP <= POOL_CHUNK, "chunk");
+  static_assert(64u * NP <= POOL_CHUNK / 2u, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
 #ifdef ZD_MATCH_COUNTS
@@ -584,7 +605,7 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
     return pool.take(oldest);
   };
   uint32_t next = fetch(true);  // my chunk is [next, cend)
-  uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
+  uint32_t cend = pend - next > pool.size ? next + pool.size : pend;
   bool empty = next >= pend;
   // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
   // may end within a chunk of 2^32 and a sum must not wrap into a position that looks valid)
@@ -611,7 +632,7 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
         uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
           const uint32_t c = fetch(false);
-          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
+          const uint32_t ce = pend - c > pool.size ? c + pool.size : pend;
           empty = c >= pend;
           if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
           next = ce - c > taken - rem ? c + (taken - rem) : ce;
@@ -749,7 +770,7 @@ __device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun (&r)[NP], ScanSlotMa
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, uint32_t cs, int K, int Kq, Sink sink) {
-  static_assert(64u * NP <= POOL_CHUNK, "chunk");
+  static_assert(64u * NP <= POOL_CHUNK / 2u, "chunk");
   ScanRun r[NP];
   ScanSlotMasks m[NP];
   uint32_t h[NP];      // the two bytes a run's last step read (scan_rounds_lds)
@@ -774,7 +795,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
     return pool.take(oldest);
   };
   uint32_t next = fetch(true);  // my chunk is [next, cend)
-  uint32_t cend = pend - next > POOL_CHUNK ? next + POOL_CHUNK : pend;
+  uint32_t cend = pend - next > pool.size ? next + pool.size : pend;
   bool empty = next >= pend;
   // (positions are formed as "start + offset if offset < what is left, else the limit": a stream
   // may end within a chunk of 2^32 and a sum must not wrap into a position that looks valid)
@@ -879,7 +900,7 @@ __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &
         uint32_t np = rank < rem ? next + rank : cend, lim = cend;
         if (taken > rem && !empty) {  // wave-uniform: the chunk runs out within this handout
           const uint32_t c = fetch(false);
-          const uint32_t ce = pend - c > POOL_CHUNK ? c + POOL_CHUNK : pend;
+          const uint32_t ce = pend - c > pool.size ? c + pool.size : pend;
           empty = c >= pend;
           if (rank >= rem) { np = rank - rem < ce - c ? c + (rank - rem) : ce; lim = ce; }
           next = ce - c > taken - rem ? c + (taken - rem) : ce;
