@@ -527,6 +527,9 @@ ZD_HD void lz_match_scan_serial(const uint8_t *s, uint32_t len, uint32_t first, 
 #define ZD_POOL_TAPER 4096
 #endif
 constexpr uint32_t POOL_TAPER = ZD_POOL_TAPER;
+#ifndef ZD_POOL_TAPER_Q
+#define ZD_POOL_TAPER_Q 2
+#endif
 constexpr uint32_t POOL_CHUNK = 256;  // >= 64 * NP: a fresh chunk serves any one handout.  Measured, same box, 128 / 256 / 512:
                                       // C2 5.58 / 5.44-5.48 / 5.83 ms, real text 145.5 / 150.1 / 167.5 ms
 // first form of the walk (match_run_step: every candidate's 8 bytes are read): the faster one
@@ -555,7 +558,8 @@ struct MatchCounts {
 // (size: what the chunk taken last holds.  A pool with a taper hands its tile's last positions out in chunks of half the size: a
 // tile ends when its last wave has walked its last chunk, and the waves that found the pool empty wait for it at the barrier -- the
 // gap between a tile's mean wave and its slowest is 7 to 12 % of the tile, tools/exp_match_phases.py.  The second form's pool has
-// one, of POOL_TAPER positions: text 46.0 -> 44.0 ms per GiB (2048 and 8192: the same); the first form's has none: its handouts
+// one, of POOL_TAPER positions (and chunks of a quarter for the last half of those: 1 MiB members of 3-bit symbols 31.0 -> 30.5 ms per
+// 2 GiB, text the same): text 46.0 -> 44.0 ms per GiB (2048 and 8192: the same); the first form's has none: its handouts
 // run out of their chunk more often with the small ones, the benchmark's streams 4.5 -> 4.8 ms.)
 struct TilePool {
   static constexpr bool WANTS_OLDEST = false;
@@ -568,15 +572,16 @@ struct TilePool {
     if (lane == 0) {
       if (taper) {
         const uint32_t seen = __hip_atomic_load(pool_next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t small = pend - pbeg - seen <= taper || seen > pend - pbeg ? 1u : 0u;  // (what another wave takes in between: a chunk more or less)
-        c = atomicAdd(pool_next, small ? POOL_CHUNK / 2u : POOL_CHUNK) | (small << 31);
+        const uint32_t left = seen > pend - pbeg ? 0u : pend - pbeg - seen;  // (what another wave takes in between: a chunk more or less)
+        const uint32_t small = left <= taper / ZD_POOL_TAPER_Q ? 2u : left <= taper ? 1u : 0u;
+        c = atomicAdd(pool_next, POOL_CHUNK >> small) | (small << 30);
       } else {
         c = atomicAdd(pool_next, POOL_CHUNK);
       }
     }
     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-    size = c >> 31 ? POOL_CHUNK / 2u : POOL_CHUNK;
-    c &= 0x7FFFFFFFu;
+    size = POOL_CHUNK >> (c >> 30);
+    c &= 0x3FFFFFFFu;
     return c < pend - pbeg ? pbeg + c : pend;
   }
 };
@@ -589,7 +594,7 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, int K, int Kq, Sink sink) {
-  static_assert(64u * NP <= POOL_CHUNK / 2u, "chunk");
+  static_assert(64u * NP <= POOL_CHUNK, "chunk");
   MatchRun r[NP];
   uint32_t iters = 0;
 #ifdef ZD_MATCH_COUNTS
@@ -770,7 +775,7 @@ __device__ __forceinline__ uint32_t scan_rounds_lds(ScanRun (&r)[NP], ScanSlotMa
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_scan_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, uint32_t cs, int K, int Kq, Sink sink) {
-  static_assert(64u * NP <= POOL_CHUNK / 2u, "chunk");
+  static_assert(64u * NP <= POOL_CHUNK, "chunk");
   ScanRun r[NP];
   ScanSlotMasks m[NP];
   uint32_t h[NP];      // the two bytes a run's last step read (scan_rounds_lds)
