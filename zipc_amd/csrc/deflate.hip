@@ -2784,6 +2784,11 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
       // the benchmark's streams 4.70 / 4.60 / 4.50 / 4.50 ms, text 48.6 / 47.0 / 45.7 / 46.2, 1 MiB members of 3-bit symbols 31.9 / 32.2 / 32.7 / 30.6)
       size_t gpw = m * gps / 2048;
       gpw = gpw < 1 ? 1 : gpw > (size_t)ZD_MATCH_GROUPS_PER_WG ? (size_t)ZD_MATCH_GROUPS_PER_WG : gpw;
+      // (... of groups that are short: a launch ends when its last workgroup does, and at `Best a group of text takes milliseconds --
+      // 2048 streams: 8 workgroups of two groups a CU 76.8 ms, 16 of one 66.5.  Taking the groups from a counter instead of by
+      // position in the grid evened that out -- 66.0 -- and cost 1 MiB members 13 % and the benchmark's streams 2-10 %; three
+      // quarters of the groups in workgroups of several and the rest in workgroups of one: 73.0.  Both measured, neither kept.)
+      if (K >= 1024) gpw = 1;
       const size_t wgs = (m * gps + gpw - 1) / gpw;
       ZD_LAUNCH(ctx, "lz_match", lz_match_window_kernel, dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(MATCHW_THREADS),
                 0, d_src, dd, Q, (uint32_t)m, (uint32_t)tps, (uint32_t)tpg, (uint32_t)gpw, K, K / 4, form_env);
