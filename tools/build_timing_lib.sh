@@ -9,7 +9,7 @@
 # other objects (make -C zipc_amd/csrc first).  Such a build returns clock stamps where the
 # product returns results, or exports a debug entry point: never ship or test parity with it.
 set -eu
-MACRO=${1:?ZD_MATCH_PHASES | ZD_MATCH_COUNTS | ZD_PARSE_COUNTS | ZD_EMIT_PHASES | ZD_INFLATE_PHASES}
+MACRO=${1:?ZD_MATCH_PHASES | ZD_MATCH_COUNTS | ZD_PARSE_COUNTS | ZD_PARSE_PHASES | ZD_EMIT_PHASES | ZD_INFLATE_PHASES}
 ROOT=$(cd "$(dirname "$0")/.." && pwd); C=$ROOT/zipc_amd/csrc
 OUT=${2:-$C/build/timing_$MACRO.so}
 case $MACRO in ZD_INFLATE_PHASES) SRC=inflate;; *) SRC=deflate;; esac

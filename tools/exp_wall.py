@@ -122,6 +122,7 @@ def main():
         batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, level, crc)
         assert dbg(cnt, 0) == 0
         line["parse_counts"] = {k: int(cnt[i]) for i, k in enumerate(["tiles", "turns", "tiles_with_a_turn", "chaining_lanes"])}
+        line["parse_phases (a -DZD_PARSE_PHASES build: tiles, then shader clocks to macro steps / visited / symbols / tile end)"] = [int(cnt[i]) for i in range(5)]
     if os.environ.get("KERNELS", "0") == "1":
         ctx.set_profiling(True); ctx.reset_kernel_times()
         for _ in range(2):

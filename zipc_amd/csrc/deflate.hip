@@ -899,6 +899,10 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
 // from a wave scan and write their symbols.  The only serial dependency left
 // between tiles is the entry position.
 constexpr int PARSE_TILE = 64;
+#ifdef ZD_PARSE_PHASES  // timing-only build: shader clocks of a wave's tiles, summed: [0] tiles [1] loads issued -> macro steps done [2] -> visited
+// known (doubling, search) [3] -> symbols written [4] -> tile done (block cut, next entry, skipped tiles' loads)
+static __device__ unsigned long long zd_parse_phases[8];
+#endif
 #ifdef ZD_PARSE_COUNTS  // counting-only build: [0] tiles, [1] turns of the lazy chains' loop, [2] tiles with a turn, [3] chaining lanes over the turns
 static __device__ unsigned long long zd_parse_counts[8];
 #define ZD_PCOUNT(i, v) do { if (lane == 0) atomicAdd(&zd_parse_counts[i], (unsigned long long)(v)); } while (0)
@@ -1085,8 +1089,18 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   // variable to variable at the end of an iteration, a value that had just been requested had to arrive first
   // (s_waitcnt vmcnt(0) before the v_mov), and every tile waited a full memory round trip for loads it would
   // only need two tiles later.
+#ifdef ZD_PARSE_PHASES
+  unsigned long long pp[5] = {0, 0, 0, 0, 0};
+#define ZD_PP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); pp[i] += now_ - pp_t; pp_t = now_; } while (0)
+#else
+#define ZD_PP(i) ((void)0)
+#endif
   auto tile_step = [&](uint64_t &m_cur, uint64_t &m_nxt, uint64_t &m_nx2, uint64_t &m_nx3, uint32_t &lit_cur,
                        uint32_t &lit_nxt, uint32_t &lit_nx2, uint32_t &lit_nx3) {
+#ifdef ZD_PARSE_PHASES
+    unsigned long long pp_t = __builtin_readcyclecounter();
+    pp[0] += 1;
+#endif
     uint32_t Bn = B + PARSE_TILE;
     m_nx3 = load_match(Bn + 2u * PARSE_TILE);
     lit_nx3 = load_lit(Bn + 2u * PARSE_TILE);
@@ -1097,6 +1111,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     // following positions' matches taken from the neighbouring lanes)
     uint32_t br, st;
     parse_tile_macro(lane, p, valid, has_match, max_pos, len, m_cur, m_nxt, match, snap, good_match, br, st);
+    ZD_PP(1);
     const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
     const uint32_t lits = br ? macro_lits(st) : 0u;
     const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
@@ -1118,6 +1133,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
       if (y <= lane4) v = y;
     }
     const bool visited = valid && v == lane4;
+    ZD_PP(2);
     if (MODE == 1) {
       const unsigned long long vm = __builtin_amdgcn_ballot_w64(visited);
       if (lane == 0) { G.vis[(base + B) >> 6] = vm; G.tile_sym0[(base + B) >> 6] = nsym; }
@@ -1142,11 +1158,15 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
       while (__builtin_amdgcn_ballot_w64(lit_run && k < lits)) {  // rarely more than one turn
         const uint32_t at = (uint32_t)lane + k;
         const uint32_t a = lane_value((at & 63u) * 4u, byte_cur), b2 = lane_value((at & 63u) * 4u, byte_nxt);
+        // (the third alternative's load stands behind a branch, and at its join the compiler waits for everything in flight
+        // whenever a lane's literals reach into the next tile; moving it out of the loop -- a flag, a loop of its own behind a
+        // ballot -- was measured: lz_parse 3.35 -> 3.58 ms on the benchmark's streams, lz_parse_spec 8.5 -> 9.4 on 1 MiB members)
         if (lit_run && k < lits) tsyms[first_rel + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
         k++;
       }
       if (visited) tsyms[first_rel + (br ? lits : 0u)] = br ? br : byte_cur;
     }
+    ZD_PP(3);
     // block cut: the first visited node that ends past blk_start + 65534
     // (a visited position is at or behind blk_start, so the test runs on 32-bit
     // distances from it; lanes that are not visited are masked out)
@@ -1185,6 +1205,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     } else {
       B = Bn;
     }
+    ZD_PP(4);
   };
   uint64_t ma = 0, mb = 0, mc = 0, md = 0;
   uint32_t la = 0, lb = 0, lc = 0, ld = 0;
@@ -1205,6 +1226,9 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     if (B >= lim) break;
     tile_step(md, ma, mb, mc, ld, la, lb, lc);
   }
+#ifdef ZD_PARSE_PHASES
+  if (lane == 0) for (int i = 0; i < 5; i++) atomicAdd(&zd_parse_phases[i], pp[i]);
+#endif
   if (MODE == 1) {
     if (lane == 0) { G.seg_exit[seg_slot] = entry; G.seg_total[seg_slot] = nsym; }
     return;
@@ -2867,6 +2891,14 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
 
 }  // namespace zd
 
+#ifdef ZD_PARSE_PHASES
+extern "C" int zipc_hip_debug_parse_counts(unsigned long long *out8, int reset) {  // (the same entry point: tools/exp_wall.py PARSE_COUNTS=1)
+  unsigned long long host[8] = {};
+  if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(zd::zd_parse_phases), sizeof host) != hipSuccess) return 1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(zd::zd_parse_phases), host, sizeof host) != hipSuccess) return 1;
+  return 0;
+}
+#endif
 #ifdef ZD_PARSE_COUNTS
 extern "C" int zipc_hip_debug_parse_counts(unsigned long long *out8, int reset) {
   unsigned long long host[8] = {};
