@@ -196,12 +196,15 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
  * arguments or HIP errors.
  * Staging: the call runs as a pipeline of a few sub-batches.  Each is gathered into
  * pinned memory the context keeps (sized to the batch; the first call of a size pays
- * for pinning it) on a few host threads, copied H2D, run, copied D2H and scattered to
- * the caller's buffers, on streams of its own -- so bus copies and kernels of one
- * sub-batch run under the host memcpys of the others.  Environment, read once per
- * process: ZIPC_HIP_HOST_THREADS (default 8 or the core count), ZIPC_HIP_HOST_CHUNKS
- * (sub-batches, default 3; fewer when a sub-batch would hold under 1024 streams),
- * ZIPC_HIP_HOST_TIMING=1 (wall time of the call's host phases on stderr). */
+ * for pinning it) by a few host threads the library keeps, copied to the device as
+ * it is gathered, run, brought back -- the outputs end to end, by a kernel that
+ * writes the pinned memory -- and scattered to the caller's buffers by a second
+ * thread, so bus copies and kernels of one sub-batch run under the host memcpys of
+ * the others.  A call that fails may have filled some of the caller's buffers.
+ * Environment, read once per process: ZIPC_HIP_HOST_THREADS (default 8 or the core
+ * count), ZIPC_HIP_HOST_CHUNKS (sub-batches, default 4, 6 from a GiB of staging on;
+ * fewer when a sub-batch would hold under 1024 streams), ZIPC_HIP_HOST_TIMING=1
+ * (where each sub-batch was when, on stderr); csrc/tuning.h has the rest. */
 struct zipc_hip_stream_result_s;
 int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           int level, int crc_op, void *const *dst, const size_t *dst_cap,

@@ -10,8 +10,11 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "ctx.h"
@@ -167,35 +170,114 @@ static size_t host_threads() {
   }();
   return nt;
 }
-// ZIPC_HIP_HOST_CHUNKS: sub-batches a many-stream call is cut into; each goes through
-// gather, H2D, kernels, D2H and scatter on its own, so those overlap (1 = one after the other)
-static size_t host_chunks() {
-  static const size_t k = [] {
-    long v = zd::tuning().host_chunks;
-    if (v < 1) v = 3;  // profiles/r01_host_forms_sweep.txt: medians of 11 calls, 2 / 3 / 4 sub-batches:
-                       // deflate 49 / 41.5 / 55 ms, inflate 45 / 38 / 36 ms (4 has the best single calls, unstable medians)
-    return (size_t)(v > 64 ? 64 : v);
-  }();
-  return k;
+// ZIPC_HIP_HOST_CHUNKS: sub-batches a many-stream call is cut into; each goes through gather, copy in, kernels, the
+// way back and scatter on its own, so those overlap (1 = one after the other).  Default: by the bytes staged (many_streams).
+static size_t host_chunks(uint64_t staged_bytes) {
+  long v = zd::tuning().host_chunks;
+  if (v < 1) v = staged_bytes >= ((uint64_t)1 << 30) ? 6 : 4;
+  return (size_t)(v > 64 ? 64 : v);
 }
-template <class F>
-static void parallel_for(size_t lo, size_t hi, F f) {
-  const size_t n = hi - lo;
-  const size_t nt = n < 64 ? 1 : host_threads();
-  if (nt == 1) { for (size_t i = lo; i < hi; i++) f(i); return; }
-  std::vector<std::thread> th;
-  for (size_t t = 0; t < nt; t++)
-    th.emplace_back([&, t] { for (size_t i = lo + t; i < hi; i += nt) f(i); });
-  for (auto &x : th) x.join();
+// The threads behind the host memcpys of the many-stream forms: made once (a call creates none), parked on a condition
+// variable between jobs, handing out work in grains from one counter (a thread that loses its core for a while holds
+// up one grain, not its whole share).  The caller of run() works too.  The pools are never destroyed: their threads are
+// detached and a process that exits takes them along.
+class HostPool {
+ public:
+  explicit HostPool(size_t workers) : workers_(workers) {
+    for (size_t t = 0; t < workers; t++) std::thread([this] { worker(); }).detach();
+  }
+  // f(i) for every i of [lo, hi); returns when all of them have run
+  template <class F>
+  void run(size_t lo, size_t hi, size_t grain, F f) {
+    if (hi <= lo) return;
+    if (workers_ == 0 || hi - lo <= grain) { for (size_t i = lo; i < hi; i++) f(i); return; }
+    std::lock_guard<std::mutex> one_job(run_m_);
+    {
+      std::lock_guard<std::mutex> l(m_);
+      fn_ = [](void *a, size_t i) { (*(F *)a)(i); };
+      arg_ = &f; hi_ = hi; grain_ = grain;
+      next_.store(lo, std::memory_order_relaxed);
+      busy_ = workers_;
+      gen_++;
+    }
+    work_.notify_all();
+    take();
+    std::unique_lock<std::mutex> l(m_);
+    done_.wait(l, [&] { return busy_ == 0; });  // every worker has seen this job and left it: f and the fields are free again
+  }
+
+ private:
+  void take() {
+    for (;;) {
+      const size_t a = next_.fetch_add(grain_, std::memory_order_relaxed);
+      if (a >= hi_) return;
+      const size_t b = hi_ - a < grain_ ? hi_ : a + grain_;
+      for (size_t i = a; i < b; i++) fn_(arg_, i);
+    }
+  }
+  void worker() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> l(m_);
+    for (;;) {
+      work_.wait(l, [&] { return gen_ != seen; });
+      seen = gen_;
+      l.unlock();
+      take();
+      l.lock();
+      if (--busy_ == 0) done_.notify_one();
+    }
+  }
+  std::mutex run_m_, m_;
+  std::condition_variable work_, done_;
+  void (*fn_)(void *, size_t) = nullptr;
+  void *arg_ = nullptr;
+  size_t hi_ = 0, grain_ = 1, busy_ = 0;
+  const size_t workers_;
+  std::atomic<size_t> next_{0};
+  uint64_t gen_ = 0;
+};
+// A copy whose destination is not read again by this core: stores that go around the cache (no line is fetched to be
+// overwritten: two passes over memory instead of three, and the caches keep what they held).  The gathers and scatters
+// of the many-stream forms are bound by the host's memory, beside the bus copies that read and write the same DIMMs:
+// against memcpy the calls take 3-7 % less (profiles/r05_host_forms_sweep.txt).
+static void copy_streaming(void *dst, const void *src, size_t len) {
+#if defined(__x86_64__)
+  typedef long long v2di __attribute__((vector_size(16)));
+  uint8_t *d = (uint8_t *)dst;
+  const uint8_t *s = (const uint8_t *)src;
+  if (len < 4096) { memcpy(d, s, len); return; }
+  const size_t head = (64 - ((uintptr_t)d & 63)) & 63;
+  memcpy(d, s, head);
+  d += head; s += head; len -= head;
+  const size_t body = len & ~(size_t)63;
+  for (size_t i = 0; i < body; i += 64) {
+    v2di a, b, c, e;
+    memcpy(&a, s + i, 16); memcpy(&b, s + i + 16, 16); memcpy(&c, s + i + 32, 16); memcpy(&e, s + i + 48, 16);
+    __builtin_nontemporal_store(a, (v2di *)(d + i));
+    __builtin_nontemporal_store(b, (v2di *)(d + i + 16));
+    __builtin_nontemporal_store(c, (v2di *)(d + i + 32));
+    __builtin_nontemporal_store(e, (v2di *)(d + i + 48));
+  }
+  __builtin_ia32_sfence();
+  memcpy(d + body, s + body, len - body);
+#else
+  memcpy(dst, src, len);
+#endif
+}
+// two of them: a call's gathers (the thread that feeds the device) and its scatters (the thread that takes results
+// back) run side by side
+static HostPool &host_pool(int which) {
+  static HostPool *const pools[2] = {new HostPool(host_threads() - 1), new HostPool(host_threads() - 1)};
+  return *pools[which];
 }
 // events of one call, destroyed on every exit path
 struct EventSet {
   std::vector<hipEvent_t> ev;
   ~EventSet() { for (auto e : ev) (void)hipEventDestroy(e); }
-  hipError_t make(size_t k) {
+  hipError_t make(size_t k, bool timed = false) {
     for (size_t i = 0; i < k; i++) {
       hipEvent_t e;
-      hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+      hipError_t r = hipEventCreateWithFlags(&e, timed ? hipEventDefault : hipEventDisableTiming);
       if (r != hipSuccess) return r;
       ev.push_back(e);
     }
@@ -228,6 +310,13 @@ const Tuning &tuning() {
     x.checksum_fused = num("ZIPC_HIP_CHECKSUM_FUSED", 1) != 0;
     x.host_threads = num("ZIPC_HIP_HOST_THREADS", 0);
     x.host_chunks = num("ZIPC_HIP_HOST_CHUNKS", 0);
+    x.host_chunk_min = num("ZIPC_HIP_HOST_CHUNK_MIN", 1024);
+    if (x.host_chunk_min < 1) x.host_chunk_min = 1;
+    x.host_pack = num("ZIPC_HIP_HOST_PACK", 1) != 0;
+    x.host_pack_wgs = num("ZIPC_HIP_HOST_PACK_WGS", 6);
+    if (x.host_pack_wgs < 1) x.host_pack_wgs = 1;
+    x.host_h2d_mib = num("ZIPC_HIP_HOST_H2D_MIB", 16);
+    x.host_timing = num("ZIPC_HIP_HOST_TIMING", 0) != 0;
     return x;
   }();
   return t;
@@ -360,6 +449,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   for (auto &p : ctx->pending) { (void)hipEventDestroy(p.start); (void)hipEventDestroy(p.stop); }
   for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
   free_buf(ctx->io_src); free_buf(ctx->io_dst); free_buf(ctx->io_desc); free_buf(ctx->io_res);
+  free_buf(ctx->io_pack_off);
   free_buf(ctx->io_small); free_buf(ctx->crc_partials); free_buf(ctx->crc_nib); free_buf(ctx->adler_sums);
   free_buf(ctx->deflate_scratch); free_buf(ctx->parse_scratch);
   free_buf(ctx->inflate_scratch);
@@ -1180,6 +1270,78 @@ int zipc_hip_deflate(zipc_hip_ctx *ctx, const void *src, size_t len, int level, 
   return one_stream(ctx, false, src, len, 0, 0, level, crc_op, dst, dst_cap, out_len, checksum);
 }
 
+// ---- the many-stream forms' way back: a sub-batch's outputs end to end, written by a kernel ----------------
+// What a sub-batch made goes into the pinned host buffer by a KERNEL's stores, one output behind the other on 16-byte
+// boundaries, not by the copy engine:
+//  * how many bytes that is is known on the device when the kernels are through -- deflate's destination slots are as
+//    large as the caller's capacities (the bound: more than the source), what is in them is half of that or less; an
+//    engine copy's size would have to come from the host, which would have to wait for the results first;
+//  * on this pool an engine copy out beside an engine copy in runs at a third of the bus whenever no kernel happens to
+//    be running (tools/probes/host_copy.hip, profiles/r05_host_copy.txt: 256 MiB each way 13.4 / 14.1 ms, 4.8 / 5.5 with
+//    a kernel spinning beside them; a kernel's stores beside an engine copy in: 5.3 / 6.3): the calls took 8 or 15 ms,
+//    30 or 55, from one process to the next.
+// The price: stores that wait for the bus hold up the memory path they share with everybody else (the same probe: a
+// kernel that copies device memory takes 2.9 ms instead of 1.5 beside 8 such workgroups, 5.9 beside 64), so the kernel
+// is as few workgroups as fill the bus.  The host makes the same sums from the results (many_streams below).
+
+__host__ __device__ static inline uint64_t packed_size(uint32_t status, uint64_t out_len, uint64_t dst_cap) {
+  return status == ST_OK && out_len <= dst_cap ? (out_len + 15) / 16 * 16 : 0;
+}
+
+// off[i] = base + the packed sizes of streams [0, i), i = 0 .. n (one workgroup)
+__global__ __launch_bounds__(1024) void pack_offsets_kernel(const StreamDesc *descs, const StreamResult *res, uint32_t n,
+                                                            uint64_t base, uint64_t *off) {
+  __shared__ uint64_t part[1024];
+  const uint32_t per = (n + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  uint64_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += packed_size(res[i].status, res[i].out_len, descs[i].dst_cap);
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d *= 2) {
+    const uint64_t v = threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint64_t at = base + part[threadIdx.x] - sum;
+  for (uint32_t i = lo; i < hi; i++) {
+    off[i] = at;
+    at += packed_size(res[i].status, res[i].out_len, descs[i].dst_cap);
+  }
+  if (threadIdx.x == 1023) off[n] = base + part[1023];
+}
+
+// Workgroup w of G moves the w-th part of the packed bytes (parts of whole 4 KiB): the stream its part begins in is
+// found by bisection of off[], the next ones follow; every thread moves 16 bytes at a time, four loads in flight (slots
+// begin on 256-byte boundaries).
+__global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t *dst_arena, uint8_t *pack_arena, const StreamDesc *descs,
+                                                        const uint64_t *off, uint32_t n, uint64_t base) {
+  const uint64_t total_end = off[n];
+  const uint64_t per = ((total_end - base + gridDim.x - 1) / gridDim.x + 4095) / 4096 * 4096;
+  uint64_t pos = base + blockIdx.x * per;
+  if (pos >= total_end) return;
+  const uint64_t end = total_end - pos < per ? total_end : pos + per;
+  uint32_t a = 0, b = n;  // the last stream that begins at or before pos
+  while (b - a > 1) {
+    const uint32_t m = a + (b - a) / 2;
+    if (off[m] <= pos) a = m; else b = m;
+  }
+  for (uint32_t s = a; s < n && pos < end; s++) {
+    const uint64_t s_beg = off[s], s_end = off[s + 1] < end ? off[s + 1] : end;
+    if (s_end <= pos) continue;  // (a stream with nothing to hand over)
+    const uint4 *from = (const uint4 *)(dst_arena + descs[s].dst_off + (pos - s_beg));
+    uint4 *to = (uint4 *)(pack_arena + pos);
+    const uint64_t n16 = (s_end - pos) / 16;
+    uint64_t i = threadIdx.x;
+    for (; i + 768 < n16; i += 1024) {
+      const uint4 v0 = from[i], v1 = from[i + 256], v2 = from[i + 512], v3 = from[i + 768];
+      to[i] = v0; to[i + 256] = v1; to[i + 512] = v2; to[i + 768] = v3;
+    }
+    for (; i < n16; i += 256) to[i] = from[i];
+    pos = s_end;
+  }
+}
+
 // n host-resident streams through the batch kernels: arenas are the context's
 // staging buffers, streams packed at 256-byte aligned offsets
 static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void *const *src, const size_t *src_len,
@@ -1189,7 +1351,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (crc_op < 0 || crc_op > 3 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  constexpr bool timing = false;  // (true: wall time of the call's three host phases on stderr)
+  const bool timing = zd::tuning().host_timing;
   const auto t_begin = std::chrono::steady_clock::now();
   auto since = [&](std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
@@ -1209,20 +1371,28 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     max_cap = dst_cap[i] > max_cap ? dst_cap[i] : max_cap;
   }
   if (!is_inflate && max_src > MAX_STREAM_LEN) return ZIPC_HIP_ERR_INVALID_ARG;  // (inflate reports it per stream)
-  // The batch is cut into K sub-batches of about equal source bytes, and sub-batch g
-  // goes through  gather (host threads, into pinned memory) -> H2D (copy_in) -> kernels
-  // (the context's stream) -> D2H (copy_out) -> scatter (host threads)  on its own, so
-  // the bus copies and kernels of one sub-batch run under the host memcpys of the
-  // others; PCIe is full duplex and the kernels do not touch it.  Thousands of small
-  // pageable copies -- the first version of this function -- cost far more than the
-  // kernels.  K: ZIPC_HIP_HOST_CHUNKS, fewer when sub-batches would get too small to
-  // fill the chip.
-  size_t K = host_chunks();
-  while (K > 1 && n / K < 1024) K--;
+  // The batch is cut into K sub-batches, and sub-batch g goes through
+  //   gather (host threads, into pinned memory) -> copy in (the engine, queue copy_in, in runs of 16 MiB as they are
+  //   gathered) -> kernels (the context's queue) -> the way back (the kernel above, queue copy_out) -> scatter (host threads)
+  // on its own, so the bus and the kernels of one sub-batch run under the host memcpys of the others; PCIe is full
+  // duplex and the kernels do not touch it.  This thread gathers and feeds the device; a second one (`taker` below)
+  // waits for what comes back and scatters it with threads of its own, so the first sub-batch's results are in the
+  // caller's buffers while the last one's sources are still being gathered.  Thousands of small pageable copies -- the
+  // first version of this function -- cost far more than the kernels.
+  // K (ZIPC_HIP_HOST_CHUNKS): 4, or 6 from a GiB of staging on; fewer when sub-batches would get too small to fill the
+  // chip.  The first and the last sub-batch are half as large as the others: the first is what the bus and the kernels
+  // wait for before they have anything to do, the last what the caller waits for when everything else is through.
+  // (profiles/r05_host_forms_sweep.txt: 4096 x 64 KiB: 3 / 4 / 5 / 6 sub-batches deflate 9.9 / 9.8 / 9.4 / 10.0 ms,
+  // inflate 8.3 / 8.9 / 8.9 / 9.5; 16 384 x 64 KiB: 34.0 / 31.2 / 29.8 / 30.2 and 29.4 / 27.6 / 26.6 / 25.7.)
+  size_t K = host_chunks(so + dof);
+  while (K > 1 && n / K < (size_t)zd::tuning().host_chunk_min) K--;
   std::vector<size_t> cut(K + 1, n);
   cut[0] = 0;
+  const bool taper = K >= 3;
+  const size_t shares = taper ? 2 * K - 2 : K;
   for (size_t g = 1, i = 0; g < K; g++) {
-    while (i < n && descs[i].src_off < so / K * g) i++;
+    const size_t before = taper ? 2 * g - 1 : g;  // shares of sub-batches [0, g)
+    while (i < n && descs[i].src_off < so / shares * before) i++;
     cut[g] = i;
   }
   size_t n_max = 0, total_max = 0;
@@ -1232,12 +1402,14 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     n_max = cut[g + 1] - cut[g] > n_max ? cut[g + 1] - cut[g] : n_max;
     total_max = t > total_max ? t : total_max;
   }
+  const bool packed = zd::tuning().host_pack;  // (false: whole destination slots by the copy engine)
   // everything is allocated before the first sub-batch is under way (growing a buffer
   // synchronises the stream)
   HIP_TRY(ctx, ctx->ensure(ctx->io_src, so + 64));
   HIP_TRY(ctx, ctx->ensure(ctx->io_dst, dof + 64));
   HIP_TRY(ctx, ctx->ensure(ctx->io_desc, n * sizeof(StreamDesc)));
   HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
+  if (packed) HIP_TRY(ctx, ctx->ensure(ctx->io_pack_off, (n + K + 1) * sizeof(uint64_t)));
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, dof + 64));
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_res, n * sizeof(StreamResult)));
@@ -1255,99 +1427,204 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   if (!ctx->copy_in) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
   if (!ctx->copy_out) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
   EventSet ev_in, ev_k, ev_out;
-  HIP_TRY(ctx, ev_in.make(K));
-  HIP_TRY(ctx, ev_k.make(K));
-  HIP_TRY(ctx, ev_out.make(K));
+  HIP_TRY(ctx, ev_in.make(K, timing));
+  HIP_TRY(ctx, ev_k.make(K, timing));
+  HIP_TRY(ctx, ev_out.make(K, timing));
+  EventSet ev_t;  // timing: the call's begin on the device, a sub-batch's first copy in, its kernels' begin
+  if (timing) HIP_TRY(ctx, ev_t.make(1 + 2 * K, true));
+  std::vector<double> t_gathered(K, 0), t_scatter_begin(K, 0), t_scatter_end(K, 0);
   // earlier work of this context (the previous call's kernels read io_src / io_desc; a call that
   // failed half way may have left copies on the two copy streams) first
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));
-  // From here on copies and kernels are in flight on three streams, reading `descs` and the pinned
-  // buffers and recording into the event sets above: every error exit goes through drain(), which
-  // waits for all three before anything is freed or the next call reuses the buffers.
-  auto drain = [&]() {
-    (void)hipStreamSynchronize(ctx->copy_in);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->copy_out);
+  const double ms_setup = since(t_begin);
+  static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
+  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
+  auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
+
+  // A long stream is moved in pieces of 1 MiB so that a few long members keep every thread busy too.
+  struct Piece { uint32_t stream; uint64_t at, len; };
+  constexpr uint64_t PIECE = 1 << 20;
+  auto pieces_of = [&](size_t lo, size_t hi, auto len_of, std::vector<Piece> &out) {
+    out.clear();
+    for (size_t i = lo; i < hi; i++)
+      for (uint64_t at = 0, L = len_of(i); at < L; at += PIECE) out.push_back({(uint32_t)i, at, L - at < PIECE ? L - at : PIECE});
   };
+  auto grain_of = [&](size_t count) {
+    const size_t g = count / (host_threads() * 8);
+    return g < 1 ? (size_t)1 : (g > 16 ? (size_t)16 : g);
+  };
+
+  // ---- what the two threads share: how many sub-batches have been enqueued (their events recorded), and whether the
+  // feeding thread gave up.  From here on copies and kernels are in flight on three queues, reading `descs` and the
+  // pinned buffers and recording into the event sets above: every exit waits for the taker and, after a failure, for
+  // all three queues before anything is freed or the next call reuses the buffers.
+  std::mutex pm;
+  std::condition_variable pcv;
+  size_t fed = 0;
+  bool gave_up = false;
+  std::string taker_error;
+  double ms_scatter = 0;
+
+  // ---- the taker: sub-batch g is back -> its results as the caller gets them, where each output lies -> scatter
+  auto taker = [&]() -> int {
+    const hipError_t e_dev = hipSetDevice(ctx->device);
+    if (e_dev != hipSuccess) { taker_error = std::string("hipSetDevice: ") + hipGetErrorString(e_dev); return ZIPC_HIP_ERR_HIP; }
+    const StreamResult *pr = (const StreamResult *)ctx->pin_res.p;
+    std::vector<Piece> pieces;
+    std::vector<uint64_t> from(n_max);  // where a stream's output begins in pin_dst
+    for (size_t g = 0; g < K; g++) {
+      const size_t lo = cut[g], hi = cut[g + 1];
+      {
+        std::unique_lock<std::mutex> l(pm);
+        pcv.wait(l, [&] { return fed > g || gave_up; });
+        if (fed <= g) return ZIPC_HIP_OK;  // the feeding thread gave up before this one: its status is the call's
+      }
+      if (lo == hi) continue;
+      const hipError_t e = hipEventSynchronize(ev_out.ev[g]);  // (behind ev_k[g]: the results have landed too)
+      if (e != hipSuccess) { taker_error = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return ZIPC_HIP_ERR_HIP; }
+      uint64_t at = dst_end(lo);
+      for (size_t i = lo; i < hi; i++) {
+        results[i].status = pr[i].status; results[i].checksum = pr[i].checksum; results[i].out_len = pr[i].out_len;
+        from[i - lo] = packed ? at : descs[i].dst_off;
+        at += packed_size(pr[i].status, pr[i].out_len, dst_cap[i]);
+        if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
+        if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; }
+      }
+      const auto t_sc = std::chrono::steady_clock::now();
+      t_scatter_begin[g] = since(t_begin);
+      pieces_of(lo, hi, [&](size_t i) { return results[i].status == ST_OK ? (uint64_t)results[i].out_len : 0; }, pieces);
+      host_pool(1).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
+        const Piece &p = pieces[j];
+        copy_streaming((uint8_t *)dst[p.stream] + p.at, (const uint8_t *)ctx->pin_dst.p + from[p.stream - lo] + p.at, p.len);
+      });
+      ms_scatter += since(t_sc);
+      t_scatter_end[g] = since(t_begin);
+    }
+    return ZIPC_HIP_OK;
+  };
+  int taker_status = ZIPC_HIP_OK;
+  std::thread taker_thread([&] { taker_status = taker(); });
+
+  // ---- this thread: gather, copy in, kernels, the way back
+  double ms_gather = 0;
+  const uint64_t h2d_bytes = zd::tuning().host_h2d_mib > 0 ? (uint64_t)zd::tuning().host_h2d_mib << 20 : 0;
+  auto feed = [&]() -> int {
 #define PIPE_TRY(expr)                                                                   \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess) {                                                              \
       ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
-      drain();                                                                           \
       return ZIPC_HIP_ERR_HIP;                                                           \
     }                                                                                    \
   } while (0)
-  const double ms_setup = since(t_begin);
-  const auto t_feed = std::chrono::steady_clock::now();
-  static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
-  PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
-  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
-  auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
-  int failed = 0;
-  bool first_batch = true;
-  for (size_t g = 0; g < K && !failed; g++) {
-    const size_t lo = cut[g], hi = cut[g + 1];
-    if (lo == hi) continue;
-    parallel_for(lo, hi, [&](size_t i) {
-      if (src_len[i]) memcpy((uint8_t *)ctx->pin_src.p + descs[i].src_off, src[i], src_len[i]);
-    });
-    const uint64_t a = src_end(lo), b = src_end(hi);
-    PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + a, (const uint8_t *)ctx->pin_src.p + a, b - a,
-                                hipMemcpyHostToDevice, ctx->copy_in));
-    PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
-    PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
-    zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
-    zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
-    size_t total_g = 0;
-    for (size_t i = lo; i < hi; i++) total_g += src_len[i];
-    if (is_inflate)  // (with the descriptors it has on the host: no read-back, nothing waited for unless a stream goes by blocks)
-      failed = inflate_batch_impl(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op, descs.data() + lo, first_batch);
-    else
-      failed = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
-    first_batch = false;
-    if (failed) break;
-    PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
+    if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[0], ctx->copy_in));
+    PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
+    std::vector<Piece> pieces;
+    bool first_batch = true;
+    for (size_t g = 0; g < K; g++) {
+      const size_t lo = cut[g], hi = cut[g + 1];
+      if (lo < hi) {
+        // gathered and sent in runs of streams of about h2d_bytes: the bus starts on the first run while the next is gathered
+        for (size_t a = lo; a < hi;) {
+          size_t b = a + 1;
+          while (b < hi && (h2d_bytes == 0 || src_end(b) - src_end(a) < h2d_bytes)) b++;
+          const auto t_g = std::chrono::steady_clock::now();
+          pieces_of(a, b, [&](size_t i) { return (uint64_t)src_len[i]; }, pieces);
+          host_pool(0).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
+            const Piece &p = pieces[j];
+            copy_streaming((uint8_t *)ctx->pin_src.p + descs[p.stream].src_off + p.at, (const uint8_t *)src[p.stream] + p.at, p.len);
+          });
+          ms_gather += since(t_g);
+          if (timing && a == lo) PIPE_TRY(hipEventRecord(ev_t.ev[1 + 2 * g], ctx->copy_in));
+          const uint64_t from = src_end(a), to = src_end(b);
+          PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + from, (const uint8_t *)ctx->pin_src.p + from, to - from,
+                                  hipMemcpyHostToDevice, ctx->copy_in));
+          a = b;
+        }
+        t_gathered[g] = since(t_begin);
+        PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
+        PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
+        if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[2 + 2 * g], ctx->stream));
+        zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
+        zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
+        size_t total_g = 0;
+        for (size_t i = lo; i < hi; i++) total_g += src_len[i];
+        int st;
+        if (is_inflate)  // (with the descriptors it has on the host: no read-back, nothing waited for unless a stream goes by blocks)
+          st = inflate_batch_impl(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op, descs.data() + lo, first_batch);
+        else
+          st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
+        first_batch = false;
+        if (st) return st;
+        PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
                                 hipMemcpyDeviceToHost, ctx->stream));
-    PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
-    // the whole destination slots of the sub-batch: what is used of them is only known on the
-    // host, and waiting for that would stall the feeding of the next sub-batch
-    PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
-    const uint64_t c = dst_end(lo), e = dst_end(hi);
-    PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
-                                hipMemcpyDeviceToHost, ctx->copy_out));
-    PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->copy_out));
-  }
-  if (failed) {  // a batch call refused its arguments or a HIP call failed: nothing is handed out
-    drain();
-    return failed;
-  }
-  const double ms_feed = since(t_feed);
-  const auto t_drain = std::chrono::steady_clock::now();
-  for (size_t g = 0; g < K; g++) {
-    const size_t lo = cut[g], hi = cut[g + 1];
-    if (lo == hi) continue;
-    PIPE_TRY(hipEventSynchronize(ev_out.ev[g]));  // behind ev_k[g]: the results have landed too
-    const StreamResult *pr = (const StreamResult *)ctx->pin_res.p;
-    for (size_t i = lo; i < hi; i++) {
-      results[i].status = pr[i].status; results[i].checksum = pr[i].checksum; results[i].out_len = pr[i].out_len;
-      if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
-      if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; }
+        const uint64_t c = dst_end(lo), e = dst_end(hi);
+        uint64_t *off = packed ? (uint64_t *)ctx->io_pack_off.p + lo + g : nullptr;
+        if (packed)
+          ZD_LAUNCH(ctx, "pack_offsets", pack_offsets_kernel, dim3(1), dim3(1024), 0, (const StreamDesc *)dd,
+                    (const StreamResult *)dr, (uint32_t)(hi - lo), c, off);
+        PIPE_TRY(hipGetLastError());
+        PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
+        PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
+        if (packed) {  // its stores ARE the copy back, of as many bytes as the device knows it made, beside the next sub-batch's kernels
+          hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)zd::tuning().host_pack_wgs), dim3(256), 0, ctx->copy_out,
+                             (const uint8_t *)ctx->io_dst.p, (uint8_t *)ctx->pin_dst.p, (const StreamDesc *)dd,
+                             (const uint64_t *)off, (uint32_t)(hi - lo), c);
+          PIPE_TRY(hipGetLastError());
+        } else {
+          PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
+                                  hipMemcpyDeviceToHost, ctx->copy_out));
+        }
+        PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->copy_out));
+      }
+      {
+        std::lock_guard<std::mutex> l(pm);
+        fed = g + 1;
+      }
+      pcv.notify_all();
     }
-    parallel_for(lo, hi, [&](size_t i) {
-      if (results[i].status == ST_OK && results[i].out_len)
-        memcpy(dst[i], (const uint8_t *)ctx->pin_dst.p + descs[i].dst_off, results[i].out_len);
-    });
-  }
-  PIPE_TRY(hipStreamSynchronize(ctx->copy_in));
 #undef PIPE_TRY
-  if (timing)
-    fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_arena=%llu ms: setup %.2f feed (gather + enqueue) %.2f "
-                    "drain (wait + scatter) %.2f (threads %zu sub-batches %zu)\n",
+    return ZIPC_HIP_OK;
+  };
+  const auto t_feed = std::chrono::steady_clock::now();
+  const int feed_status = feed();
+  const double ms_feed = since(t_feed);
+  if (feed_status) {
+    {
+      std::lock_guard<std::mutex> l(pm);
+      gave_up = true;
+    }
+    pcv.notify_all();
+  }
+  taker_thread.join();
+  if (feed_status || taker_status) {  // a batch call refused its arguments or a HIP call failed: the call fails as a whole
+    (void)hipStreamSynchronize(ctx->copy_in);  // (sub-batches scattered before that stay where they are)
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_out);
+    if (!feed_status) ctx->last_error = taker_error;
+    return feed_status ? feed_status : taker_status;
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
+  if (timing) {  // where each sub-batch was when: host clock from the call's begin, device clock from the first copy's begin
+    fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_arena=%llu ms: setup %.2f feed %.2f (of it gather %.2f) "
+                    "scatter %.2f whole %.2f (threads %zu sub-batches %zu)\n",
             is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)dof, ms_setup, ms_feed,
-            since(t_drain), host_threads(), K);
+            ms_gather, ms_scatter, since(t_begin), host_threads(), K);
+    for (size_t g = 0; g < K; g++) {
+      if (cut[g] == cut[g + 1]) continue;
+      float h0 = 0, h1 = 0, k0 = 0, k1 = 0, o1 = 0;
+      (void)hipEventElapsedTime(&h0, ev_t.ev[0], ev_t.ev[1 + 2 * g]);
+      (void)hipEventElapsedTime(&h1, ev_t.ev[0], ev_in.ev[g]);
+      (void)hipEventElapsedTime(&k0, ev_t.ev[0], ev_t.ev[2 + 2 * g]);
+      (void)hipEventElapsedTime(&k1, ev_t.ev[0], ev_k.ev[g]);
+      (void)hipEventElapsedTime(&o1, ev_t.ev[0], ev_out.ev[g]);
+      fprintf(stderr, "  sub-batch %zu (%zu streams): host gathered at %.2f, scatter %.2f - %.2f | device copy in %.2f - %.2f, "
+                      "kernels %.2f - %.2f, back by %.2f\n",
+              g, cut[g + 1] - cut[g], t_gathered[g], t_scatter_begin[g], t_scatter_end[g], h0, h1, k0, k1, o1);
+    }
+  }
   return ZIPC_HIP_OK;
 }
 

@@ -41,7 +41,8 @@ struct zipc_hip_ctx {
   };
   Buf io_src, io_dst, io_desc, io_res, io_small;  // staging of the host forms
   Buf pin_src, pin_dst, pin_res;                  // pinned host memory of the many-stream host forms
-  hipStream_t copy_in = nullptr, copy_out = nullptr;  // their H2D / D2H streams (made on first use)
+  Buf io_pack_off;                                // ... where each output of a sub-batch begins once they lie end to end (api.hip pack_offsets_kernel)
+  hipStream_t copy_in = nullptr, copy_out = nullptr;  // their H2D / D2H queues (made on first use)
   Buf crc_partials, adler_sums;                   // checksum kernels
   Buf crc_nib;                                    // nibble tables of the CRC merge constants (kernels.h)
   Buf deflate_scratch;                            // deflate pipeline (deflate.hip)

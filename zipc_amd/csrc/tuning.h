@@ -5,7 +5,7 @@
 // a process of its own) or sizes something for an experiment (tools/).  They are read once per process, the first time
 // zd::tuning() is called; the defaults are what measured faster (DESIGN.md section 6 has the numbers).
 // Switches whose experiment lost and that nothing uses any more are gone: ZIPC_HIP_CHECKSUM_QUEUES (the two checksum
-// passes of a large buffer on one queue), ZIPC_HIP_INFLATE_EXPLORE, ZIPC_HIP_INFLATE_BLOCKS_TRACE, ZIPC_HIP_HOST_TIMING.
+// passes of a large buffer on one queue), ZIPC_HIP_INFLATE_EXPLORE, ZIPC_HIP_INFLATE_BLOCKS_TRACE.
 #pragma once
 
 #include <stddef.h>
@@ -33,9 +33,16 @@ struct Tuning {
   int resolve_hops0, resolve_hops1;  // ZIPC_HIP_RESOLVE_HOPS0 / 1  links a thread follows in the first / a later resolve round (default 256)
   // ---- checksums
   bool checksum_fused;         // ZIPC_HIP_CHECKSUM_FUSED=0  both checksums of one buffer by two passes instead of one
-  // ---- host forms
-  long host_threads, host_chunks;  // ZIPC_HIP_HOST_THREADS / ZIPC_HIP_HOST_CHUNKS  staging threads and chunks of the many-stream host forms
-                               //                          (default 0: by the call's size)
+  // ---- host forms (api.hip many_streams)
+  long host_threads, host_chunks;  // ZIPC_HIP_HOST_THREADS / ZIPC_HIP_HOST_CHUNKS  staging threads and sub-batches of the many-stream host forms
+                               //                          (default 0: 8 threads or the core count; 4 sub-batches, 6 from a GiB staged)
+  long host_chunk_min;         // ZIPC_HIP_HOST_CHUNK_MIN  fewest streams a sub-batch of those forms holds (default 1024)
+  bool host_pack;              // ZIPC_HIP_HOST_PACK=0     a sub-batch's whole destination slots come back by the copy engine instead of
+                               //                          its outputs end to end by a kernel that writes the pinned memory
+  long host_pack_wgs;          // ZIPC_HIP_HOST_PACK_WGS   workgroups of that kernel (default 6)
+  long host_h2d_mib;           // ZIPC_HIP_HOST_H2D_MIB    a sub-batch's sources go to the device in copies of about this size as they are
+                               //                          gathered (default 16; 0: one copy per sub-batch)
+  bool host_timing;            // ZIPC_HIP_HOST_TIMING=1   those forms print where each sub-batch was when on stderr (tools/gpu_host_check.sh)
 };
 
 const Tuning &tuning();  // api.hip
