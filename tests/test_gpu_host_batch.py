@@ -1,9 +1,10 @@
 """zipc_hip_deflate_many / zipc_hip_inflate_many (include/zipc_hip.h) on batches big and
 ragged enough that the call runs as a pipeline of several sub-batches (api.hip many_streams:
-3 of them from 3072 streams on, each through gather, H2D, kernels, D2H and scatter on its
-own streams and events).  Every
-stream's bytes, length, checksum and status against the oracle; guard bytes behind every
-destination.  The archive-level tests (test_gpu_zipc.py) only reach these entry points
+4 of them from 4096 streams on, the first and the last half as large as the others, each
+through gather, copy in, kernels, the way back -- the outputs end to end, written into the
+pinned buffer by a kernel -- and scatter on its own queues, events and host threads; a
+stream of more than a MiB is moved in pieces).  Every stream's bytes, length, checksum and
+status against the oracle; guard bytes behind every destination.  The archive-level tests (test_gpu_zipc.py) only reach these entry points
 with a handful of members."""
 import ctypes as C
 import random
@@ -23,6 +24,7 @@ ERR_DST_TOO_SMALL = 16
 def _ragged_inputs(n, seed):
     rnd = random.Random(seed)
     big_at = {rnd.randrange(n): rnd.randrange(100_000, 300_000) for _ in range(6)}  # uneven chunks
+    big_at[rnd.randrange(n // 2, n)] = 2_400_000 + rnd.randrange(1000)  # (several pieces for the host threads)
     out = []
     for i in range(n):
         if i in big_at:
@@ -74,7 +76,7 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
 
     lib = _lib.lib()
     n = 4500
-    assert n // 3 >= 1024  # many_streams() keeps its default of 3 sub-batches only if each holds >= 1024 streams
+    assert n // 4 >= 1024  # many_streams() keeps its default of 4 sub-batches only if each holds >= 1024 streams
     plain = _ragged_inputs(n, 5)
     level = 2
 
@@ -106,7 +108,7 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
     # stored block only changes the data), and the oracle must reject what was made of them.
     rnd = random.Random(9)
     huff = [i for i in range(n) if len(comp[i]) > 120 and len(comp[i]) < 0.8 * len(plain[i])]
-    bad = next(i for i in huff if 600 < i < 900)       # in the first sub-batch (of about 1500 streams each)
+    bad = next(i for i in huff if 300 < i < 600)       # in the first sub-batch (a sixth of the bytes)
     for attempt in range(50):
         c = bytearray(comp[bad])
         for k in range(4, min(60, len(c))):
@@ -114,7 +116,7 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
         if oracle.inflate(bytes(c), decompressed_size=len(plain[bad]))[0] != 0:
             break
     comp[bad] = bytes(c)
-    trunc = next(i for i in huff if 1700 < i < 2100)   # in the second
+    trunc = next(i for i in huff if 1700 < i < 2100)   # in a middle one
     comp[trunc] = comp[trunc][: len(comp[trunc]) // 2]
     short = next(i for i, d in enumerate(plain) if len(d) > 100 and i > 4400)  # in the last
     limits = [len(d) for d in plain]
@@ -173,3 +175,39 @@ def test_a_few_long_members_inflate_by_blocks(gpu_ctx, oracle):
         else:
             assert int(ires[i].out_len) == 0, i
     assert int(ires[0].status) == 0 and int(ires[1].status) == 0 and int(ires[2].status) == 2
+
+
+def test_a_few_long_members_deflate(gpu_ctx, oracle):
+    """zipc_hip_deflate_many with a handful of long members: one sub-batch, every member gathered and scattered in
+    pieces of a MiB, outputs of megabytes end to end on the way back -- bytes, lengths and CRC-32 against the oracle"""
+    from zipc_amd import _lib
+
+    lib = _lib.lib()
+    rng = np.random.default_rng(11)
+    text = util.text(2_200_000, 6)
+    plain = [bytes(text), (rng.integers(0, 8, 3_000_001, dtype=np.uint8) * 31).astype(np.uint8).tobytes(), b"",
+             rng.integers(0, 256, 1_100_000, dtype=np.uint8).tobytes(), bytes(text[:77])]
+    n = len(plain)
+    caps = [int(lib.zipc_hip_deflate_bound(len(d))) for d in plain]
+    dst = _Bufs(caps)
+    keep, sp, sl = _srcs(plain)
+    res = (_lib.StreamResult * n)()
+    assert lib.zipc_hip_deflate_many(gpu_ctx.handle, n, sp, sl, 2, 1, dst.ptrs, dst.cap, res) == 0
+    assert dst.guards_intact()
+    for i, d in enumerate(plain):
+        st, want, crc = oracle.deflate(d, level=2, crc_op=oracle.CRC_CRC32)
+        assert st == 0 and int(res[i].status) == 0 and int(res[i].out_len) == len(want), (i, len(d))
+        assert dst.bytes(i, len(want)) == want and int(res[i].checksum) == crc, i
+
+
+def test_the_copy_engine_as_the_way_back():
+    """ZIPC_HIP_HOST_PACK=0 (csrc/tuning.h: a sub-batch's whole destination slots come back by the copy engine): the
+    same tests in a process of its own, since the switch is read once per process"""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, ZIPC_HIP_HOST_PACK="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "not way_back"], env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
