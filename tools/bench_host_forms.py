@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the host-buffer batch forms (zipc_hip_deflate_many /
-zipc_hip_inflate_many): C2's 16 384 x 64 KiB streams held in pageable host memory, staged
-H2D, run, copied back D2H.  Context for DESIGN.md; bench.py's value is device-resident."""
+zipc_hip_inflate_many): C2's 16 384 x 64 KiB streams (N_STREAMS x STREAM_LEN) held in pageable host memory,
+staged H2D, run, copied back D2H.  Context for DESIGN.md; bench.py's value is device-resident."""
 import ctypes as C, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +9,7 @@ import numpy as np
 import zipc_amd
 from zipc_amd import _lib, synth
 
-n = int(os.environ.get("N_STREAMS", "16384")); L = 65536
+n = int(os.environ.get("N_STREAMS", "16384")); L = int(os.environ.get("STREAM_LEN", "65536"))
 lib = _lib.lib()
 ctx = zipc_amd.Context(0)
 plain = [synth.stream_bytes_np(2, j, L, 4) for j in range(n)]
@@ -39,7 +39,7 @@ def inflate():
 ts_inf = timed(inflate); t_inf = min(ts_inf)
 ok = all(int(ires[i].status) == 0 for i in range(n)) and all(np.array_equal(out[i], plain[i]) for i in range(0, n, 97))
 gib = n * L / float(1 << 30)
-print(json.dumps({"streams": n, "round_trip_ok": bool(ok), "deflate_many_gib_s": gib / t_def, "inflate_many_gib_s": gib / t_inf,
+print(json.dumps({"streams": n, "stream_len": L, "round_trip_ok": bool(ok), "deflate_many_gib_s": gib / t_def, "inflate_many_gib_s": gib / t_inf,
                   "round_trip_gib_s": gib / (t_def + t_inf), "reps": REPS, "rate_is": "best of reps",
                   "deflate_many_gib_s_median": gib / med(ts_def), "inflate_many_gib_s_median": gib / med(ts_inf),
                   "deflate_ms_all": [round(t * 1e3, 2) for t in ts_def], "inflate_ms_all": [round(t * 1e3, 2) for t in ts_inf],

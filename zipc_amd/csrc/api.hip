@@ -1380,12 +1380,15 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   // caller's buffers while the last one's sources are still being gathered.  Thousands of small pageable copies -- the
   // first version of this function -- cost far more than the kernels.
   // K (ZIPC_HIP_HOST_CHUNKS): 4, or 6 from a GiB of staging on; fewer when sub-batches would get too small to fill the
-  // chip.  The first and the last sub-batch are half as large as the others: the first is what the bus and the kernels
+  // chip (under 1024 streams AND under 64 MiB of sources).  The first and the last sub-batch are half as large as the others: the first is what the bus and the kernels
   // wait for before they have anything to do, the last what the caller waits for when everything else is through.
   // (profiles/r05_host_forms_sweep.txt: 4096 x 64 KiB: 3 / 4 / 5 / 6 sub-batches deflate 9.9 / 9.8 / 9.4 / 10.0 ms,
   // inflate 8.3 / 8.9 / 8.9 / 9.5; 16 384 x 64 KiB: 34.0 / 31.2 / 29.8 / 30.2 and 29.4 / 27.6 / 26.6 / 25.7.)
   size_t K = host_chunks(so + dof);
-  while (K > 1 && n / K < (size_t)zd::tuning().host_chunk_min) K--;
+  {  // a sub-batch holds host_chunk_min streams, or as many source bytes as that many streams of 64 KiB (long members)
+    const uint64_t least = (uint64_t)zd::tuning().host_chunk_min;
+    while (K > 1 && n / K < least && so / K < least * 65536) K--;
+  }
   std::vector<size_t> cut(K + 1, n);
   cut[0] = 0;
   const bool taper = K >= 3;
