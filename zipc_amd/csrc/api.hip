@@ -1526,28 +1526,41 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
     std::vector<Piece> pieces;
     bool first_batch = true;
+    // sub-batch g's sources: gathered and sent in runs of streams of about h2d_bytes -- the bus starts on the first run
+    // while the next is gathered
+    auto gather_and_send = [&](size_t g) -> int {
+      const size_t lo = cut[g], hi = cut[g + 1];
+      for (size_t a = lo; a < hi;) {
+        size_t b = a + 1;
+        while (b < hi && (h2d_bytes == 0 || src_end(b) - src_end(a) < h2d_bytes)) b++;
+        const auto t_g = std::chrono::steady_clock::now();
+        pieces_of(a, b, [&](size_t i) { return (uint64_t)src_len[i]; }, pieces);
+        host_pool(0).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
+          const Piece &p = pieces[j];
+          copy_streaming((uint8_t *)ctx->pin_src.p + descs[p.stream].src_off + p.at, (const uint8_t *)src[p.stream] + p.at, p.len);
+        });
+        ms_gather += since(t_g);
+        if (timing && a == lo) PIPE_TRY(hipEventRecord(ev_t.ev[1 + 2 * g], ctx->copy_in));
+        const uint64_t from = src_end(a), to = src_end(b);
+        PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + from, (const uint8_t *)ctx->pin_src.p + from, to - from,
+                                hipMemcpyHostToDevice, ctx->copy_in));
+        a = b;
+      }
+      t_gathered[g] = since(t_begin);
+      if (lo < hi) PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
+      return ZIPC_HIP_OK;
+    };
+    // Long members' inflate may go by blocks inside inflate_batch, which waits for the device on the way (api.hip
+    // inflate_by_blocks): the NEXT sub-batch's sources are gathered and sent before this one's kernels are asked for, or
+    // they would not leave the host before those kernels are through (256 x 1 MiB: 22.0 -> 21.4 ms: what is left is the
+    // blocks' kernels, 7-8 ms a sub-batch of 128 MiB).  Everywhere else the
+    // kernels of a sub-batch are enqueued the moment its sources are under way.
+    const bool ahead = is_inflate && max_cap >= BLOCKS_BATCH_MIN_DST;
+    if (ahead) { const int st = gather_and_send(0); if (st) return st; }
     for (size_t g = 0; g < K; g++) {
       const size_t lo = cut[g], hi = cut[g + 1];
+      if (ahead ? g + 1 < K : true) { const int st = gather_and_send(ahead ? g + 1 : g); if (st) return st; }
       if (lo < hi) {
-        // gathered and sent in runs of streams of about h2d_bytes: the bus starts on the first run while the next is gathered
-        for (size_t a = lo; a < hi;) {
-          size_t b = a + 1;
-          while (b < hi && (h2d_bytes == 0 || src_end(b) - src_end(a) < h2d_bytes)) b++;
-          const auto t_g = std::chrono::steady_clock::now();
-          pieces_of(a, b, [&](size_t i) { return (uint64_t)src_len[i]; }, pieces);
-          host_pool(0).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
-            const Piece &p = pieces[j];
-            copy_streaming((uint8_t *)ctx->pin_src.p + descs[p.stream].src_off + p.at, (const uint8_t *)src[p.stream] + p.at, p.len);
-          });
-          ms_gather += since(t_g);
-          if (timing && a == lo) PIPE_TRY(hipEventRecord(ev_t.ev[1 + 2 * g], ctx->copy_in));
-          const uint64_t from = src_end(a), to = src_end(b);
-          PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + from, (const uint8_t *)ctx->pin_src.p + from, to - from,
-                                  hipMemcpyHostToDevice, ctx->copy_in));
-          a = b;
-        }
-        t_gathered[g] = since(t_begin);
-        PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
         PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
         if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[2 + 2 * g], ctx->stream));
         zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
