@@ -34,8 +34,9 @@
 //            steps later, any other match leaves its {distance, length} in the first 3 bytes
 //            of its own hole and its bytes in a bitmap of unfilled bytes.
 //   holes    listed (tile positions, stream order) and from there on work for any lane, 64 at
-//            a time: sources wholly before the tile in one pipelined pass, the others in
-//            rounds -- filled when the bitmap shows every source byte final, else kept.  The
+//            a time: sources wholly before the tile in one pipelined pass, the others 64 at a
+//            time in stream order, a group going round -- filled when the bitmap shows every
+//            source byte final -- until none of it is open.  The
 //            tile leaves with coalesced 16-byte stores; literals never go to memory one by one.
 //
 // Codes longer than the tables' index bits -- rare per symbol, not per 64 symbols -- are found by
@@ -256,6 +257,7 @@ ZD_WV void span_advance(SpanReader &R, const SpanEnv &E, uint32_t p) {  // the p
 
 #ifdef SPAN_TRACE
 static uint64_t span_trace_steps[8];
+static uint64_t span_trace_seq;  // holes filled one after the other by the whole wave
 static uint32_t span_lane_steps[64];
 #endif
 // ---- phase A: a lane's walk over a region, recording the index
@@ -910,12 +912,12 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     // work that follows is spread evenly over the lanes whatever granule a hole came from.
     //   Those whose source lies wholly before the tile (and that are not long) depend on nothing in
     // it: one pass over the list, the bytes a step requested from memory written by the step after.
-    //   The rest in rounds over what is still open, 64 holes at a time: a hole is filled as soon
-    // as the bitmap shows that every byte of its source is final (its own bytes count as final: an
-    // overlapping match is copied front to back), else it is kept for the next round.  The first
-    // open hole of the tile always is, so every round makes progress; the rounds a tile takes
-    // are the depth of its matches' dependences, not their number.  Holes of up to 32 bytes are
-    // copied by their lanes side by side, longer ones by the whole wave one after the other.
+    //   The rest 64 at a time in stream order, a group going round until none of it is open: a hole
+    // is filled as soon as the bitmap shows that every byte of its source is final (its own bytes
+    // count as final: an overlapping match is copied front to back).  The first open hole in stream
+    // order always is, so every round makes progress; the rounds a group takes are the depth of its
+    // matches' dependences, not their number.  Holes of up to 32 bytes are copied by their lanes
+    // side by side, longer ones by the whole wave one after the other.
     uint16_t *list = (uint16_t *)E.ring;  // (the input ring is idle: SPAN_LIST_MAX entries)
     // (A tile of 3-byte matches has up to 1365 holes: the list takes the first SPAN_LIST_MAX in
     // stream order, and when those are filled the rest -- nothing before a hole depends on it.)
@@ -976,139 +978,137 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         wv::sync();
       }
       ZD_SPAN_PH(4);
-      // (The list's open part is [head, n_open).  A round looks at all of it -- until one fills less than an eighth of 128
-      // holes and more: tables of records, each field a copy of the record before's, are a few long chains side by side, a
-      // round fills a link of each and looked at hundreds of holes to find them (an ELF symbol table: 170 rounds over 400
-      // holes a tile, 55 % of the stream's time).  From then on a round looks at the FRONT 64 only -- the earliest open
-      // hole is always ready, and what a hole waits for lies before it -- until a round fills 48 of them again.)
-      uint32_t head = 0;
-      bool front = false;
-      for (;;) {
-        uint32_t kept = 0;
+      // What the far pass left: the list closes up (still stream order), then 64 holes at a time IN THAT ORDER.  Everything
+      // before a group is final when its turn comes, so a hole of the group waits for holes of the same group only: the
+      // group's lanes keep their holes in registers and go round -- test, copy what is ready, clear its bits -- until none is
+      // open.  Nothing is listed again, no record is read twice, and a round that moves a few short holes skips the words none
+      // of them has.  (Rounds over ALL open holes of the tile, which this replaces, kept what was not ready in the list for the
+      // next round: text took 10 rounds a tile and looked at 15 groups of 64 in them, a third of its streams' time.  In
+      // stream order a group of text is still 4.6 rounds deep -- a hole's source is mostly the text just before it -- so the
+      // rounds are as many; they cost less: inflate_batch on text 4.73 -> 4.48 ms per GiB, the corpus 7.84 -> 7.5, a table
+      // of records 2.37 -> 2.0, the benchmark's symbols 3.32 -> 3.30.)  A round that fills less than an eighth of what is
+      // open is a chain, or a few side by side (tables of records: every field a copy of the record before's): the rest of
+      // the group one after the other in stream order, each ready when its turn comes, by the whole wave.  (Only then: a
+      // hole filled that way costs a third of a round -- finishing every group's last 8 / 16 / 24 open holes so: text 4.59 /
+      // 4.85 / 5.13 ms.)
+      {
+        uint32_t n_near = 0;
+        for (uint32_t c0 = 0; c0 < n_open; c0 += 64u) {
+          const uint32_t dp = c0 + ulane < n_open ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
+          const uint64_t km = wv::ballot(dp != 0xFFFFu);
+          if (dp != 0xFFFFu) list[n_near + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
+          n_near += (uint32_t)__builtin_popcountll(km);
+        }
+        wv::sync();
+        for (uint32_t c0 = 0; c0 < n_near; c0 += 64u) {
 #ifdef SPAN_TRACE
-        if (lane == 0) span_trace_steps[3]++;
+          if (lane == 0) span_trace_steps[3]++;
 #endif
-        const uint32_t lim = front && n_open - head > 64u ? head + 64u : n_open;
-        for (uint32_t c0 = head; c0 < lim; c0 += 64u) {
-#ifdef SPAN_TRACE
-          if (lane == 0) span_trace_steps[7]++;
-#endif
-          const uint32_t dp = c0 + ulane < lim ? (uint32_t)list[c0 + ulane] : 0xFFFFu;
-          const bool open = dp != 0xFFFFu;
+          const bool have = c0 + ulane < n_near;
+          const uint32_t dp = have ? (uint32_t)list[c0 + ulane] : 0u;
           uint32_t dist = 1, len = 0;
-          if (open) {
+          if (have) {
             const uint32_t rec = span_rec(tile, dp);
             dist = (rec & 0x7FFFu) + 1u;
             len = (rec >> 16) + 3u;
           }
           const int sp = (int)dp - (int)dist;
-          bool ready = false;
-          if (open) {
-            const int a = sp > 0 ? sp : 0;
-            const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
-            ready = b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b);
-          }
-          const bool go = ready && len <= SPAN_LONG;
-          // a period of 1, 2 or 3 bytes: twelve bytes of it in registers
-          uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
-          const bool pat = go && dist < 4u;
-          if (pat) {
-            const uint32_t b0 = span_byte_at(tile, gbase, sp), b1 = span_byte_at(tile, gbase, sp + (dist > 1u ? 1 : 0)),
-                           b2 = span_byte_at(tile, gbase, sp + (dist > 2u ? 2 : 0));
-            if (dist == 3u) {
-              pw0 = b0 | b1 << 8 | b2 << 16 | b0 << 24;
-              pw1 = b1 | b2 << 8 | b0 << 16 | b1 << 24;
-              pw2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
-            } else {
-              pw0 = pw1 = pw2 = (b0 | b1 << 8) * 0x00010001u;  // (dist 1: b1 is b0)
+          // the part of the source that lies in the tile and before the hole (its own bytes count as final: an
+          // overlapping match is copied front to back)
+          const int a = sp > 0 ? sp : 0;
+          const int b = sp + (int)len < (int)dp ? sp + (int)len : (int)dp;
+          bool open = have;
+          for (;;) {
+#ifdef SPAN_TRACE
+            if (lane == 0) span_trace_steps[7]++;
+#endif
+            const bool ready = open && (b <= a || !span_bits_any(mbits, (uint32_t)a, (uint32_t)b));
+            const bool go = ready && len <= SPAN_LONG;
+            // a period of 1, 2 or 3 bytes: twelve bytes of it in registers
+            uint32_t pw0 = 0, pw1 = 0, pw2 = 0;
+            const bool pat = go && dist < 4u;
+            if (pat) {
+              const uint32_t b0 = span_byte_at(tile, gbase, sp), b1 = span_byte_at(tile, gbase, sp + (dist > 1u ? 1 : 0)),
+                             b2 = span_byte_at(tile, gbase, sp + (dist > 2u ? 2 : 0));
+              if (dist == 3u) {
+                pw0 = b0 | b1 << 8 | b2 << 16 | b0 << 24;
+                pw1 = b1 | b2 << 8 | b0 << 16 | b1 << 24;
+                pw2 = b2 | b0 << 8 | b1 << 16 | b2 << 24;
+              } else {
+                pw0 = pw1 = pw2 = (b0 | b1 << 8) * 0x00010001u;  // (dist 1: b1 is b0)
+              }
             }
-          }
-          wv::sync();  // records and bits are read before anybody writes bytes over them
-          // three ways to move the bytes: four at a time inside the tile (distance >= 4), the period's
-          // words, byte by byte (what reaches before the tile from close to its start: rare)
-          const bool words = go && !pat && sp >= 0;
-          if (words || pat) {
-            uint8_t *t = tile + dp;
-            const uint8_t *f = tile + (sp >= 0 ? sp : 0);
+            wv::sync();  // records and bits are read before anybody writes bytes over them
+            // three ways to move the bytes: four at a time inside the tile (distance >= 4), the period's
+            // words, byte by byte (what reaches before the tile from close to its start: rare)
+            const bool words = go && !pat && sp >= 0;
+            const bool any_w2 = wv::any((words || pat) && len >= 12u), any_w4 = wv::any((words || pat) && len >= 20u);  // (a word 2, a word 4 to move)
+            if (words || pat) {
+              uint8_t *t = tile + dp;
+              const uint8_t *f = tile + (sp >= 0 ? sp : 0);
 #pragma unroll
-            for (uint32_t i = 0; i < 8u; i++) {
-              if (4u * i + 4u <= len) {
-                const uint32_t pv = i % 3u == 0u ? pw0 : i % 3u == 1u ? pw1 : pw2;
-                store_u32_le(t + 4u * i, pat ? pv : load_u32_le(f + 4u * i));
+              for (uint32_t i = 0; i < 8u; i++) {
+                // (the later rounds of a group move a few short holes: where no lane has a word 2, or a word 4, nobody pays for the rest)
+                if ((i == 2u && !any_w2) || (i == 4u && !any_w4)) break;
+                if (4u * i + 4u <= len) {
+                  const uint32_t pv = i % 3u == 0u ? pw0 : i % 3u == 1u ? pw1 : pw2;
+                  store_u32_le(t + 4u * i, pat ? pv : load_u32_le(f + 4u * i));
+                }
+              }
+              if ((len & 3u) != 0u) {
+                const uint32_t k = len >> 2, pv = k % 3u == 0u ? pw0 : k % 3u == 1u ? pw1 : pw2;
+                if (!pat && len >= 4u) store_u32_le(t + (len - 4u), load_u32_le(f + (len - 4u)));  // (over bytes just written)
+                else {
+                  const uint32_t v = pat ? pv : load_u32_le(f + 4u * k);  // len 3: (the tile has 16 bytes behind it)
+                  t[4u * k] = (uint8_t)v;
+                  if ((len & 3u) >= 2u) t[4u * k + 1u] = (uint8_t)(v >> 8);
+                  if ((len & 3u) == 3u) t[4u * k + 2u] = (uint8_t)(v >> 16);
+                }
               }
             }
-            if ((len & 3u) != 0u) {
-              const uint32_t k = len >> 2, pv = k % 3u == 0u ? pw0 : k % 3u == 1u ? pw1 : pw2;
-              if (!pat && len >= 4u) store_u32_le(t + (len - 4u), load_u32_le(f + (len - 4u)));  // (over bytes just written)
-              else {
-                const uint32_t v = pat ? pv : load_u32_le(f + 4u * k);  // len 3: (the tile has 16 bytes behind it)
-                t[4u * k] = (uint8_t)v;
-                if ((len & 3u) >= 2u) t[4u * k + 1u] = (uint8_t)(v >> 8);
-                if ((len & 3u) == 3u) t[4u * k + 2u] = (uint8_t)(v >> 16);
+            if (wv::any(go && !words && !pat)) {
+              for (uint32_t i = 0;; i++) {
+                const bool g = go && !words && !pat && i < len;
+                if (!wv::any(g)) break;
+                if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
               }
             }
-          }
-          if (wv::any(go && !words && !pat)) {
-            for (uint32_t i = 0;; i++) {
-              const bool g = go && !words && !pat && i < len;
-              if (!wv::any(g)) break;
-              if (g) tile[dp + i] = (uint8_t)span_byte_at(tile, gbase, sp + (int)i);
+            // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
+            for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
+              const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+              const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
+              span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
+            }
+            if (ready) span_bits_clear(mbits, dp, len);
+            open = open && !ready;
+            const uint64_t om = wv::ballot(open), rm = wv::ballot(ready);  // (and every lane's bytes and bits are written)
+            if (om == 0ull) break;
+            if ((uint32_t)__builtin_popcountll(rm) * 8u < (uint32_t)__builtin_popcountll(om)) {
+              // (open holes in neighbouring lanes that follow each other at one distance -- a period cut into short matches --
+              // are one periodic copy)
+              const uint32_t pdp = wv::shfl(dp, ulane - 1u), plen = wv::shfl(len, ulane - 1u), pdist = wv::shfl(dist, ulane - 1u);
+              const bool joins = ulane != 0u && open && ((om >> (ulane - 1u)) & 1ull) != 0ull && dp == pdp + plen && dist == pdist;
+              const uint64_t jm = wv::ballot(joins);
+              const uint32_t lincl = wv::scan_incl(open ? len : 0u);
+              for (uint64_t lm = om; lm != 0ull;) {
+                const uint32_t l = (uint32_t)__builtin_ctzll(lm);
+                const uint64_t after = l == 63u ? 0ull : ~(jm >> (l + 1u));  // the first lane behind l that does not join
+                const uint32_t run = 1u + (after == 0ull ? 63u - l : (uint32_t)__builtin_ctzll(after));
+                const uint32_t last = l + run - 1u > 63u ? 63u : l + run - 1u;
+                const uint32_t ldp = wv::readlane(dp, l), ldist = wv::readlane(dist, l);
+                const uint32_t total = wv::readlane(lincl, last) - wv::readlane(lincl, l) + wv::readlane(len, l);
+#ifdef SPAN_TRACE
+                if (lane == 0) span_trace_seq++;
+#endif
+                span_fill_by_wave(tile, gbase, ldp, ldist, total, ulane);
+                if (ulane == 0u) span_bits_mark<false>(mbits, ldp, total);
+                wv::sync();
+                lm &= last == 63u ? 0ull : ~((2ull << last) - 1ull);
+              }
+              break;
             }
           }
-          // the long ones that are ready: Buf.recopy zd.ml:63-75, byte i is the source's byte i mod dist
-          for (uint64_t lm = wv::ballot(ready && len > SPAN_LONG); lm != 0ull; lm &= lm - 1ull) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(lm);
-            const uint32_t ldp = wv::readlane(dp, l), llen = wv::readlane(len, l), ldist = wv::readlane(dist, l);
-            span_fill_by_wave(tile, gbase, ldp, ldist, llen, ulane);
-          }
-          if (ready) span_bits_clear(mbits, dp, len);
-          // what is still open moves up in the list (a round over the front only: back against what it did not look at)
-          const uint64_t km = wv::ballot(open && !ready);
-          const uint32_t nk = (uint32_t)__builtin_popcountll(km);
-          const uint32_t to = lim != n_open ? lim - nk : head + kept;
-          if (open && !ready) list[to + (uint32_t)__builtin_popcountll(km & ((1ull << ulane) - 1ull))] = (uint16_t)dp;
-          kept += nk;
-          wv::sync();
         }
-        if (lim != n_open) {  // a round over the front: what it kept sits in front of the rest
-          const uint32_t filled = 64u - kept;
-          head = lim - kept;
-          front = filled < 48u;
-          continue;
-        }
-        if (kept == 0u) break;
-        // A round that filled one or two of many open holes: they form a chain (each
-        // copying from the one before: hand-made streams, short periods cut into short matches), and
-        // rounds would take as many passes as it has links.  In stream order every hole's source is
-        // final when its turn comes: the rest one after the other, each by the whole wave.
-        // (Holes that follow each other at one distance -- a period cut into short matches -- are one
-        // periodic copy: lane k looks at the k-th hole from here, and the run is as long as they agree.)
-        if (n_open - head - kept <= 2u && kept >= 64u) {
-          for (uint32_t h = 0; h < kept;) {
-            const bool have = h + ulane < kept;
-            const uint32_t dp = have ? (uint32_t)list[head + h + ulane] : 0u;
-            uint32_t dist = 0, len = 0;
-            if (have) {
-              const uint32_t rec = span_rec(tile, dp);
-              dist = (rec & 0x7FFFu) + 1u;
-              len = (rec >> 16) + 3u;
-            }
-            const uint32_t pdp = wv::shfl(dp, ulane - 1u), plen = wv::shfl(len, ulane - 1u), pdist = wv::shfl(dist, ulane - 1u);
-            const bool joins = ulane == 0u || (have && dp == pdp + plen && dist == pdist);
-            const uint64_t jm = wv::ballot(joins);
-            const uint32_t run = ~jm == 0ull ? 64u : (uint32_t)__builtin_ctzll(~jm);  // >= 1: lane 0 has a hole
-            const uint32_t total = wv::readlane(wv::scan_incl(len), run - 1u);
-            const uint32_t dp0 = wv::readlane(dp, 0u), dist0 = wv::readlane(dist, 0u);
-            wv::sync();  // (the records are read before any lane writes over them)
-            span_fill_by_wave(tile, gbase, dp0, dist0, total, ulane);
-            if (ulane == 0u) span_bits_mark<false>(mbits, dp0, total);
-            wv::sync();
-            h += run;
-          }
-          break;
-        }
-        front = (n_open - head - kept) * 8u < n_open - head && kept >= 128u;
-        n_open = head + kept;
       }
       if (h_total <= SPAN_LIST_MAX) break;
       {  // what is still open of my own holes
@@ -1150,7 +1150,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
   // ---- the stream goes on behind the committed symbols
 #ifdef SPAN_TRACE
   if (lane == 0) { for (int i = 0; i < 64; i++) fprintf(stderr, "%u ", span_lane_steps[i]); fprintf(stderr, "\n"); }
-  if (lane == 0) fprintf(stderr, "hole rounds %llu word-iters %llu tiles-so-far; ", (unsigned long long)span_trace_steps[3], (unsigned long long)span_trace_steps[7]);
+  if (lane == 0) fprintf(stderr, "hole groups %llu rounds %llu one-by-one %llu so far; ", (unsigned long long)span_trace_steps[3], (unsigned long long)span_trace_steps[7], (unsigned long long)span_trace_seq);
   if (lane == 0) fprintf(stderr, "steps: A %llu stitch %llu B %llu; lane-steps starved %llu running %llu lane5 %llu\n", (unsigned long long)span_trace_steps[0], (unsigned long long)span_trace_steps[1], (unsigned long long)span_trace_steps[2], (unsigned long long)span_trace_steps[4], (unsigned long long)span_trace_steps[5], (unsigned long long)span_trace_steps[6]);
 #endif
   const bool progress = p_end != base || out_pos != out_pos0;
