@@ -849,7 +849,7 @@ static int inflate_blocks_group(zipc_hip_ctx *ctx, const uint8_t *src, uint8_t *
   for (int r = 0; r < rounds; r++)
     ZD_LAUNCH(ctx, "inflate_resolve", inflate_resolve_kernel, dim3(r == 0 || out_grid < 2048u ? out_grid : 2048u, na), dim3(256), 0,
               (const BlocksJob *)d_jobs, r, r == 0 ? hops0 : hops1);
-  ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3((out_grid + 3u) / 4u, na), dim3(256), 0, dst, dd, (const BlocksJob *)d_jobs);  // (four bytes a thread)
+  ZD_LAUNCH(ctx, "inflate_gather", inflate_gather_kernel, dim3(out_grid, na), dim3(256), 0, dst, dd, (const BlocksJob *)d_jobs);
   HIP_TRY(ctx, read_counts());
   // (12 bytes of scratch per output byte: what a long stream took goes back -- a context lives as long as its thread,
   // and a 1 GiB member would pin 12 GiB per device; the stream is idle here, the gather has been waited for)

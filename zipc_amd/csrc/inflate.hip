@@ -1579,32 +1579,19 @@ __global__ void inflate_blocks_result_kernel(const BlocksJob *__restrict__ jobs,
   r.status = ST_OK; r.checksum = 0; r.out_len = jobs[j].out_len;
   results[jobs[j].stream] = r;
 }
-// every byte of a match takes the literal its chain of sources ends in (tok[i] after the resolve rounds; a literal's is i):
-// four bytes a thread -- their four words in one load, the bytes that are literals as they stand, one word stored where the
-// destination is word-aligned (a byte a thread took 0.23 ms per 64 MiB of text, x.xx so)
+// every byte of a match takes the literal its chain of sources ends in (tok[i] after the resolve rounds; a literal's is i).
+// (Four bytes a thread -- one load of their four words, one word stored -- takes the same 0.21-0.23 ms per 64 MiB of text: the
+// kernel is its scattered byte reads.)
 __global__ __launch_bounds__(256) void inflate_gather_kernel(uint8_t *__restrict__ dst_arena, const StreamDesc *__restrict__ descs,
                                                             const BlocksJob *__restrict__ jobs) {
   const BlocksJob J = jobs[blockIdx.y];
   const uint32_t *tok = J.tok;
   const uint32_t n = J.out_len;
   uint8_t *o = dst_arena + descs[J.stream].dst_off;
-  const uint32_t i = (blockIdx.x * 256u + threadIdx.x) * 4u;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= n) return;
-  if (i + 4u <= n && ((uintptr_t)o & 3u) == 0u) {
-    const uint4 t = *(const uint4 *)(tok + i);  // (tok is 256-byte aligned: api.hip)
-    const uint32_t w = *(const uint32_t *)(o + i);
-    const uint32_t b0 = t.x != i ? (uint32_t)o[t.x] : w & 0xFFu;
-    const uint32_t b1 = t.y != i + 1u ? (uint32_t)o[t.y] : (w >> 8) & 0xFFu;
-    const uint32_t b2 = t.z != i + 2u ? (uint32_t)o[t.z] : (w >> 16) & 0xFFu;
-    const uint32_t b3 = t.w != i + 3u ? (uint32_t)o[t.w] : w >> 24;
-    const uint32_t v = b0 | b1 << 8 | b2 << 16 | b3 << 24;
-    if (v != w) *(uint32_t *)(o + i) = v;  // (a literal is stored again as what it is: the threads that read it see the same byte)
-    return;
-  }
-  for (uint32_t k = i; k < n && k < i + 4u; k++) {
-    const uint32_t j = tok[k];
-    if (j != k) o[k] = o[j];
-  }
+  const uint32_t j = tok[i];
+  if (j != i) o[i] = o[j];
 }
 
 
