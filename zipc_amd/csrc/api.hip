@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <new>
 #include <thread>
 #include <vector>
 #include "ctx.h"
@@ -1507,8 +1508,18 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     }
     return ZIPC_HIP_OK;
   };
+  // (nothing that throws may leave this function while the taker runs: a joinable thread's destructor ends the process)
   int taker_status = ZIPC_HIP_OK;
-  std::thread taker_thread([&] { taker_status = taker(); });
+  std::thread taker_thread;
+  try {
+    taker_thread = std::thread([&] {
+      try { taker_status = taker(); }
+      catch (...) { taker_error = "out of memory in the thread that takes the results back"; taker_status = ZIPC_HIP_ERR_NOMEM; }
+    });
+  } catch (...) {  // (no thread to be had; nothing is enqueued yet)
+    ctx->last_error = "zipc_hip: could not start the thread that takes the results back";
+    return ZIPC_HIP_ERR_NOMEM;
+  }
 
   // ---- this thread: gather, copy in, kernels, the way back
   double ms_gather = 0;
@@ -1605,7 +1616,9 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     return ZIPC_HIP_OK;
   };
   const auto t_feed = std::chrono::steady_clock::now();
-  const int feed_status = feed();
+  int feed_status;
+  try { feed_status = feed(); }
+  catch (...) { ctx->last_error = "zipc_hip: out of memory while feeding the device"; feed_status = ZIPC_HIP_ERR_NOMEM; }
   const double ms_feed = since(t_feed);
   if (feed_status) {
     {
@@ -1644,14 +1657,17 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   return ZIPC_HIP_OK;
 }
 
+// (host vectors sized by n: what they throw when memory runs out stays on this side of the C boundary)
 int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len, int level,
                           int crc_op, void *const *dst, const size_t *dst_cap, zipc_hip_stream_result *results) {
-  return many_streams(ctx, false, n, src, src_len, nullptr, level, crc_op, dst, dst_cap, results);
+  try { return many_streams(ctx, false, n, src, src_len, nullptr, level, crc_op, dst, dst_cap, results); }
+  catch (const std::bad_alloc &) { return ZIPC_HIP_ERR_NOMEM; }
 }
 int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
                           zipc_hip_stream_result *results) {
-  return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, dst, dst_cap, results);
+  try { return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, dst, dst_cap, results); }
+  catch (const std::bad_alloc &) { return ZIPC_HIP_ERR_NOMEM; }
 }
 
 // zlib_decompress src/zipc_deflate.ml:720-740 (start = 0): header checks on the
