@@ -1119,16 +1119,18 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     // leaves the tile points to itself, so the tables need no range tests
     const uint32_t lane4 = (uint32_t)lane * 4u;
     const uint32_t j0 = (uint32_t)lane + adv;  // <= 63 + 512
-    uint32_t J[7];
+    // (six tables, 1 .. 32 steps: a path has at most 63 steps inside a tile -- every step advances -- and 32 + 16 + .. + 1
+    // of them reach every one of its nodes from the entry; a seventh table and search step were there until round 5)
+    uint32_t J[6];
     J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
 #pragma unroll
-    for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+    for (int k = 1; k < 6; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
     // Is lane t on the path from the entry?  Every lane searches the path for the
     // largest element <= t, descending through the 2^k-step tables (the path is
-    // strictly increasing): 7 shuffles, no memory.
+    // strictly increasing): 6 shuffles, no memory.
     uint32_t v = (entry - B) * 4u;  // < 64: tiles the parse jumps over are skipped below
 #pragma unroll
-    for (int k = 6; k >= 0; k--) {
+    for (int k = 5; k >= 0; k--) {
       const uint32_t y = lane_value(v, J[k]);
       if (y <= lane4) v = y;
     }
@@ -1314,13 +1316,13 @@ __device__ __forceinline__ ParseTile parse_eval_tile(const ParseStream &P, uint3
     t.visited = valid && ((mask >> lane) & 1ull);
     t.next_entry = 0;
   } else {
-    uint32_t J[7];
+    uint32_t J[6];  // (as in lz_parse_wave's tile_step: six tables reach every node of a tile's path)
     J[0] = j0 < (uint32_t)PARSE_TILE ? j0 * 4u : lane4;
 #pragma unroll
-    for (int k = 1; k < 7; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
+    for (int k = 1; k < 6; k++) J[k] = lane_value(J[k - 1], J[k - 1]);
     uint32_t v = (entry - B) * 4u;
 #pragma unroll
-    for (int k = 6; k >= 0; k--) {
+    for (int k = 5; k >= 0; k--) {
       const uint32_t y = lane_value(v, J[k]);
       if (y <= lane4) v = y;
     }
