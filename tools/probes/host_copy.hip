@@ -9,6 +9,7 @@
 //  * a kernel's stores out beside an engine copy in: 5.3 / 6.3 ms; a kernel's loads in beside an engine copy out: 4.7 / 9.0;
 //  * kernels that copy device memory take 1.5 ms alone, 1.55 beside engine copies, 2.9 beside 8 workgroups storing to the
 //    host, 5.9 beside 64 of them, 5.7 beside a kernel loading from the host.
+//  * the kind of pinned memory (default, coherent, non-coherent) changes none of it.
 //   hipcc --offload-arch=gfx950 -O2 tools/probes/host_copy.hip -o /tmp/host_copy && /tmp/host_copy
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -124,5 +125,29 @@ int main() {
         printf("in: %-7s out: %-10s%-28s 256 MiB in %6.2f ms, 256 MiB out %6.2f ms, the work %6.2f ms\n", im[in_mode], om[out_mode],
                work_name[kind], in_mode ? ms_in : 0.f, out_mode ? ms_out : 0.f, kind ? ms_w : 0.f);
       }
+  // the kind of pinned memory: does a kernel's way out disturb less when the host buffer may be cached by the device?
+  {
+    const unsigned flags[3] = {hipHostMallocDefault, hipHostMallocCoherent, hipHostMallocNonCoherent};
+    const char *fname[3] = {"hipHostMallocDefault", "hipHostMallocCoherent", "hipHostMallocNonCoherent"};
+    for (int f = 0; f < 3; f++) {
+      void *p2;
+      CK(hipHostMalloc(&p2, bytes, flags[f]));
+      memset(p2, 3, bytes);
+      for (int wgs : {8, 64}) {
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(a, s)); CK(hipEventRecord(a2, s2)); CK(hipEventRecord(a3, s3));
+        CK(hipMemcpyAsync(dev2, pin, bytes, hipMemcpyHostToDevice, s2));
+        hipLaunchKernelGGL((copy_kernel<false, 4>), dim3(wgs), dim3(256), 0, s, (u32x4 *)p2, (const u32x4 *)dev, n16);
+        work(2);
+        CK(hipEventRecord(b, s)); CK(hipEventRecord(b2, s2)); CK(hipEventRecord(b3, s3));
+        CK(hipDeviceSynchronize());
+        float ms_out, ms_in, ms_w;
+        CK(hipEventElapsedTime(&ms_out, a, b)); CK(hipEventElapsedTime(&ms_in, a2, b2)); CK(hipEventElapsedTime(&ms_w, a3, b3));
+        printf("%-26s engine in %6.2f ms, kernel (%2d workgroups) out %6.2f ms, kernels on device memory %6.2f ms\n", fname[f], ms_in, wgs,
+               ms_out, ms_w);
+      }
+      CK(hipHostFree(p2));
+    }
+  }
   return 0;
 }
