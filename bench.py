@@ -154,33 +154,43 @@ def algorithmic_bytes(kernel, N, C):
 
 def design_bytes(kernel, N, C):
     """What one launch of `kernel` moves at minimum IN THIS DESIGN (its own inputs and outputs, intermediates
-    included: 2-byte chain links, 8-byte match records, 4-byte symbols; DESIGN.md 'Kernels')."""
+    included: 2-byte chain links, 4-byte match records, 4-byte symbols; DESIGN.md 'Kernels')."""
     return {
         "inflate_batch": C + N,            # read compressed, write plain
         "crc32_segments": N,               # one pass over the checked bytes
         "lz_chain": N + 2 * N,             # read source, write 2-byte links
-        "lz_match": N + 2 * N + 8 * N,     # source + links in, 8-byte match records out
-        "lz_parse": 8 * N + N + 4 * N,     # match records + literals in, <= 4 B/symbol out
+        "lz_match": N + 2 * N + 4 * N,     # source + links in, 4-byte match records out (round 5; the second table only where K/4 differs)
+        "lz_parse": 4 * N + N + 4 * N,     # match records + literals in, <= 4 B/symbol out
         "deflate_emit": 4 * N + C,         # symbols in, compressed out
-        "lz_parse_spec": 8 * N + N + 4 * N,    # as lz_parse, symbols to the segments' buffers
+        "lz_parse_spec": 4 * N + N + 4 * N,    # as lz_parse, symbols to the segments' buffers
         "lz_parse_gather": 4 * N + 4 * N,      # ... and from there to the stream's symbol array
         "deflate_plan": 4 * N,                 # symbols in (histograms), a 3 KiB record per block out
         "deflate_pack": 4 * N + C,             # symbols in, compressed out
     }.get(kernel, 0)
 
 
-def latest_profile(pattern):
+# Which workload's counter passes the line may quote: "c2" (profiles/rNN_hbm_traffic.json, rNN_sq_counters.json: passes of
+# the default command), "c4" (rNN_hbm_traffic_c4.json, rNN_sq_counters_c4.json: passes of --config c4) or None -- a shape
+# of the caller's own has no counters of its own, and one workload's bytes over another's time are not evidence.
+WORKLOAD = None
+
+
+def latest_profile(kind):
+    """the newest committed counter file of `kind` ("hbm_traffic" | "sq_counters") for WORKLOAD, or None"""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    if WORKLOAD is None:
+        return None
+    suffix = "" if WORKLOAD == "c2" else "_" + WORKLOAD
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s%s.json" % (kind, suffix))))
     return files[-1] if files else None
 
 
 def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*hbm_traffic.json,
+    """HBM bytes per launch of `kernel` from the committed PMC passes of THIS workload (profiles/rNN_hbm_traffic[_c4].json,
     made by tools/pmc_report.py --hbm-json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command), or None."""
-    f = latest_profile("*hbm_traffic.json")
+    f = latest_profile("hbm_traffic")
     if not f:
         return None, None
     try:
@@ -206,7 +216,7 @@ def issue_bound(kernel, launch_ms, share=None):
     they are vector-issue bound -- lz_match alone: 2.56 G vector instructions x 4 / 1024 SIMDs / clock = its time).
     share: the part of the batch the priced launch covers; the counters are per launch of the counter run
     ("launch_share" in the file, 0.5: two slices) and are scaled to it."""
-    f = latest_profile("*sq_counters.json")
+    f = latest_profile("sq_counters")
     if not f:
         return None
     try:
@@ -321,7 +331,9 @@ def cpu_leg(name, all_threads=True):
         "unit": "GiB/s",
         "cores": 1,
         "kind": "port",
-        "sample": "%d streams x %d B of the same workload (%s level %s, oracle/zd_oracle.c, gcc -O2)" % (n, stream_len, what, LEVELS[level]),
+        "sample": "%d streams x %d B of the same workload (%s level %s); timed: oracle/zd_oracle.c, this repository's C restatement of "
+                  "src/zipc_deflate.ml (gcc -O2, 1 thread) -- NOT the OCaml reference, which cannot be built on this box"
+                  % (n, stream_len, what, LEVELS[level]),
         "deflate_gib_s": n * stream_len / GIB / t_def,
     }
     if do_inflate:
@@ -478,6 +490,32 @@ def roofline_of(ctx, per_step_fn, psteps, N, C, wall=None, alone_pass=False):
     return roof, per_step
 
 
+def headline_scalars(roof, N, C, deflate_gib_s, inflate_gib_s=None):
+    """The claims of the line as SCALARS (a record that keeps only the scalar fields of `roofline` and the `config` object
+    still holds them): each direction's GiB/s of uncompressed bytes on its own, its fraction of the HBM roofline on
+    SURVEY 8(d)'s bytes (N + C over the direction's wall time / 8 TB/s), and -- where this workload has committed
+    counter passes -- the counters' traffic of the direction over those bytes, raw and with the guide's 2 x FETCH."""
+    h = {"uncompressed_bytes": N, "compressed_bytes": C, "algorithmic_bytes_per_direction": N + C, "deflate_gib_s": deflate_gib_s}
+    if inflate_gib_s is not None:
+        h["inflate_gib_s"] = inflate_gib_s
+    for key, name in (("deflate_pipeline", "deflate"), ("inflate", "inflate")):
+        e = roof.get(key)
+        if not e:
+            continue
+        h[name + "_ms"] = e["ms_per_step"]
+        h[name + "_gb_s"] = e["achieved"]
+        h[name + "_frac"] = e["frac"]
+        if "traffic_over_algorithmic" in e:
+            h[name + "_traffic_over_algorithmic_raw"], h[name + "_traffic_over_algorithmic_corrected"] = e["traffic_over_algorithmic"]
+            h[name + "_traffic_source"] = e["traffic_source"]
+    if isinstance(roof.get("traffic_over_algorithmic"), list):  # the dominant kernel's, as two scalars beside the list
+        h["traffic_over_algorithmic_raw"], h["traffic_over_algorithmic_corrected"] = roof["traffic_over_algorithmic"]
+    if isinstance(roof.get("issue_bound"), dict):
+        h["issue_bound_frac"] = roof["issue_bound"]["frac"]
+        h["issue_bound_source"] = roof["issue_bound"]["source"]
+    return h
+
+
 def sum_traffic(kernels, launches=None):
     """the kernels' counter traffic per STEP: the PMC passes give bytes per launch (profiles/*_hbm_traffic.json)"""
     tot = {"bytes": 0.0, "fetch_bytes": 0.0, "write_bytes": 0.0}
@@ -546,11 +584,13 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
     import zipc_amd
     from zipc_amd import batch, synth
 
+    global WORKLOAD
     ctx = zipc_amd.Context(local_rank)
     n = args.streams or 16384
     L = args.stream_len or 65536
     bits = args.bits or 4
     N = n * L
+    WORKLOAD = "c2" if (n, L, bits, args.level) == (16384, 65536, 4, 2) else None  # whose committed counter passes the line may quote
     # member-sharded: rank r owns streams [r*n, (r+1)*n) of the synthetic archive
     src = synth.batch_bytes_torch(2, rank * n, n, L, bits, dev)
     cap = batch.deflate_bound(L)
@@ -607,6 +647,8 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
     roof, per_step = roofline_of(ctx, profiled, psteps, N, C, wall=t, alone_pass=args.alone_pass)
     if rank != 0:
         return None
+    headline = headline_scalars(roof, N, C, N / GIB * psteps / t["def"], N / GIB * psteps / t["inf"])
+    roof.update(headline)
     line = {
         "metric": METRIC,
         "value": world * N / GIB * args.steps / elapsed,
@@ -630,6 +672,7 @@ def run_c2(args, rank, local_rank, world, dev, cpu=None):
             "streams_per_gpu": n, "stream_len": L, "level": args.level,
             "compressed_ratio": C / N, "parallelism": "member-shard x%d" % world,
             "sampled_bytes_equal_oracle": same,
+            **headline,
         },
         **ranks,
         "roofline": roof,
@@ -830,10 +873,12 @@ def run_c4(args, rank, local_rank, world, dev, cpu=None):
     import zipc_amd
     from zipc_amd import batch, shard, synth
 
+    global WORKLOAD
     ctx = zipc_amd.Context(local_rank)
     members = args.streams or 8192
     L = args.stream_len or (1 << 20)
     bits = args.bits or 3
+    WORKLOAD = "c4" if (members, L, bits, args.level, world) == (8192, 1 << 20, 3, 2, 1) else None  # counters of a C4 pass on one GPU, or none
     paths = shard.member_paths(members)           # m/%05d.bin: already in the order Zipc writes them
     parts = shard.partition([L] * members, world)
     lo, hi = parts[rank]
@@ -876,10 +921,18 @@ def run_c4(args, rank, local_rank, world, dev, cpu=None):
     C_all = int(records["compressed_size"].astype(np.uint64).sum())
     check = c4_check(ctx, dev, rank, world, parts, paths, records, comp, descs, L, bits, args.level)
 
-    roof, per_step = roofline_of(ctx, lambda: batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1),
-                                 1, N, int(res["out_len"].sum()))
+    t4 = {"def": 0.0, "inf": 0.0}
+
+    def profiled4():
+        a = time.perf_counter()
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, N, args.level, 1)
+        t4["def"] += time.perf_counter() - a
+
+    roof, per_step = roofline_of(ctx, profiled4, 1, N, int(res["out_len"].sum()), wall=t4)
     if rank != 0:
         return None
+    headline = headline_scalars(roof, N, int(res["out_len"].sum()), N / GIB / t4["def"])
+    roof.update(headline)
     line = {
         "metric": METRIC,
         "value": members * L / GIB * args.steps / elapsed,
@@ -899,6 +952,7 @@ def run_c4(args, rank, local_rank, world, dev, cpu=None):
                         % (members, L, bits, LEVELS[args.level], world),
             "members": members, "member_len": L, "level": args.level, "compressed_ratio": C_all / (members * L),
             "parallelism": "member-shard x%d" % world, "members_per_rank": counts,
+            **{k: v for k, v in headline.items()},  # rank 0's own shard (N = its members' bytes)
         },
         **ranks,
         "roofline": roof,
