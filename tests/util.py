@@ -106,6 +106,50 @@ def record_table(n_records, seed=31):
     return bytes(out)
 
 
+_VECTOR_INPUTS = {}
+
+
+def vector_input(name):
+    """the named inputs of tests/golden/deflate_vectors.json (made by tests/golden/make_deflate_vectors.py from a second,
+    independent reading of the reference's encoder); rebuilt here, nothing but hashes is stored"""
+    if name in _VECTOR_INPUTS:
+        return _VECTOR_INPUTS[name]
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.dirname(HERE))
+    from zipc_amd import synth
+
+    if name.startswith("trip"):
+        v = trip_strings()[int(name[4:])][0]
+    elif name.startswith("zipdocs_"):
+        m, raw = [(m, raw) for m, raw in zip_docs_members() if name[8:] in m["path"].lower().replace(".txt", "")][0]
+        v = zlib.decompress(raw, -15)
+        assert len(v) == m["decompressed_size"] and zlib.crc32(v) == m["crc32"]
+    elif name.startswith("c2_stream"):
+        v = synth.stream_bytes_np(2, int(name[9:]), 65536, 4).tobytes()
+    elif name.startswith("c4_stream"):
+        parts = name[9:].split("_")
+        v = synth.stream_bytes_np(4, int(parts[0]), 1 << 20, 3).tobytes()
+        if len(parts) > 1:
+            v = v[:int(parts[1][:-1]) * 1024]
+    elif name == "zeros1M":
+        v = bytes(1 << 20)
+    elif name == "ff4200":
+        v = b"\xff" * 4200
+    elif name == "rand200k":
+        v = rand_bytes(200000, 77)
+    elif name == "fox":
+        v = FOX
+    elif name == "empty":
+        v = b""
+    else:
+        v = deflate_cases()[name]
+    _VECTOR_INPUTS[name] = v
+    return v
+
+
 def deflate_cases(small=False):
     """name -> plaintext: the edge cases the reference tests plus multi-block, run,
     period, incompressible and mixed inputs"""

@@ -19,6 +19,7 @@
 #include <thread>
 #include <vector>
 #include "ctx.h"
+#include "host_pipeline.h"
 #include "tuning.h"
 
 using namespace zd;
@@ -178,98 +179,13 @@ static size_t host_chunks(uint64_t staged_bytes) {
   if (v < 1) v = staged_bytes >= ((uint64_t)1 << 30) ? 6 : 4;
   return (size_t)(v > 64 ? 64 : v);
 }
-// The threads behind the host memcpys of the many-stream forms: made once (a call creates none), parked on a condition
-// variable between jobs, handing out work in grains from one counter (a thread that loses its core for a while holds
-// up one grain, not its whole share).  The caller of run() works too.  The pools are never destroyed: their threads are
-// detached and a process that exits takes them along.
-class HostPool {
- public:
-  explicit HostPool(size_t workers) : workers_(workers) {
-    for (size_t t = 0; t < workers; t++) std::thread([this] { worker(); }).detach();
-  }
-  // f(i) for every i of [lo, hi); returns when all of them have run
-  template <class F>
-  void run(size_t lo, size_t hi, size_t grain, F f) {
-    if (hi <= lo) return;
-    if (workers_ == 0 || hi - lo <= grain) { for (size_t i = lo; i < hi; i++) f(i); return; }
-    std::lock_guard<std::mutex> one_job(run_m_);
-    {
-      std::lock_guard<std::mutex> l(m_);
-      fn_ = [](void *a, size_t i) { (*(F *)a)(i); };
-      arg_ = &f; hi_ = hi; grain_ = grain;
-      next_.store(lo, std::memory_order_relaxed);
-      busy_ = workers_;
-      gen_++;
-    }
-    work_.notify_all();
-    take();
-    std::unique_lock<std::mutex> l(m_);
-    done_.wait(l, [&] { return busy_ == 0; });  // every worker has seen this job and left it: f and the fields are free again
-  }
-
- private:
-  void take() {
-    for (;;) {
-      const size_t a = next_.fetch_add(grain_, std::memory_order_relaxed);
-      if (a >= hi_) return;
-      const size_t b = hi_ - a < grain_ ? hi_ : a + grain_;
-      for (size_t i = a; i < b; i++) fn_(arg_, i);
-    }
-  }
-  void worker() {
-    uint64_t seen = 0;
-    std::unique_lock<std::mutex> l(m_);
-    for (;;) {
-      work_.wait(l, [&] { return gen_ != seen; });
-      seen = gen_;
-      l.unlock();
-      take();
-      l.lock();
-      if (--busy_ == 0) done_.notify_one();
-    }
-  }
-  std::mutex run_m_, m_;
-  std::condition_variable work_, done_;
-  void (*fn_)(void *, size_t) = nullptr;
-  void *arg_ = nullptr;
-  size_t hi_ = 0, grain_ = 1, busy_ = 0;
-  const size_t workers_;
-  std::atomic<size_t> next_{0};
-  uint64_t gen_ = 0;
-};
-// A copy whose destination is not read again by this core: stores that go around the cache (no line is fetched to be
-// overwritten: two passes over memory instead of three, and the caches keep what they held).  The gathers and scatters
-// of the many-stream forms are bound by the host's memory, beside the bus copies that read and write the same DIMMs:
-// against memcpy the calls take 3-7 % less (profiles/r05_host_forms_sweep.txt).
-static void copy_streaming(void *dst, const void *src, size_t len) {
-#if defined(__x86_64__)
-  typedef long long v2di __attribute__((vector_size(16)));
-  uint8_t *d = (uint8_t *)dst;
-  const uint8_t *s = (const uint8_t *)src;
-  if (len < 4096) { memcpy(d, s, len); return; }
-  const size_t head = (64 - ((uintptr_t)d & 63)) & 63;
-  memcpy(d, s, head);
-  d += head; s += head; len -= head;
-  const size_t body = len & ~(size_t)63;
-  for (size_t i = 0; i < body; i += 64) {
-    v2di a, b, c, e;
-    memcpy(&a, s + i, 16); memcpy(&b, s + i + 16, 16); memcpy(&c, s + i + 32, 16); memcpy(&e, s + i + 48, 16);
-    __builtin_nontemporal_store(a, (v2di *)(d + i));
-    __builtin_nontemporal_store(b, (v2di *)(d + i + 16));
-    __builtin_nontemporal_store(c, (v2di *)(d + i + 32));
-    __builtin_nontemporal_store(e, (v2di *)(d + i + 48));
-  }
-  __builtin_ia32_sfence();
-  memcpy(d + body, s + body, len - body);
-#else
-  memcpy(dst, src, len);
-#endif
-}
-// two of them: a call's gathers (the thread that feeds the device) and its scatters (the thread that takes results
-// back) run side by side
-static HostPool &host_pool(int which) {
-  static HostPool *const pools[2] = {new HostPool(host_threads() - 1), new HostPool(host_threads() - 1)};
-  return *pools[which];
+// The threads behind the host memcpys of the many-stream forms, the copies that go around the cache and the pipeline of a
+// call's sub-batches live in host_pipeline.h (no HIP in it: tests/host_sim compiles the same code under the thread and
+// address sanitizers with host threads standing in for the device).  The pools are shared by the process's contexts,
+// made on first use, and their threads are joined when the last context is destroyed.
+static zd_host::Pools &host_pools() {
+  static zd_host::Pools *const p = new zd_host::Pools;  // (the object outlives every context; its threads do not)
+  return *p;
 }
 // events of one call, destroyed on every exit path
 struct EventSet {
@@ -421,6 +337,7 @@ int zipc_hip_create(zipc_hip_ctx **out, int device) {
     return ZIPC_HIP_ERR_HIP;
   }
   ctx->cur = ctx->stream;
+  host_pools().acquire();  // (released by zipc_hip_destroy: the last context to go joins the staging threads)
   // CRC merge constants (zd_common.h), computed with the same GF(2) routines the
   // kernels use
   uint32_t x = gf2_xpow8n(CRC_PIECE_BYTES);
@@ -468,6 +385,7 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
+  host_pools().release();
 }
 
 void *zipc_hip_stream(zipc_hip_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
@@ -1285,7 +1203,8 @@ int zipc_hip_deflate(zipc_hip_ctx *ctx, const void *src, size_t len, int level, 
 // kernel that copies device memory takes 2.9 ms instead of 1.5 beside 8 such workgroups, 5.9 beside 64), so the kernel
 // is as few workgroups as fill the bus.  The host makes the same sums from the results (many_streams below).
 
-__host__ __device__ static inline uint64_t packed_size(uint32_t status, uint64_t out_len, uint64_t dst_cap) {
+// (the host makes the same sums: zd_host::packed_size, host_pipeline.h)
+__device__ static inline uint64_t packed_size(uint32_t status, uint64_t out_len, uint64_t dst_cap) {
   return status == ST_OK && out_len <= dst_cap ? (out_len + 15) / 16 * 16 : 0;
 }
 
@@ -1436,7 +1355,6 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   HIP_TRY(ctx, ev_out.make(K, timing));
   EventSet ev_t;  // timing: the call's begin on the device, a sub-batch's first copy in, its kernels' begin
   if (timing) HIP_TRY(ctx, ev_t.make(1 + 2 * K, true));
-  std::vector<double> t_gathered(K, 0), t_scatter_begin(K, 0), t_scatter_end(K, 0);
   // earlier work of this context (the previous call's kernels read io_src / io_desc; a call that
   // failed half way may have left copies on the two copy streams) first
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1444,203 +1362,114 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_out));
   const double ms_setup = since(t_begin);
   static_assert(sizeof(StreamResult) == sizeof(zipc_hip_stream_result), "result layout");
-  auto src_end = [&](size_t i) { return i < n ? descs[i].src_off : so; };
   auto dst_end = [&](size_t i) { return i < n ? descs[i].dst_off : dof; };
 
-  // A long stream is moved in pieces of 1 MiB so that a few long members keep every thread busy too.
-  struct Piece { uint32_t stream; uint64_t at, len; };
-  constexpr uint64_t PIECE = 1 << 20;
-  auto pieces_of = [&](size_t lo, size_t hi, auto len_of, std::vector<Piece> &out) {
-    out.clear();
-    for (size_t i = lo; i < hi; i++)
-      for (uint64_t at = 0, L = len_of(i); at < L; at += PIECE) out.push_back({(uint32_t)i, at, L - at < PIECE ? L - at : PIECE});
-  };
-  auto grain_of = [&](size_t count) {
-    const size_t g = count / (host_threads() * 8);
-    return g < 1 ? (size_t)1 : (g > 16 ? (size_t)16 : g);
-  };
-
-  // ---- what the two threads share: how many sub-batches have been enqueued (their events recorded), and whether the
-  // feeding thread gave up.  From here on copies and kernels are in flight on three queues, reading `descs` and the
-  // pinned buffers and recording into the event sets above: every exit waits for the taker and, after a failure, for
-  // all three queues before anything is freed or the next call reuses the buffers.
-  std::mutex pm;
-  std::condition_variable pcv;
-  size_t fed = 0;
-  bool gave_up = false;
-  std::string taker_error;
-  double ms_scatter = 0;
-
-  // ---- the taker: sub-batch g is back -> its results as the caller gets them, where each output lies -> scatter
-  auto taker = [&]() -> int {
-    const hipError_t e_dev = hipSetDevice(ctx->device);
-    if (e_dev != hipSuccess) { taker_error = std::string("hipSetDevice: ") + hipGetErrorString(e_dev); return ZIPC_HIP_ERR_HIP; }
-    const StreamResult *pr = (const StreamResult *)ctx->pin_res.p;
-    std::vector<Piece> pieces;
-    std::vector<uint64_t> from(n_max);  // where a stream's output begins in pin_dst
-    for (size_t g = 0; g < K; g++) {
-      const size_t lo = cut[g], hi = cut[g + 1];
-      {
-        std::unique_lock<std::mutex> l(pm);
-        pcv.wait(l, [&] { return fed > g || gave_up; });
-        if (fed <= g) return ZIPC_HIP_OK;  // the feeding thread gave up before this one: its status is the call's
-      }
-      if (lo == hi) continue;
-      const hipError_t e = hipEventSynchronize(ev_out.ev[g]);  // (behind ev_k[g]: the results have landed too)
-      if (e != hipSuccess) { taker_error = std::string("hipEventSynchronize: ") + hipGetErrorString(e); return ZIPC_HIP_ERR_HIP; }
-      uint64_t at = dst_end(lo);
-      for (size_t i = lo; i < hi; i++) {
-        results[i].status = pr[i].status; results[i].checksum = pr[i].checksum; results[i].out_len = pr[i].out_len;
-        from[i - lo] = packed ? at : descs[i].dst_off;
-        at += packed_size(pr[i].status, pr[i].out_len, dst_cap[i]);
-        if (results[i].status != ST_OK) { results[i].out_len = 0; continue; }
-        if (results[i].out_len > dst_cap[i]) { results[i].status = ZIPC_HIP_ERR_DST_TOO_SMALL; results[i].out_len = 0; }
-      }
-      const auto t_sc = std::chrono::steady_clock::now();
-      t_scatter_begin[g] = since(t_begin);
-      pieces_of(lo, hi, [&](size_t i) { return results[i].status == ST_OK ? (uint64_t)results[i].out_len : 0; }, pieces);
-      host_pool(1).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
-        const Piece &p = pieces[j];
-        copy_streaming((uint8_t *)dst[p.stream] + p.at, (const uint8_t *)ctx->pin_dst.p + from[p.stream - lo] + p.at, p.len);
-      });
-      ms_scatter += since(t_sc);
-      t_scatter_end[g] = since(t_begin);
-    }
-    return ZIPC_HIP_OK;
-  };
-  // (nothing that throws may leave this function while the taker runs: a joinable thread's destructor ends the process)
-  int taker_status = ZIPC_HIP_OK;
-  std::thread taker_thread;
-  try {
-    taker_thread = std::thread([&] {
-      try { taker_status = taker(); }
-      catch (...) { taker_error = "out of memory in the thread that takes the results back"; taker_status = ZIPC_HIP_ERR_NOMEM; }
-    });
-  } catch (...) {  // (no thread to be had; nothing is enqueued yet)
-    ctx->last_error = "zipc_hip: could not start the thread that takes the results back";
-    return ZIPC_HIP_ERR_NOMEM;
-  }
-
-  // ---- this thread: gather, copy in, kernels, the way back
-  double ms_gather = 0;
-  const uint64_t h2d_bytes = zd::tuning().host_h2d_mib > 0 ? (uint64_t)zd::tuning().host_h2d_mib << 20 : 0;
-  auto feed = [&]() -> int {
+  // ---- the device's part of the pipeline (host_pipeline.h Device): copies, kernels and events on three queues.  From
+  // begin() on, work is in flight that reads `descs` and the pinned buffers and records into the event sets above:
+  // many_pipeline returns only when its second thread is through, and after a failure all three queues are waited for
+  // below before anything is freed or the next call reuses the buffers.
+  struct Dev {
+    zipc_hip_ctx *ctx;
+    bool is_inflate, timing, packed, first_batch = true;
+    size_t n, max_src, max_cap;
+    int level, crc_op;
+    const size_t *src_len;
+    const std::vector<StreamDesc> &descs;
+    EventSet &ev_in, &ev_k, &ev_out, &ev_t;
+    decltype(dst_end) &dst_end_of;
+    std::string error;
 #define PIPE_TRY(expr)                                                                   \
   do {                                                                                   \
     hipError_t _e = (expr);                                                              \
     if (_e != hipSuccess) {                                                              \
-      ctx->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+      error = std::string(#expr) + ": " + hipGetErrorString(_e);                         \
       return ZIPC_HIP_ERR_HIP;                                                           \
     }                                                                                    \
   } while (0)
-    if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[0], ctx->copy_in));
-    PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
-    std::vector<Piece> pieces;
-    bool first_batch = true;
-    // sub-batch g's sources: gathered and sent in runs of streams of about h2d_bytes -- the bus starts on the first run
-    // while the next is gathered
-    auto gather_and_send = [&](size_t g) -> int {
-      const size_t lo = cut[g], hi = cut[g + 1];
-      for (size_t a = lo; a < hi;) {
-        size_t b = a + 1;
-        while (b < hi && (h2d_bytes == 0 || src_end(b) - src_end(a) < h2d_bytes)) b++;
-        const auto t_g = std::chrono::steady_clock::now();
-        pieces_of(a, b, [&](size_t i) { return (uint64_t)src_len[i]; }, pieces);
-        host_pool(0).run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
-          const Piece &p = pieces[j];
-          copy_streaming((uint8_t *)ctx->pin_src.p + descs[p.stream].src_off + p.at, (const uint8_t *)src[p.stream] + p.at, p.len);
-        });
-        ms_gather += since(t_g);
-        if (timing && a == lo) PIPE_TRY(hipEventRecord(ev_t.ev[1 + 2 * g], ctx->copy_in));
-        const uint64_t from = src_end(a), to = src_end(b);
-        PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + from, (const uint8_t *)ctx->pin_src.p + from, to - from,
-                                hipMemcpyHostToDevice, ctx->copy_in));
-        a = b;
-      }
-      t_gathered[g] = since(t_begin);
-      if (lo < hi) PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
+    int begin() {
+      if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[0], ctx->copy_in));
+      PIPE_TRY(hipMemcpyAsync(ctx->io_desc.p, descs.data(), n * sizeof(StreamDesc), hipMemcpyHostToDevice, ctx->copy_in));
       return ZIPC_HIP_OK;
-    };
-    // Long members' inflate may go by blocks inside inflate_batch, which waits for the device on the way (api.hip
-    // inflate_by_blocks): the NEXT sub-batch's sources are gathered and sent before this one's kernels are asked for, or
-    // they would not leave the host before those kernels are through (256 x 1 MiB: 22.0 -> 21.4 ms: what is left is the
-    // blocks' kernels, 7-8 ms a sub-batch of 128 MiB).  Everywhere else the
-    // kernels of a sub-batch are enqueued the moment its sources are under way.
-    const bool ahead = is_inflate && max_cap >= BLOCKS_BATCH_MIN_DST;
-    if (ahead) { const int st = gather_and_send(0); if (st) return st; }
-    for (size_t g = 0; g < K; g++) {
-      const size_t lo = cut[g], hi = cut[g + 1];
-      if (ahead ? g + 1 < K : true) { const int st = gather_and_send(ahead ? g + 1 : g); if (st) return st; }
-      if (lo < hi) {
-        PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
-        if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[2 + 2 * g], ctx->stream));
-        zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
-        zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
-        size_t total_g = 0;
-        for (size_t i = lo; i < hi; i++) total_g += src_len[i];
-        int st;
-        if (is_inflate)  // (with the descriptors it has on the host: no read-back, nothing waited for unless a stream goes by blocks)
-          st = inflate_batch_impl(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op, descs.data() + lo, first_batch);
-        else
-          st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
-        first_batch = false;
-        if (st) return st;
-        PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
-                                hipMemcpyDeviceToHost, ctx->stream));
-        const uint64_t c = dst_end(lo), e = dst_end(hi);
-        uint64_t *off = packed ? (uint64_t *)ctx->io_pack_off.p + lo + g : nullptr;
-        if (packed)
-          ZD_LAUNCH(ctx, "pack_offsets", pack_offsets_kernel, dim3(1), dim3(1024), 0, (const StreamDesc *)dd,
-                    (const StreamResult *)dr, (uint32_t)(hi - lo), c, off);
+    }
+    int send(size_t g, bool first, uint64_t from, uint64_t to) {
+      if (timing && first) PIPE_TRY(hipEventRecord(ev_t.ev[1 + 2 * g], ctx->copy_in));
+      PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->io_src.p + from, (const uint8_t *)ctx->pin_src.p + from, to - from,
+                              hipMemcpyHostToDevice, ctx->copy_in));
+      return ZIPC_HIP_OK;
+    }
+    int sent(size_t g) {
+      PIPE_TRY(hipEventRecord(ev_in.ev[g], ctx->copy_in));
+      return ZIPC_HIP_OK;
+    }
+    int launch(size_t g, size_t lo, size_t hi) {
+      PIPE_TRY(hipStreamWaitEvent(ctx->stream, ev_in.ev[g], 0));
+      if (timing) PIPE_TRY(hipEventRecord(ev_t.ev[2 + 2 * g], ctx->stream));
+      zipc_hip_stream_desc *dd = (zipc_hip_stream_desc *)ctx->io_desc.p + lo;
+      zipc_hip_stream_result *dr = (zipc_hip_stream_result *)ctx->io_res.p + lo;
+      size_t total_g = 0;
+      for (size_t i = lo; i < hi; i++) total_g += src_len[i];
+      int st;
+      if (is_inflate)  // (with the descriptors it has on the host: no read-back, nothing waited for unless a stream goes by blocks)
+        st = inflate_batch_impl(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_cap, crc_op, descs.data() + lo, first_batch);
+      else
+        st = zipc_hip_deflate_batch(ctx, ctx->io_src.p, ctx->io_dst.p, dd, dr, hi - lo, max_src, total_g, level, crc_op);
+      first_batch = false;
+      if (st) { error = ctx->last_error; return st; }
+      PIPE_TRY(hipMemcpyAsync((StreamResult *)ctx->pin_res.p + lo, dr, (hi - lo) * sizeof(StreamResult),
+                              hipMemcpyDeviceToHost, ctx->stream));
+      const uint64_t c = dst_end_of(lo), e = dst_end_of(hi);
+      uint64_t *off = packed ? (uint64_t *)ctx->io_pack_off.p + lo + g : nullptr;
+      if (packed)
+        ZD_LAUNCH(ctx, "pack_offsets", pack_offsets_kernel, dim3(1), dim3(1024), 0, (const StreamDesc *)dd,
+                  (const StreamResult *)dr, (uint32_t)(hi - lo), c, off);
+      PIPE_TRY(hipGetLastError());
+      PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
+      PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
+      if (packed) {  // its stores ARE the copy back, of as many bytes as the device knows it made, beside the next sub-batch's kernels
+        hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)zd::tuning().host_pack_wgs), dim3(256), 0, ctx->copy_out,
+                           (const uint8_t *)ctx->io_dst.p, (uint8_t *)ctx->pin_dst.p, (const StreamDesc *)dd,
+                           (const uint64_t *)off, (uint32_t)(hi - lo), c);
         PIPE_TRY(hipGetLastError());
-        PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
-        PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
-        if (packed) {  // its stores ARE the copy back, of as many bytes as the device knows it made, beside the next sub-batch's kernels
-          hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)zd::tuning().host_pack_wgs), dim3(256), 0, ctx->copy_out,
-                             (const uint8_t *)ctx->io_dst.p, (uint8_t *)ctx->pin_dst.p, (const StreamDesc *)dd,
-                             (const uint64_t *)off, (uint32_t)(hi - lo), c);
-          PIPE_TRY(hipGetLastError());
-        } else {
-          PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
-                                  hipMemcpyDeviceToHost, ctx->copy_out));
-        }
-        PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->copy_out));
+      } else {
+        PIPE_TRY(hipMemcpyAsync((uint8_t *)ctx->pin_dst.p + c, (const uint8_t *)ctx->io_dst.p + c, e - c,
+                                hipMemcpyDeviceToHost, ctx->copy_out));
       }
-      {
-        std::lock_guard<std::mutex> l(pm);
-        fed = g + 1;
-      }
-      pcv.notify_all();
+      PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->copy_out));
+      return ZIPC_HIP_OK;
+    }
+    int wait_back(size_t g) {  // (the taker's thread)
+      PIPE_TRY(hipSetDevice(ctx->device));
+      PIPE_TRY(hipEventSynchronize(ev_out.ev[g]));  // (behind ev_k[g]: the results have landed too)
+      return ZIPC_HIP_OK;
     }
 #undef PIPE_TRY
-    return ZIPC_HIP_OK;
-  };
-  const auto t_feed = std::chrono::steady_clock::now();
-  int feed_status;
-  try { feed_status = feed(); }
-  catch (...) { ctx->last_error = "zipc_hip: out of memory while feeding the device"; feed_status = ZIPC_HIP_ERR_NOMEM; }
-  const double ms_feed = since(t_feed);
-  if (feed_status) {
-    {
-      std::lock_guard<std::mutex> l(pm);
-      gave_up = true;
-    }
-    pcv.notify_all();
-  }
-  taker_thread.join();
-  if (feed_status || taker_status) {  // a batch call refused its arguments or a HIP call failed: the call fails as a whole
-    (void)hipStreamSynchronize(ctx->copy_in);  // (sub-batches scattered before that stay where they are)
-    (void)hipStreamSynchronize(ctx->stream);
+  } dev{ctx, is_inflate, timing, packed, true, n, max_src, max_cap, level, crc_op, src_len, descs, ev_in, ev_k, ev_out, ev_t, dst_end, {}};
+
+  zd_host::ManyJob<StreamDesc> job;
+  job.n = n; job.src = src; job.src_len = src_len; job.dst = dst; job.dst_cap = dst_cap; job.results = results;
+  job.descs = descs.data(); job.src_arena_end = so; job.dst_arena_end = dof;
+  job.cut = cut; job.n_max = n_max; job.packed = packed;
+  job.ahead = is_inflate && max_cap >= BLOCKS_BATCH_MIN_DST;
+  job.h2d_bytes = zd::tuning().host_h2d_mib > 0 ? (uint64_t)zd::tuning().host_h2d_mib << 20 : 0;
+  job.pin_src = (uint8_t *)ctx->pin_src.p; job.pin_dst = (const uint8_t *)ctx->pin_dst.p;
+  job.pin_res = (const zipc_hip_stream_result *)ctx->pin_res.p;
+  job.threads = host_threads();
+  zd_host::ManyTimes times;
+  std::string why;
+  const int pst = zd_host::many_pipeline(job, dev, host_pools(), why, timing ? &times : nullptr);
+  if (pst) {  // a batch call refused its arguments or a HIP call failed: the call fails as a whole
+    (void)hipStreamSynchronize(ctx->copy_in);  // (sub-batches scattered before that stay where they are, with their results;
+    (void)hipStreamSynchronize(ctx->stream);   //  every other entry of results[] carries the call's status and no bytes)
     (void)hipStreamSynchronize(ctx->copy_out);
-    if (!feed_status) ctx->last_error = taker_error;
-    return feed_status ? feed_status : taker_status;
+    ctx->last_error = why;
+    return pst;
   }
   HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_in));
   if (timing) {  // where each sub-batch was when: host clock from the call's begin, device clock from the first copy's begin
     fprintf(stderr, "zipc_hip %s_many n=%zu src_arena=%llu dst_arena=%llu ms: setup %.2f feed %.2f (of it gather %.2f) "
                     "scatter %.2f whole %.2f (threads %zu sub-batches %zu)\n",
-            is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)dof, ms_setup, ms_feed,
-            ms_gather, ms_scatter, since(t_begin), host_threads(), K);
+            is_inflate ? "inflate" : "deflate", n, (unsigned long long)so, (unsigned long long)dof, ms_setup, times.ms_feed,
+            times.ms_gather, times.ms_scatter, since(t_begin), host_threads(), K);
     for (size_t g = 0; g < K; g++) {
       if (cut[g] == cut[g + 1]) continue;
       float h0 = 0, h1 = 0, k0 = 0, k1 = 0, o1 = 0;
@@ -1651,23 +1480,30 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
       (void)hipEventElapsedTime(&o1, ev_t.ev[0], ev_out.ev[g]);
       fprintf(stderr, "  sub-batch %zu (%zu streams): host gathered at %.2f, scatter %.2f - %.2f | device copy in %.2f - %.2f, "
                       "kernels %.2f - %.2f, back by %.2f\n",
-              g, cut[g + 1] - cut[g], t_gathered[g], t_scatter_begin[g], t_scatter_end[g], h0, h1, k0, k1, o1);
+              g, cut[g + 1] - cut[g], times.gathered[g], times.scatter_begin[g], times.scatter_end[g], h0, h1, k0, k1, o1);
     }
   }
   return ZIPC_HIP_OK;
 }
 
-// (host vectors sized by n: what they throw when memory runs out stays on this side of the C boundary)
+// (host vectors sized by n: whatever they throw -- bad_alloc when memory runs out, length_error, system_error from a mutex
+// or a thread -- stays on this side of the C boundary: the call fails as out of memory, says so in zipc_hip_last_error, and
+// every entry of results[] is defined.  Only the setup before the pipeline can throw: many_pipeline itself does not.)
+static int many_threw(zipc_hip_ctx *ctx, size_t n, zipc_hip_stream_result *results) {
+  try { if (ctx) ctx->last_error = "zipc_hip: out of memory (or no thread) on the host while setting up a many-stream call"; } catch (...) {}
+  if (results) for (size_t i = 0; i < n; i++) results[i] = zipc_hip_stream_result{ZIPC_HIP_ERR_NOMEM, 0, 0};
+  return ZIPC_HIP_ERR_NOMEM;
+}
 int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len, int level,
                           int crc_op, void *const *dst, const size_t *dst_cap, zipc_hip_stream_result *results) {
   try { return many_streams(ctx, false, n, src, src_len, nullptr, level, crc_op, dst, dst_cap, results); }
-  catch (const std::bad_alloc &) { return ZIPC_HIP_ERR_NOMEM; }
+  catch (...) { return many_threw(ctx, n, results); }
 }
 int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
                           zipc_hip_stream_result *results) {
   try { return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, dst, dst_cap, results); }
-  catch (const std::bad_alloc &) { return ZIPC_HIP_ERR_NOMEM; }
+  catch (...) { return many_threw(ctx, n, results); }
 }
 
 // zlib_decompress src/zipc_deflate.ml:720-740 (start = 0): header checks on the

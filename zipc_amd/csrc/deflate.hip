@@ -879,7 +879,16 @@ __global__ __launch_bounds__(MATCHW_THREADS) void lz_match_window_kernel(const u
     // run-slot steps the tile took per position (a tile with a successor is a full one): chain steps / lane use
     if (has_next && form == 0) scan_form = (uint64_t)tile_iters[c.tile & 1u] * (64u * (scan_form ? MATCHW_SCAN_NP : MATCHW_NP)) > (uint64_t)MATCHW_SCAN_STEPS * (g.t1 - g.t0);
     store(n, gn);
-    if (tid == 0) { pool_next = 0; tile_iters[0] = tile_iters[1] = 0; probe_deep = 0; }  // the next tile's counters: nobody touches them now
+    // The next tile's counters: nobody touches them now.  NOT the counter the line above reads -- a wave may still be on its way
+    // to that read (round 5 cleared both here: a slow wave could then read 0 and take another form than the rest of its
+    // workgroup; the results were the same, the form rule and its timings were not deterministic).  With a successor the next
+    // tile's parity is the other one, and this tile's counter is cleared a tile later; without one nobody reads either.
+    if (tid == 0) {
+      pool_next = 0;
+      tile_iters[n.tile & 1u] = 0;
+      if (!has_next) tile_iters[(n.tile & 1u) ^ 1u] = 0;
+      probe_deep = 0;
+    }
     __syncthreads();
     first_of_group = !has_next;
     c = n;

@@ -72,7 +72,8 @@ def lib():
     global _host
     if _host is None:
         _lib.lib()  # libzipc_hip.so first (and torch before it, see _lib.py)
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzipc_host.so")
+        # ZIPC_HOST_LIB: another build of the same sources (tests/test_sanitizers.py: the host layer under the address sanitizer)
+        path = os.environ.get("ZIPC_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libzipc_host.so")
         if not os.path.exists(path):
             raise ImportError("libzipc_host.so is not built: run `make -C zipc_amd/host` (%s)" % path)
         L = C.CDLL(path)
