@@ -118,6 +118,13 @@ unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx);
  * order, which is the order insert_hash (zipc_deflate.ml:1150-1152) inserts positions in.  0: the probe failed and the
  * context keeps the kernel that orders them itself (same links either way).  For tests and measurements. */
 int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx);
+/* What the guards of that property have seen so far (round 6): positions whose links BOTH chain kernels made and were
+ * compared -- the create-time probe runs lz_chain_xchg_kernel itself, whole and by segments, on a stream made of runs,
+ * short periods and few-symbol alphabets; the context's first deflate batch has its first streams (ZIPC_HIP_CHAIN_CHECK,
+ * default 32, at most 16 MiB) chained by both kernels under that batch's load -- and how many differed.  A difference in
+ * the first batch fails that batch's streams with ZIPC_HIP_ERR_HIP and moves the context to the ordering kernel.
+ * Synchronises the context's stream. */
+int zipc_hip_chain_check(zipc_hip_ctx *ctx, unsigned long long *compared, unsigned long long *differences);
 /* Measurements only: the number of slices the batch forms cut a call into (side queues, api.hip batch_slices), for
  * every context of the process from now on; 0 = the default again (two slices of at least 2048 streams, or
  * ZIPC_HIP_SLICES).  bench.py times a kernel alone on the device with 1.  Results are the same for every value. */

@@ -137,3 +137,38 @@ def test_both_chain_kernels_make_the_same_links(gpu_ctx, shape):
         assert False, "%d links differ, the first at slot %d (exchange %d, peel %d)" % (
             bad.numel(), int(bad[0]), int(a[bad[0]]) & 0xFFFF, int(b[bad[0]]) & 0xFFFF)
     assert int(torch.count_nonzero(a)) > total // 8 or shape == "ragged"  # (the links are there: most positions of these inputs have one)
+
+
+def test_the_exchange_order_guards_have_run_and_agree():
+    """lz_chain_xchg_kernel is exact only if one LDS exchange serves same-address lanes in lane order.  Round 6's guards:
+    the context's create-time probe runs THE KERNEL (whole and by segments) on a stream of runs, short periods and
+    few-symbol alphabets and compares every link with the ordering kernel's; the context's first deflate batch has its
+    first streams chained by both kernels under that batch's load.  A fresh context: both have run, nothing differed, and
+    the batch's bytes are the oracle's."""
+    import oracle
+    import torch
+    import zipc_amd
+    from zipc_amd import batch, synth
+
+    ctx = zipc_amd.Context(0)
+    assert ctx.lds_exchange_ordered()
+    probed, bad = ctx.chain_check()
+    assert probed > 2 * 200000 and bad == 0  # the probe's stream twice: whole and by segments
+    dev = torch.device("cuda", 0)
+    n, L = 4096, 65536
+    src = synth.batch_bytes_torch(2, 0, n, L, 4, dev)
+    cap = batch.deflate_bound(L)
+    descs = batch.uniform_layout(n, L, cap)
+    comp = torch.zeros(n * int(descs["dst_off"][1]) + 256, dtype=torch.uint8, device=dev)
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device=dev)
+    d_descs = batch.to_device(descs, dev)
+    for rep in range(2):  # (the second batch is not checked again: once per context)
+        batch.deflate_batch(ctx, src, comp, d_descs, d_res, n, L, n * L, 2, 1)
+        res = batch.results_from_device(d_res)
+        assert (res["status"] == 0).all()
+        after, bad = ctx.chain_check()
+        assert bad == 0 and after == probed + 32 * (L - 3) and ctx.lds_exchange_ordered()
+    for j in (0, 31, 32, 4095):
+        st, c0, crc0 = oracle.deflate(synth.stream_bytes_np(2, j, L, 4).tobytes(), level=2, crc_op=oracle.CRC_CRC32)
+        o = int(descs["dst_off"][j])
+        assert comp[o:o + int(res["out_len"][j])].cpu().numpy().tobytes() == c0 and int(res["checksum"][j]) == crc0

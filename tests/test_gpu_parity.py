@@ -827,3 +827,69 @@ def test_unknown_descriptor_flags_are_an_invalid_argument(gpu_ctx, oracle):
         assert not bool(dst[20480:20480 * 3].any())
         if n > 3:
             assert (res["status"][3:] == 0).all() and dst[20480 * (n - 1):20480 * (n - 1) + len(data)].cpu().numpy().tobytes() == data
+
+
+# ---- double entry for the encode side (round 6): the GPU against tests/golden/deflate_vectors.json -------------------
+# The file is what a second, independent reading of src/zipc_deflate.ml's encoder makes of 50 named inputs (see
+# tests/test_oracle_pins.py, tests/golden/make_deflate_vectors.py): no oracle in these two tests -- the kernels' bytes are held
+# directly against the hashes, through the one-stream host forms and through one ragged call of the batch form.
+
+def _vectors():
+    import json
+    import os
+
+    return json.load(open(os.path.join(util.GOLDEN, "deflate_vectors.json")))
+
+
+def test_deflate_host_forms_equal_the_second_readings_vectors(gpu_ctx):
+    import hashlib
+
+    from zipc_amd import zipc_deflate as Z
+
+    doc = _vectors()
+    checked = 0
+    for name, v in doc["vectors"].items():
+        data = util.vector_input(name)
+        for level, want in v["levels"].items():
+            crc, cs = Z.crc_32_and_deflate(data, level=level).get_ok()
+            assert (len(cs), hashlib.sha256(cs).hexdigest(), crc) == (want["clen"], want["sha256"], want["crc32"]), (name, level)
+            adler, cs2 = Z.adler_32_and_deflate(data, level=level).get_ok()
+            assert cs2 == cs and adler == want["adler32_fused"], (name, level)  # per-block chaining, signed remainder (Q6/Q7)
+            checked += 1
+    assert checked >= 130
+    for name, want in doc["adler32_whole"].items():
+        assert Z.Adler_32.string(util.vector_input(name)) == want, name
+
+
+def test_deflate_batch_form_equals_the_second_readings_vectors(gpu_ctx):
+    import hashlib
+
+    import torch
+
+    from zipc_amd import batch
+
+    dev = torch.device("cuda", 0)
+    doc = _vectors()
+    for level, lv in (("fast", 1), ("default", 2), ("best", 3)):
+        names = [n for n, v in doc["vectors"].items() if level in v["levels"]]
+        streams = [util.vector_input(n) for n in names]
+        src_off = np.cumsum([0] + [len(s) for s in streams[:-1]]).astype(np.uint64)
+        caps = [batch.deflate_bound(len(s)) for s in streams]
+        slots = [(c + 255) // 256 * 256 for c in caps]
+        dst_off = np.cumsum([0] + slots[:-1]).astype(np.uint64)
+        descs = batch.make_descs(src_off, [len(s) for s in streams], dst_off, caps)
+        src = torch.from_numpy(np.frombuffer(b"".join(streams) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+        d_descs = batch.to_device(descs, dev)
+        total = int(sum(len(s) for s in streams))
+        for crc_op, key in ((1, "crc32"), (2, "adler32_fused")):
+            dst = torch.zeros(int(sum(slots)) + 256, dtype=torch.uint8, device=dev)
+            d_res = torch.zeros(len(streams) * 16, dtype=torch.uint8, device=dev)
+            batch.deflate_batch(gpu_ctx, src, dst, d_descs, d_res, len(streams), max(len(s) for s in streams), total, lv, crc_op)
+            res = batch.results_from_device(d_res)
+            out = dst.cpu().numpy()
+            for i, n in enumerate(names):
+                want = doc["vectors"][n]["levels"][level]
+                assert res["status"][i] == 0 and int(res["out_len"][i]) == want["clen"], (n, level)
+                o = int(dst_off[i])
+                assert hashlib.sha256(out[o:o + want["clen"]].tobytes()).hexdigest() == want["sha256"], (n, level)
+                assert int(res["checksum"][i]) == want[key], (n, level, key)

@@ -1,6 +1,8 @@
 """Pins the CPU oracle (oracle/zd_oracle.c) to everything the reference's own
 tests hold for this path and to Python zlib as an independent
 decoder / checksum.  No GPU."""
+import os
+import sys
 import zlib
 
 import pytest
@@ -188,3 +190,75 @@ def test_huffman_length_limit_retry(oracle):
     assert max(lens7) <= 7
     assert oracle.huffman_lengths([0, 5, 0], 15) == [0, 1, 0]  # single symbol -> length 1
     assert oracle.huffman_lengths([0, 0, 0], 15) == [0, 0, 0]
+
+
+# ---- double entry for the encode side (round 6) --------------------------------------------------------------------
+# tests/golden/deflate_vectors.json is what a SECOND reading of src/zipc_deflate.ml:166-206,404-528,742-1277 -- naive Python
+# written from the .ml without looking at oracle/zd_oracle.c (tests/golden/zd_second_reading.py, run by
+# make_deflate_vectors.py in the build container) -- makes of 50 named inputs at `Fast / `Default / `Best: the reference
+# itself holds no vector for compressed bytes (test/test.ml:33-36 only round-trips).  Two readings that must agree.
+
+def _vectors():
+    import json
+
+    return json.load(open(os.path.join(util.GOLDEN, "deflate_vectors.json")))
+
+
+def test_oracle_equals_the_second_reading_of_the_encoder(oracle):
+    import hashlib
+
+    doc = _vectors()
+    kinds = {0: "none", 1: "fixed", 2: "dynamic"}
+    checked = 0
+    for name, v in doc["vectors"].items():
+        data = util.vector_input(name)
+        assert len(data) == v["len"] and hashlib.sha256(data).hexdigest() == v["sha256_plain"], name
+        for level, want in v["levels"].items():
+            lv = oracle.LEVELS[level]
+            oracle.huffman_retries(reset=True)
+            st, c, crc, blocks = oracle.deflate_trace(data, level=lv, crc_op=oracle.CRC_CRC32)
+            retries = sum(oracle.huffman_retries())
+            assert st == 0 and len(c) == want["clen"] and hashlib.sha256(c).hexdigest() == want["sha256"], (name, level)
+            assert crc == want["crc32"] == zlib.crc32(data), (name, level)
+            # the kind of every block (the chooser, zd.ml:1094-1104) and how often lengths_of_freqs retried (zd.ml:470-473)
+            got_kinds = " ".join(k if n == 1 else "%s*%d" % (k, n) for k, n in _runs([kinds[b.kind] for b in blocks]))
+            assert got_kinds == want["blocks"], (name, level, got_kinds)
+            assert retries == want["huffman_retries"], (name, level, retries)
+            # the fused Adler-32: one update per block (Q7), signed remainder (Q6)
+            st, c2, adler = oracle.deflate(data, level=lv, crc_op=oracle.CRC_ADLER32)
+            assert c2 == c and adler == want["adler32_fused"], (name, level)
+            checked += 1
+    assert checked >= 130
+    # Adler_32.string over whole buffers: the values no standard library gives (0xFF x 4200 -> a2045889)
+    for name, want in doc["adler32_whole"].items():
+        assert oracle.adler32(util.vector_input(name)) == want, name
+    assert doc["adler32_whole"]["ff4200"] == 0xA2045889 and zlib.adler32(b"\xff" * 4200) != 0xA2045889
+
+
+def _runs(xs):
+    out = []
+    for x in xs:
+        if out and out[-1][0] == x:
+            out[-1][1] += 1
+        else:
+            out.append([x, 1])
+    return out
+
+
+def test_the_second_reading_is_live_and_reproduces_its_vectors():
+    """the generator's own code on the quick inputs: the committed file is what this code makes (not a stale artefact)"""
+    import hashlib
+
+    sys.path.insert(0, util.GOLDEN)
+    import zd_second_reading as Z2
+
+    doc = _vectors()
+    for name in ("trip0", "trip1", "trip2", "trip3", "trip4", "fib_codelen", "ff4200", "zipdocs_rfc1951", "c2_stream0"):
+        data = util.vector_input(name)
+        for level, want in doc["vectors"][name]["levels"].items():
+            crc, comp, stats = Z2.crc_and_deflate(data, level, Z2.CRC_32)
+            assert (len(comp), hashlib.sha256(comp).hexdigest(), crc) == (want["clen"], want["sha256"], want["crc32"]), (name, level)
+    # the block kinds the reference's own test comments expect (test/test.ml:38-42): Fixed, Fixed, Fixed, Dynamic, None
+    assert [doc["vectors"]["trip%d" % i]["levels"]["default"]["blocks"] for i in range(5)] == ["fixed", "fixed", "fixed", "dynamic", "none"]
+    assert Z2.adler_32_string(b"\xff" * 4200) == doc["adler32_whole"]["ff4200"]
+    assert Z2.zlib_compress(b"hello world", "default")[1][:2].hex() == "789c"

@@ -58,6 +58,7 @@ SYMBOLS = [
     ("zipc_hip_stream", _P, [_P]),
     ("zipc_hip_synchronize", C.c_int, [_P]),
     ("zipc_hip_last_error", C.c_char_p, [_P]),
+    ("zipc_hip_chain_check", C.c_int, [_P, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]),
     ("zipc_hip_last_inflate_blocks", C.c_uint, [_P]),
     ("zipc_hip_lds_exchange_ordered", C.c_int, [_P]),
     ("zipc_hip_debug_set_slices", None, [C.c_long]),
@@ -154,6 +155,13 @@ class Context:
     def lds_exchange_ordered(self) -> bool:
         """hash chains are built by ordered LDS exchange (the context's probe passed; include/zipc_hip.h)"""
         return bool(lib().zipc_hip_lds_exchange_ordered(self._h))
+
+    def chain_check(self):
+        """(positions whose links both chain kernels made and were compared, how many differed): the create-time probe in
+        the kernel's own shape plus the first streams of this context's first deflate batch (include/zipc_hip.h)"""
+        a, b = C.c_ulonglong(), C.c_ulonglong()
+        self.check(lib().zipc_hip_chain_check(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
 
     def set_profiling(self, on: bool):
         self.check(lib().zipc_hip_set_profiling(self._h, int(on)))

@@ -209,6 +209,7 @@ const Tuning &tuning() {
     auto is = [](const char *name, const char *v) { const char *e = getenv(name); return e && !strcmp(e, v); };
     Tuning x;
     x.chain_peel = is("ZIPC_HIP_CHAIN", "peel");
+    x.chain_check = num("ZIPC_HIP_CHAIN_CHECK", 32);
     x.parse_segments = num("ZIPC_HIP_PARSE_SEGMENTS", -1);
     x.parse_seg = num("ZIPC_HIP_PARSE_SEG", 0);
     x.match_tiles_per_group = num("ZIPC_HIP_MATCH_TILES_PER_GROUP", 0);
@@ -375,6 +376,8 @@ void zipc_hip_destroy(zipc_hip_ctx *ctx) {
   free_buf(ctx->tok_scratch);
   free_buf(ctx->descs_marked);
   free_buf(ctx->stored_list);
+  free_buf(ctx->chain_check_links);
+  if (ctx->chain_check_host) (void)hipHostFree(ctx->chain_check_host);
   if (ctx->pin_src.p) (void)hipHostFree(ctx->pin_src.p);
   if (ctx->pin_dst.p) (void)hipHostFree(ctx->pin_dst.p);
   if (ctx->pin_res.p) (void)hipHostFree(ctx->pin_res.p);
@@ -399,6 +402,16 @@ int zipc_hip_synchronize(zipc_hip_ctx *ctx) {
 const char *zipc_hip_last_error(zipc_hip_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
 unsigned zipc_hip_last_inflate_blocks(zipc_hip_ctx *ctx) { return ctx ? ctx->last_inflate_blocks : 0u; }
 int zipc_hip_lds_exchange_ordered(zipc_hip_ctx *ctx) { return ctx && ctx->xchg_ordered ? 1 : 0; }
+int zipc_hip_chain_check(zipc_hip_ctx *ctx, unsigned long long *compared, unsigned long long *differences) {
+  if (!ctx || !compared || !differences) return ZIPC_HIP_ERR_INVALID_ARG;
+  *compared = *differences = 0;
+  if (!ctx->chain_check_host) return ZIPC_HIP_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  *compared = ctx->chain_check_host[1] + ctx->chain_check_host[3];
+  *differences = ctx->chain_check_host[0] + ctx->chain_check_host[2];
+  return ZIPC_HIP_OK;
+}
 void zipc_hip_debug_set_slices(long k) { zd::g_slices_override = k; }
 
 int zipc_hip_set_adler_rfc1950(zipc_hip_ctx *ctx, int enabled) {

@@ -51,6 +51,9 @@ struct zipc_hip_ctx {
   Buf stored_list;                                // inflate of one stream beyond 4 GiB: the stored blocks a walk listed
   Buf blocks_scratch, tok_scratch;                // inflate of streams by a wave per block: candidates, chains; a word per output byte
   Buf descs_marked;                               // ... a call's descriptors with those streams marked as done, for the one waves of the rest
+  Buf chain_check_links;                          // lz_chain's run-time check: the links the exchange kernel made of a batch's first streams
+  unsigned long long *chain_check_host = nullptr; // ... [0] differences, [1] positions compared in the context's first batch; [2], [3]: the same for the create-time probe (device-visible host memory)
+  bool chain_checked = false;                     // ... that first batch has been seen
   uint32_t last_inflate_blocks = 0;               // blocks of the last one-stream inflate that went that way (0: it did not)
 
   int name_index(const char *name);

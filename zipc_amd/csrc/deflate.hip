@@ -516,6 +516,68 @@ __global__ __launch_bounds__(64) void xchg_order_probe_kernel(uint32_t *__restri
   if (lane == 0) out[0] = bad;
 }
 
+// ---- the guard in the kernel's own shape (round 6) ---------------------------------------------------------------
+// The toy above is one wave on 64 words.  lz_chain_xchg_kernel is four waves taking turns on a 128 KiB table, 16 exchanges
+// a turn, with loads in flight beside them: a chip (or a firmware) that served same-address lanes out of order only
+// under that load would pass the toy and write valid streams with the wrong bytes.  So the context also runs THE KERNEL
+// on a stream made for it and compares its links with lz_chain_kernel's, which orders equal hashes itself:
+//   runs of one byte (every lane of every round on one address, 16 rounds a turn, turn after turn), periods of 2, 3, 5
+//   and 7 bytes (a few addresses a round, each hit by many lanes), symbols of 1 and 2 bits (a few dozen addresses,
+//   chains thousands deep), nibbles, bytes, and the same runs again more than a window later (links beyond 32768).
+// And every context checks the first streams of its first real batch the same way, under the load of that batch
+// (chain_check below).
+static std::vector<uint8_t> xchg_probe_stream() {
+  std::vector<uint8_t> v;
+  uint32_t x = 0x2545F491u;
+  auto rnd = [&] { x ^= x << 13; x ^= x >> 17; x ^= x << 5; return x; };
+  auto run = [&](size_t n, uint8_t b) { v.insert(v.end(), n, b); };
+  auto period = [&](size_t n, int k) { for (size_t i = 0; i < n; i++) v.push_back((uint8_t)('a' + i % k)); };
+  auto symbols = [&](size_t n, int bits) { for (size_t i = 0; i < n; i++) v.push_back((uint8_t)(rnd() >> 9 & ((1u << bits) - 1))); };
+  run(20000, 0); period(9000, 2); period(9000, 3); period(6000, 5); period(6000, 7);
+  symbols(24000, 1); symbols(24000, 2); symbols(20000, 4); symbols(12000, 8);
+  run(3000, 0xFF); run(5000, 0); symbols(9000, 1);            // (these zeros: 130 000 positions behind the first ones)
+  run(70000, 7); period(5000, 2); symbols(8000, 3); run(1031, 0);  // a run longer than two windows, an odd end
+  return v;
+}
+
+__global__ __launch_bounds__(256) void chain_links_save_kernel(const StreamDesc *__restrict__ descs, DeflateScratch S, uint16_t *__restrict__ saved) {
+  const StreamDesc sd = descs[blockIdx.x];
+  if (S.error[0] || sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
+  const uint64_t base = S.pos_base[blockIdx.x], base0 = S.pos_base[0];
+  for (uint64_t p = threadIdx.x; p < sd.src_len - 3; p += 256) saved[base - base0 + p] = S.prev[base + p];
+}
+// out[0] += positions whose saved link differs from the one in the scratch now, out[1] += positions compared; a difference
+// also sets the batch's error word to 2: every stream of the call then reports ZIPC_HIP_ERR_HIP instead of bytes nobody checked.
+__global__ __launch_bounds__(256) void chain_links_compare_kernel(const StreamDesc *__restrict__ descs, DeflateScratch S, const uint16_t *__restrict__ saved,
+                                                                  unsigned long long *__restrict__ out) {
+  const StreamDesc sd = descs[blockIdx.x];
+  if (S.error[0] == 1u || sd.src_len < 4 || sd.src_len > MAX_STREAM_LEN) return;
+  const uint64_t base = S.pos_base[blockIdx.x], base0 = S.pos_base[0];
+  uint32_t bad = 0;
+  for (uint64_t p = threadIdx.x; p < sd.src_len - 3; p += 256) bad += saved[base - base0 + p] != S.prev[base + p] ? 1u : 0u;
+  bad = wave_sum(bad);
+  if ((threadIdx.x & 63u) == 0 && bad) {
+    __hip_atomic_fetch_add(&out[0], (unsigned long long)bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    S.error[0] = 2u;
+  }
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(&out[1], (unsigned long long)(sd.src_len - 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Streams [0, k) of a batch whose links lz_chain_xchg(_segments)_kernel has just written (S.prev): keep a copy, let
+// lz_chain_kernel write them again -- exact links either way from here on -- and count the differences into `counts`
+// (device-visible host memory: nothing waits for it).  Enqueued on ctx->cur.
+static hipError_t chain_check_enqueue(zipc_hip_ctx *ctx, const uint8_t *d_src, const StreamDesc *dd, DeflateScratch Q, size_t k, size_t max_src_len,
+                                      unsigned long long *counts) {
+  const size_t positions = k * (size_t)padded_positions(max_src_len);
+  const hipError_t e = ctx->ensure(ctx->chain_check_links, positions * 2);
+  if (e != hipSuccess) return e;
+  uint16_t *saved = (uint16_t *)ctx->chain_check_links.p;
+  ZD_LAUNCH(ctx, "chain_check", chain_links_save_kernel, dim3((unsigned)k), dim3(256), 0, dd, Q, saved);
+  ZD_LAUNCH(ctx, "chain_check", lz_chain_kernel, dim3((unsigned)k), dim3(CHAIN_THREADS), 0, d_src, dd, Q);
+  ZD_LAUNCH(ctx, "chain_check", chain_links_compare_kernel, dim3((unsigned)k), dim3(256), 0, dd, Q, (const uint16_t *)saved, counts);
+  return hipGetLastError();
+}
+
 bool xchg_order_probe(zipc_hip_ctx *ctx) {
   if (ctx->ensure(ctx->io_small, 256) != hipSuccess) return false;
   uint32_t *d = (uint32_t *)ctx->io_small.p;
@@ -524,7 +586,45 @@ bool xchg_order_probe(zipc_hip_ctx *ctx) {
   hipLaunchKernelGGL(xchg_order_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, d);
   if (hipMemcpyAsync(&h, d, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return false;
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;
-  return h == 0;
+  if (h != 0) return false;
+  // ... and the kernel itself, whole and by segments, against the kernel that orders equal hashes itself
+  if (!ctx->chain_check_host) {
+    if (hipHostMalloc((void **)&ctx->chain_check_host, 4 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess) { ctx->chain_check_host = nullptr; return false; }
+    memset(ctx->chain_check_host, 0, 4 * sizeof(unsigned long long));
+  }
+  const std::vector<uint8_t> v = xchg_probe_stream();
+  const size_t len = v.size();
+  StreamDesc sd;
+  memset(&sd, 0, sizeof sd);
+  sd.src_len = len; sd.dst_cap = len;
+  zipc_hip_ctx::Buf src, desc;
+  bool ok = false;
+  do {
+    if (ctx->ensure(src, len + 64) != hipSuccess || ctx->ensure(desc, sizeof sd) != hipSuccess) break;
+    if (ctx->ensure(ctx->deflate_scratch, deflate_scratch_bytes(1, len, len, LEVEL_DEFAULT)) != hipSuccess) break;
+    if (hipMemcpyAsync(src.p, v.data(), len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) break;
+    if (hipMemcpyAsync(desc.p, &sd, sizeof sd, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) break;
+    DeflateScratch S = carve(ctx->deflate_scratch.p, 1, len, LEVEL_DEFAULT);
+    unsigned long long *counts = ctx->chain_check_host + 2;  // [2], [3]: the probe's; [0], [1]: the first batch's
+    counts[0] = counts[1] = 0;
+    bool launched = true;
+    for (int form = 0; form < 2 && launched; form++) {
+      hipLaunchKernelGGL(deflate_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, (const StreamDesc *)desc.p, 1u, S, (uint64_t)len);
+      if (form == 0)
+        hipLaunchKernelGGL(lz_chain_xchg_kernel, dim3(1), dim3(64 * XCHG_WAVES), 0, ctx->stream, (const uint8_t *)src.p, (const StreamDesc *)desc.p, S);
+      else {
+        const uint32_t xseg = 96u << 10, xsegs = (uint32_t)((len + xseg - 1) / xseg);
+        hipLaunchKernelGGL(lz_chain_xchg_segments_kernel, dim3(xsegs), dim3(64 * XCHG_WAVES), 0, ctx->stream, (const uint8_t *)src.p,
+                           (const StreamDesc *)desc.p, S, xsegs, xseg);
+      }
+      launched = chain_check_enqueue(ctx, (const uint8_t *)src.p, (const StreamDesc *)desc.p, S, 1, len, counts) == hipSuccess;
+    }
+    if (!launched || hipStreamSynchronize(ctx->stream) != hipSuccess) break;
+    ok = counts[0] == 0 && counts[1] == 2 * (unsigned long long)(len - 3);
+  } while (0);
+  if (src.p) (void)hipFree(src.p);
+  if (desc.p) (void)hipFree(desc.p);
+  return ok;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2041,7 +2141,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
   const int lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
-    if (MODE == 0 && lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
+    if (MODE == 0 && lane == 0) { StreamResult r; r.status = S.error[0] == 2u ? ST_HIP : ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
     return;
   }
   const uint8_t *src = src_arena + sd.src_off;
@@ -2478,7 +2578,7 @@ __global__ __launch_bounds__(64) void deflate_scan_kernel(const StreamDesc *__re
   const uint32_t lane = threadIdx.x;
   const StreamDesc sd = descs[stream];
   if (S.error[0] || sd.src_len > MAX_STREAM_LEN || sd.dst_cap > MAX_STREAM_LEN) {
-    if (lane == 0) { StreamResult r; r.status = ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
+    if (lane == 0) { StreamResult r; r.status = S.error[0] == 2u ? ST_HIP : ST_INVALID_ARG; r.checksum = 0; r.out_len = 0; results[stream] = r; }
     return;
   }
   const uint32_t nblk = S.n_blocks[stream];
@@ -2787,7 +2887,23 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // lz_chain: by ordered exchange where the context's probe passed (ZIPC_HIP_CHAIN=peel keeps the peel kernel: tests, A/B).
   // A wave per stream leaves most of the chip idle while there are fewer streams than CUs: a long stream is then cut into
   // segments of xseg positions, each warmed up with the 32 Ki positions before it (at most a third more work at 96 Ki).
+  // A context whose first batch's check found a difference (counted in device-visible host memory, read here without waiting:
+  // the next call at the latest sees it) keeps the other kernel from then on.
+  if (ctx->xchg_ordered && ctx->chain_check_host && ctx->chain_check_host[0] != 0) {
+    ctx->xchg_ordered = false;
+    ctx->last_error = "zipc_hip: lz_chain by ordered LDS exchange disagreed with the ordering kernel on this context's first batch; "
+                      "that batch's streams reported ZIPC_HIP_ERR_HIP, the context now orders equal hashes itself";
+  }
   const bool xchg_chain = ctx->xchg_ordered && !tuning().chain_peel;
+  // ZIPC_HIP_CHAIN_CHECK=N (default 32; 0: never): the first N streams of the context's FIRST batch -- as many of them as hold
+  // 16 MiB of source -- are chained by both kernels and compared (chain_check_enqueue)
+  size_t check_k = 0;
+  if (xchg_chain && !ctx->chain_checked && tuning().chain_check > 0 && ctx->chain_check_host) {
+    check_k = (size_t)tuning().chain_check < n ? (size_t)tuning().chain_check : n;
+    const size_t fit = max_src_len ? ((size_t)16 << 20) / max_src_len : check_k;
+    check_k = check_k > fit ? (fit ? fit : 1) : check_k;
+    ctx->chain_checked = true;
+  }
   size_t xseg = 0, xsegs = 1;
   if (xchg_chain && n < 1024 && max_src_len > ((size_t)192 << 10)) {
     xseg = (size_t)96 << 10;
@@ -2806,6 +2922,10 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
                   (uint32_t)xsegs, (uint32_t)xseg);
       else
         ZD_LAUNCH(ctx, "lz_chain", lz_chain_xchg_kernel, dim3((unsigned)m), dim3(64 * XCHG_WAVES), 0, d_src, dd, Q);
+      if (lo == 0 && check_k) {
+        const hipError_t ce = chain_check_enqueue(ctx, d_src, dd, Q, check_k < m ? check_k : m, max_src_len, ctx->chain_check_host);
+        if (ce != hipSuccess) slice_err = ce;
+      }
     } else if (segmented && csegs > 1 && m <= 128)  // (the run-up is a quarter more work: only while workgroups are what is missing)
       ZD_LAUNCH(ctx, "lz_chain", lz_chain_segments_kernel, dim3((unsigned)(m * csegs)), dim3(CHAIN_THREADS), 0, d_src, dd,
                 Q, (uint32_t)csegs, (uint32_t)chain_seg);

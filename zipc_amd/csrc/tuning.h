@@ -18,6 +18,9 @@ struct Tuning {
   bool chain_peel;             // ZIPC_HIP_CHAIN=peel     hash chains by the kernel that orders equal hashes itself (lz_chain_kernel)
                                //                          instead of ordered LDS exchange (lz_chain_xchg_kernel, the default where the
                                //                          context's probe passes)
+  long chain_check;            // ZIPC_HIP_CHAIN_CHECK=N   the first N streams of a context's first deflate batch are chained by BOTH kernels and
+                               //                          compared, under that batch's load (default 32, at most 16 MiB of source; 0: never).  A
+                               //                          difference fails the batch (ZIPC_HIP_ERR_HIP) and moves the context to the ordering kernel
   long parse_segments;         // ZIPC_HIP_PARSE_SEGMENTS  -1 (default): parse and blocks by many waves for few long streams; 0 never;
                                //                          1 whenever a stream has two segments
   long parse_seg;              // ZIPC_HIP_PARSE_SEG       positions per parse segment (default 0: by stream length, 4096-16384)

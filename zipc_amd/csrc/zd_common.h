@@ -29,6 +29,7 @@ enum : uint32_t {
   ST_CORRUPTED = 1,
   ST_SIZE_EXCEEDED = 2,
   ST_DST_TOO_SMALL = 16,
+  ST_HIP = 17,  // a device-side check of the library itself failed (lz_chain: deflate.hip chain_check)
   ST_INVALID_ARG = 18,
 };
 enum : int { CRC_NOP = 0, CRC_CRC32 = 1, CRC_ADLER32 = 2, CRC_ADLER32_RFC = 3 };  // 3: RFC 1950's Adler-32, not the reference's (Q6/Q7)
