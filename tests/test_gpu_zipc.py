@@ -269,20 +269,50 @@ def test_command_line_like_the_reference_tool(host, oracle, tmp_path):
     run("unzip", "-d", str(out), str(arc))
     for p, d in files.items():
         assert (out / "tree" / p).read_bytes() == d
-    # recode at another level: same members, same bytes back
+    # recode at another level: same members, same bytes back (the default, --as-is, writes the members as they are)
     rec = tmp_path / "r.zip"
-    run("recode", "--level", "fast", "-o", str(rec), str(arc))
+    run("recode", "--deflate", "--level", "fast", "-o", str(rec), str(arc))
     with zipfile.ZipFile(rec) as zf:
         assert zf.testzip() is None and zf.read("tree/a.txt") == files["a.txt"]
     assert os.path.getsize(rec) != os.path.getsize(arc)
-    # a damaged archive member is reported by unzip -t
+    same = tmp_path / "same.zip"
+    run("recode", "-o", str(same), str(arc))
+    assert same.read_bytes() == arc.read_bytes()
+    st = tmp_path / "stored.zip"
+    run("recode", "-u", "-o", str(st), str(arc))
+    with zipfile.ZipFile(st) as zf:
+        assert zf.testzip() is None and all(i.compress_type == zipfile.ZIP_STORED for i in zf.infolist())
+    # recode -t: nothing written, the recoded archive decoded again -- in memory, or by a command (test/zipc_tool.ml:485-545)
+    assert run("recode", "--deflate", "-t", str(arc)) == b""
+    if shutil.which("unzip"):
+        assert run("recode", "--deflate", "--level", "default", "-t", "--check-cmd=unzip -P '' -q -q -t", str(arc)) == b""
+    rr = subprocess.run([tool, "recode", "--deflate", "-t", "--check-cmd", "false", str(arc)], capture_output=True)
+    assert rr.returncode == 123 and b"check command returned 1" in rr.stderr
+    # a damaged archive member is reported by unzip -t: exit 2, "corrupted" (test/zipc_tool.ml:282-311)
     b = bytearray(arc.read_bytes())
     off = zo[b"tree/sub/deep/c.dat"]["kind"]["start"]
     b[off + 100] ^= 0x55
     bad = tmp_path / "bad.zip"
     bad.write_bytes(bytes(b))
     rr = subprocess.run([tool, "unzip", "-t", str(bad)], capture_output=True)
-    assert rr.returncode == 1 and b"tree/sub/deep/c.dat" in rr.stderr
+    assert rr.returncode == 2 and b"tree/sub/deep/c.dat" in rr.stderr
+    # a member in a format the codec does not decode: exit 3 unless --skip (test/zipc_tool.ml:650-656)
+    other = tmp_path / "bz.zip"
+    with zipfile.ZipFile(other, "w") as zf:
+        zf.writestr("plain.txt", files["a.txt"], compress_type=zipfile.ZIP_DEFLATED)
+        zf.writestr("packed.bz2", files["a.txt"], compress_type=zipfile.ZIP_BZIP2)
+    rr = subprocess.run([tool, "unzip", "-t", str(other)], capture_output=True)
+    assert rr.returncode == 3 and b"packed.bz2: Cannot decompress format bz2" in rr.stderr
+    rr = subprocess.run([tool, "unzip", "-t", "--skip", "-v", str(other)], capture_output=True)
+    assert rr.returncode == 0 and b"[ OK ] plain.txt" in rr.stderr and b"[ ?? ] packed.bz2" in rr.stderr
+    run("recode", "--deflate", "-t", str(other))  # the bzip2 member is kept as it is
+    # sniff: the ZIP files below a directory, NUL separated; a file without the magic is exit 4 (test/zipc_tool.ml:556-579)
+    got = run("sniff", "-0", "-r", "-P", str(tmp_path)).split(b"\0")
+    assert got[-1] == b"" and {os.path.basename(g) for g in got[:-1]} == {b"t.zip", b"r.zip", b"same.zip", b"stored.zip", b"bad.zip", b"bz.zip"}
+    assert run("sniff", str(arc)).strip() == str(arc).encode()
+    assert run("sniff", str(tree)) == b""  # (no -r: a directory's own files only; the tree holds no archive)
+    rr = subprocess.run([tool, "sniff", str(tree / "a.txt"), str(arc)], capture_output=True)
+    assert rr.returncode == 4 and b"Not a ZIP archive" in rr.stderr and rr.stdout.strip() == str(arc).encode()
 
 
 def test_real_files_at_every_level_equal_oracle(host, oracle):
