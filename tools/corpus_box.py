@@ -40,10 +40,18 @@ def run(cmd, **kw):
     return r.returncode, r.stdout, r.stderr, time.perf_counter() - t
 
 
-def sniff(roots):
-    """zipc-hip sniff -0 -P -r ROOTS -> paths (DEVEL.md:9)"""
-    rc, out, err, dt = run([TOOL, "sniff", "-0", "-P", "-r"] + list(roots))
-    return [p.decode("utf-8", "surrogateescape") for p in out.split(b"\0") if p], rc, dt
+def sniff(roots, timeout_s):
+    """zipc-hip sniff -0 -P -r ROOTS -> paths (DEVEL.md:9); a walk that outlasts timeout_s is cut and what it found so far is used"""
+    t = time.perf_counter()
+    p = subprocess.Popen([TOOL, "sniff", "-0", "-P", "-r"] + list(roots), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        out, _ = p.communicate(timeout=timeout_s)
+        rc = p.returncode
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, _ = p.communicate()
+        rc = -1
+    return [q.decode("utf-8", "surrogateescape") for q in out.split(b"\0")[:None if rc != -1 else -1] if q], rc, time.perf_counter() - t
 
 
 def verdict_ours(rc):
@@ -96,24 +104,32 @@ def shell_quote(p):
     return "'" + p.replace("'", "'\\''") + "'"
 
 
-def tree_files(tree, want_bytes, max_file=1 << 30):
-    """regular files below `tree`, largest directories first come as they come (sorted walk), until want_bytes are in"""
-    out, total = [], 0
-    for base, dirs, names in os.walk(tree):
-        dirs.sort()
-        for n in sorted(names):
-            p = os.path.join(base, n)
-            try:
-                st = os.lstat(p)
-            except OSError:
-                continue
-            if not os.path.isfile(p) or os.path.islink(p) or st.st_size == 0 or st.st_size > max_file:
-                continue
-            out.append((p, st.st_size))
-            total += st.st_size
-            if total >= want_bytes:
-                return out, total
-    return out, total
+def tree_files(trees, want_bytes, max_file, read_budget_s):
+    """Regular files below `trees` (sorted walk) until want_bytes are in -- each READ once here, so that what is timed later
+    is not the image's pages coming in from wherever a fresh box keeps them (the first read of 1 GB of /opt/rocm/lib took
+    minutes on one box, seconds on the next); the walk stops when the reads have taken read_budget_s."""
+    out, total, t_read = [], 0, 0.0
+    for tree in trees:
+        for base, dirs, names in os.walk(tree):
+            dirs.sort()
+            for n in sorted(names):
+                p = os.path.join(base, n)
+                try:
+                    st = os.lstat(p)
+                    if not os.path.isfile(p) or os.path.islink(p) or st.st_size == 0 or st.st_size > max_file:
+                        continue
+                    t = time.perf_counter()
+                    with open(p, "rb") as f:
+                        while f.read(1 << 24):
+                            pass
+                    t_read += time.perf_counter() - t
+                except OSError:
+                    continue
+                out.append((p, st.st_size))
+                total += st.st_size
+                if total >= want_bytes or t_read > read_budget_s:
+                    return out, total, t_read
+    return out, total, t_read
 
 
 def member_compressed_bytes(zf, info, blob_path):
@@ -127,12 +143,12 @@ def member_compressed_bytes(zf, info, blob_path):
         return f.read(info.compress_size)
 
 
-def zip_tree(tree, want_bytes, per_archive, workdir, sample_per_archive=6, sample_max=8 << 20):
+def zip_tree(trees, want_bytes, per_archive, workdir, max_file, read_budget_s, sample_per_archive=6, sample_max=8 << 20):
     """part (ii): zip on the GPU, sample against the oracle, time unzip -t both ways"""
     sys.path.insert(0, ROOT)
     import oracle
 
-    files, total = tree_files(tree, want_bytes)
+    files, total, t_read = tree_files(trees, want_bytes, max_file, read_budget_s)
     groups, cur, cur_b = [], [], 0
     for p, sz in files:
         if cur and (cur_b + sz > per_archive or len(cur) >= 60000):
@@ -144,7 +160,7 @@ def zip_tree(tree, want_bytes, per_archive, workdir, sample_per_archive=6, sampl
         groups.append((cur, cur_b))
     have_unzip = shutil.which("unzip") is not None
     rows = []
-    sums = {"source_bytes": 0, "archive_bytes": 0, "members": 0, "zip_s": 0.0, "gpu_unzip_t_s": 0.0, "infozip_tq_s": 0.0, "sampled": 0, "sampled_equal_oracle": 0}
+    sums = {"first_read_s": round(t_read, 2), "source_bytes": 0, "archive_bytes": 0, "members": 0, "zip_s": 0.0, "gpu_unzip_t_s": 0.0, "infozip_tq_s": 0.0, "sampled": 0, "sampled_equal_oracle": 0}
     for k, (paths, nbytes) in enumerate(groups):
         arc = os.path.join(workdir, "tree%02d.zip" % k)
         rc, _, err, dt_zip = run([TOOL, "zip", "--level", "default", "-o", arc] + paths)
@@ -202,7 +218,10 @@ def main():
     ap.add_argument("--roots", nargs="*", default=["/usr", "/opt"])
     ap.add_argument("--max-archives", type=int, default=400)
     ap.add_argument("--max-archive-mib", type=int, default=512)
-    ap.add_argument("--tree", default="/opt/rocm/lib")
+    ap.add_argument("--tree", nargs="*", default=["/opt/rocm/lib"])
+    ap.add_argument("--max-file-mib", type=int, default=256)
+    ap.add_argument("--read-budget-s", type=float, default=900.0)
+    ap.add_argument("--sniff-timeout-s", type=float, default=900.0)
     ap.add_argument("--bytes-gib", type=float, default=8.0)
     ap.add_argument("--per-archive-gib", type=float, default=1.0)
     ap.add_argument("--workdir", default=None)
@@ -211,7 +230,7 @@ def main():
     doc = {"tool": "zipc_amd/bin/zipc-hip", "procedure": "DEVEL.md:7-31 (sniff, unzip --skip -t, recode --deflate -t --check-cmd) and :41-53 (unzip -t timed beside Info-ZIP)"}
     roots = [r for r in a.roots if os.path.isdir(r)]
     if roots:
-        paths, rc, dt = sniff(roots)
+        paths, rc, dt = sniff(roots, a.sniff_timeout_s)
         rows, skipped = check_archives(paths, a.max_archives, a.max_archive_mib << 20)
         by_ext = {}
         for r in rows:
@@ -230,11 +249,12 @@ def main():
             "infozip_s": round(sum(r.get("infozip", {}).get("s", 0) for r in rows), 2),
             "recode_t_s": round(sum(r["recode_t"]["s"] for r in rows), 2),
         }
-    if a.tree and os.path.isdir(a.tree) and a.bytes_gib > 0:
+    trees = [t for t in a.tree if os.path.isdir(t)]
+    if trees and a.bytes_gib > 0:
         work = a.workdir or tempfile.mkdtemp(prefix="zipc_box_")
         try:
-            rows, sums = zip_tree(a.tree, int(a.bytes_gib * 2 ** 30), int(a.per_archive_gib * 2 ** 30), work)
-            doc["tree"] = {"root": a.tree, "archives": rows, **sums}
+            rows, sums = zip_tree(trees, int(a.bytes_gib * 2 ** 30), int(a.per_archive_gib * 2 ** 30), work, a.max_file_mib << 20, a.read_budget_s)
+            doc["tree"] = {"roots": trees, "archives": rows, **sums}
         finally:
             if not a.workdir:
                 shutil.rmtree(work, ignore_errors=True)

@@ -166,7 +166,7 @@ int recode_check_in_memory(const std::string &archive, std::size_t oldlen, const
   if (!z.ok) die("recode check: " + z.error);
   int exit_code = ok;
   for (const auto &r : z.value.extract_all())
-    if (!r.second.ok) {
+    if (!r.second.ok && z.value.find(r.first) && z.value.find(r.first)->file().can_extract()) {
       if (verbose) std::cerr << archive << ": " << r.first << ": " << r.second.error << "\n";
       exit_code = err_corrupted;
     }
@@ -341,8 +341,9 @@ int main(int argc, char **argv) {
         std::vector<std::string> datas;
         std::vector<zipc::Archive::NewFile> files;
         for (const auto &r : z.extract_all()) {  // (members that cannot be decoded are kept as they are; so are directories)
-          if (!r.second.ok) die(r.first + ": " + r.second.error);
           const zipc::Member *m = z.find(r.first);
+          if (!m || m->is_dir() || !m->file().can_extract()) continue;  // (File.can_extract: kept as it is, zipc_tool.ml:432)
+          if (!r.second.ok) die(r.first + ": " + r.second.error);
           datas.push_back(r.second.value);
           zipc::Archive::NewFile f;
           f.path = r.first;
