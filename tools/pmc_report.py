@@ -11,7 +11,7 @@
 """
 import collections, csv, glob, json, sys
 
-_vals = {sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a in ("--hbm-json", "--sq-json")}
+_vals = {sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a in ("--hbm-json", "--sq-json", "--workload")}
 args = [a for a in sys.argv[1:] if not a.startswith("--") and a not in _vals]
 pat = args[0] if args else "gpurun_out/pmc*/*/*counter_collection.csv"
 hbm_out = sys.argv[sys.argv.index("--hbm-json") + 1] if "--hbm-json" in sys.argv else None
@@ -42,14 +42,18 @@ for k, v in agg.items():
         fetch = mean.get("FETCH_SIZE", 0.0) * 1024
         write = mean.get("WRITE_SIZE", 0.0) * 1024
         out[name] = {"fetch_bytes": fetch, "write_bytes": write, "bytes": fetch + write}
+workload = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "c2"
 if sq_out:
-    json.dump({"note": "mean wave-instructions per launch, rocprofv3 --pmc SQ passes of tools/exp_inflate.py on C2 "
-                       "(tools/exp_sq_counters.sh: 16 384 streams in two slices, a launch covers half the batch); issue bounds: "
+    what = ("tools/exp_inflate.py on C2 (tools/exp_sq_counters.sh: 16 384 streams in two slices, a launch covers half the batch)" if workload == "c2" else
+            "bench.py --config c4 (tools/measure_c4_counters.sh: 8192 members of 1 MiB in two slices, a launch covers half the batch)")
+    json.dump({"note": "mean wave-instructions per launch, rocprofv3 --pmc SQ passes of " + what + "; issue bounds: "
                        "vector = VALU x 4 clocks / (1024 SIMDs x f), scalar = (SALU + BRANCH + SMEM) / (256 CUs x f), f = shader clock",
+               "workload": workload,
                "launch_share": 0.5,
                "kernels": out}, open(sq_out, "w"), indent=1)
 if hbm_out:
     json.dump({"note": "bytes per launch = (FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes; on gfx950 "
                        "FETCH_SIZE reads half the bytes of a 16 B/lane coalesced stream and is uncalibrated for "
                        "narrower accesses (MI355X_MICROARCH.md): raw counter values are kept here",
+               "workload": workload,
                "kernels": out}, open(hbm_out, "w"), indent=1)
