@@ -219,6 +219,13 @@ int zipc_hip_deflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, c
 int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
                           const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
                           struct zipc_hip_stream_result_s *results);
+/* The same decode with nothing brought back but the results: every stream is inflated into the context's device arena
+ * (dst_cap[i] bytes of room each), its checksum taken there, and results[i] = {status, checksum, out_len}.  What a caller
+ * that TESTS an archive needs -- File.to_binary_string of every member for its Ok / Error alone, the reference's
+ * `zipc unzip -t` (test/zipc_tool.ml:635-660 check_archive) -- without the decompressed bytes crossing the bus. */
+int zipc_hip_inflate_many_check(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
+                                const size_t *limit, int crc_op, const size_t *dst_cap,
+                                struct zipc_hip_stream_result_s *results);
 
 /* ---- batch forms (device-resident) ----------------------------------------- */
 

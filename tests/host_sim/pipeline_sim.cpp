@@ -115,7 +115,9 @@ struct SimDevice {
       }
       memcpy(pin_res + lo, dev_res.data() + lo, (hi - lo) * sizeof(zipc_hip_stream_result));
       done_k->fire();
+      if (!job.want_bytes) ev_out[g].fire();  // results only: nothing else comes back (api.hip records ev_out behind the kernels)
     });
+    if (!job.want_bytes) return ZIPC_HIP_OK;
     copy_out.push([this, g, lo, hi, done_k] {
       done_k->wait();
       uint64_t at = job.descs[lo].dst_off;
@@ -171,7 +173,8 @@ static int one_call(std::mt19937_64 &rng, Pools &pools, int inject) {
   std::vector<zipc_hip_stream_result> pin_res(n), results(n, zipc_hip_stream_result{0xDEAD, 0xDEAD, 0xDEAD});
   job.n = n; job.src = src.data(); job.src_len = src_len.data(); job.dst = dst.data(); job.dst_cap = dst_cap.data();
   job.results = results.data(); job.descs = descs.data(); job.src_arena_end = so; job.dst_arena_end = dof;
-  job.packed = rng() % 4 != 0; job.ahead = rng() % 3 == 0; job.h2d_bytes = rng() % 3 == 0 ? 0 : 1 << (12 + rng() % 10);
+  job.want_bytes = rng() % 5 != 0;
+  job.packed = job.want_bytes && rng() % 4 != 0; job.ahead = rng() % 3 == 0; job.h2d_bytes = rng() % 3 == 0 ? 0 : 1 << (12 + rng() % 10);
   job.pin_src = pin_src.data(); job.pin_dst = pin_dst.data(); job.pin_res = pin_res.data();
   job.threads = 1 + rng() % 6;
   SimDevice dev(job, pin_dst.data(), pin_res.data());
@@ -199,6 +202,10 @@ static int one_call(std::mt19937_64 &rng, Pools &pools, int inject) {
     if (r.status != want) { fprintf(stderr, "stream %zu: status %u, expected %u\n", i, r.status, want); return 1; }
     if (want != ZIPC_HIP_OK) { if (r.out_len != 0) return 1; continue; }
     if (r.out_len != ol || r.checksum != (uint32_t)(src_len[i] * 2654435761u)) { fprintf(stderr, "stream %zu: result differs\n", i); return 1; }
+    if (!job.want_bytes) {  // a call for the results alone touches no destination
+      for (size_t k = 0; k <= dst_cap[i]; k++) if (dsts[i][k] != 0xEE) { fprintf(stderr, "stream %zu: bytes written by a results-only call\n", i); return 1; }
+      continue;
+    }
     std::vector<uint8_t> expect(ol);
     transform(expect.data(), srcs[i].data(), src_len[i], ol);
     if (ol && memcmp(expect.data(), dsts[i].data(), ol) != 0) { fprintf(stderr, "stream %zu: bytes differ\n", i); return 1; }

@@ -140,6 +140,12 @@ def test_many_streams_chunked_staging_equals_oracle(gpu_ctx, oracle):
         assert int(ires[i].out_len) == len(want) and out.bytes(i, len(want)) == want == d, i
         assert int(ires[i].checksum) == crc, i
     assert int(ires[short].status) == 2  # "Expected decompression size exceeded"
+    # ---- the same call for its results alone (zipc_hip_inflate_many_check: `zipc unzip -t`): the same statuses, lengths and
+    # checksums, no destination at all
+    cres = (_lib.StreamResult * n)()
+    assert lib.zipc_hip_inflate_many_check(gpu_ctx.handle, n, cp, cl, lim, 1, out.cap, cres) == 0
+    for i in range(n):
+        assert (int(cres[i].status), int(cres[i].out_len), int(cres[i].checksum)) == (int(ires[i].status), int(ires[i].out_len), int(ires[i].checksum)), i
 
 
 def test_a_few_long_members_inflate_by_blocks(gpu_ctx, oracle):

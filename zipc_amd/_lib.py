@@ -80,6 +80,7 @@ SYMBOLS = [
     ("zipc_hip_zlib_compress", C.c_int, [_P, _P, _SZ, C.c_int, _P, _SZ, _SZP, _U32P]),
     ("zipc_hip_deflate_many", C.c_int, [_P, _SZ, _P, _P, C.c_int, C.c_int, _P, _P, _P]),
     ("zipc_hip_inflate_many", C.c_int, [_P, _SZ, _P, _P, _P, C.c_int, _P, _P, _P]),
+    ("zipc_hip_inflate_many_check", C.c_int, [_P, _SZ, _P, _P, _P, C.c_int, _P, _P]),
     ("zipc_hip_inflate_batch", C.c_int, [_P, _P, _P, _P, _P, _SZ, _SZ, C.c_int]),
     ("zipc_hip_deflate_batch", C.c_int, [_P, _P, _P, _P, _P, _SZ, _SZ, _SZ, C.c_int, C.c_int]),
     ("zipc_hip_checksum_device", C.c_int, [_P, _P, _SZ, C.c_int, C.c_int, _P]),

@@ -1279,8 +1279,8 @@ __global__ __launch_bounds__(256) void pack_copy_kernel(const uint8_t *dst_arena
 // staging buffers, streams packed at 256-byte aligned offsets
 static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void *const *src, const size_t *src_len,
                         const size_t *limit, int level, int crc_op, void *const *dst, const size_t *dst_cap,
-                        zipc_hip_stream_result *results) {
-  if (!ctx || (n && (!src || !src_len || !dst || !dst_cap || !results))) return ZIPC_HIP_ERR_INVALID_ARG;
+                        zipc_hip_stream_result *results, bool want_bytes = true) {
+  if (!ctx || (n && (!src || !src_len || (!dst && want_bytes) || !dst_cap || !results))) return ZIPC_HIP_ERR_INVALID_ARG;
   if (crc_op < 0 || crc_op > 3 || level < 0 || level > 3 || n > 0x7FFFFFFFull) return ZIPC_HIP_ERR_INVALID_ARG;
   if (n == 0) return ZIPC_HIP_OK;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1293,7 +1293,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   uint64_t so = 0, dof = 0;
   size_t max_src = 0, max_cap = 0;
   for (size_t i = 0; i < n; i++) {
-    if ((!src[i] && src_len[i]) || (!dst[i] && dst_cap[i])) return ZIPC_HIP_ERR_INVALID_ARG;
+    if ((!src[i] && src_len[i]) || (want_bytes && !dst[i] && dst_cap[i])) return ZIPC_HIP_ERR_INVALID_ARG;
     StreamDesc &d = descs[i];
     memset(&d, 0, sizeof d);
     d.src_off = so; d.src_len = src_len[i]; d.dst_off = dof; d.dst_cap = dst_cap[i];
@@ -1338,7 +1338,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
     n_max = cut[g + 1] - cut[g] > n_max ? cut[g + 1] - cut[g] : n_max;
     total_max = t > total_max ? t : total_max;
   }
-  const bool packed = zd::tuning().host_pack;  // (false: whole destination slots by the copy engine)
+  const bool packed = zd::tuning().host_pack && want_bytes;  // (false: whole destination slots by the copy engine)
   // everything is allocated before the first sub-batch is under way (growing a buffer
   // synchronises the stream)
   HIP_TRY(ctx, ctx->ensure(ctx->io_src, so + 64));
@@ -1347,7 +1347,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   HIP_TRY(ctx, ctx->ensure(ctx->io_res, n * sizeof(StreamResult)));
   if (packed) HIP_TRY(ctx, ctx->ensure(ctx->io_pack_off, (n + K + 1) * sizeof(uint64_t)));
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_src, so + 64));
-  HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, dof + 64));
+  if (want_bytes) HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_dst, dof + 64));
   HIP_TRY(ctx, ctx->ensure_pinned(ctx->pin_res, n * sizeof(StreamResult)));
   if (!is_inflate) {
     const int st = zipc_hip_reserve(ctx, n_max, max_src, total_max);
@@ -1383,7 +1383,7 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
   // below before anything is freed or the next call reuses the buffers.
   struct Dev {
     zipc_hip_ctx *ctx;
-    bool is_inflate, timing, packed, first_batch = true;
+    bool is_inflate, timing, packed, want_bytes, first_batch = true;
     size_t n, max_src, max_cap;
     int level, crc_op;
     const size_t *src_len;
@@ -1437,6 +1437,10 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
                   (const StreamResult *)dr, (uint32_t)(hi - lo), c, off);
       PIPE_TRY(hipGetLastError());
       PIPE_TRY(hipEventRecord(ev_k.ev[g], ctx->stream));
+      if (!want_bytes) {  // results only: they are on their way behind the kernels, nothing else comes back
+        PIPE_TRY(hipEventRecord(ev_out.ev[g], ctx->stream));
+        return ZIPC_HIP_OK;
+      }
       PIPE_TRY(hipStreamWaitEvent(ctx->copy_out, ev_k.ev[g], 0));
       if (packed) {  // its stores ARE the copy back, of as many bytes as the device knows it made, beside the next sub-batch's kernels
         hipLaunchKernelGGL(pack_copy_kernel, dim3((unsigned)zd::tuning().host_pack_wgs), dim3(256), 0, ctx->copy_out,
@@ -1456,15 +1460,15 @@ static int many_streams(zipc_hip_ctx *ctx, bool is_inflate, size_t n, const void
       return ZIPC_HIP_OK;
     }
 #undef PIPE_TRY
-  } dev{ctx, is_inflate, timing, packed, true, n, max_src, max_cap, level, crc_op, src_len, descs, ev_in, ev_k, ev_out, ev_t, dst_end, {}};
+  } dev{ctx, is_inflate, timing, packed, want_bytes, true, n, max_src, max_cap, level, crc_op, src_len, descs, ev_in, ev_k, ev_out, ev_t, dst_end, {}};
 
   zd_host::ManyJob<StreamDesc> job;
   job.n = n; job.src = src; job.src_len = src_len; job.dst = dst; job.dst_cap = dst_cap; job.results = results;
   job.descs = descs.data(); job.src_arena_end = so; job.dst_arena_end = dof;
-  job.cut = cut; job.n_max = n_max; job.packed = packed;
+  job.cut = cut; job.n_max = n_max; job.packed = packed; job.want_bytes = want_bytes;
   job.ahead = is_inflate && max_cap >= BLOCKS_BATCH_MIN_DST;
   job.h2d_bytes = zd::tuning().host_h2d_mib > 0 ? (uint64_t)zd::tuning().host_h2d_mib << 20 : 0;
-  job.pin_src = (uint8_t *)ctx->pin_src.p; job.pin_dst = (const uint8_t *)ctx->pin_dst.p;
+  job.pin_src = (uint8_t *)ctx->pin_src.p; job.pin_dst = want_bytes ? (const uint8_t *)ctx->pin_dst.p : nullptr;
   job.pin_res = (const zipc_hip_stream_result *)ctx->pin_res.p;
   job.threads = host_threads();
   zd_host::ManyTimes times;
@@ -1516,6 +1520,11 @@ int zipc_hip_inflate_many(zipc_hip_ctx *ctx, size_t n, const void *const *src, c
                           const size_t *limit, int crc_op, void *const *dst, const size_t *dst_cap,
                           zipc_hip_stream_result *results) {
   try { return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, dst, dst_cap, results); }
+  catch (...) { return many_threw(ctx, n, results); }
+}
+int zipc_hip_inflate_many_check(zipc_hip_ctx *ctx, size_t n, const void *const *src, const size_t *src_len,
+                                const size_t *limit, int crc_op, const size_t *dst_cap, zipc_hip_stream_result *results) {
+  try { return many_streams(ctx, true, n, src, src_len, limit, 0, crc_op, nullptr, dst_cap, results, false); }
   catch (...) { return many_threw(ctx, n, results); }
 }
 

@@ -197,6 +197,7 @@ struct ManyJob {
   uint64_t src_arena_end = 0, dst_arena_end = 0;
   std::vector<size_t> cut;                    // sub-batch g holds streams [cut[g], cut[g + 1])
   size_t n_max = 0;                           // streams of the largest sub-batch
+  bool want_bytes = true;                     // false: results only (status, checksum, length) -- nothing comes back, nothing is scattered, dst may be NULL
   bool packed = true;                         // a sub-batch's outputs come back end to end (from dst_off of its first stream on)
   bool ahead = false;                         // sub-batch g + 1 is gathered and sent before g's kernels are asked for
   uint64_t h2d_bytes = 0;                     // a sub-batch's sources are sent in runs of about this many bytes (0: one run)
@@ -289,6 +290,7 @@ int many_pipeline(const ManyJob<Desc> &job, Device &dev, Pools &pools, std::stri
         }
         const auto t_sc = std::chrono::steady_clock::now();
         if (times) times->scatter_begin[g] = since(t_begin);
+        if (!job.want_bytes) { taken = g + 1; continue; }
         pieces_of(lo, hi, [&](size_t i) { return job.results[i].status == ZIPC_HIP_OK ? (uint64_t)job.results[i].out_len : 0; }, pieces);
         pool.run(0, pieces.size(), grain_of(pieces.size()), [&](size_t j) {
           const Piece &p = pieces[j];

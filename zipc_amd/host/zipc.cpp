@@ -561,4 +561,39 @@ std::vector<std::pair<Fpath::t, Result<std::string>>> Archive::extract_all() con
   return out;
 }
 
+std::vector<std::pair<Fpath::t, Result<Unit>>> Archive::test_all() const {
+  std::vector<std::pair<Fpath::t, Result<Unit>>> out;
+  std::vector<zipc_deflate::ManyItem> items;
+  std::vector<std::size_t> slot;
+  std::vector<const File *> files;
+  for (const auto &kv : members_) {
+    const Member &m = kv.second;
+    if (m.is_dir()) continue;
+    const File &f = m.file();
+    if (f.compression_().kind == compression::Deflate && !f.is_encrypted()) {
+      zipc_deflate::ManyItem it;
+      it.data = f.compressed_bytes().data() + f.start();
+      it.len = (std::size_t)f.compressed_size();
+      it.decompressed_size = (std::size_t)f.decompressed_size();
+      items.push_back(it);
+      slot.push_back(out.size());
+      files.push_back(&f);
+      out.push_back({m.path(), Result<Unit>::Error("")});
+    } else {
+      auto r = f.to_binary_string();  // stored, encrypted, unsupported: the single-member path
+      out.push_back({m.path(), r.ok ? Result<Unit>::Ok(Unit{}) : Result<Unit>::Error(r.error)});
+    }
+  }
+  auto res = zipc_deflate::inflate_and_crc_32_many_check(items);
+  for (std::size_t k = 0; k < items.size(); k++) {
+    auto &dst = out[slot[k]].second;
+    if (!res[k].ok) dst = Result<Unit>::Error("deflate: " + res[k].error);
+    else {
+      auto c = zipc_deflate::Crc_32::check(files[k]->decompressed_crc_32(), res[k].checksum);
+      dst = c.ok ? Result<Unit>::Ok(Unit{}) : Result<Unit>::Error(c.error);
+    }
+  }
+  return out;
+}
+
 }  // namespace zipc

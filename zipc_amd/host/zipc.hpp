@@ -165,6 +165,10 @@ class Archive {  // type t and its functions, zipc.mli:287-384
   // File.to_binary_string of every extractable Deflate/Stored file member, in path
   // order; per member the reference's result (bytes, or its error message)
   std::vector<std::pair<Fpath::t, Result<std::string>>> extract_all() const;
+  // ... for its Ok / Error alone (`zipc unzip -t`, test/zipc_tool.ml:635-660): deflated members are decoded and CRC-checked on
+  // the device and only their results come back; the others take the single-member path.  Same members, same order, same
+  // messages as extract_all.
+  std::vector<std::pair<Fpath::t, Result<Unit>>> test_all() const;
 
  private:
   std::map<std::string, Member> members_;

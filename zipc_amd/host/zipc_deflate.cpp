@@ -380,6 +380,34 @@ std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &ite
   return out;
 }
 
+std::vector<ManyResult> inflate_and_crc_32_many_check(const std::vector<ManyItem> &items) {
+  const std::size_t n = items.size();
+  std::vector<ManyResult> out(n);
+  std::vector<const void *> src(n);
+  std::vector<std::size_t> len(n), cap(n), limit(n);
+  std::vector<ManyItem> by_output(n);
+  for (std::size_t i = 0; i < n; i++) {
+    if (!items[i].decompressed_size) throw std::invalid_argument("inflate_and_crc_32_many_check: decompressed_size missing");
+    src[i] = items[i].data;
+    len[i] = items[i].len;
+    cap[i] = limit[i] = *items[i].decompressed_size;
+    by_output[i].len = cap[i];
+  }
+  std::vector<zipc_hip_stream_result> res(n);
+  over_devices(by_output, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
+    const int st = zipc_hip_inflate_many_check(ctx, hi - lo, src.data() + lo, len.data() + lo, limit.data() + lo, ZIPC_HIP_CRC_CRC32,
+                                               cap.data() + lo, res.data() + lo);
+    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many_check: ") + message(st));
+  });
+  for (std::size_t i = 0; i < n; i++) {
+    throw_if_library_failure((int)res[i].status);
+    out[i].ok = res[i].status == ZIPC_HIP_OK;
+    out[i].checksum = res[i].checksum;
+    if (!out[i].ok) out[i].error = message((int)res[i].status);
+  }
+  return out;
+}
+
 std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &items) {
   const std::size_t n = items.size();
   std::vector<ManyResult> out(n);

@@ -146,5 +146,8 @@ std::vector<std::pair<std::size_t, std::size_t>> partition_items(const std::vect
 // inflate_and_crc_32 of every item; items need decompressed_size (the members of
 // an archive have it)
 std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &items);
+// ... for its verdict alone: ok / error and the CRC-32 found, value left empty -- nothing but the results comes back
+// from the device (zipc_hip_inflate_many_check: what testing an archive takes)
+std::vector<ManyResult> inflate_and_crc_32_many_check(const std::vector<ManyItem> &items);
 
 }  // namespace zipc_deflate
