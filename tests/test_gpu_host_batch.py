@@ -217,3 +217,39 @@ def test_the_copy_engine_as_the_way_back():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k", "not way_back"], env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_one_huge_member_among_hundreds_of_small_ones(gpu_ctx, oracle):
+    """An archive's ragged members in one call: 400 files of a few KiB to 100 KiB and ONE of 256 MiB (a library directory:
+    tools/corpus_box.py met it on /opt/rocm/lib).  The many-wave parse sized its segment buffers by streams x the LONGEST
+    stream's segments -- 401 x 15 625 x 66 KiB = 425 GB -- and the call failed with "out of memory"; the slots are compact
+    now (deflate.hip ParseSegs::slot).  Every stream round-trips through zlib with the right CRC-32; the small ones and the
+    giant's length are the oracle's."""
+    from zipc_amd import _lib
+
+    lib = _lib.lib()
+    rnd = random.Random(41)
+    plain = []
+    for i in range(400):
+        ln = rnd.randrange(2000, 100_000)
+        plain.append(util.text(ln, i) if i % 3 else util.rand_bytes(ln, i, 4))
+    piece = util.text(1 << 20, 77) + util.rand_bytes(1 << 20, 78, 3) + bytes(1 << 19) + util.rand_bytes(1 << 19, 79)
+    giant = (piece * ((256 << 20) // len(piece) + 1))[: (256 << 20) + 12345]
+    at = 137
+    plain.insert(at, giant)
+    n = len(plain)
+    caps = [int(lib.zipc_hip_deflate_bound(len(d))) for d in plain]
+    dst = _Bufs(caps)
+    keep, sp, sl = _srcs(plain)
+    res = (_lib.StreamResult * n)()
+    st = lib.zipc_hip_deflate_many(gpu_ctx.handle, n, sp, sl, 2, 1, dst.ptrs, dst.cap, res)
+    assert st == 0, (st, lib.zipc_hip_last_error(gpu_ctx.handle))
+    assert dst.guards_intact()
+    for i, d in enumerate(plain):
+        assert int(res[i].status) == 0, i
+        c = dst.bytes(i, int(res[i].out_len))
+        assert zlib.decompress(c, -15) == d and int(res[i].checksum) == zlib.crc32(d), i
+        if i % 57 == 0 and i != at:
+            assert c == oracle.deflate(d, level=2)[1], i
+    st0, c0, _ = oracle.deflate(giant, level=2)
+    assert st0 == 0 and dst.bytes(at, int(res[at].out_len)) == c0

@@ -1103,7 +1103,15 @@ struct ParseSegs {
   uint32_t *meet_syms;            // [segments * MEET_CAP] lz_parse_meet_kernel: the symbols parsed again from the expected entry
   uint32_t *meet_f, *meet_from, *meet_exit, *meet_end;  // [segments] ... and what parse_again returned (f = ~0: no room)
   uint32_t *fix_dst, *fix_n;      // [segments] the stitch's verdict on them: meet_syms[0, n) go to the stream's symbols at dst
-  uint32_t segs_per_stream;       // of the longest stream: segment slot of (stream, k) = stream * segs_per_stream + k
+  uint32_t segs_per_stream;       // of the longest stream: the grids are streams x segs_per_stream (a block whose segment lies behind its stream's end leaves at once)
+  // Segment slot of (stream, k): COMPACT, not stream * segs_per_stream + k -- a batch of ragged members (492 files of a library
+  // directory, one of them 233 MB: 14 247 segments) sized by its longest stream asked for 475 GB of symbols (round 6:
+  // tools/corpus_box.py met it).  pos_base is the prefix sum of the streams' padded positions, a stream has at most
+  // padded / seg_positions + 1 segments, so pos_base / seg_positions + stream + k never collides and stays below
+  // cap_positions / seg_positions + n_streams.
+  __device__ __forceinline__ size_t slot(const DeflateScratch &S, uint32_t stream, uint32_t k) const {
+    return (size_t)(S.pos_base[stream] / seg_positions) + stream + k;
+  }
   uint32_t seg_positions, seg_syms;  // positions per segment; symbol slots per segment (seg_positions + PARSE_SEG_SLACK)
 };
 
@@ -1130,7 +1138,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   if (MODE == 1 && (uint64_t)seg * G.seg_positions >= len && !(len == 0 && seg == 0)) return;
   const uint32_t B0 = MODE == 1 ? seg * G.seg_positions : 0u;  // where this wave starts,
   const uint32_t lim = MODE == 1 ? (len - B0 > G.seg_positions ? B0 + G.seg_positions : len) : len;  // and the tiles it takes: those below lim
-  const size_t seg_slot = (size_t)stream * G.segs_per_stream + seg;
+  const size_t seg_slot = MODE == 1 ? G.slot(S, stream, seg) : 0;
   uint32_t *syms = MODE == 1 ? G.spec_syms + seg_slot * G.seg_syms : S.syms + base;
   BlockDesc *blocks = MODE == 1 ? nullptr : S.blocks + S.blk_base[stream];
 
@@ -1577,7 +1585,7 @@ __global__ __launch_bounds__(64) void lz_parse_meet_kernel(const uint8_t *__rest
   const uint32_t len = (uint32_t)sd.src_len;
   if (k == 0 || (uint64_t)k * G.seg_positions >= len) return;
   const uint64_t base = S.pos_base[stream];
-  const size_t slot = (size_t)stream * G.segs_per_stream + k;
+  const size_t slot = G.slot(S, stream, k);
   ParseStream P;
   P.lane = threadIdx.x; P.len = len; P.max_pos = len - MIN_MATCH_LEN; P.s = src_arena + sd.src_off;
   P.match = S.match + base; P.snap = S.snap + base; P.good_match = good_match;
@@ -1633,7 +1641,7 @@ __global__ __launch_bounds__(64) void lz_parse_stitch_kernel(const uint8_t *__re
   P.match = S.match + base; P.snap = S.snap + base; P.good_match = good_match;
   P.own_vis = G.vis + (base >> 6); P.own_sym0 = G.tile_sym0 + (base >> 6);
   P.vis2 = G.vis2 + (base >> 6); P.sym02 = G.sym02 + (base >> 6);
-  const size_t slot0 = (size_t)stream * G.segs_per_stream;
+  const size_t slot0 = G.slot(S, stream, 0);
   const uint32_t PARSE_SEG = G.seg_positions;
   const uint32_t nseg = (uint32_t)(((uint64_t)len + PARSE_SEG - 1) / PARSE_SEG);
 
@@ -1744,7 +1752,7 @@ __global__ __launch_bounds__(64) void lz_parse_gather_kernel(const StreamDesc *_
   const uint32_t stream = blockIdx.x / G.segs_per_stream, seg = blockIdx.x % G.segs_per_stream;
   const uint64_t len = descs[stream].src_len;
   if (len > MAX_STREAM_LEN || len < (uint64_t)MIN_MATCH_LEN || (uint64_t)seg * G.seg_positions >= len) return;
-  const size_t slot = (size_t)stream * G.segs_per_stream + seg;
+  const size_t slot = G.slot(S, stream, seg);
   uint32_t *syms = S.syms + S.pos_base[stream];
   {  // the symbols lz_parse_meet_kernel parsed again, if the stitch took them
     const uint32_t n = G.fix_n[slot];
@@ -2854,7 +2862,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   ParseSegs segs{};
   EmitPlan *plans = nullptr;
   if (segmented) {
-    const size_t n_slots = n * sps, tiles = (size_t)(S.cap_positions / 64) + 4;
+    const size_t n_slots = (size_t)(S.cap_positions / segp) + n + 1, tiles = (size_t)(S.cap_positions / 64) + 4;  // (ParseSegs::slot)
     const size_t plan_bytes = align_up((size_t)S.cap_blocks * sizeof(EmitPlan), 256);
     const size_t seg_syms = segp + PARSE_SEG_SLACK;
     const size_t bytes = plan_bytes + align_up(n_slots * seg_syms * 4, 256) + 2 * align_up(tiles * 8, 256) +

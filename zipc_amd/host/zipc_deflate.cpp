@@ -368,7 +368,7 @@ std::vector<ManyResult> crc_32_and_deflate_many(const std::vector<ManyItem> &ite
   over_devices(items, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
     const int st = zipc_hip_deflate_many(ctx, hi - lo, src.data() + lo, len.data() + lo, level_of(lvl), ZIPC_HIP_CRC_CRC32,
                                          dst.data() + lo, cap.data() + lo, res.data() + lo);
-    if (st) throw std::runtime_error(std::string("zipc_hip_deflate_many: ") + message(st));
+    if (st) throw std::runtime_error(std::string("zipc_hip_deflate_many: ") + message(st) + " (" + zipc_hip_last_error(ctx) + ")");
   });
   for (std::size_t i = 0; i < n; i++) {
     throw_if_library_failure((int)res[i].status);
@@ -397,7 +397,7 @@ std::vector<ManyResult> inflate_and_crc_32_many_check(const std::vector<ManyItem
   over_devices(by_output, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
     const int st = zipc_hip_inflate_many_check(ctx, hi - lo, src.data() + lo, len.data() + lo, limit.data() + lo, ZIPC_HIP_CRC_CRC32,
                                                cap.data() + lo, res.data() + lo);
-    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many_check: ") + message(st));
+    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many_check: ") + message(st) + " (" + zipc_hip_last_error(ctx) + ")");
   });
   for (std::size_t i = 0; i < n; i++) {
     throw_if_library_failure((int)res[i].status);
@@ -428,7 +428,7 @@ std::vector<ManyResult> inflate_and_crc_32_many(const std::vector<ManyItem> &ite
   over_devices(by_output, [&](zipc_hip_ctx *ctx, std::size_t lo, std::size_t hi) {
     const int st = zipc_hip_inflate_many(ctx, hi - lo, src.data() + lo, len.data() + lo, limit.data() + lo, ZIPC_HIP_CRC_CRC32,
                                          dst.data() + lo, cap.data() + lo, res.data() + lo);
-    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many: ") + message(st));
+    if (st) throw std::runtime_error(std::string("zipc_hip_inflate_many: ") + message(st) + " (" + zipc_hip_last_error(ctx) + ")");
   });
   for (std::size_t i = 0; i < n; i++) {
     throw_if_library_failure((int)res[i].status);
