@@ -2958,7 +2958,7 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     }
     if (segmented) {
       ParseSegs G = segs;
-      const size_t o = lo * sps;  // the slice's segment slots
+      const size_t o = lo;  // the slice's segment slots: ParseSegs::slot counts streams from the slice's first (Q.pos_base is the slice's too)
       G.spec_syms += o * G.seg_syms;
       G.seg_exit += o; G.seg_total += o; G.seg_dst += o; G.seg_from += o; G.seg_n += o;
       G.meet_syms += o * MEET_CAP;
