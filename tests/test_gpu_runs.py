@@ -152,3 +152,88 @@ def test_a_repeated_header_longer_than_what_stays_staged(gpu_ctx, oracle):
                 st0, d0, c0 = oracle.inflate(srcs[i], decompressed_size=len(plains[i]), crc_op=crc_op)
                 assert st0 == 0 and d0 == plains[i]
                 assert got[i] == (0, plains[i], c0), (n, i, crc_op, got[i][0])
+
+
+def _one_length_streams():
+    """payloads whose literals nearly all have ONE code length (base64: 64 letters, 6 bits; hex: 16, 4 bits) -- what the
+    strided turn of the one-wave inflate takes (inflate.hip strided_turn, round 5) -- cut into many blocks so that strides
+    run up to, across and from block boundaries: sync flushes every few KiB, Huffman-only and default strategies, and
+    stretches of text and zeros between them (a stride must stop at the first symbol of another length)."""
+    import base64
+
+    rnd = random.Random(61)
+    out = []
+    for k, (n, flush, strategy) in enumerate([(60_000, 3000, zlib.Z_HUFFMAN_ONLY), (48_000, 0, zlib.Z_DEFAULT_STRATEGY),
+                                              (200_000, 7000, zlib.Z_DEFAULT_STRATEGY), (33_000, 500, zlib.Z_HUFFMAN_ONLY),
+                                              (150_000, 4096, zlib.Z_FIXED), (90_000, 11_000, zlib.Z_HUFFMAN_ONLY)]):
+        raw = rnd.randbytes(n)
+        b64, hx = base64.b64encode(raw), raw.hex().encode()
+        plain = b64[: n // 2] + util.text(700 + k, k) + hx[: n // 3] + bytes(300) + b64[n // 2:n] + b"=" * (k % 3)
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, strategy)
+        comp = b""
+        if flush:
+            for i in range(0, len(plain), flush):
+                comp += c.compress(plain[i:i + flush]) + c.flush(zlib.Z_SYNC_FLUSH if (i // flush) % 3 else zlib.Z_FULL_FLUSH)
+        else:
+            comp = c.compress(plain)
+        out.append((plain, comp + c.flush()))
+    return out
+
+
+def test_strides_of_one_code_length_across_blocks_limits_and_cuts(gpu_ctx, oracle):
+    """the review of round 5: "strided_turn is a new decode path that exists only in the device build ... add a directed GPU
+    test with base64 or hex payloads that cross block boundaries in each mode the function is compiled for (IM_REAL, IM_TOKEN
+    via the block path, limit / cap cuts mid-stride, input ending inside a stride)"."""
+    import ctypes as C
+
+    from zipc_amd import _lib
+    from zipc_amd import zipc_deflate as Z
+
+    lib = _lib.lib()
+    streams = _one_length_streams()
+    for plain, comp in streams:
+        assert zlib.decompress(comp, -15) == plain
+    # ---- ONE stream per call: the long ones go by blocks (IM_DRY, IM_TOKEN), the short ones by their one wave (IM_REAL)
+    by_blocks = 0
+    for plain, comp in streams:
+        for crc_op in (oracle.CRC_CRC32, oracle.CRC_ADLER32):
+            st, want, k = oracle.inflate(comp, decompressed_size=len(plain), crc_op=crc_op)
+            got, kk = (Z.inflate_and_crc_32 if crc_op == oracle.CRC_CRC32 else Z.inflate_and_adler_32)(comp, decompressed_size=len(plain)).get_ok()
+            assert st == 0 and got == want == plain and kk == k
+        by_blocks += int(gpu_ctx.last_inflate_blocks() >= 2)
+    assert by_blocks >= 2
+    # ---- calls of many streams (inflate_batch_kernel: more than 256; the few-streams form: 40): whole streams, limits that
+    # end a stream inside a stride, inputs that end inside one, destinations a byte short
+    rnd = random.Random(62)
+    for n in (300, 40):
+        comps, limits, caps = [], [], []
+        for i in range(n):
+            plain, comp = streams[i % len(streams)]
+            kind = i % 5
+            if kind == 1:
+                limits.append(rnd.randrange(1, len(plain)))  # the size limit falls somewhere inside
+                comps.append(comp)
+            elif kind == 2:
+                limits.append(len(plain))
+                comps.append(comp[: rnd.randrange(8, len(comp) - 1)])  # the input ends early
+            else:
+                limits.append(len(plain))
+                comps.append(comp)
+            caps.append(limits[-1])
+        keep = [np.frombuffer(c, np.uint8) for c in comps]
+        outs = [np.full(c + 16, 0xA5, np.uint8) for c in caps]
+        P, S = C.c_void_p * n, C.c_size_t * n
+        res = (_lib.StreamResult * n)()
+        assert lib.zipc_hip_inflate_many(gpu_ctx.handle, n, P(*[a.ctypes.data for a in keep]), S(*[len(c) for c in comps]), S(*limits), 1,
+                                         P(*[a.ctypes.data for a in outs]), S(*caps), res) == 0
+        failed = 0
+        for i in range(n):
+            st, want, crc = oracle.inflate(comps[i], decompressed_size=limits[i], crc_op=oracle.CRC_CRC32)
+            assert int(res[i].status) == st, (n, i, st, int(res[i].status))
+            assert bool((outs[i][caps[i]:] == 0xA5).all()), (n, i)
+            if st != 0:
+                failed += 1
+                assert int(res[i].out_len) == 0
+                continue
+            assert int(res[i].out_len) == len(want) and outs[i][:len(want)].tobytes() == want and int(res[i].checksum) == crc, (n, i)
+        assert failed >= n // 4

@@ -774,6 +774,7 @@ __device__ __forceinline__ BlockEnd inflate_wave(uint8_t *lds_raw, const uint8_t
           }
           prev_hdr_bits = 0;
         }
+        lit_stride = 0;  // (a block whose tables are not built -- a fixed block's table-free start -- has no stride of the block before's)
         bool ok = true;
         if (lane == 0) ok = lane_header_step(d, L, src_arena);
         uniformize(d);  // lane 0 is the first active lane: everybody takes its state
