@@ -11,7 +11,7 @@ import zipfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DIRS = ["zipc_amd", "oracle", "tests", "tools", "include", "bindings", "profiles"]
-SKIP_DIRS = {"__pycache__", "build", ".pytest_cache", "gpurun_out", ".git"}
+SKIP_DIRS = {"__pycache__", "build", "build_san", ".pytest_cache", "gpurun_out", ".git"}  # (build_san: the sanitizer builds of tests/test_sanitizers.py)
 TOP = ["SURVEY.md", "DESIGN.md", "INTEGRATION.md", "README.md", "BASELINE.md", "bench.py", "__graft_entry__.py"]
 
 
@@ -21,7 +21,7 @@ def files():
         for base, dirs, names in os.walk(os.path.join(ROOT, d)):
             dirs[:] = sorted(x for x in dirs if x not in SKIP_DIRS)
             for n in sorted(names):
-                if n.endswith((".pyc", ".o")) or "libzipc_hip_" in n:  # (variant builds of experiments are not part of it)
+                if n.endswith((".pyc", ".o")) or "libzipc_hip_" in n or "_asan" in n or "_tsan" in n:  # (variant and sanitizer builds are not part of it)
                     continue
                 out.append(os.path.join(base, n))
     return out
