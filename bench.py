@@ -24,7 +24,10 @@ WORLD_SIZE must equal --gpus.
 Extra objects in the JSON line: "roofline" (dominant kernel: the algorithmic bytes of the streams ONE launch covers --
 a step is two slices on two queues, a launch half the batch -- over its HIP-event duration, against the 8 TB/s HBM peak;
 its "others" lists the step's other kernels the same way, "deflate_pipeline" / "inflate" the directions over their wall
-time; --alone-pass adds every kernel launched alone over the whole batch), "cpu_baseline" (the oracle's C port timed
+time; --alone-pass adds every kernel launched alone over the whole batch; SCALARS inside it -- and again inside "config" --
+carry the line's claims for a record that keeps nothing else: deflate_gib_s / inflate_gib_s, deflate_frac / inflate_frac (N + C
+over the direction's wall time over 8 TB/s), *_traffic_over_algorithmic_raw / _corrected and issue_bound_frac, the last two kinds
+only from counter passes of THIS workload: profiles/rNN_hbm_traffic[_c4].json, rNN_sq_counters[_c4].json), "cpu_baseline" (the oracle's C port timed
 on this host on a bounded sample: 1 thread and all host threads, the headline's workload and the legs'; with the digests
 of sampled streams the legs check their bytes against; rank 0 / N=1 only), "kernels_ms_per_step", "inflate_gib_s" /
 "deflate_gib_s", and the untimed legs, each with its parity sample and its share of the roofline: "e2e_gib_s"
