@@ -145,3 +145,21 @@ def test_chains_are_built_by_ordered_exchange(gpu_ctx):
     """The context's probe (deflate.hip xchg_order_probe) passes on gfx950, so the suite's deflate tests run
     lz_chain_xchg_kernel; the peel kernel is compared with the oracle by the overrides above."""
     assert gpu_ctx.lds_exchange_ordered()
+
+
+@pytest.mark.parametrize("env", [{}, {"ZIPC_HIP_SLICES": "3", "ZIPC_HIP_SLICE_MIN": "1"}, {"ZIPC_HIP_HOST_CHUNKS": "6", "ZIPC_HIP_HOST_CHUNK_MIN": "8"}],
+                         ids=["default", "slices", "many-sub-batches"])
+def test_ragged_calls_of_the_many_stream_forms_bounded(env):
+    """tools/fuzz_many_ragged.py, bounded: calls of 1 .. 2500 members with heavy-tailed lengths (bytes to tens of MiB) through
+    zipc_hip_deflate_many, inflate_many and inflate_many_check against zlib and the oracle -- the shape of a directory of real
+    files, which round 6's corpus run showed the suite did not reach (one 233 MB member among 491: 475 GB of parse scratch)."""
+    import subprocess
+    import sys
+
+    day = _day()
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_many_ragged.py"), str(300 + day), "3"],
+                       env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    tail = r.stdout.decode()[-800:]
+    assert r.returncode == 0 and "0 mismatches" in tail, ("tools/fuzz_many_ragged.py %d 3 under %s (ZIPC_TEST_DAY=%d)" % (300 + day, env, day), tail)
