@@ -4,7 +4,7 @@
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$ROOT"
 LIBS="zipc_amd/lib/libzipc_hip.so"
-for v in dh16 dh64 dh128 mw8 mw32 ho16 ho32 ho48 cm8 cm16 cm24 cm40; do [ -f zipc_amd/lib/libzipc_hip_$v.so ] && LIBS="$LIBS zipc_amd/lib/libzipc_hip_$v.so"; done
+for v in dh16 dh64 dh128 mw8 mw32 ho16 ho32 ho48 cm8 cm16 cm24 cm40 np3 np4; do [ -f zipc_amd/lib/libzipc_hip_$v.so ] && LIBS="$LIBS zipc_amd/lib/libzipc_hip_$v.so"; done
 for lvl in 3 2; do
   for data in text corpus; do
     for lib in $LIBS; do
