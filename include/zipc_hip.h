@@ -207,7 +207,12 @@ int zipc_hip_zlib_compress(zipc_hip_ctx *ctx, const void *src, size_t len, int l
  * it is gathered, run, brought back -- the outputs end to end, by a kernel that
  * writes the pinned memory -- and scattered to the caller's buffers by a second
  * thread, so bus copies and kernels of one sub-batch run under the host memcpys of
- * the others.  A call that fails may have filled some of the caller's buffers.
+ * the others.  A call that FAILS (bad arguments, a HIP error, no memory or thread on the host) may have filled some of
+ * the caller's buffers, and results[] is defined all the same: the streams of sub-batches that had come back keep their
+ * results, every other stream carries the call's status and out_len 0; zipc_hip_last_error says what happened.  No C++
+ * exception crosses this boundary.  The staging threads are shared by the process's contexts and joined when the last
+ * context is destroyed; a forked child makes its own (csrc/host_pipeline.h, which tests/test_sanitizers.py runs under
+ * the thread and address sanitizers with host threads standing in for the device).
  * Environment, read once per process: ZIPC_HIP_HOST_THREADS (default 8 or the core
  * count), ZIPC_HIP_HOST_CHUNKS (sub-batches, default 4, 6 from a GiB of staging on;
  * fewer when a sub-batch would hold under 1024 streams), ZIPC_HIP_HOST_TIMING=1
