@@ -1028,6 +1028,55 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
                                                uint32_t &st) {
   br = 0; st = 1u | (1u << 16);
   uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
+#ifndef ZD_PARSE_CHAIN_INTS
+  // The lanes whose lazy chain goes on are a LANE MASK (round 6).  Rounds 3-5 kept the flag as an integer in a vector
+  // register -- a select to make it, a compare to read it back, twice a turn -- because the kernel was thought to wait for
+  // scalar issue; it waits for vector issue, and a mask's and / or are scalar instructions.
+  // A turn: 29 -> 20 vector instructions (-DZD_PARSE_CHAIN_INTS keeps the old form for A/B runs).
+  auto ballot = [](bool b) { return (unsigned long long)__builtin_amdgcn_ballot_w64(b); };
+  auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
+  unsigned long long chain_m = ballot((pend & 0x1FF) != 0);
+  uint32_t n_lits = 0, j = p + 1;
+  const uint32_t cur_hi = (uint32_t)(m_cur >> 32), nxt_hi = (uint32_t)(m_nxt >> 32);
+  // one step of the lanes' lazy chains with the entry c of position j (zd.ml:1224-1240): which lanes take it
+  auto chain_step = [&](uint32_t c) {
+    const uint32_t pl = pend & 0x1FF;
+    const uint32_t rem = len - j;  // (j > max_pos: the value is not used)
+    const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
+    const unsigned long long take_m = chain_m & ballot(j <= max_pos) & ballot(pl < maxlen) & ballot((c & 0x1FF) > pl);
+    const bool take = mine(take_m);
+    n_lits += take ? 1u : 0u;
+    pend = take ? c : pend;
+    j += take ? 1u : 0u;
+    chain_m = take_m;
+  };
+  uint32_t sh_cur = (uint32_t)m_cur, sh_nxt = (uint32_t)m_nxt;  // after k turns: the words of positions p + k (this tile's lanes), p + 64 + k
+  ZD_PCOUNT(0, 1); ZD_PCOUNT(2, chain_m ? 1 : 0);
+  for (uint32_t ahead = 1; ahead < 128u - 63u && chain_m; ahead++) {
+    ZD_PCOUNT(1, 1); ZD_PCOUNT(3, __builtin_popcountll(chain_m));
+    {  // the two tiles' best-of-K words shifted down a lane (v_mov_b32_dpp wave_shl:1: lane i takes lane i + 1's, lane 63 the next tile's lane 0)
+      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)sh_nxt, 0);
+      sh_cur = (uint32_t)__builtin_amdgcn_update_dpp((int)n0, (int)sh_cur, 0x130, 0xf, 0xf, false);
+      sh_nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh_nxt, 0x130, 0xf, 0xf, false);
+    }
+    uint32_t c = sh_cur;
+    // best-of-K/4 only where a pending match is that long (and only where the stream has second answers at all: else hi = lo)
+    const unsigned long long want_hi = chain_m & ballot((pend & 0x1FF) >= (uint32_t)good_match);
+    if (want_hi) {
+      const uint32_t off = (uint32_t)lane + ahead;
+      const uint32_t addr = (off & 63u) * 4u;
+      const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
+      c = mine(want_hi) ? (off < 64u ? a_hi : b_hi) : c;
+    }
+    chain_step(c);
+  }
+  // a chain of 64 strictly growing matches and more: straight from the table
+  // (kept out of the loop above: its load would make that loop wait for memory)
+  while (chain_m) {
+    const uint64_t mj = j <= max_pos ? match_pair(match, snap, j) : 0ull;
+    chain_step((pend & 0x1FF) >= (uint32_t)good_match ? (uint32_t)(mj >> 32) : (uint32_t)mj);
+  }
+#else
   // (flags as integers and selects instead of branches: a loop-carried bool lives in a scalar mask that
   // costs three scalar instructions per update, and the CU's ONE scalar issue per clock is what this
   // kernel's 32 waves per CU queue for)
@@ -1082,6 +1131,7 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
       chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
     }
   }
+#endif
   if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
 }
 
