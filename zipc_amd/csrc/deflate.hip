@@ -1301,11 +1301,13 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
       const uint32_t y = lane_value(v, J[k]);
       if (y <= lane4) v = y;
     }
-    const bool visited = valid && v == lane4;
+    // (the visited lanes as a mask first: every ballot below is a compare's own -- a compound condition's ballot goes through a
+    // 0 / 1 in a vector register and a second compare)
+    const unsigned long long vis_m = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(v == lane4);
+    const bool visited = __builtin_amdgcn_inverse_ballot_w64(vis_m);
     ZD_PP(2);
     if (MODE == 1) {
-      const unsigned long long vm = __builtin_amdgcn_ballot_w64(visited);
-      if (lane == 0) { G.vis[(base + B) >> 6] = vm; G.tile_sym0[(base + B) >> 6] = nsym; }
+      if (lane == 0) { G.vis[(base + B) >> 6] = vis_m; G.tile_sym0[(base + B) >> 6] = nsym; }
     }
     // the path leaves the tile after the last visited position (lane 63's answer)
     const uint32_t last = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
@@ -1323,8 +1325,11 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     {
       const uint32_t byte_cur = lit_byte(lit_cur, B), byte_nxt = lit_byte(lit_nxt, Bn);
       const bool lit_run = visited && br != 0 && lits != 0;
+      // (a ballot of a compound condition makes the compiler turn its mask into 0 / 1 in a vector register and compare that
+      // again: two vector instructions; the compare's own ballot and a scalar `and` are one -- round 6, like the chains' masks)
+      const unsigned long long lit_m = vis_m & __builtin_amdgcn_ballot_w64(br != 0) & __builtin_amdgcn_ballot_w64(lits != 0);
       uint32_t k = 0;
-      while (__builtin_amdgcn_ballot_w64(lit_run && k < lits)) {  // rarely more than one turn
+      while (lit_m & __builtin_amdgcn_ballot_w64(k < lits)) {  // rarely more than one turn
         const uint32_t at = (uint32_t)lane + k;
         const uint32_t a = lane_value((at & 63u) * 4u, byte_cur), b2 = lane_value((at & 63u) * 4u, byte_nxt);
         // (the third alternative's load stands behind a branch, and at its join the compiler waits for everything in flight
@@ -1340,7 +1345,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     // (a visited position is at or behind blk_start, so the test runs on 32-bit
     // distances from it; lanes that are not visited are masked out)
     const uint32_t rel = p - blk_start;
-    const unsigned long long cb = MODE == 0 ? __ballot(visited && rel + adv > (uint32_t)MAX_BLOCK_SRC_LEN) : 0ull;
+    const unsigned long long cb = MODE == 0 ? vis_m & __builtin_amdgcn_ballot_w64(rel + adv > (uint32_t)MAX_BLOCK_SRC_LEN) : 0ull;
     if (MODE == 0 && cb) {
       const int c = __ffsll((long long)cb) - 1;
       uint32_t cutpos, symidx;
