@@ -1021,43 +1021,60 @@ static __device__ unsigned long long zd_parse_counts[8];
 
 // The macro step of the 64 positions of a tile, one per lane (lz_macro_position, with the following
 // positions' entries taken from the neighbouring lanes: m_cur is this tile's entry of the lane, m_nxt the
-// next tile's).  br: the match the step ends with (0: the position is a literal), st: advance | literals << 16.
-__device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool valid, bool has_match, uint32_t max_pos,
+// next tile's).  br: the match the step ends with (0: the position is a literal), lits: the literals in front of it
+// (0 for a literal position), adv: the step's advance, literals + match length (1 for a literal position, 0 for a lane behind the
+// stream's end).  valid_m: the lanes whose position lies in the stream, as a mask.
+__device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, unsigned long long valid_m, bool has_match, uint32_t max_pos,
                                                uint32_t len, uint64_t m_cur, uint64_t m_nxt,
                                                const uint32_t *__restrict__ match, const uint32_t *__restrict__ snap, int good_match, uint32_t &br,
-                                               uint32_t &st) {
-  br = 0; st = 1u | (1u << 16);
-  uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
+                                               uint32_t &adv, uint32_t &lits) {
 #ifndef ZD_PARSE_CHAIN_INTS
   // The lanes whose lazy chain goes on are a LANE MASK (round 6).  Rounds 3-5 kept the flag as an integer in a vector
   // register -- a select to make it, a compare to read it back, twice a turn -- because the kernel was thought to wait for
   // scalar issue; it waits for vector issue, and a mask's and / or are scalar instructions.
   // A turn: 29 -> 20 vector instructions (-DZD_PARSE_CHAIN_INTS keeps the old form for A/B runs).
+  // Round 6, second pass over the loop's assembly (22 -> 13 vector instructions a turn):
+  //  * a chaining lane's j is p + the turn: every lane of chain_m has taken every turn so far (a lane that does not take one
+  //    leaves the mask for good), so j is not a register -- and "j <= max_pos" follows from "pl < maxlen" (a pending length is
+  //    at least 3, so len - j > 3);
+  //  * the literals are counted by an add-with-carry whose carry is the take mask (one instruction; the compiler's form is a
+  //    select of 0 / 1 and an add, and it has no builtin for this one);
+  //  * the shifts are in place: wave_shl with "a lane without a source reads 0" and lane 63 written by v_writelane (with an
+  //    "old" operand the compiler copies the register every turn).
   auto ballot = [](bool b) { return (unsigned long long)__builtin_amdgcn_ballot_w64(b); };
   auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
-  unsigned long long chain_m = ballot((pend & 0x1FF) != 0);
-  uint32_t n_lits = 0, j = p + 1;
+  const unsigned long long ok_m = has_match ? valid_m & ballot(p <= max_pos) : 0ull;
+  uint32_t pend = mine(ok_m) ? (uint32_t)m_cur : 0u;
+  unsigned long long chain_m = ok_m & ballot((pend & 0x1FF) != 0);
+  uint32_t n_lits = 0;
+  const uint32_t lenp = len - p;  // (lanes behind the end: never in chain_m)
   const uint32_t cur_hi = (uint32_t)(m_cur >> 32), nxt_hi = (uint32_t)(m_nxt >> 32);
-  // one step of the lanes' lazy chains with the entry c of position j (zd.ml:1224-1240): which lanes take it
-  auto chain_step = [&](uint32_t c) {
+  // one step of the lanes' lazy chains with the entry c of position j = p + ahead (zd.ml:1224-1240): which lanes take it
+  auto chain_step = [&](uint32_t c, uint32_t rem) {
     const uint32_t pl = pend & 0x1FF;
-    const uint32_t rem = len - j;  // (j > max_pos: the value is not used)
     const uint32_t maxlen = rem < (uint32_t)MAX_MATCH_LEN ? rem : (uint32_t)MAX_MATCH_LEN;
-    const unsigned long long take_m = chain_m & ballot(j <= max_pos) & ballot(pl < maxlen) & ballot((c & 0x1FF) > pl);
-    const bool take = mine(take_m);
-    n_lits += take ? 1u : 0u;
-    pend = take ? c : pend;
-    j += take ? 1u : 0u;
+    const unsigned long long take_m = chain_m & ballot(pl < maxlen) & ballot((c & 0x1FF) > pl);
+    pend = mine(take_m) ? c : pend;
+    unsigned long long carry_out;
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(n_lits), "=s"(carry_out) : "v"(n_lits), "s"(take_m));  // n_lits += take
     chain_m = take_m;
   };
   uint32_t sh_cur = (uint32_t)m_cur, sh_nxt = (uint32_t)m_nxt;  // after k turns: the words of positions p + k (this tile's lanes), p + 64 + k
   ZD_PCOUNT(0, 1); ZD_PCOUNT(2, chain_m ? 1 : 0);
-  for (uint32_t ahead = 1; ahead < 128u - 63u && chain_m; ahead++) {
+  uint32_t ahead = 1;
+  for (; ahead < 128u - 63u && chain_m; ahead++) {
     ZD_PCOUNT(1, 1); ZD_PCOUNT(3, __builtin_popcountll(chain_m));
-    {  // the two tiles' best-of-K words shifted down a lane (v_mov_b32_dpp wave_shl:1: lane i takes lane i + 1's, lane 63 the next tile's lane 0)
-      const uint32_t n0 = (uint32_t)__builtin_amdgcn_readlane((int)sh_nxt, 0);
-      sh_cur = (uint32_t)__builtin_amdgcn_update_dpp((int)n0, (int)sh_cur, 0x130, 0xf, 0xf, false);
-      sh_nxt = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)sh_nxt, 0x130, 0xf, 0xf, false);
+    {  // the two tiles' best-of-K words shifted down a lane (wave_shl:1: lane i takes lane i + 1's, lane 63 the next tile's lane 0)
+      // (by hand: four instructions, in place.  The leading s_nop: a DPP read wants two wait states behind the register's
+      // writer, and the compiler does not look into an asm; the two shifts are the wait states between v_readlane and the
+      // v_writelane that reads its scalar)
+      uint32_t n0;
+      asm("s_nop 1\n\t"
+          "v_readlane_b32 %2, %1, 0\n\t"
+          "v_mov_b32_dpp %0, %0 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_mov_b32_dpp %1, %1 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+          "v_writelane_b32 %0, %2, 63"
+          : "+v"(sh_cur), "+v"(sh_nxt), "=&s"(n0));
     }
     uint32_t c = sh_cur;
     // best-of-K/4 only where a pending match is that long (and only where the stream has second answers at all: else hi = lo)
@@ -1068,18 +1085,26 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
       const uint32_t a_hi = lane_value(addr, cur_hi), b_hi = lane_value(addr, nxt_hi);
       c = mine(want_hi) ? (off < 64u ? a_hi : b_hi) : c;
     }
-    chain_step(c);
+    chain_step(c, lenp - ahead);
   }
   // a chain of 64 strictly growing matches and more: straight from the table
   // (kept out of the loop above: its load would make that loop wait for memory)
   while (chain_m) {
-    const uint64_t mj = j <= max_pos ? match_pair(match, snap, j) : 0ull;
-    chain_step((pend & 0x1FF) >= (uint32_t)good_match ? (uint32_t)(mj >> 32) : (uint32_t)mj);
+    const uint32_t j = p + ahead;
+    const uint64_t mj = mine(chain_m) && j <= max_pos ? match_pair(match, snap, j) : 0ull;
+    chain_step((pend & 0x1FF) >= (uint32_t)good_match ? (uint32_t)(mj >> 32) : (uint32_t)mj, lenp - ahead);
+    ahead++;
   }
+  br = pend;  // (0 where no match is pending: the lanes outside ok_m, and the positions without a match)
+  lits = n_lits;
+  const uint32_t step = n_lits + (pend & 0x1FF);
+  adv = mine(valid_m) ? (step ? step : 1u) : 0u;
 #else
   // (flags as integers and selects instead of branches: a loop-carried bool lives in a scalar mask that
   // costs three scalar instructions per update, and the CU's ONE scalar issue per clock is what this
   // kernel's 32 waves per CU queue for)
+  const bool valid = __builtin_amdgcn_inverse_ballot_w64(valid_m);
+  uint32_t pend = (valid && has_match && p <= max_pos) ? (uint32_t)m_cur : 0u;
   uint32_t chaining = (pend & 0x1FF) != 0 ? 1u : 0u;
   uint32_t n_lits = 0, j = p + 1;
   const uint32_t cur_lo = (uint32_t)m_cur, cur_hi = (uint32_t)(m_cur >> 32);
@@ -1131,8 +1156,9 @@ __device__ __forceinline__ void parse_tile_macro(int lane, uint32_t p, bool vali
       chain_step((uint32_t)mj, (uint32_t)(mj >> 32), (pend & 0x1FF) >= (uint32_t)good_match ? 1u : 0u);
     }
   }
+  br = 0; lits = 0; adv = valid ? 1u : 0u;
+  if ((pend & 0x1FF) != 0) { br = pend; lits = n_lits; adv = n_lits + (pend & 0x1FF); }
 #endif
-  if ((pend & 0x1FF) != 0) { br = pend; st = (n_lits + (pend & 0x1FF)) | (n_lits << 16); }
 }
 
 // Streams parsed by several waves (lz_parse_spec_kernel / lz_parse_stitch_kernel / lz_parse_gather_kernel below):
@@ -1234,21 +1260,29 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
   // the end of the iteration that issued the load (where the value moves into the next iteration's variable),
   // and with it an s_waitcnt vmcnt(0): every tile waited for the loads it had just requested for two tiles
   // ahead, and for its own symbol stores.
-  auto lit_index = [&](uint32_t tile, uint32_t &i, uint32_t &c) {
-    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    const uint32_t tc = t < len ? t : len - 1;  // len >= 1 inside the loop; len <= MAX_STREAM_LEN: no wrap below
-    i = tc + (uint32_t)lane;
-    i = i < len ? i : len - 1;
-    c = i < len - 4u ? i : len - 4u;  // where an in-bounds word that holds byte i starts (len >= 4 here)
+  // The lane's byte is byte i = min(tile + lane, len - 1), its word starts at c = min(tile + lane, len - 4) (an in-bounds word
+  // that holds byte i; len >= 4 here, len <= MAX_STREAM_LEN: no wrap) -- formed as a SCALAR part min(tile, len - 4) and a lane
+  // part min(lane, len - 4 - that): one vector instruction per load.  And in every tile but a stream's last (tile + 67 <= len)
+  // c = i: the byte is the word's lowest, found by a mask where the general form is seven instructions (round 6: 14 of a tile's
+  // ~130 vector instructions were these two extractions).
+  auto lit_word = [&](uint32_t t, uint32_t &tcl) -> uint32_t {
+    tcl = t < len - 4u ? t : len - 4u;
+    const uint32_t room = len - 4u - tcl;
+    return (uint32_t)lane < room ? (uint32_t)lane : room;
   };
   auto load_lit = [&](uint32_t tile) -> uint32_t {
-    uint32_t i, c;
-    lit_index(tile, i, c);
-    return load_u32_le(s + c);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    uint32_t tcl;
+    const uint32_t v = lit_word(t, tcl);
+    return load_u32_le((s + tcl) + v);
   };
   auto lit_byte = [&](uint32_t raw, uint32_t tile) -> uint32_t {
-    uint32_t i, c;
-    lit_index(tile, i, c);
+    const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (t + 67u <= len) return raw & 0xFFu;  // (wave-uniform)
+    uint32_t tcl;
+    const uint32_t c = lit_word(t, tcl) + tcl;
+    uint32_t i = (t < len ? t : len - 1u) + (uint32_t)lane;
+    i = i < len ? i : len - 1u;
     return (raw >> 8u * (i - c)) & 0xFFu;
   };
   // One tile.  The three sets of registers -- current tile, next tile, the one requested now -- change
@@ -1273,15 +1307,15 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     lit_nx3 = load_lit(Bn + 2u * PARSE_TILE);
 
     const uint32_t p = B + (uint32_t)lane;
-    const bool valid = p < len;
+    // (the lanes inside the stream as a mask, taken where the compare is: a ballot of a flag that comes from elsewhere goes
+    // through a 0 / 1 in a vector register and a second compare)
+    const unsigned long long valid_m = __builtin_amdgcn_ballot_w64(p < len);
     // macro step of every position of the tile (lz_macro_position, with the
     // following positions' matches taken from the neighbouring lanes)
-    uint32_t br, st;
-    parse_tile_macro(lane, p, valid, has_match, max_pos, len, m_cur, m_nxt, match, snap, good_match, br, st);
+    uint32_t br, adv, lits;
+    parse_tile_macro(lane, p, valid_m, has_match, max_pos, len, m_cur, m_nxt, match, snap, good_match, br, adv, lits);
     ZD_PP(1);
-    const uint32_t adv = valid ? (br ? macro_advance(st) : 1u) : 0u;
-    const uint32_t lits = br ? macro_lits(st) : 0u;
-    const uint32_t cnt = valid ? (br ? lits + 1u : 1u) : 0u;
+    const uint32_t cnt = lits + 1u;  // (of a visited lane: a literal position's one symbol, or the literals and the match)
     // J[k]: position reached after 2^k steps as a ds_bpermute address; a step that
     // leaves the tile points to itself, so the tables need no range tests
     const uint32_t lane4 = (uint32_t)lane * 4u;
@@ -1303,7 +1337,7 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     }
     // (the visited lanes as a mask first: every ballot below is a compare's own -- a compound condition's ballot goes through a
     // 0 / 1 in a vector register and a second compare)
-    const unsigned long long vis_m = __builtin_amdgcn_ballot_w64(valid) & __builtin_amdgcn_ballot_w64(v == lane4);
+    const unsigned long long vis_m = valid_m & __builtin_amdgcn_ballot_w64(v == lane4);
     const bool visited = __builtin_amdgcn_inverse_ballot_w64(vis_m);
     ZD_PP(2);
     if (MODE == 1) {
@@ -1314,9 +1348,13 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     uint32_t next_entry = B + (uint32_t)__builtin_amdgcn_readlane((int)j0, (int)(last >> 2));
     if (next_entry > len) next_entry = len;
     // symbol indices: exclusive scan of cnt over the visited lanes
-    const uint32_t incl = wave_scan_incl(visited ? cnt : 0u);
+    // (the scan's result goes through an empty asm: seeing through it, the compiler forms "incl - x" as the sum of the six
+    // shifted pieces, keeps each in a register of its own and spends 15 vector instructions where the scan is 6 and the difference 1)
+    const uint32_t mycnt = visited ? cnt : 0u;
+    uint32_t incl = wave_scan_incl(mycnt);
+    asm("" : "+v"(incl));
     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);  // scalar: nsym stays in an SGPR
-    const uint32_t first_rel = incl - (visited ? cnt : 0u);  // within the tile's symbols (< 64 * 513)
+    const uint32_t first_rel = incl - mycnt;  // within the tile's symbols (< 64 * 513)
     const uint32_t first = nsym + first_rel;
     uint32_t *tsyms = syms + nsym;  // scalar base of the tile's symbols
     // symbols (lz_emit_position): a literal position writes its byte, a match
@@ -1324,10 +1362,9 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
     // from their lanes -- then its match
     {
       const uint32_t byte_cur = lit_byte(lit_cur, B), byte_nxt = lit_byte(lit_nxt, Bn);
-      const bool lit_run = visited && br != 0 && lits != 0;
       // (a ballot of a compound condition makes the compiler turn its mask into 0 / 1 in a vector register and compare that
       // again: two vector instructions; the compare's own ballot and a scalar `and` are one -- round 6, like the chains' masks)
-      const unsigned long long lit_m = vis_m & __builtin_amdgcn_ballot_w64(br != 0) & __builtin_amdgcn_ballot_w64(lits != 0);
+      const unsigned long long lit_m = vis_m & __builtin_amdgcn_ballot_w64(lits != 0);  // (literals in front of a match)
       uint32_t k = 0;
       while (lit_m & __builtin_amdgcn_ballot_w64(k < lits)) {  // rarely more than one turn
         const uint32_t at = (uint32_t)lane + k;
@@ -1335,10 +1372,10 @@ __device__ __forceinline__ void lz_parse_wave(const uint8_t *__restrict__ src_ar
         // (the third alternative's load stands behind a branch, and at its join the compiler waits for everything in flight
         // whenever a lane's literals reach into the next tile; moving it out of the loop -- a flag, a loop of its own behind a
         // ballot -- was measured: lz_parse 3.35 -> 3.58 ms on the benchmark's streams, lz_parse_spec 8.5 -> 9.4 on 1 MiB members)
-        if (lit_run && k < lits) tsyms[first_rel + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
+        if (__builtin_amdgcn_inverse_ballot_w64(lit_m) && k < lits) tsyms[first_rel + k] = at < 64u ? a : at < 128u ? b2 : (uint32_t)s[p + k];
         k++;
       }
-      if (visited) tsyms[first_rel + (br ? lits : 0u)] = br ? br : byte_cur;
+      if (visited) tsyms[first_rel + lits] = br ? br : byte_cur;
     }
     ZD_PP(3);
     // block cut: the first visited node that ends past blk_start + 65534
@@ -1477,11 +1514,9 @@ __device__ __forceinline__ ParseTile parse_eval_tile(const ParseStream &P, uint3
   const uint32_t p = B + (uint32_t)lane;
   const bool valid = p < P.len;
   const uint64_t m_cur = match_pair(P.match, P.snap, p), m_nxt = match_pair(P.match, P.snap, p + PARSE_TILE);  // (PARSE_PAD zero entries behind the last position)
-  uint32_t st;
-  parse_tile_macro(lane, p, valid, true, P.max_pos, P.len, m_cur, m_nxt, P.match, P.snap, P.good_match, t.br, st);
-  t.adv = valid ? (t.br ? macro_advance(st) : 1u) : 0u;
-  t.lits = t.br ? macro_lits(st) : 0u;
-  t.cnt = valid ? (t.br ? t.lits + 1u : 1u) : 0u;
+  parse_tile_macro(lane, p, __builtin_amdgcn_ballot_w64(p < P.len), true, P.max_pos, P.len, m_cur, m_nxt, P.match, P.snap, P.good_match, t.br,
+                   t.adv, t.lits);
+  t.cnt = valid ? t.lits + 1u : 0u;
   const uint32_t lane4 = (uint32_t)lane * 4u;
   const uint32_t j0 = (uint32_t)lane + t.adv;
   if (use_mask) {

@@ -26,12 +26,15 @@ __device__ __forceinline__ void wave_copy(uint8_t *dst, const uint8_t *src, uint
 
 // inclusive wave scan: Kogge-Stone inside the rows of 16 on DPP row shifts,
 // then the row totals broadcast down (row_bcast:15 to rows 1 and 3,
-// row_bcast:31 to rows 2 and 3)
+// row_bcast:31 to rows 2 and 3).
+// (bound_ctrl on the row shifts -- a lane without a source reads 0 -- is what lets the compiler fold each step into ONE
+// v_add_u32_dpp: with "old = 0, bound_ctrl off", the same values, it emitted v_mov 0 + v_mov_dpp + v_add per step, 18 vector
+// instructions a scan where this is 6; round 6, found in lz_parse's assembly)
 __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);  // row_shr:8
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31
   return x;
