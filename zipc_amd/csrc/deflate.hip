@@ -2332,12 +2332,16 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     // counted.  The loads are unconditional (clamped index, validity tested at use) so
     // that the wait counters stay exact and nothing waits for the newest requests.
     {
-      const uint32_t last_sym = bd.n_syms ? bd.n_syms - 1u : 0u;
+      // (the block's numbers came by a vector load: made scalar here, the loop's bounds and bases are scalar work and a
+      // symbol's address is a scalar base plus a lane part -- round 6, from the assembly: 5 vector instructions a load were 8)
+      const uint32_t n_syms_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.n_syms);
+      const uint32_t last_sym = n_syms_s ? n_syms_s - 1u : 0u;
+      const uint32_t *bsyms = syms + (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.sym_start);
       auto load4 = [&](uint32_t k0, uint32_t *v) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
-          v[u] = syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
+          v[u] = bsyms[k < last_sym ? k : last_sym];
         }
       };
       // (two sets of registers that swap roles by name: copied from "next" to "current" at the end of a turn,
@@ -2346,7 +2350,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const uint32_t k = k0 + 64u * (uint32_t)u + (uint32_t)lane;
-          if (k < bd.n_syms) {
+          if (k < n_syms_s) {
             if ((v[u] >> 9) == 0) atomicAdd(&lit_freq[v[u]], 1u);
             else {
               atomicAdd(&lit_freq[heap[v[u] & 0x1FF]], 1u);
@@ -2357,7 +2361,7 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
       };
       uint32_t va[4], vb[4];
       load4(0, va);
-      for (uint32_t k0 = 0; k0 < bd.n_syms; k0 += 512) {
+      for (uint32_t k0 = 0; k0 < n_syms_s; k0 += 512) {
         load4(k0 + 256u, vb);
         count4(k0, va);
         load4(k0 + 512u, va);
@@ -2438,8 +2442,11 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     }
     const uint32_t *hl = kind == 1 ? fix_lit : dyn_lit;
     const uint32_t *hd = kind == 1 ? fix_dist : dyn_dist;
-    const uint32_t n_hdr = kind == 2 ? (uint32_t)dyn_header_items(c) : 0u;
-    const uint32_t n_items = 1 + n_hdr + bd.n_syms + 1;  // type bits, header, symbols, EOB
+    const uint32_t n_syms_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.n_syms);  // (scalar: see the histogram loop)
+    const uint32_t *bsyms = syms + (uint32_t)__builtin_amdgcn_readfirstlane((int)bd.sym_start);
+    kind = __builtin_amdgcn_readfirstlane(kind);  // (wave-uniform by construction; the compiler cannot see it)
+    const uint32_t n_hdr = (uint32_t)__builtin_amdgcn_readfirstlane(kind == 2 ? dyn_header_items(c) : 0);
+    const uint32_t n_items = 1 + n_hdr + n_syms_s + 1;  // type bits, header, symbols, EOB
     // What a match length turns into -- code and extra bits merged, like the
     // reference's single write_bits (zd.ml:893-899) -- depends on the length and the
     // block's code only: one table entry per length, (bits << 5) | count, and per
@@ -2463,14 +2470,32 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
     // item idx of the block: 0 type bits, 1..n_hdr the dynamic header, then the symbols,
     // then EOB.  Symbol loads are unconditional (clamped); what an item is gets decided
     // when it is used, a turn after its load was issued.
-    const uint32_t last_sym = bd.n_syms ? bd.n_syms - 1u : 0u;
+    const uint32_t last_sym = n_syms_s ? n_syms_s - 1u : 0u;
     // MODE 2: this part's items -- the type bits and the header go with part 0, the end-of-block symbol with the last
-    const uint32_t n_parts = MODE == 2 ? emit_parts_of(split, (uint32_t)kind, bd.n_syms) : 1u;
-    const uint32_t item_lo = (MODE == 2 && part != 0) ? 1u + n_hdr + part * EMIT_PART : 0u;
-    const uint32_t item_hi = (MODE == 2 && part + 1 != n_parts) ? 1u + n_hdr + (part + 1u) * EMIT_PART : n_items;
-    auto fetch = [&](uint32_t idx) -> uint32_t {
-      const uint32_t k = idx > n_hdr ? idx - 1u - n_hdr : 0u;
-      return syms[bd.sym_start + (k < bd.n_syms ? k : last_sym)];
+    const uint32_t n_parts = MODE == 2 ? emit_parts_of(split, (uint32_t)kind, n_syms_s) : 1u;
+    const uint32_t item_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)((MODE == 2 && part != 0) ? 1u + n_hdr + part * EMIT_PART : 0u));
+    const uint32_t item_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)((MODE == 2 && part + 1 != n_parts) ? 1u + n_hdr + (part + 1u) * EMIT_PART : n_items));
+    auto fetch = [&](uint32_t idx) -> uint32_t {  // (item counts are far below 2^31)
+      int32_t k = (int32_t)(idx - 1u - n_hdr);
+      k = k < 0 ? 0 : k;
+      k = k < (int32_t)last_sym ? k : (int32_t)last_sym;
+      return bsyms[(uint32_t)k];
+    };
+    // a symbol's bits (write_block_symbols zd.ml:879-910, symbol_bits), by table
+    auto encode = [&](uint32_t sr, uint64_t &value, int &nbits) {
+      const uint32_t dist = sr >> 9, len = sr & 0x1FF;
+      if (dist == 0) {
+        const uint32_t si = hl[len];
+        value = si >> 5;
+        nbits = (int)(si & 0x1F);
+      } else {
+        const uint32_t li = len_item[len];
+        const int dsym = dist_to_sym((int)dist);
+        const uint32_t si = hd[dsym], di = dist_info[dsym];
+        const uint32_t n = li & 0x1F, count = si & 0x1F;
+        value = (uint64_t)(li >> 5) | (((uint64_t)(si >> 5) | ((uint64_t)(dist - (di >> 5)) << count)) << n);
+        nbits = (int)(n + count + (di & 0x1F));
+      }
     };
     // one turn: PACK_TILES tiles of items from `base` on, their symbols in sref (requested a turn ago)
     auto pack_turn = [&](uint32_t base, const uint32_t *sref) {
@@ -2478,10 +2503,13 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
       int nbits[PACK_TILES];
 #pragma unroll
       for (int u = 0; u < PACK_TILES; u++) {
-        const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
+        const uint32_t t_lo = base + 64u * (uint32_t)u;  // (scalar)
+        const uint32_t idx = t_lo + (uint32_t)lane;
         value[u] = 0;
         nbits[u] = 0;
-        if (idx < item_hi) {
+        if (t_lo > n_hdr && t_lo + 64u <= 1u + n_hdr + n_syms_s && t_lo + 64u <= item_hi) {  // wave-uniform: 64 symbols, nothing else -- all but a block's first and last tiles
+          encode(sref[u], value[u], nbits[u]);
+        } else if (idx < item_hi) {
           if (idx == 0) {
             value[u] = (final ? 1u : 0u) | ((uint32_t)kind << 1);
             nbits[u] = 3;
@@ -2490,31 +2518,17 @@ __device__ __forceinline__ void deflate_emit_wave(const uint8_t *__restrict__ sr
             dyn_header_item(c, (int)idx - 1, v, nbits[u]);
             value[u] = v;
           } else {
-            const uint32_t sr = idx - 1u - n_hdr < bd.n_syms ? sref[u] : (uint32_t)LITLEN_EOB;
-            // write_block_symbols zd.ml:879-910 (symbol_bits), by table
-            const uint32_t dist = sr >> 9, len = sr & 0x1FF;
-            if (dist == 0) {
-              const uint32_t si = hl[len];
-              value[u] = si >> 5;
-              nbits[u] = (int)(si & 0x1F);
-            } else {
-              const uint32_t li = len_item[len];
-              const int dsym = dist_to_sym((int)dist);
-              const uint32_t si = hd[dsym], di = dist_info[dsym];
-              const uint32_t n = li & 0x1F, count = si & 0x1F;
-              value[u] = (uint64_t)(li >> 5) | (((uint64_t)(si >> 5) | ((uint64_t)(dist - (di >> 5)) << count)) << n);
-              nbits[u] = (int)(n + count + (di & 0x1F));
-            }
+            encode(idx - 1u - n_hdr < n_syms_s ? sref[u] : (uint32_t)LITLEN_EOB, value[u], nbits[u]);
           }
         }
       }
       pack_tiles(bo, stage, value, nbits, lane);
     };
     if (MODE == 3) {  // the bits of the part's symbols (not the end-of-block symbol)
-      const uint32_t s_lo = part * EMIT_PART, s_hi = bd.n_syms - s_lo > EMIT_PART ? s_lo + EMIT_PART : bd.n_syms;
+      const uint32_t s_lo = part * EMIT_PART, s_hi = n_syms_s - s_lo > EMIT_PART ? s_lo + EMIT_PART : n_syms_s;
       uint64_t acc = 0;
       for (uint32_t k = s_lo + (uint32_t)lane; k < s_hi; k += 64u) {
-        const uint32_t sr = syms[bd.sym_start + k];
+        const uint32_t sr = bsyms[k];
         const uint32_t dist = sr >> 9, len = sr & 0x1FF;
         if (dist == 0) acc += hl[len] & 0x1F;
         else {
