@@ -770,8 +770,16 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
     uint32_t stop_p = mine ? pe : 0u;
     uint32_t nh = 0;  // holes the lane leaves in the tile
     uint32_t has_far = 0;
-    for (;;) {
-      if (!wv::any(p < stop_p)) break;
+    // (round 6, from the assembly.  Written as "for (;;) { if (no lane decodes) break; four steps }" the loop began with twelve
+    // register moves -- the far matches' three words per slot, carried round the loop -- and with them a wait for ALL the
+    // loads in flight: a request landed one group of steps later at the earliest, not SPAN_FLY steps later.  And the
+    // reader's first words come by global loads too: the compiler's count of them is merged into the loop's, and every
+    // group's first peek waited for vmcnt(0).  The test at the bottom, and the reader's words made to land here, once a tile:
+    // the landings wait for exactly their own two loads (vmcnt(7), vmcnt(6)).)
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(R.w0), "+v"(R.w1), "+v"(R.w2), "+v"(R.w3));  // (an operand of an asm has landed; a bare s_waitcnt the loads are moved behind)
+#endif
+    if (wv::any(p < stop_p)) do {
 #pragma unroll
       for (int u = 0; u < SPAN_FLY; u++) {
         if (MODE == IM_REAL) span_land(tile, f_meta[u], f_a[u], f_b[u]);
@@ -818,7 +826,7 @@ ZD_WV int span_decode(InflateLane &d, const LaneLds &L, const uint8_t *src_strea
         p += good ? s.tot : 0u;
         span_advance(R, E, p);
       }
-    }
+    } while (wv::any(p < stop_p));
     if (MODE == IM_REAL) {
 #pragma unroll
       for (int u = 0; u < SPAN_FLY; u++) span_land(tile, f_meta[u], f_a[u], f_b[u]);
