@@ -2953,11 +2953,17 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
   // 1.09 / 1.38 / 1.94, 16 MiB 2.18 / 1.89 / 1.87 / 2.10 / 2.57 -- since lz_parse_meet_kernel the stitch's turn per
   // segment is a quarter of a microsecond)
   size_t segp = max_src_len <= ((size_t)4 << 20) ? 4096 : max_src_len <= ((size_t)32 << 20) ? 8192 : 16384;
+  // (many long streams: as long as the call keeps 64 Ki waves, longer segments -- fewer seams to stitch and to gather across.
+  // 8192 x 1 MiB, ms a step at 4096 / 8192 / 16 384 / 32 768 positions: 175.2 / 174.3 / 172.7 / 171.9, profiles/r06_c4_parse_segments.txt)
+  while (segp < 32768 && n * ((max_src_len + 2 * segp - 1) / (2 * segp)) >= 65536) segp *= 2;
   if (segp_env >= (long)PARSE_SEG_MIN && segp_env % 64 == 0 && segp_env <= (1L << 20)) segp = (size_t)segp_env;
   const size_t sps = (max_src_len + segp - 1) / segp;
-  // (8192 x 1 MiB: the same either way; 4096 x 1 MiB: 133 -> 124 ms; 64 KiB streams, 256 / 1024 / 2048 / 4096 / 16 384 of them:
-  // 1.77 -> 0.73, 2.38 -> 1.67, 3.16 -> 2.85, 4.78 -> 5.11, 15.6 -> 17.4 ms)
-  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1 : (sps >= 8 && (n <= 2048 || (n <= 4096 && max_src_len >= ((size_t)512 << 10))));
+  // (4096 x 1 MiB: 133 -> 124 ms; 64 KiB streams, 256 / 1024 / 2048 / 4096 / 16 384 of them:
+  // 1.77 -> 0.73, 2.38 -> 1.67, 3.16 -> 2.85, 4.78 -> 5.11, 15.6 -> 17.4 ms; 8192 x 1 MiB, BASELINE's C4: the same either way
+  // until round 6, then -- both parses a third shorter in instructions, the one wave per member still waiting for the LDS
+  // 60 % of its cycles -- 182.1 -> 175.2 ms a step, profiles/r06_c4_parse_segments.txt)
+  bool segmented = segs_env == 0 ? false : segs_env == 1 ? sps > 1
+                   : (sps >= 8 && (n <= 2048 || (n <= 4096 && max_src_len >= ((size_t)512 << 10)) || (n <= 8192 && max_src_len >= ((size_t)1 << 20))));
   const size_t bps = (size_t)max_blocks_of(max_src_len);  // block slots of the longest stream
   const size_t chain_seg = n * ((max_src_len + CHAIN_SEG_MIN - 1) / CHAIN_SEG_MIN) <= 512 ? CHAIN_SEG_MIN
                            : n * ((max_src_len + 2 * CHAIN_SEG_MIN - 1) / (2 * CHAIN_SEG_MIN)) <= 1024 ? 2 * CHAIN_SEG_MIN : CHAIN_SEG_MAX;
