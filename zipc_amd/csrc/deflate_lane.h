@@ -591,6 +591,54 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   return v;
 }
 
+// match_run_step_to for the device alone (round 6): the same step, with every condition a lane mask made of its compares' own
+// ballots -- which is what the compiler makes of the shared form's bools too, EXCEPT where a bool is asked for as a mask or an
+// integer again: `ballot(fin)` went through v_cndmask 0 / 1 + v_cmp_ne, `steps + (walk ? 1 : 0)` through a select and an add.
+// Here the finished runs come back as a mask and the steps are counted by an add-with-carry of the walk mask: three vector
+// instructions fewer per run slot and iteration, no scalar instruction more (the mask form that moved MORE to the scalar
+// unit lost: tools/experiments/lz_match_walk_masks).  Returns the lanes whose position is finished.
+template <typename Sink, typename S, typename P>
+__device__ __forceinline__ unsigned long long match_run_step_masks(MatchRun &r, S s, P prev, uint32_t K, uint32_t Kq, Sink sink) {
+  auto ballot = [](bool b) { return (unsigned long long)__builtin_amdgcn_ballot_w64(b); };
+  auto mine = [](unsigned long long m) { return __builtin_amdgcn_inverse_ballot_w64(m); };
+  const uint32_t qn = r.q - r.dn;
+  const unsigned long long alive_m = ballot(r.alive != 0);
+  const unsigned long long walk_m = alive_m & ballot(r.dn != LinkNone<P>::value) & ballot(r.steps != K) & ballot(r.best_len < r.maxlen) &
+                                    ballot(r.p - qn <= (uint32_t)MAX_MATCH_DIST);  // zd.ml:1181,1187
+  const bool walk = mine(walk_m);
+  const uint32_t qc = walk ? qn : r.p;
+  const uint64_t x = load_u64_words(s, qc) ^ r.pw;
+  const uint32_t d2 = prev[qc];
+  uint32_t l = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+  if (walk && (x == 0 || r.maxlen < 8)) {  // (as in match_run_step_to)
+    bool compare = true;
+    if (x == 0 && r.best_len >= 8u) {
+      const uint32_t toff = r.best_len - 7u;
+      compare = load_u64_words(s, qc + toff) == load_u64_words(s, r.p + toff);
+    }
+    if (compare) l = common_prefix_t<true>(s, qc, r.p, r.maxlen, r.maxlen >= 8u ? 8u : 0u);
+  }
+  unsigned long long carry_out;
+  uint32_t steps;
+  asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(steps), "=s"(carry_out) : "v"(r.steps), "s"(walk_m));  // steps + walk
+  const bool better = mine(walk_m & ballot(l > r.best_len));
+  const uint32_t best = better ? (((r.p - qc) << 9) | l) : r.best;
+  r.best_len = better ? l : r.best_len;
+  r.best = best;
+  r.snap = mine(walk_m & ballot(steps == Kq)) ? best : r.snap;
+  r.q = qc;
+  r.steps = steps;
+  r.dn = d2;
+  const unsigned long long more_m = walk_m & ballot(l != r.maxlen) & ballot(d2 != LinkNone<P>::value) & ballot(steps != K) &
+                                    ballot(r.p - qc + d2 <= (uint32_t)MAX_MATCH_DIST);
+  const unsigned long long fin_m = alive_m & ~more_m;
+  if (mine(fin_m)) {
+    const uint32_t snap = Kq == 0 ? 0u : (r.snap != SNAP_NONE ? r.snap : best);
+    sink(r.p, best, snap);
+  }
+  return fin_m;
+}
+
 template <int NP, typename Sink, typename S, typename P, typename Pool>
 __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &pool, uint32_t pend, uint32_t lane,
                                                         P prev, int K, int Kq, Sink sink) {
@@ -627,8 +675,13 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
 #pragma unroll
     for (int i = 0; i < NP; i++) {
       ZD_COUNT(8, __builtin_popcountll(__builtin_amdgcn_ballot_w64(r[i].alive != 0)));
+#ifdef ZD_MATCH_FIRST_SHARED
       const bool fin = match_run_step_to<true>(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, sink);
       const unsigned long long fm = __builtin_amdgcn_ballot_w64(fin);
+#else
+      const unsigned long long fm = match_run_step_masks(r[i], s, prev, (uint32_t)K, (uint32_t)Kq, sink);
+      const bool fin = __builtin_amdgcn_inverse_ballot_w64(fm);
+#endif
       if (fm) {  // wave-uniform
         ZD_COUNT(6, 1); ZD_COUNT(7, __builtin_popcountll(fm));
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
