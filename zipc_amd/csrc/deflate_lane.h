@@ -698,7 +698,22 @@ __device__ __forceinline__ uint32_t lz_match_runs_pool(S s, uint32_t len, Pool &
         } else {
           next = rem > taken ? next + taken : cend;
         }
+#ifdef ZD_MATCH_FIRST_SHARED
         if (fin) match_run_start<true>(r[i], s, len, np < lim ? np : lim, lim, prev);
+#else
+        if (fin) {  // match_run_start with the position's test made once (the shared form clamps np to lim and then compares again)
+          MatchRun &n = r[i];
+          const uint32_t park = lim ? lim - 1u : 0u;  // a finished run parks on a valid position
+          n.alive = np < lim ? 1u : 0u;
+          n.p = np < park ? np : park;
+          n.q = n.p;
+          n.best_len = MIN_MATCH_LEN - 1;
+          n.best = 0; n.snap = SNAP_NONE; n.steps = 0;
+          n.maxlen = len - n.p < (uint32_t)MAX_MATCH_LEN ? len - n.p : (uint32_t)MAX_MATCH_LEN;
+          n.pw = load_u64_words(s, n.p);
+          n.dn = prev[n.p];
+        }
+#endif
       }
       alive |= r[i].alive;
     }
