@@ -2977,7 +2977,18 @@ static hipError_t launch_deflate_group(zipc_hip_ctx *ctx, const uint8_t *d_src, 
     const size_t seg_syms = segp + PARSE_SEG_SLACK;
     const size_t bytes = plan_bytes + align_up(n_slots * seg_syms * 4, 256) + 2 * align_up(tiles * 8, 256) +
                          2 * align_up(tiles * 4, 256) + 11 * align_up(n_slots * 4, 256) + align_up(n_slots * MEET_CAP * 4, 256);
-    if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) return hipErrorOutOfMemory;
+    if (ctx->ensure(ctx->parse_scratch, bytes) != hipSuccess) {
+      // (8192 members of 1 MiB ask for 39 GB of segment symbols here: where the device cannot give them, the forms by a wave per
+      // stream -- which need none -- take the call, as they did for this shape until round 6; only a call that ASKED for segments fails)
+      (void)hipGetLastError();
+      if (segs_env == 1) return hipErrorOutOfMemory;
+      segmented = false;
+    }
+  }
+  if (segmented) {
+    const size_t n_slots = (size_t)(S.cap_positions / segp) + n + 1, tiles = (size_t)(S.cap_positions / 64) + 4;
+    const size_t plan_bytes = align_up((size_t)S.cap_blocks * sizeof(EmitPlan), 256);
+    const size_t seg_syms = segp + PARSE_SEG_SLACK;
     uint8_t *q = (uint8_t *)ctx->parse_scratch.p;
     plans = (EmitPlan *)q; q += plan_bytes;
     segs.spec_syms = (uint32_t *)q; q += align_up(n_slots * seg_syms * 4, 256);
