@@ -248,10 +248,16 @@ ZD_WV void span_advance(SpanReader &R, const SpanEnv &E, uint32_t p) {  // the p
   R.w2 = s1 ? R.w3 : R.w2;
   R.w3 = s1 ? nx : R.w3;
   R.cw += s1 ? 1u : 0u;
-  if (ncw != R.cw) {  // a symbol of more than 32 bits
-    R.w0 = R.w1; R.w1 = R.w2; R.w2 = R.w3;
-    R.w3 = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
-    R.cw++;
+  // a symbol of more than 32 bits: rare, and behind a WAVE-UNIFORM test -- behind a lane's own `if` the compiler kept both
+  // versions of the words alive across it: three register moves in every step of every lane (round 6, from the assembly)
+  if (wv::any(ncw != R.cw)) {
+    const bool s2 = ncw != R.cw;
+    const uint32_t nx2 = r[((R.cw + 4u) & (SPAN_RING - 1)) * 64u];
+    R.w0 = s2 ? R.w1 : R.w0;
+    R.w1 = s2 ? R.w2 : R.w1;
+    R.w2 = s2 ? R.w3 : R.w2;
+    R.w3 = s2 ? nx2 : R.w3;
+    R.cw += s2 ? 1u : 0u;
   }
 }
 
